@@ -1,0 +1,63 @@
+"""Oracle: margin-softmax heads, soft-target CE and batch mixup (fp32 CPU).  Test infrastructure only."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def cosface_logits(x, weight, label, s=64.0, m=0.4):
+    """CosFace.forward (face_pre_pro/ViT_face.py:49-89): s * (cos(x, W) - m * y).
+
+    ``label`` is [B] integer class ids or a dense [B, C] soft target (the mixup branch
+    :69-73 multiplies the margin by the soft label itself)."""
+    cos = F.linear(F.normalize(x), F.normalize(weight))
+    if label.dim() > 1:
+        y = label.to(cos.dtype)
+    else:
+        y = torch.zeros_like(cos).scatter_(1, label.view(-1, 1).long(), 1.0)
+    return s * (y * (cos - m) + (1.0 - y) * cos)
+
+
+def arcface_logits(x, weight, label, s=64.0, m=0.5):
+    """ArcFace s*cos(theta + m) on the target class.  PARITY UNPINNED: the reference only
+    names the class (ViT_face.py:416-417, 654-655) and never defines it; this follows
+    Deng et al. 2019 with the InsightFace defaults, hard labels only."""
+    cos = F.linear(F.normalize(x), F.normalize(weight)).clamp(-1, 1)
+    theta = torch.acos(cos)
+    y = torch.zeros_like(cos).scatter_(1, label.view(-1, 1).long(), 1.0)
+    return s * torch.where(y > 0, torch.cos(theta + m), cos)
+
+
+def soft_target_cross_entropy(logits, target):
+    """timm SoftTargetCrossEntropy (external package; call site train_largescale.py:602, 820):
+    mean_b sum_k -y_k log_softmax(x)_k."""
+    return torch.sum(-target * F.log_softmax(logits, dim=-1), dim=-1).mean()
+
+
+def mixup_batch(x, target, num_classes, lam, smoothing=0.0):
+    """Batch-mode mixup given lambda (util/mixup_my.py:189-200, 18-24, 202-211).
+
+    x is mixed in place with its batch-flip when lam != 1; the dense target is
+    lam*onehot(y) + (1-lam)*onehot(flip(y)) with label smoothing folded in."""
+    if lam != 1.0:
+        xf = x.flip(0).mul_(1.0 - lam)
+        x.mul_(lam).add_(xf)
+    off = smoothing / num_classes
+    on = 1.0 - smoothing + off
+    oh = lambda t: torch.full((t.numel(), num_classes), off).scatter_(1, t.long().view(-1, 1), on)
+    return x, oh(target) * lam + oh(target.flip(0)) * (1.0 - lam)
+
+
+def draw_mixup_lambda(rng: np.random.RandomState, mixup_alpha=0.2, prob=0.1):
+    """lambda draw of _params_per_batch for mixup-only (util/mixup_my.py:134-150):
+    one uniform for the apply decision, then Beta(alpha, alpha)."""
+    if rng.rand() < prob:
+        return float(rng.beta(mixup_alpha, mixup_alpha))
+    return 1.0
+
+
+def partial_fc_reference(emb, weight, labels, s=64.0, m=0.4):
+    """Unsharded full-FC CosFace + hard-label CE, the self-check target for the sharded
+    PartialFC path at sample_rate=1.  PARITY UNPINNED (PartialFC is absent from the
+    reference: only a commented import, ViT_face.py:645-649)."""
+    logits = cosface_logits(emb, weight, labels, s, m)
+    return F.cross_entropy(logits, labels.long())

@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Generate the golden parity fixtures under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container, where the read-only reference checkout is mounted at
+/root/reference.  It imports the reference's own modules on CPU (fp32), feeds them small seeded
+inputs and stores inputs + parameters + outputs as .npz files.  The fixtures are data only; no
+reference source travels with the repo.  Import recipe follows SURVEY.md section 8c:
+
+  * `utils`, `vision_transformer`, `util.mixup_my` import unmodified;
+  * `lafs_train` needs empty `torchvision{,.datasets,.transforms,.models}` stubs;
+  * `face_pre_pro.ViT_face` additionally needs `IPython.embed` and
+    `timm.models.layers.{DropPath, trunc_normal_}` (mapped to vision_transformer.DropPath and
+    torch.nn.init.trunc_normal_);
+  * hard-coded `.cuda()` calls are neutralised with `torch.Tensor.cuda = identity`;
+  * DINOLoss needs a process group -> gloo, world_size 1.
+
+Usage:  python tools/make_golden.py   (rewrites tests/golden/*.npz deterministically)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("LAFS_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    for name in ("torchvision", "torchvision.datasets", "torchvision.transforms", "torchvision.models"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    tv = sys.modules["torchvision"]
+    tv.datasets, tv.transforms, tv.models = (sys.modules["torchvision.datasets"],
+                                             sys.modules["torchvision.transforms"],
+                                             sys.modules["torchvision.models"])
+    ip = types.ModuleType("IPython"); ip.embed = lambda *a, **k: None
+    sys.modules.setdefault("IPython", ip)
+    import utils as ref_utils                      # noqa: E402  (reference module)
+    import vision_transformer as ref_vit           # noqa: E402
+    timm = types.ModuleType("timm"); tm = types.ModuleType("timm.models"); tl = types.ModuleType("timm.models.layers")
+    tl.DropPath = ref_vit.DropPath
+    tl.trunc_normal_ = torch.nn.init.trunc_normal_
+    timm.models, tm.layers = tm, tl
+    for n, m in (("timm", timm), ("timm.models", tm), ("timm.models.layers", tl)):
+        sys.modules.setdefault(n, m)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import lafs_train as ref_lafs                  # noqa: E402
+    import face_pre_pro.ViT_face as ref_face       # noqa: E402
+    import util.mixup_my as ref_mix                # noqa: E402
+    return ref_utils, ref_vit, ref_lafs, ref_face, ref_mix
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print(f"  wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays)")
+
+
+def sd(module, prefix="p."):
+    return {prefix + k: v for k, v in module.state_dict().items()}
+
+
+def grads(module, prefix="g."):
+    return {prefix + k: p.grad for k, p in module.named_parameters() if p.grad is not None}
+
+
+def main():
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    ref_utils, ref_vit, ref_lafs, ref_face, ref_mix = _import_reference()
+    torch.set_num_threads(4)
+
+    # ---------------------------------------------------------------- F1 VisionTransformer fwd/bwd
+    # tiny geometry that the HIP kernels also accept (head_dim 64): D=128, 2 heads, depth 2, p=8,
+    # pos table 28x28 (img_size 224) resampled to 14x14 and 6x6.
+    print("F1 vit")
+    torch.manual_seed(1)
+    vitm = ref_vit.VisionTransformer(img_size=[224], patch_size=8, embed_dim=128, depth=2, num_heads=2,
+                                     mlp_ratio=4, qkv_bias=True,
+                                     norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6), drop_path_rate=0.0)
+    with torch.no_grad():                           # non-trivial affine / biases so that they are exercised
+        for n_, p_ in vitm.named_parameters():
+            if n_.endswith("bias") or "norm" in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+    xg = torch.randn(2, 3, 112, 112).clamp(-1, 1)
+    xl = torch.randn(3, 3, 48, 48).clamp(-1, 1)
+    wg, wl = torch.randn(2, 128), torch.randn(3, 128)
+    og = vitm(xg); ol = vitm(xl)
+    ((og * wg).sum() + (ol * wl).sum()).backward()
+    pos14 = vitm.interpolate_pos_encoding(torch.zeros(1, 197, 128), 112, 112)
+    pos6 = vitm.interpolate_pos_encoding(torch.zeros(1, 37, 128), 48, 48)
+    save("f1_vit", xg=xg, xl=xl, wg=wg, wl=wl, og=og, ol=ol, pos14=pos14, pos6=pos6, **sd(vitm), **grads(vitm))
+
+    # ---------------------------------------------------------------- F2 DINOHead fwd/bwd
+    print("F2 dino head")
+    torch.manual_seed(2)
+    head = ref_vit.DINOHead(128, 1000, use_bn=False, norm_last_layer=True, nlayers=3, hidden_dim=256,
+                            bottleneck_dim=64)
+    xh = torch.randn(6, 128, requires_grad=True)
+    wh = torch.randn(6, 1000)
+    oh = head(xh)
+    (oh * wh).sum().backward()
+    save("f2_head", x=xh, w=wh, out=oh, gx=xh.grad, **sd(head), **grads(head))
+    head2 = ref_vit.DINOHead(128, 1000, use_bn=False, norm_last_layer=False, nlayers=3, hidden_dim=256,
+                             bottleneck_dim=64)
+    with torch.no_grad():
+        head2.last_layer.weight_g.mul_(1 + 0.2 * torch.randn_like(head2.last_layer.weight_g))
+    xh2 = torch.randn(6, 128, requires_grad=True)
+    oh2 = head2(xh2)
+    (oh2 * wh).sum().backward()
+    save("f2_head_freeg", x=xh2, w=wh, out=oh2, gx=xh2.grad, **sd(head2), **grads(head2))
+
+    # ---------------------------------------------------------------- F3 MultiCropWrapper
+    print("F3 multicrop")
+    torch.manual_seed(3)
+    vit3 = ref_vit.VisionTransformer(img_size=[112], patch_size=8, embed_dim=64, depth=1, num_heads=1,
+                                     qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    head3 = ref_vit.DINOHead(64, 200, hidden_dim=128, bottleneck_dim=64)
+    mc = ref_utils.MultiCropWrapper(vit3, head3)
+    crops = [torch.randn(2, 3, 112, 112).clamp(-1, 1) for _ in range(2)] + \
+            [torch.randn(2, 3, 48, 48).clamp(-1, 1) for _ in range(3)]
+    out3 = mc(crops)
+    save("f3_multicrop", out=out3, **{f"crop{i}": c for i, c in enumerate(crops)}, **sd(mc))
+
+    # ---------------------------------------------------------------- F4 DINOLoss
+    print("F4 dino loss")
+    for ncrops in (4, 10):
+        torch.manual_seed(40 + ncrops)
+        K, B = 1000, 3
+        crit = ref_lafs.DINOLoss(K, ncrops, 0.07, 0.04, 6, 10)
+        crit.center.copy_(0.05 * torch.randn(1, K))
+        res = {}
+        for epoch in (0, 7):
+            s = (0.5 * torch.randn(ncrops * B, K)).requires_grad_(True)
+            t = 0.5 * torch.randn(2 * B, K)
+            c0 = crit.center.clone()
+            loss = crit(s, t, epoch)
+            loss.backward()
+            res.update({f"e{epoch}_student": s, f"e{epoch}_teacher": t, f"e{epoch}_center_before": c0,
+                        f"e{epoch}_loss": loss, f"e{epoch}_grad": s.grad, f"e{epoch}_center_after": crit.center,
+                        f"e{epoch}_temp": np.float64(crit.teacher_temp_schedule[epoch])})
+        save(f"f4_dinoloss_nc{ncrops}", schedule=crit.teacher_temp_schedule, **res)
+
+    # ---------------------------------------------------------------- F5 full LAFS step x2
+    # Re-assembled from the reference's own components in the order of lafs_train.py:577-613.
+    print("F5 lafs step")
+    torch.manual_seed(5)
+    K, B, ncrops = 512, 2, 5
+    mk = lambda dpr: ref_vit.VisionTransformer(img_size=[112], patch_size=8, embed_dim=64, depth=2, num_heads=1,
+                                               qkv_bias=True, drop_path_rate=dpr,
+                                               norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    student = ref_utils.MultiCropWrapper(mk(0.0), ref_vit.DINOHead(64, K, hidden_dim=128, bottleneck_dim=64,
+                                                                   norm_last_layer=True))
+    teacher = ref_utils.MultiCropWrapper(mk(0.0), ref_vit.DINOHead(64, K, hidden_dim=128, bottleneck_dim=64))
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad = False
+    crit = ref_lafs.DINOLoss(K, ncrops, 0.07, 0.04, 3, 10)
+    opt = torch.optim.AdamW(ref_utils.get_params_groups(student))
+    groups = ref_utils.get_params_groups(student)
+    reg_ids = {id(p) for p in groups[0]["params"]}
+    membership = {n: (id(p) in reg_ids) for n, p in student.named_parameters() if p.requires_grad}
+    fx = {"init." + k: v.clone() for k, v in student.state_dict().items()}
+    lrs, wds, moms = [5e-4, 4e-4], [0.04, 0.05], [0.9, 0.95]           # large (1-m) so EMA is visible
+    for step in range(2):
+        epoch = step                                 # step 0 -> epoch 0 (last layer frozen), step 1 -> epoch 1
+        imgs = [torch.randn(B, 3, 112, 112).clamp(-1, 1) for _ in range(2)] + \
+               [torch.randn(B, 3, 48, 48).clamp(-1, 1) for _ in range(ncrops - 2)]
+        for i, g in enumerate(opt.param_groups):
+            g["lr"] = lrs[step]
+            if i == 0:
+                g["weight_decay"] = wds[step]
+        t_out = teacher(imgs[:2]); s_out = student(imgs)
+        loss = crit(s_out, t_out, epoch)
+        opt.zero_grad()
+        loss.backward()
+        norms = ref_utils.clip_gradients(student, 3.0)
+        post = {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
+        ref_utils.cancel_gradients_last_layer(epoch, student, 1)
+        opt.step()
+        with torch.no_grad():
+            for pq, pk in zip(student.parameters(), teacher.parameters()):
+                pk.data.mul_(moms[step]).add_((1 - moms[step]) * pq.detach().data)
+        fx.update({f"s{step}.crop{i}": im for i, im in enumerate(imgs)})
+        fx.update({f"s{step}.loss": loss, f"s{step}.center": crit.center, f"s{step}.t_out": t_out,
+                   f"s{step}.s_out": s_out, f"s{step}.norms": np.array(norms)})
+        fx.update({f"s{step}.grad_post.{n}": g for n, g in post.items()})
+        fx.update({f"s{step}.student.{k}": v.clone() for k, v in student.state_dict().items()})
+        fx.update({f"s{step}.teacher.{k}": v.clone() for k, v in teacher.state_dict().items()})
+    fx["hyper"] = np.array([lrs, wds, moms])
+    fx["norm_names"] = np.array([n for n, p in student.named_parameters() if p.requires_grad])
+    fx["membership_names"] = np.array(list(membership.keys()))
+    fx["membership_reg"] = np.array(list(membership.values()))
+    save("f5_lafs_step", **fx)
+
+    # ---------------------------------------------------------------- F6 schedules
+    print("F6 schedules")
+    save("f6_schedules",
+         lr=ref_utils.cosine_scheduler(5e-4 * 64 / 256, 1e-6, 6, 11, warmup_epochs=2),
+         wd=ref_utils.cosine_scheduler(0.04, 0.4, 6, 11),
+         mom=ref_utils.cosine_scheduler(0.996, 1, 6, 11))
+
+    # ---------------------------------------------------------------- F7 Part-fViT
+    print("F7 part-fvit")
+    torch.manual_seed(7)
+    pv = ref_face.ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112,
+                                           patch_size=8, dim=128, depth=2, heads=3, mlp_dim=256, dropout=0.0,
+                                           emb_dropout=0.0, with_land=False)
+    for m in pv.modules():                          # Residual_droppath hard-codes rate 0.1 -> parity mode = 0
+        if isinstance(m, ref_vit.DropPath):
+            m.drop_prob = 0.0
+    ximg = torch.randn(2, 3, 112, 112).clamp(-1, 1)
+    xpat = torch.randn(3, 36, 192)                  # 3-D patch input (local views, 36 landmarks)
+    w1, w2 = torch.randn(2, 128), torch.randn(3, 128)
+    e1, e2 = pv(ximg), pv(xpat)
+    ((e1 * w1).sum() + (e2 * w2).sum()).backward()
+    save("f7_partfvit", ximg=ximg, xpat=xpat, w1=w1, w2=w2, e1=e1, e2=e2, **sd(pv), **grads(pv))
+
+    # ---------------------------------------------------------------- F8 landmark patch gather
+    print("F8 gather")
+    torch.manual_seed(8)
+    for n in (196, 36):
+        img = torch.randn(2, 3, 112, 112, requires_grad=True)
+        th = (torch.rand(2, n, 2) * 130 - 10).requires_grad_(True)      # includes out-of-image landmarks
+        out = ref_face.extract_patches_pytorch_gridsample(img, th, patch_shape=torch.tensor([8, 8]), num_landm=n)
+        w = torch.randn_like(out)
+        (out * w).sum().backward()
+        save(f"f8_gather_n{n}", img=img, theta=th, w=w, out=out, gtheta=th.grad, gimg=img.grad)
+
+    # ---------------------------------------------------------------- F10 CosFace
+    print("F10 cosface")
+    torch.manual_seed(10)
+    cf = ref_face.CosFace(64, 300, None, s=64.0, m=0.4)
+    x = torch.randn(4, 64, requires_grad=True)
+    y = torch.tensor([3, 299, 0, 17])
+    o_hard = cf(x, y)
+    wcf = torch.randn(4, 300)
+    (o_hard * wcf).sum().backward()
+    gx_h, gw_h = x.grad.clone(), cf.weight.grad.clone()
+    x.grad = None; cf.weight.grad = None
+    ysoft = 0.3 * torch.nn.functional.one_hot(y, 300).float() + 0.7 * torch.nn.functional.one_hot(y.flip(0), 300).float()
+    o_soft = cf(x, ysoft)
+    ce = torch.sum(-ysoft * torch.nn.functional.log_softmax(o_soft, dim=-1), dim=-1).mean()
+    ce.backward()
+    save("f10_cosface", x=x, y=y, weight=cf.weight, w=wcf, out_hard=o_hard, gx_hard=gx_h, gw_hard=gw_h,
+         ysoft=ysoft, out_soft=o_soft, ce_soft=ce, gx_soft=x.grad, gw_soft=cf.weight.grad)
+
+    # ---------------------------------------------------------------- F11 Mixup (batch mode)
+    print("F11 mixup")
+    mix = ref_mix.Mixup(mixup_alpha=0.2, cutmix_alpha=0.0, cutmix_minmax=None, prob=1.0, switch_prob=0.5,
+                        mode="batch", label_smoothing=0.0, num_classes=50)
+    np.random.seed(11)
+    xm = torch.randn(4, 3, 16, 16)
+    ym = torch.tensor([1, 7, 7, 49])
+    x_in = xm.clone()
+    xo, yo = mix(xm, ym, device="cpu")
+    np.random.seed(11)
+    np.random.rand(); lam = float(np.random.beta(0.2, 0.2))
+    save("f11_mixup", x_in=x_in, y=ym, x_out=xo, target=yo, lam=np.float64(lam))
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
