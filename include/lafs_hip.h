@@ -1,0 +1,252 @@
+/* lafs_hip.h -- C ABI of liblafs_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the LAFS
+ * data-parallel hot path.
+ *
+ * The reference (szlbiubiubiu/LAFS_CVPR2024) has no FFI of its own: the hot path sits behind
+ * torch.nn.Module objects that dispatch to ATen/cuBLAS/cuDNN.  Each entry point below replaces the
+ * implicit device kernels behind one reference call site (cited as file:line, relative to the reference
+ * root).  Conventions:
+ *   - plain pointers and sizes only (device pointers unless stated), no torch types;
+ *   - the CALLER allocates every buffer including workspaces; the library keeps no device state;
+ *   - every function enqueues work on `stream` and never synchronises the device;
+ *   - return value: 0 = success, < 0 = bad argument (see lafs_last_error()), > 0 = hipError_t;
+ *   - "bf16" = raw 16-bit bfloat16, "f32" = IEEE float; row-major everywhere, ld* in ELEMENTS.
+ */
+#ifndef LAFS_HIP_H
+#define LAFS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define LAFS_ABI_VERSION 1
+
+int lafs_version(void);
+/* Diagnostic: lane l of one wave issues ds_read_b64_tr_b16 at LDS byte 8*l over in(i16)[512]; out(i16)[256] gets
+ * the 4 values each lane received.  Pins the LDS-transpose-read model used by the attention / wgrad kernels. */
+int lafs_debug_tr16(const void* in, void* out, hipStream_t stream);
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char* lafs_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * GEMMs (nn.Linear / nn.Conv2d(k=s=p) forward, dgrad, wgrad)
+ *   vision_transformer.py:59-65 (Mlp), :75-90 (qkv/proj), :126-131 (PatchEmbed conv), :295-301 (DINOHead)
+ *   face_pre_pro/ViT_face.py:126-137 (FeedForward), :147-149 (to_qkv/to_out), :761 (patch_to_embedding)
+ * ------------------------------------------------------------------------------------------------ */
+enum {
+  LAFS_EPI_BF16 = 0,       /* C(bf16) = acc + bias                                                   */
+  LAFS_EPI_BF16_GELU = 1,  /* C(bf16) = u = acc + bias ; C2(bf16) = GELU_erf(u)                      */
+  LAFS_EPI_RESID_F32 = 2,  /* C(f32) = resid + seq_scale[row2seq[m]] * (acc + bias)   (DropPath)     */
+  LAFS_EPI_F32 = 3,        /* C(f32) = acc + bias                                                    */
+  LAFS_EPI_DGELU_BF16 = 4, /* C(bf16) = acc * GELU'(aux[m][n])                                       */
+  LAFS_EPI_ATOMIC_F32 = 5, /* C(f32) += acc, K split into `splits` slices (C must be pre-zeroed)     */
+  LAFS_EPI_EMBED_F32 = 6   /* C(f32)[m + m/npatch + 1] = acc + bias + pos[1 + m%npatch]  (tokens)    */
+};
+
+typedef struct lafs_gemm_nt_args {
+  const void* A; int lda;          /* bf16 [M, K]                                  */
+  const void* B; int ldb;          /* bf16 [N, K]  (nn.Linear weight layout)       */
+  int M, N, K;                     /* K % 64 == 0                                  */
+  int epilogue;                    /* LAFS_EPI_*                                   */
+  void* C; int ldc;                /* bf16 or f32 [M, N]                           */
+  void* C2; int ldc2;              /* second output (BF16_GELU)                    */
+  const float* bias;               /* f32 [N] or NULL                              */
+  const float* resid; int ldr;     /* f32 [M, N] (RESID_F32; may alias C)          */
+  const float* seq_scale;          /* f32 [n_seq] or NULL (RESID_F32)              */
+  const int32_t* row2seq;          /* i32 [M]  row -> sequence index               */
+  const void* aux; int ldaux;      /* bf16 [M, N] pre-activation (DGELU_BF16)      */
+  const float* pos; int npatch;    /* f32 [npatch+1, N] (EMBED_F32)                */
+  int splits;                      /* ATOMIC_F32: number of K slices (>=1)         */
+} lafs_gemm_nt_args;
+
+/* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue. */
+int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
+
+/* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
+ * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0. */
+int lafs_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                     int M, int N1, int N2, int splits, hipStream_t stream);
+
+/* out(f32)[n] += sum_m X(bf16)[m, n]   (bias gradients). */
+int lafs_colsum_bf16_acc(const void* X, int ldx, int M, int N, float* out, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm  (vision_transformer.py:99,103,156 eps 1e-6; face_pre_pro/ViT_face.py:117 eps 1e-5)
+ * ------------------------------------------------------------------------------------------------ */
+/* y(bf16)[r,:] = (x(f32)[r,:] - mean) * rstd * gamma + beta ; stats(f32)[r] = {mean, rstd}.
+ * y_f32 (optional, may be NULL) receives the same result in fp32.  D % 4 == 0, D <= 2048. */
+int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                       void* y_bf16, int ldy, float* y_f32, int ldyf, float* stats, int rows, int D,
+                       hipStream_t stream);
+/* Backward.  dy is bf16 [rows, D] (dy_f32 != NULL: use that fp32 gradient instead).
+ *   dx = LN'(dy);  g_io(f32)[r,:] = (accumulate ? g_io : 0) + dx
+ *   dgamma(f32)[D] += sum_r dy*xhat ; dbeta(f32)[D] += sum_r dy
+ *   gb_out(bf16, optional)[r,:] = bf16(seq_scale[row2seq[r]] * g_io[r,:])  -- the DropPath-scaled gradient fed to
+ *   the previous residual branch's GEMMs (seq_scale NULL -> scale 1). */
+int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf, const float* x, int ldx,
+                       const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
+                       void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
+                       float* dgamma, float* dbeta, int rows, int D, hipStream_t stream);
+
+/* gb(bf16)[r,:] = bf16(seq_scale[row2seq[r]] * g(f32)[r,:])  (seq_scale NULL -> plain cast). */
+int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb, const float* seq_scale,
+                         const int32_t* row2seq, int rows, int D, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-head attention over variable-length sequences, head_dim = 64
+ *   vision_transformer.py:80-89 (scale = head_dim^-0.5); face_pre_pro/ViT_face.py:155-179 (scale = dim^-0.5)
+ * qkv(bf16) [T, 3*H*64]: columns [q | k | v], each H*64 wide, head-major.  cu_seqlens(i32, device) [n_seq+1].
+ * All sequences of one call must have length <= max_len <= 256.
+ * ------------------------------------------------------------------------------------------------ */
+int lafs_attention_fwd(const void* qkv, int ldqkv, const int32_t* cu_seqlens, int n_seq, int max_len, int heads,
+                       float scale, void* out_bf16, int ldo, float* lse, hipStream_t stream);
+/* dqkv(bf16) [T, 3*H*64] from dout(bf16) [T, H*64]; `delta` is an f32 [T, H] scratch; n_tok = T. */
+int lafs_attention_bwd(const void* qkv, int ldqkv, const void* out_bf16, int ldo, const void* dout_bf16, int lddo,
+                       const float* lse, float* delta, const int32_t* cu_seqlens, int n_seq, int n_tok, int max_len,
+                       int heads, float scale, void* dqkv, int lddqkv, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Patch embedding front end  (vision_transformer.py:126-131, 196-207; face_pre_pro/ViT_face.py:760-766)
+ * ------------------------------------------------------------------------------------------------ */
+enum { LAFS_PATCH_ORDER_CHW = 0 /* Conv2d weight [D,c,p1,p2] */, LAFS_PATCH_ORDER_HWC = 1 /* '(p1 p2 c)' */ };
+/* img(f32) [B,3,S,S] -> patches(bf16) [B*(S/p)^2, 3*p*p], p = 8. */
+int lafs_patchify(const float* img, int B, int S, int order, void* patches, hipStream_t stream);
+/* tokens(f32)[b*(np+1), :] = cls[:] + pos[0,:]  for every sequence (the patch rows are written by the
+ * LAFS_EPI_EMBED_F32 GEMM epilogue). */
+int lafs_embed_cls(const float* cls, const float* pos, float* tokens, int ldt, int n_seq, int npatch, int D,
+                   hipStream_t stream);
+/* Backward of the token assembly: g(f32) [n_seq*(np+1), D] ->
+ *   gp(bf16) [n_seq*np, D] (patch rows only), dpos(f32)[np+1, D] += sum over sequences, dcls(f32)[D] += sum g[cls rows]. */
+int lafs_embed_bwd(const float* g, int ldg, int n_seq, int npatch, int D, void* gp, float* dpos, float* dcls,
+                   hipStream_t stream);
+/* feat(bf16 and/or f32) [n_seq, D] = x[row of cls token of each sequence]; and its scatter-back. */
+int lafs_gather_cls(const float* x, int ldx, const int32_t* cu_seqlens, int n_seq, int D, float* out_f32,
+                    hipStream_t stream);
+/* g(f32)[first row of each sequence, :] = src[n_seq, D]  (g is expected to be zero elsewhere). */
+int lafs_scatter_cls(const float* src, const int32_t* cu_seqlens, int n_seq, int D, float* g, int ldg,
+                     hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DINO head pieces  (vision_transformer.py:284-287, 299-300)
+ * ------------------------------------------------------------------------------------------------ */
+/* y = x / max(||x||_2, 1e-12) row-wise: x f32 [rows, D] -> y bf16 (+ inv_norm f32 [rows]). */
+int lafs_l2norm_fwd(const float* x, int ldx, void* y_bf16, int ldy, float* inv_norm, int rows, int D,
+                    hipStream_t stream);
+/* dx(f32) = inv_norm * (dy - y * <y, dy>)   with y recomputed from x. */
+int lafs_l2norm_bwd(const float* x, int ldx, const float* dy, int lddy, const float* inv_norm, float* dx, int lddx,
+                    int rows, int D, hipStream_t stream);
+/* weight_norm (dim=0): w(bf16)[k,:] = g[k] * v[k,:] / ||v[k,:]|| ; also w_t(bf16) [D, ldwt] transposed copy
+ * (NULL to skip); rows k in [K, Kpad) of w and columns of w_t are zero-filled.  inv_norm f32 [K]. */
+int lafs_weightnorm_fwd(const float* v, const float* g, int K, int Kpad, int D, void* w, void* w_t, int ldwt,
+                        float* inv_norm, hipStream_t stream);
+/* dv(f32)[k,:] (+)= g/||v|| * (dw - vhat * <dw, vhat>) ; dg(f32)[k] (+)= <dw, vhat>  (dg may be NULL). */
+int lafs_weightnorm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, int K, int D,
+                        float* dv, float* dg, int accumulate, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DINO loss (lafs_train.py:643-679), closed form:
+ *   q_i = softmax((t_i - c)/tau_t),  p_v = softmax(s_v / tau_s)
+ *   loss = 1/n_terms * sum_{i in {0,1}, v != i} mean_b [ lse(s_v/tau_s) - <q_i, s_v/tau_s> ]
+ *   dL/ds_v = 1/(n_terms * B * tau_s) * sum_{i != v} (p_v - q_i)
+ * student f32 [ncrops*B, ld], teacher f32 [2*B, ld], center f32 [K]; grad bf16 or f32 [ncrops*B, ldg].
+ * workspace f32: lafs_dino_loss_workspace(ncrops, B, K) floats.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t lafs_dino_loss_workspace(int ncrops, int B, int K);
+int lafs_dino_loss_fwd_bwd(const float* student, const float* teacher, int ld, const float* center, int ncrops,
+                           int B, int K, float student_temp, float teacher_temp, float* loss_out,
+                           void* grad, int ldg, int grad_is_bf16, float grad_scale, float* workspace,
+                           hipStream_t stream);
+/* colsum(f32)[k] = sum_rows teacher[r, k]   (lafs_train.py:674; all-reduced by the caller) */
+int lafs_colsum_f32(const float* x, int ld, int rows, int K, float* out, hipStream_t stream);
+/* center = center*m + colsum/(rows_total) * (1-m)   (lafs_train.py:676-679) */
+int lafs_center_ema(float* center, const float* colsum, int K, float inv_rows_total, float momentum,
+                    hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-tensor step glue over a flat parameter arena split into 1024-element chunks
+ *   utils.py:132-141 (per-tensor clip), lafs_train.py:400 + torch AdamW, lafs_train.py:610-613 (EMA)
+ * chunk_seg(i32)[n_chunks] maps each chunk to its tensor (segment).  seg_flags bit0 = weight decay on,
+ * bit1 = "last_layer" (skipped while frozen), bit2 = trainable.  Hyper-parameters live in a device f32[16]:
+ * {lr, wd, beta1, beta2, eps, clip, ema_m, freeze_last_layer(0/1), grad_scale, ...}.
+ * ------------------------------------------------------------------------------------------------ */
+#define LAFS_CHUNK 1024
+enum { LAFS_SEG_DECAY = 1, LAFS_SEG_LAST_LAYER = 2, LAFS_SEG_TRAINABLE = 4 };
+enum { LAFS_HP_LR = 0, LAFS_HP_WD, LAFS_HP_BETA1, LAFS_HP_BETA2, LAFS_HP_EPS, LAFS_HP_CLIP, LAFS_HP_EMA_M,
+       LAFS_HP_FREEZE_LAST, LAFS_HP_GRAD_SCALE, LAFS_HP_COUNT = 16 };
+/* seg_sumsq(f32)[n_seg] += sum of (grad_scale*g)^2 per segment (seg_sumsq must be pre-zeroed). */
+int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, const float* hyper,
+                    float* seg_sumsq, hipStream_t stream);
+/* Fused per-tensor clip + AdamW + teacher EMA + bf16 shadow refresh.  seg_step(i32)[n_seg] counts the
+ * optimizer steps each tensor has actually taken.  teacher/shadow pointers may be NULL. */
+int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* teacher,
+                        void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t n_chunks,
+                        const int32_t* seg_flags, int32_t* seg_step, int n_seg, const float* seg_sumsq,
+                        const float* hyper, hipStream_t stream);
+/* dst(bf16)[i] = src(f32)[i] */
+int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
+/* dst(bf16)[c, r] = src(f32)[r, c]   (W^T shadows used by the dgrad GEMMs) */
+int lafs_transpose_cast_bf16(const float* src, int rows, int cols, void* dst, int ld_dst, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Transformer engine: whole pre-LN ViT trunk forward/backward over a packed token batch
+ *   vision_transformer.py:107-113, 209-215; face_pre_pro/ViT_face.py:106-120, 184-213
+ * Offsets are in ELEMENTS into the caller's arenas: `master` (f32 parameters), `shadow` (bf16 copy, same
+ * offsets), `shadow_t` (bf16 transposed weights, offsets *_t), `grad` (f32, same offsets as master).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct lafs_block_offsets {
+  int64_t ln1_g, ln1_b, w_qkv, b_qkv /* -1 if none */, w_proj, b_proj, ln2_g, ln2_b, w_fc1, b_fc1, w_fc2, b_fc2;
+  int64_t w_qkv_t, w_proj_t, w_fc1_t, w_fc2_t;     /* into shadow_t */
+} lafs_block_offsets;
+
+typedef struct lafs_trunk_desc {
+  int dim, inner /* heads*64 */, heads, mlp, depth;
+  float ln_eps, attn_scale;
+  int n_tok, n_seq, max_len;
+  const int32_t* cu_seqlens;      /* device i32 [n_seq+1] */
+  const int32_t* row2seq;         /* device i32 [n_tok]   */
+  const float* drop_scales;       /* device f32 [depth, 2, n_seq] or NULL */
+  const float* master; const void* shadow; const void* shadow_t; float* grad;
+  const lafs_block_offsets* blocks;   /* HOST array [depth] */
+} lafs_trunk_desc;
+
+/* Bytes of activation workspace for a forward with (1) / without (0) saving activations for backward. */
+int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward);
+/* x_in(f32) [n_tok, dim] -> x_out(f32) [n_tok, dim]: residual stream after the last block.  With
+ * save_for_backward != 0 x_in must stay untouched until lafs_trunk_backward has run (it is layer 0's saved input)
+ * and must not alias x_out. */
+int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, float* x_out, void* workspace,
+                       int save_for_backward, hipStream_t stream);
+/* g(f32) [n_tok, dim]: dL/dx_out on entry, dL/dx_in on exit.  Parameter gradients are ACCUMULATED into d->grad.
+ * Blocks layer_hi-1 .. layer_lo run; pass (depth, 0) for the whole trunk, or walk it in slices to start the
+ * gradient all-reduce of finished blocks early. */
+int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
+                        int layer_lo, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fine-tune path (train_largescale.py): margin-softmax head, mixup, landmark patch gather
+ * ------------------------------------------------------------------------------------------------ */
+/* CosFace logits + soft-target CE, fused over the class axis (face_pre_pro/ViT_face.py:49-89;
+ * timm SoftTargetCrossEntropy, train_largescale.py:820).  cos(f32) [B, ld] holds x_hat . w_hat^T on entry and
+ * dL/dcos on exit.  The (mixup) target is given sparsely: y1,y2 (i32 [B]) with weights lam,(1-lam).
+ * loss_out(f32)[1] = mean_b CE.  margin_type 0 = CosFace s*(cos - m*y), 1 = ArcFace (hard labels only). */
+int lafs_margin_softmax_ce(float* cos, int ld, int B, int C, const int32_t* y1, const int32_t* y2, float lam,
+                           float s, float m, int margin_type, float loss_scale, float* loss_out, float* row_ws,
+                           hipStream_t stream);
+/* x(f32) [B,3,S,S]: x = lam*x + (1-lam)*flip_batch(x) in place, from u8 or f32 source with (x/255*2-1) folded in. */
+int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, hipStream_t stream);
+/* Landmark patch gather (face_pre_pro/ViT_face.py:1615-1656): img f32 [B,3,S,S], theta f32 [B,n,2] (x,y pixels) ->
+ * mosaic f32 [B,3,8r,8r], r = sqrt(n). */
+int lafs_patch_gather_fwd(const float* img, const float* theta, int B, int S, int n, float* mosaic, hipStream_t stream);
+/* dtheta(f32) [B,n,2] from dmosaic; dimg (optional, pre-zeroed) accumulates the image gradient. */
+int lafs_patch_gather_bwd(const float* img, const float* theta, const float* dmosaic, int B, int S, int n,
+                          float* dtheta, float* dimg, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAFS_HIP_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of liblafs_hip.so (C ABI in include/lafs_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a LafsHipError is raised.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C lafs_cvpr2024_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblafs_hip.so")
+
+
+class LafsHipError(RuntimeError):
+    pass
+
+
+class GemmNTArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("epilogue", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("ldc2", C.c_int),
+                ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int),
+                ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
+                ("aux", C.c_void_p), ("ldaux", C.c_int), ("pos", C.c_void_p), ("npatch", C.c_int),
+                ("splits", C.c_int)]
+
+
+class BlockOffsets(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in
+                ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_proj", "b_proj", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2",
+                 "b_fc2", "w_qkv_t", "w_proj_t", "w_fc1_t", "w_fc2_t")]
+
+
+class TrunkDesc(C.Structure):
+    _fields_ = [("dim", C.c_int), ("inner", C.c_int), ("heads", C.c_int), ("mlp", C.c_int), ("depth", C.c_int),
+                ("ln_eps", C.c_float), ("attn_scale", C.c_float),
+                ("n_tok", C.c_int), ("n_seq", C.c_int), ("max_len", C.c_int),
+                ("cu_seqlens", C.c_void_p), ("row2seq", C.c_void_p), ("drop_scales", C.c_void_p),
+                ("master", C.c_void_p), ("shadow", C.c_void_p), ("shadow_t", C.c_void_p), ("grad", C.c_void_p),
+                ("blocks", C.POINTER(BlockOffsets))]
+
+
+EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32 = range(7)
+PATCH_ORDER_CHW, PATCH_ORDER_HWC = 0, 1
+CHUNK = 1024
+SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE = 1, 2, 4
+HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE = range(9)
+HP_COUNT = 16
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argument types (the trailing hipStream_t is appended automatically); all return int unless listed
+_PROTOS = {
+    "lafs_debug_tr16": [vp, vp],
+    "lafs_gemm_nt": [C.POINTER(GemmNTArgs)],
+    "lafs_gemm_tn_acc": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32],
+    "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
+    "lafs_layernorm_fwd": [vp, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32],
+    "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32],
+    "lafs_scale_cast_bf16": [vp, i32, vp, i32, vp, vp, i32, i32],
+    "lafs_attention_fwd": [vp, i32, vp, i32, i32, i32, f32, vp, i32, vp],
+    "lafs_attention_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, i32],
+    "lafs_patchify": [vp, i32, i32, i32, vp],
+    "lafs_embed_cls": [vp, vp, vp, i32, i32, i32, i32],
+    "lafs_embed_bwd": [vp, i32, i32, i32, i32, vp, vp, vp],
+    "lafs_gather_cls": [vp, i32, vp, i32, i32, vp],
+    "lafs_scatter_cls": [vp, vp, i32, i32, vp, i32],
+    "lafs_l2norm_fwd": [vp, i32, vp, i32, vp, i32, i32],
+    "lafs_l2norm_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, i32],
+    "lafs_weightnorm_fwd": [vp, vp, i32, i32, i32, vp, vp, i32, vp],
+    "lafs_weightnorm_bwd": [vp, vp, vp, vp, i32, i32, vp, vp, i32],
+    "lafs_dino_loss_fwd_bwd": [vp, vp, i32, vp, i32, i32, i32, f32, f32, vp, vp, i32, i32, f32, vp],
+    "lafs_colsum_f32": [vp, i32, i32, i32, vp],
+    "lafs_center_ema": [vp, vp, i32, f32, f32],
+    "lafs_grad_sumsq": [vp, vp, i64, vp, vp],
+    "lafs_clip_adamw_ema": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp],
+    "lafs_cast_bf16": [vp, vp, i64],
+    "lafs_transpose_cast_bf16": [vp, i32, i32, vp, i32],
+    "lafs_trunk_forward": [C.POINTER(TrunkDesc), vp, vp, vp, i32],
+    "lafs_trunk_backward": [C.POINTER(TrunkDesc), vp, vp, vp, i32, i32],
+    "lafs_margin_softmax_ce": [vp, i32, i32, i32, vp, vp, f32, f32, f32, i32, f32, vp, vp],
+    "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
+    "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],
+    "lafs_patch_gather_bwd": [vp, vp, vp, i32, i32, i32, vp, vp],
+}
+_NO_STREAM = {
+    "lafs_version": ([], i32),
+    "lafs_last_error": ([], C.c_char_p),
+    "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
+    "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),
+}
+EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises LafsHipError when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise LafsHipError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
+                               "there is no CPU fallback")
+        h = C.CDLL(LIB_PATH)
+        for name, args in _PROTOS.items():
+            fn = getattr(h, name)
+            fn.argtypes = list(args) + [vp]
+            fn.restype = i32
+        for name, (args, res) in _NO_STREAM.items():
+            fn = getattr(h, name)
+            fn.argtypes = list(args)
+            fn.restype = res
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().lafs_last_error().decode("utf-8", "replace")
+        raise LafsHipError(f"{what} failed with status {rc}: {msg}")
+
+
+def call(name, *args, stream=None):
+    """Invoke a stream-taking entry point on `stream` (default: torch's current HIP stream)."""
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream().cuda_stream
+    check(getattr(lib(), name)(*args, C.c_void_p(stream)), name)

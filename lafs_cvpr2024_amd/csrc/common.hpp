@@ -1,0 +1,79 @@
+// Shared device helpers for the LAFS gfx950 kernels (wave64, MFMA 16x16x32 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                            // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;        // one MFMA A/B operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+#define LAFS_WAVE 64
+
+// ---- status codes of the C ABI (include/lafs_hip.h) ----
+#define LAFS_OK 0
+#define LAFS_EINVAL (-1)
+#define LAFS_ESHAPE (-2)
+
+extern "C" void lafs_set_error(const char* fmt, ...);
+#define LAFS_CHECK_ARG(cond, msg)                                                     \
+  do {                                                                                \
+    if (!(cond)) {                                                                    \
+      lafs_set_error("%s:%d: %s (%s)", __FILE__, __LINE__, msg, #cond);               \
+      return LAFS_ESHAPE;                                                             \
+    }                                                                                 \
+  } while (0)
+#define LAFS_LAUNCH_CHECK()                                                           \
+  do {                                                                                \
+    hipError_t e_ = hipGetLastError();                                                \
+    if (e_ != hipSuccess) {                                                           \
+      lafs_set_error("%s:%d: launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return (int)e_;                                                                 \
+    }                                                                                 \
+  } while (0)
+
+// ---- bf16 <-> fp32 (round to nearest even) ----
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- exact (erf) GELU, as nn.GELU() default ----
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- wave reductions (64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- LDS transpose read: each 16-lane group reads a 4(row) x 16(col) bf16 block; lane p of the group
+// supplies the address of 4 contiguous elements (row p>>2, column chunk p&3) and receives column p. ----
+__device__ __forceinline__ s16x4_t lds_read_tr16(const void* lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds_addr));
+}
+
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,170 @@
+// Host-side transformer engine: sequences the HIP kernels of one pre-LN ViT trunk (all blocks) over a packed
+// token batch, forward and backward, with every activation in a caller-provided workspace.  One C call per
+// trunk pass -> no per-op Python/dispatcher overhead, and the whole pass is hipGraph-capturable (no allocation,
+// no synchronisation, only kernel launches on `stream`).
+//
+// Mirrors Block.forward (vision_transformer.py:107-113) / Residual_droppath(PreNorm(.)) (face_pre_pro/ViT_face.py:106-120):
+//   x1 = x0 + s_a * proj(attn(LN1(x0)));   x0' = x1 + s_m * fc2(gelu(fc1(LN2(x1))))
+// The residual stream is fp32; GEMM operands are bf16 (fp32 accumulate).
+#include <vector>
+#include "common.hpp"
+#include "lafs_hip.h"
+
+namespace {
+
+inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct LayerBuf {
+  float* x0; float* st1; bf16_t* h1; bf16_t* qkv; float* lse; bf16_t* o; float* x1; float* st2; bf16_t* h2; bf16_t* u; bf16_t* a;
+};
+struct Scratch {
+  bf16_t* gb; bf16_t* du; bf16_t* dh; bf16_t* d_o; bf16_t* dqkv; float* delta;
+};
+struct Carve {
+  std::vector<LayerBuf> layers;   // depth entries when saving, 1 otherwise (reused)
+  float* xalt;                    // ping-pong residual buffer for the no-save path
+  Scratch s;
+  size_t bytes;
+};
+
+Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
+  Carve c;
+  unsigned char* base = reinterpret_cast<unsigned char*>(ws);
+  size_t off = 0;
+  const size_t T = (size_t)d->n_tok, D = d->dim, I = d->inner, M = d->mlp, H = d->heads;
+  auto take = [&](size_t bytes) { unsigned char* p = base ? base + off : nullptr; off += al(bytes); return p; };
+  const int nl = save ? d->depth : 1;
+  c.layers.resize(nl);
+  for (int l = 0; l < nl; ++l) {
+    LayerBuf& b = c.layers[l];
+    b.x0 = (l == 0) ? nullptr : (float*)take(T * D * 4);     // layer 0 reads the caller's x_in
+    b.st1 = (float*)take(T * 2 * 4);
+    b.h1 = (bf16_t*)take(T * D * 2);
+    b.qkv = (bf16_t*)take(T * 3 * I * 2);
+    b.lse = (float*)take(T * H * 4);
+    b.o = (bf16_t*)take(T * I * 2);
+    b.x1 = (float*)take(T * D * 4);
+    b.st2 = (float*)take(T * 2 * 4);
+    b.h2 = (bf16_t*)take(T * D * 2);
+    b.u = (bf16_t*)take(T * M * 2);
+    b.a = (bf16_t*)take(T * M * 2);
+  }
+  c.xalt = save ? nullptr : (float*)take(T * D * 4);
+  if (save) {
+    c.s.gb = (bf16_t*)take(T * D * 2);
+    c.s.du = (bf16_t*)take(T * M * 2);
+    c.s.dh = (bf16_t*)take(T * D * 2);
+    c.s.d_o = (bf16_t*)take(T * I * 2);
+    c.s.dqkv = (bf16_t*)take(T * 3 * I * 2);
+    c.s.delta = (float*)take(T * H * 4);
+  } else {
+    c.s = Scratch{};
+  }
+  c.bytes = off;
+  return c;
+}
+
+int check_desc(const lafs_trunk_desc* d) {
+  LAFS_CHECK_ARG(d != nullptr, "null descriptor");
+  LAFS_CHECK_ARG(d->dim > 0 && d->dim % 64 == 0 && d->mlp % 64 == 0 && d->inner == d->heads * 64, "dims must be multiples of 64");
+  LAFS_CHECK_ARG(d->depth > 0 && d->n_tok > 0 && d->n_seq > 0 && d->max_len > 0 && d->max_len <= 256, "bad geometry");
+  LAFS_CHECK_ARG(d->cu_seqlens && d->row2seq && d->master && d->shadow && d->blocks, "null pointer in descriptor");
+  return LAFS_OK;
+}
+
+#define RUN(call)                        \
+  do {                                   \
+    const int rc_ = (call);              \
+    if (rc_ != LAFS_OK) return rc_;      \
+  } while (0)
+
+int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
+         hipStream_t s, void* C2 = nullptr, int ldc2 = 0, const float* resid = nullptr, int ldr = 0,
+         const float* seq_scale = nullptr, const int32_t* row2seq = nullptr, const void* aux = nullptr, int ldaux = 0) {
+  lafs_gemm_nt_args g = {};
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.epilogue = epi;
+  g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.resid = resid; g.ldr = ldr;
+  g.seq_scale = seq_scale; g.row2seq = row2seq; g.aux = aux; g.ldaux = ldaux; g.splits = 1;
+  return lafs_gemm_nt(&g, s);
+}
+
+}  // namespace
+
+extern "C" int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward) {
+  if (check_desc(d) != LAFS_OK) return -1;
+  return (int64_t)carve(d, nullptr, save_for_backward).bytes;
+}
+
+extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, float* x_out, void* workspace,
+                                  int save_for_backward, hipStream_t stream) {
+  RUN(check_desc(d));
+  LAFS_CHECK_ARG(x_in && x_out && workspace, "null buffer");
+  const Carve c = carve(d, workspace, save_for_backward);
+  const int T = d->n_tok, D = d->dim, I = d->inner, M = d->mlp;
+  const bf16_t* sh = reinterpret_cast<const bf16_t*>(d->shadow);
+  const float* cur = x_in;
+  for (int l = 0; l < d->depth; ++l) {
+    const lafs_block_offsets& o = d->blocks[l];
+    const LayerBuf& b = c.layers[save_for_backward ? l : 0];
+    const float* sa = d->drop_scales ? d->drop_scales + ((size_t)l * 2 + 0) * d->n_seq : nullptr;
+    const float* sm = d->drop_scales ? d->drop_scales + ((size_t)l * 2 + 1) * d->n_seq : nullptr;
+    float* nxt;
+    if (l == d->depth - 1) nxt = x_out;
+    else if (save_for_backward) nxt = c.layers[l + 1].x0;
+    else nxt = (cur == c.xalt) ? x_out : c.xalt;            // ping-pong; never aliases x_in
+    RUN(lafs_layernorm_fwd(cur, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1, D, nullptr, 0, b.st1, T, D, stream));
+    RUN(gemm(b.h1, D, sh + o.w_qkv, D, T, 3 * I, D, LAFS_EPI_BF16, b.qkv, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, stream));
+    RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, stream));
+    RUN(gemm(b.o, I, sh + o.w_proj, I, T, D, I, LAFS_EPI_RESID_F32, b.x1, D, d->master + o.b_proj, stream, nullptr, 0, cur, D, sa,
+             d->row2seq));
+    RUN(lafs_layernorm_fwd(b.x1, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2, D, nullptr, 0, b.st2, T, D, stream));
+    RUN(gemm(b.h2, D, sh + o.w_fc1, D, T, M, D, LAFS_EPI_BF16_GELU, b.u, M, d->master + o.b_fc1, stream, b.a, M));
+    RUN(gemm(b.a, M, sh + o.w_fc2, M, T, D, M, LAFS_EPI_RESID_F32, nxt, D, d->master + o.b_fc2, stream, nullptr, 0, b.x1, D, sm,
+             d->row2seq));
+    cur = nxt;
+  }
+  return LAFS_OK;
+}
+
+extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
+                                   int layer_lo, hipStream_t stream) {
+  RUN(check_desc(d));
+  LAFS_CHECK_ARG(x_in && g && workspace && d->shadow_t && d->grad, "null buffer");
+  LAFS_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= d->depth, "bad layer range");
+  const Carve c = carve(d, workspace, 1);
+  const int T = d->n_tok, D = d->dim, I = d->inner, M = d->mlp;
+  const bf16_t* sh = reinterpret_cast<const bf16_t*>(d->shadow);
+  const bf16_t* sht = reinterpret_cast<const bf16_t*>(d->shadow_t);
+  float* gr = d->grad;
+  const Scratch& s = c.s;
+  auto scale = [&](int l, int br) { return d->drop_scales ? d->drop_scales + ((size_t)l * 2 + br) * d->n_seq : nullptr; };
+  RUN(lafs_scale_cast_bf16(g, D, s.gb, D, scale(layer_hi - 1, 1), d->row2seq, T, D, stream));
+  for (int l = layer_hi - 1; l >= layer_lo; --l) {
+    const lafs_block_offsets& o = d->blocks[l];
+    const LayerBuf& b = c.layers[l];
+    const float* x0 = (l == 0) ? x_in : b.x0;
+    // ---- MLP branch ----
+    RUN(lafs_colsum_bf16_acc(s.gb, D, T, D, gr + o.b_fc2, stream));
+    RUN(lafs_gemm_tn_acc(s.gb, D, b.a, M, gr + o.w_fc2, M, T, D, M, 0, stream));
+    RUN(gemm(s.gb, D, sht + o.w_fc2_t, D, T, M, D, LAFS_EPI_DGELU_BF16, s.du, M, nullptr, stream, nullptr, 0, nullptr, 0, nullptr,
+             nullptr, b.u, M));
+    RUN(lafs_colsum_bf16_acc(s.du, M, T, M, gr + o.b_fc1, stream));
+    RUN(lafs_gemm_tn_acc(s.du, M, b.h2, D, gr + o.w_fc1, D, T, M, D, 0, stream));
+    RUN(gemm(s.du, M, sht + o.w_fc1_t, M, T, D, M, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
+    RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, b.x1, D, b.st2, d->master + o.ln2_g, g, D, 1, s.gb, D, scale(l, 0), d->row2seq,
+                           gr + o.ln2_g, gr + o.ln2_b, T, D, stream));
+    // ---- attention branch ----
+    RUN(lafs_colsum_bf16_acc(s.gb, D, T, D, gr + o.b_proj, stream));
+    RUN(lafs_gemm_tn_acc(s.gb, D, b.o, I, gr + o.w_proj, I, T, D, I, 0, stream));
+    RUN(gemm(s.gb, D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
+    RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens, d->n_seq, T, d->max_len, d->heads,
+                           d->attn_scale, s.dqkv, 3 * I, stream));
+    if (o.b_qkv >= 0) RUN(lafs_colsum_bf16_acc(s.dqkv, 3 * I, T, 3 * I, gr + o.b_qkv, stream));
+    RUN(lafs_gemm_tn_acc(s.dqkv, 3 * I, b.h1, D, gr + o.w_qkv, D, T, 3 * I, D, 0, stream));
+    RUN(gemm(s.dqkv, 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
+    const bool more = l > 0;
+    RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, x0, D, b.st1, d->master + o.ln1_g, g, D, 1, more ? s.gb : nullptr, D,
+                           more ? scale(l - 1, 1) : nullptr, d->row2seq, gr + o.ln1_g, gr + o.ln1_b, T, D, stream));
+  }
+  return LAFS_OK;
+}

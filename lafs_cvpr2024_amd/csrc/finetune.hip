@@ -1,0 +1,196 @@
+// Fine-tune step kernels (train_largescale.py): fused margin-softmax + soft-target cross-entropy over the class
+// axis, batch mixup with the u8 -> [-1,1] normalisation folded in, and the landmark patch gather.
+//   CosFace                         face_pre_pro/ViT_face.py:49-89   s*(cos - m*y), y one-hot OR dense soft label
+//   SoftTargetCrossEntropy (timm)   train_largescale.py:602,820
+//   Mixup batch mode                util/mixup_my.py:189-200, 18-24  (target has <= 2 non-zeros per row, so it is
+//                                   passed as (y1, y2, lam) and the dense [B,C] matrix is never materialised)
+//   extract_patches_pytorch_gridsample   face_pre_pro/ViT_face.py:1615-1656 (n sequential grid_sample launches -> 1)
+#include "common.hpp"
+#include "lafs_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float margin_logit(float c, float y, float s, float m, int type) {
+  if (type == 0) return s * (c - m * y);
+  if (y > 0.f) {                                      // ArcFace, hard label
+    const float cc = fminf(fmaxf(c, -1.f), 1.f);
+    return s * __cosf(acosf(cc) + m);
+  }
+  return s * c;
+}
+__device__ __forceinline__ float margin_dlogit(float c, float y, float s, float m, int type) {
+  if (type == 0 || y <= 0.f) return s;
+  const float cc = fminf(fmaxf(c, -1.f + 1e-7f), 1.f - 1e-7f);
+  const float th = acosf(cc);
+  return s * __sinf(th + m) / __sinf(th);
+}
+
+// one workgroup per sample row
+__global__ __launch_bounds__(256) void margin_ce_kernel(float* __restrict__ cosv, int ld, int C, const int* __restrict__ y1,
+                                                       const int* __restrict__ y2, float lam, float s, float m, int type,
+                                                       float gscale, float* __restrict__ row_loss) {
+  __shared__ float sm[4], ss[4];
+  __shared__ float bc[2];
+  const int b = blockIdx.x;
+  float* row = cosv + (size_t)b * ld;
+  const int a1 = y1[b], a2 = y2[b];
+  auto label = [&](int k) { return ((k == a1) ? lam : 0.f) + ((k == a2) ? (1.f - lam) : 0.f); };
+  float mx = -INFINITY, sum = 0.f;
+  for (int k = threadIdx.x; k < C; k += 256) {
+    const float z = margin_logit(row[k], label(k), s, m, type);
+    if (z > mx) { sum = sum * __expf(mx - z) + 1.f; mx = z; } else { sum += __expf(z - mx); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float mo = __shfl_xor(mx, o, 64), so = __shfl_xor(sum, o, 64);
+    const float mn = fmaxf(mx, mo);
+    sum = (mn == -INFINITY) ? 0.f : sum * __expf(mx - mn) + so * __expf(mo - mn);
+    mx = mn;
+  }
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = mx; ss[threadIdx.x >> 6] = sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float S = 0.f;
+    for (int w = 0; w < 4; ++w) if (sm[w] != -INFINITY) S += ss[w] * __expf(sm[w] - M);
+    const float lse = M + __logf(S);
+    bc[0] = lse;
+    float dot = label(a1) * margin_logit(row[a1], label(a1), s, m, type);
+    if (a2 != a1) dot += label(a2) * margin_logit(row[a2], label(a2), s, m, type);
+    row_loss[b] = lse - dot;                               // sum_k y_k = 1
+  }
+  __syncthreads();
+  const float lse = bc[0];
+  for (int k = threadIdx.x; k < C; k += 256) {
+    const float c = row[k], y = label(k);
+    const float z = margin_logit(c, y, s, m, type);
+    row[k] = gscale * (__expf(z - lse) - y) * margin_dlogit(c, y, s, m, type);
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += v[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+}
+
+__global__ __launch_bounds__(256) void mixup_norm_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int B, size_t per,
+                                                        float lam) {
+  const size_t total = (size_t)B * per;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / per, r = i % per;
+    const float x = (float)src[i] * (2.f / 255.f) - 1.f;
+    const float xf = (float)src[(B - 1 - b) * per + r] * (2.f / 255.f) - 1.f;
+    dst[i] = (lam == 1.f) ? x : x * lam + xf * (1.f - lam);
+  }
+}
+
+// ---- landmark patch gather: one wave (8x8 lanes = one patch) per (image, landmark) ----
+__device__ __forceinline__ float tap(const float* im, int S, int x, int y) {
+  return (x >= 0 && x < S && y >= 0 && y < S) ? im[y * S + x] : 0.f;
+}
+
+__global__ __launch_bounds__(64) void gather_fwd_kernel(const float* __restrict__ img, const float* __restrict__ theta, int S, int n,
+                                                       int r, float* __restrict__ out) {
+  const int b = blockIdx.y, k = blockIdx.x;
+  const int i = threadIdx.x >> 3, j = threadIdx.x & 7;          // output row i walks along x (transposed patch)
+  const float px = theta[((size_t)b * n + k) * 2 + 0] + (float)(i - 4) - 0.5f;
+  const float py = theta[((size_t)b * n + k) * 2 + 1] + (float)(j - 4) - 0.5f;
+  const float fx0 = floorf(px), fy0 = floorf(py);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float fx = px - fx0, fy = py - fy0;
+  const int R = r * 8;
+  const int Y = (k / r) * 8 + i, X = (k % r) * 8 + j;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* im = img + ((size_t)b * 3 + c) * S * S;
+    const float v = (1.f - fy) * ((1.f - fx) * tap(im, S, x0, y0) + fx * tap(im, S, x0 + 1, y0)) +
+                    fy * ((1.f - fx) * tap(im, S, x0, y0 + 1) + fx * tap(im, S, x0 + 1, y0 + 1));
+    out[(((size_t)b * 3 + c) * R + Y) * R + X] = v;
+  }
+}
+
+__global__ __launch_bounds__(64) void gather_bwd_kernel(const float* __restrict__ img, const float* __restrict__ theta,
+                                                       const float* __restrict__ dmos, int S, int n, int r,
+                                                       float* __restrict__ dtheta, float* __restrict__ dimg) {
+  const int b = blockIdx.y, k = blockIdx.x;
+  const int i = threadIdx.x >> 3, j = threadIdx.x & 7;
+  const float px = theta[((size_t)b * n + k) * 2 + 0] + (float)(i - 4) - 0.5f;
+  const float py = theta[((size_t)b * n + k) * 2 + 1] + (float)(j - 4) - 0.5f;
+  const float fx0 = floorf(px), fy0 = floorf(py);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float fx = px - fx0, fy = py - fy0;
+  const int R = r * 8;
+  const int Y = (k / r) * 8 + i, X = (k % r) * 8 + j;
+  float gx = 0.f, gy = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* im = img + ((size_t)b * 3 + c) * S * S;
+    const float d = dmos[(((size_t)b * 3 + c) * R + Y) * R + X];
+    const float v00 = tap(im, S, x0, y0), v01 = tap(im, S, x0 + 1, y0), v10 = tap(im, S, x0, y0 + 1), v11 = tap(im, S, x0 + 1, y0 + 1);
+    gx += d * ((1.f - fy) * (v01 - v00) + fy * (v11 - v10));
+    gy += d * ((1.f - fx) * (v10 - v00) + fx * (v11 - v01));
+    if (dimg != nullptr) {
+      float* di = dimg + ((size_t)b * 3 + c) * S * S;
+      auto add = [&](int x, int y, float w) { if (x >= 0 && x < S && y >= 0 && y < S) atomicAdd(di + y * S + x, d * w); };
+      add(x0, y0, (1.f - fx) * (1.f - fy)); add(x0 + 1, y0, fx * (1.f - fy));
+      add(x0, y0 + 1, (1.f - fx) * fy); add(x0 + 1, y0 + 1, fx * fy);
+    }
+  }
+  gx = wave_sum(gx); gy = wave_sum(gy);
+  if (threadIdx.x == 0) {
+    dtheta[((size_t)b * n + k) * 2 + 0] = gx;
+    dtheta[((size_t)b * n + k) * 2 + 1] = gy;
+  }
+}
+
+int isqrt_exact(int n) {
+  int r = 0;
+  while ((r + 1) * (r + 1) <= n) ++r;
+  return (r * r == n) ? r : -1;
+}
+
+}  // namespace
+
+extern "C" int lafs_margin_softmax_ce(float* cos, int ld, int B, int C, const int32_t* y1, const int32_t* y2, float lam,
+                                      float s, float m, int margin_type, float loss_scale, float* loss_out, float* row_ws,
+                                      hipStream_t stream) {
+  LAFS_CHECK_ARG(cos && y1 && y2 && loss_out && row_ws && B > 0 && C > 0 && ld >= C, "bad operand");
+  LAFS_CHECK_ARG(margin_type == 0 || margin_type == 1, "margin_type must be 0 (CosFace) or 1 (ArcFace)");
+  hipLaunchKernelGGL(margin_ce_kernel, dim3(B), dim3(256), 0, stream, cos, ld, C, y1, y2, lam, s, m, margin_type, loss_scale / (float)B,
+                     row_ws);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, row_ws, B, 1.0f / (float)B, loss_out);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, hipStream_t stream) {
+  LAFS_CHECK_ARG(src_u8 && dst && B > 0 && S > 0, "bad operand");
+  const size_t per = (size_t)3 * S * S;
+  size_t blocks = ((size_t)B * per + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mixup_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src_u8, dst, B, per, lam);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_patch_gather_fwd(const float* img, const float* theta, int B, int S, int n, float* mosaic, hipStream_t stream) {
+  const int r = isqrt_exact(n);
+  LAFS_CHECK_ARG(img && theta && mosaic && B > 0 && S > 0 && r > 0, "n must be a perfect square");
+  hipLaunchKernelGGL(gather_fwd_kernel, dim3(n, B), dim3(64), 0, stream, img, theta, S, n, r, mosaic);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_patch_gather_bwd(const float* img, const float* theta, const float* dmosaic, int B, int S, int n,
+                                     float* dtheta, float* dimg, hipStream_t stream) {
+  const int r = isqrt_exact(n);
+  LAFS_CHECK_ARG(img && theta && dmosaic && dtheta && B > 0 && S > 0 && r > 0, "n must be a perfect square");
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3(n, B), dim3(64), 0, stream, img, theta, dmosaic, S, n, r, dtheta, dimg);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}

@@ -1,0 +1,224 @@
+// LayerNorm forward/backward over the fp32 residual stream, one wave64 per token row (HBM-bound).
+// Replaces nn.LayerNorm at vision_transformer.py:99,103,156 (eps 1e-6) and face_pre_pro/ViT_face.py:117
+// (eps 1e-5).  Forward emits the bf16 GEMM operand; backward fuses the residual-gradient accumulation, the
+// DropPath-scaled bf16 cast that feeds the previous branch's GEMMs, and the gamma/beta reductions.
+#include "common.hpp"
+#include "lafs_hip.h"
+
+namespace {
+
+constexpr int MAXI = 8;   // D <= 2048: lane owns float4 at columns lane*4 + 256*i
+
+template <int NI>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float eps, bf16_t* __restrict__ y,
+                                                    int ldy, float* __restrict__ yf, int ldyf,
+                                                    float* __restrict__ stats, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * ldx;
+  float4 v[NI];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane * 4 + 256 * i;
+    v[i] = (c < D) ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < D) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += a * a + b * b + cc * cc + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane * 4 + 256 * i;
+    if (c < D) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      const float o0 = (v[i].x - mean) * rstd * g.x + b.x, o1 = (v[i].y - mean) * rstd * g.y + b.y;
+      const float o2 = (v[i].z - mean) * rstd * g.z + b.z, o3 = (v[i].w - mean) * rstd * g.w + b.w;
+      if (y != nullptr)
+        *reinterpret_cast<uint2*>(y + (size_t)row * ldy + c) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+      if (yf != nullptr) *reinterpret_cast<float4*>(yf + (size_t)row * ldyf + c) = make_float4(o0, o1, o2, o3);
+    }
+  }
+}
+
+// Each wave walks rows (grid-stride) and keeps the gamma/beta partial sums for its columns in registers;
+// they are combined across the 4 waves through LDS and leave the workgroup as one atomicAdd per column.
+template <int NI>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ dyf,
+                                                    int lddyf, const float* __restrict__ x, int ldx,
+                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                    float* __restrict__ g_io, int ldg, int accumulate,
+                                                    bf16_t* __restrict__ gb, int ldgb, const float* __restrict__ seq_scale,
+                                                    const int* __restrict__ row2seq, float* __restrict__ dgamma,
+                                                    float* __restrict__ dbeta, int rows, int D) {
+  __shared__ float red[2][4][NI * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float4 gam[NI], ag[NI], ab[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane * 4 + 256 * i;
+    gam[i] = (c < D) ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    float4 xh[NI], d[NI];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < D) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
+        if (dyf != nullptr) {
+          d[i] = *reinterpret_cast<const float4*>(dyf + (size_t)row * lddyf + c);
+        } else {
+          const uint2 w = *reinterpret_cast<const uint2*>(dy + (size_t)row * lddy + c);
+          d[i] = make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y));
+        }
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+        ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+        d[i].x *= gam[i].x; d[i].y *= gam[i].y; d[i].z *= gam[i].z; d[i].w *= gam[i].w;
+        s1 += d[i].x + d[i].y + d[i].z + d[i].w;
+        s2 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
+      } else {
+        xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); d[i] = xh[i];
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+    const float sc = (seq_scale != nullptr) ? seq_scale[row2seq[row]] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < D) {
+        float4 o = make_float4(rstd * (d[i].x - m1 - xh[i].x * m2), rstd * (d[i].y - m1 - xh[i].y * m2),
+                               rstd * (d[i].z - m1 - xh[i].z * m2), rstd * (d[i].w - m1 - xh[i].w * m2));
+        float* gp = g_io + (size_t)row * ldg + c;
+        if (accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(gp);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(gp) = o;
+        if (gb != nullptr)
+          *reinterpret_cast<uint2*>(gb + (size_t)row * ldgb + c) =
+              make_uint2(pack_bf2(sc * o.x, sc * o.y), pack_bf2(sc * o.z, sc * o.w));
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    *reinterpret_cast<float4*>(&red[0][wave][lane * 4 + 256 * i]) = ag[i];
+    *reinterpret_cast<float4*>(&red[1][wave][lane * 4 + 256 * i]) = ab[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomicAdd(dgamma + c, sg);
+    atomicAdd(dbeta + c, sb);
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ g, int ldg, bf16_t* __restrict__ gb, int ldgb,
+                                                        const float* __restrict__ seq_scale, const int* __restrict__ row2seq,
+                                                        int rows, int D) {
+  const int per_row = D >> 2;
+  const size_t total = (size_t)rows * per_row;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / per_row), c = (int)(i % per_row) * 4;
+    const float sc = (seq_scale != nullptr) ? seq_scale[row2seq[row]] : 1.0f;
+    const float4 v = *reinterpret_cast<const float4*>(g + (size_t)row * ldg + c);
+    *reinterpret_cast<uint2*>(gb + (size_t)row * ldgb + c) = make_uint2(pack_bf2(sc * v.x, sc * v.y), pack_bf2(sc * v.z, sc * v.w));
+  }
+}
+
+// out[n] += sum_m X[m, n]; each workgroup owns a 64-column x 256-row slab (4 waves x 64 rows, 64 lanes = columns)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ X, int ldx, int M, int N,
+                                                         float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (n < N) {
+    const int m0 = blockIdx.y * 256 + wave * 64;
+    const int m1 = min(M, m0 + 64);
+    for (int m = m0; m < m1; ++m) s += bf2f(X[(size_t)m * ldx + n]);
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && n < N) atomicAdd(out + n, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+}  // namespace
+
+#define LN_DISPATCH(NI_, KERNEL, ...)                                                             \
+  switch (NI_) {                                                                                  \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, grid, dim3(256), 0, stream, __VA_ARGS__); break;        \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, grid, dim3(256), 0, stream, __VA_ARGS__); break;        \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, grid, dim3(256), 0, stream, __VA_ARGS__); break;        \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, grid, dim3(256), 0, stream, __VA_ARGS__); break;        \
+    default: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), 0, stream, __VA_ARGS__); break;       \
+  }
+
+extern "C" int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps,
+                                  void* y_bf16, int ldy, float* y_f32, int ldyf, float* stats, int rows, int D,
+                                  hipStream_t stream) {
+  LAFS_CHECK_ARG(x && gamma && beta && stats && (y_bf16 || y_f32), "null operand");
+  LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
+  LAFS_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldyf % 4 == 0, "row strides must be multiples of 4");
+  const dim3 grid(ceil_div(rows, 4));
+  const int ni = ceil_div(D, 256);
+  LN_DISPATCH(ni, ln_fwd_kernel, x, ldx, gamma, beta, eps, (bf16_t*)y_bf16, ldy, y_f32, ldyf, stats, rows, D);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf, const float* x, int ldx,
+                                  const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
+                                  void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
+                                  float* dgamma, float* dbeta, int rows, int D, hipStream_t stream) {
+  LAFS_CHECK_ARG((dy_bf16 || dy_f32) && x && stats && gamma && g_io && dgamma && dbeta, "null operand");
+  LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
+  LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
+  int blocks = ceil_div(rows, 4);
+  if (blocks > 1024) blocks = 1024;
+  const dim3 grid(blocks);
+  const int ni = ceil_div(D, 256);
+  LN_DISPATCH(ni, ln_bwd_kernel, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
+              (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb, const float* seq_scale,
+                                    const int32_t* row2seq, int rows, int D, hipStream_t stream) {
+  LAFS_CHECK_ARG(g && gb && rows > 0 && D > 0 && D % 4 == 0, "bad operand");
+  LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
+  const size_t total = (size_t)rows * (D / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_cast_kernel, dim3(blocks), dim3(256), 0, stream, g, ldg, (bf16_t*)gb, ldgb, seq_scale, row2seq, rows, D);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_colsum_bf16_acc(const void* X, int ldx, int M, int N, float* out, hipStream_t stream) {
+  LAFS_CHECK_ARG(X && out && M > 0 && N > 0, "bad operand");
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(N, 64), ceil_div(M, 256)), dim3(256), 0, stream,
+                     (const bf16_t*)X, ldx, M, N, out);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}

@@ -1,0 +1,154 @@
+// Multi-tensor step glue over a flat fp32 parameter arena (HBM-bound, one launch each instead of the
+// reference's ~150-iteration Python loops with a host sync per tensor):
+//   per-tensor gradient L2 norms            utils.py:132-141 (clip_gradients: PER TENSOR, not global)
+//   clip + cancel-last-layer + AdamW        utils.py:144-149, lafs_train.py:400,606 (torch.optim.AdamW defaults)
+//   teacher EMA                             lafs_train.py:610-613
+//   bf16 shadow refresh (GEMM operands)     -- build-specific
+// The arena is cut into LAFS_CHUNK-element chunks; every tensor starts on a chunk boundary so a chunk belongs to
+// exactly one tensor (`chunk_seg`).  Padding elements are zero in every buffer and stay zero.
+#include "common.hpp"
+#include "lafs_hip.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ grad, const int* __restrict__ chunk_seg,
+                                                   const float* __restrict__ hyper, float* __restrict__ seg_sumsq) {
+  __shared__ float red[4];
+  const size_t base = (size_t)blockIdx.x * LAFS_CHUNK + threadIdx.x * 4;
+  const float4 g = *reinterpret_cast<const float4*>(grad + base);
+  const float gs = hyper[LAFS_HP_GRAD_SCALE];
+  float s = (g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w) * gs * gs;
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(seg_sumsq + chunk_seg[blockIdx.x], red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void seg_step_kernel(const int* __restrict__ seg_flags, int* __restrict__ seg_step, int n_seg,
+                                                      const float* __restrict__ hyper) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_seg) return;
+  const int f = seg_flags[s];
+  const bool frozen = (f & LAFS_SEG_LAST_LAYER) && hyper[LAFS_HP_FREEZE_LAST] != 0.f;
+  if ((f & LAFS_SEG_TRAINABLE) && !frozen) seg_step[s] += 1;
+}
+
+__global__ __launch_bounds__(256) void clip_adamw_ema_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                            float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                                                            float* __restrict__ teacher, bf16_t* __restrict__ param_bf,
+                                                            bf16_t* __restrict__ teacher_bf, const int* __restrict__ chunk_seg,
+                                                            const int* __restrict__ seg_flags, const int* __restrict__ seg_step,
+                                                            const float* __restrict__ seg_sumsq, const float* __restrict__ hyper) {
+  const size_t i = (size_t)blockIdx.x * LAFS_CHUNK + threadIdx.x * 4;
+  const int seg = chunk_seg[blockIdx.x];
+  const int flags = seg_flags[seg];
+  const bool frozen = (flags & LAFS_SEG_LAST_LAYER) && hyper[LAFS_HP_FREEZE_LAST] != 0.f;
+  const bool update = (flags & LAFS_SEG_TRAINABLE) && !frozen;
+  float4 p = *reinterpret_cast<const float4*>(param + i);
+  if (update) {
+    const float lr = hyper[LAFS_HP_LR], wd = (flags & LAFS_SEG_DECAY) ? hyper[LAFS_HP_WD] : 0.f;
+    const float b1 = hyper[LAFS_HP_BETA1], b2 = hyper[LAFS_HP_BETA2], eps = hyper[LAFS_HP_EPS], clip = hyper[LAFS_HP_CLIP];
+    float gsc = hyper[LAFS_HP_GRAD_SCALE];
+    if (clip > 0.f) {
+      const float coef = clip / (sqrtf(seg_sumsq[seg]) + 1e-6f);
+      if (coef < 1.f) gsc *= coef;
+    }
+    const float t = (float)seg_step[seg];
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    float4 g = *reinterpret_cast<const float4*>(grad + i);
+    float4 m = *reinterpret_cast<const float4*>(exp_avg + i);
+    float4 v = *reinterpret_cast<const float4*>(exp_avg_sq + i);
+    const float decay = 1.f - lr * wd;
+#define LAFS_ADAM(c)                                              \
+    {                                                             \
+      const float gg = g.c * gsc;                                 \
+      p.c *= decay;                                               \
+      m.c = m.c * b1 + gg * (1.f - b1);                           \
+      v.c = v.c * b2 + gg * gg * (1.f - b2);                      \
+      p.c -= step_size * m.c / (sqrtf(v.c) * inv_sqrt_bc2 + eps); \
+    }
+    LAFS_ADAM(x) LAFS_ADAM(y) LAFS_ADAM(z) LAFS_ADAM(w)
+#undef LAFS_ADAM
+    *reinterpret_cast<float4*>(param + i) = p;
+    *reinterpret_cast<float4*>(exp_avg + i) = m;
+    *reinterpret_cast<float4*>(exp_avg_sq + i) = v;
+    if (param_bf != nullptr) *reinterpret_cast<uint2*>(param_bf + i) = make_uint2(pack_bf2(p.x, p.y), pack_bf2(p.z, p.w));
+  }
+  if (teacher != nullptr) {                                 // EMA covers every parameter, trainable or not
+    const float em = hyper[LAFS_HP_EMA_M];
+    float4 tp = *reinterpret_cast<const float4*>(teacher + i);
+    tp.x = tp.x * em + (1.f - em) * p.x; tp.y = tp.y * em + (1.f - em) * p.y;
+    tp.z = tp.z * em + (1.f - em) * p.z; tp.w = tp.w * em + (1.f - em) * p.w;
+    *reinterpret_cast<float4*>(teacher + i) = tp;
+    if (teacher_bf != nullptr) *reinterpret_cast<uint2*>(teacher_bf + i) = make_uint2(pack_bf2(tp.x, tp.y), pack_bf2(tp.z, tp.w));
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(src + i);
+      *reinterpret_cast<uint2*>(dst + i) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+    } else {
+      for (size_t e = i; e < n; ++e) dst[e] = f2bf(src[e]);
+    }
+  }
+}
+
+// dst[c, r] = bf16(src[r, c]); 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, int rows, int cols, bf16_t* __restrict__ dst,
+                                                            int ld) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < cols && r < rows) dst[(size_t)c * ld + r] = f2bf(tile[tx][j]);
+  }
+}
+
+}  // namespace
+
+extern "C" int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, const float* hyper,
+                               float* seg_sumsq, hipStream_t stream) {
+  LAFS_CHECK_ARG(grad && chunk_seg && hyper && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31), "bad operand");
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)n_chunks), dim3(256), 0, stream, grad, chunk_seg, hyper, seg_sumsq);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* teacher,
+                                   void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t n_chunks,
+                                   const int32_t* seg_flags, int32_t* seg_step, int n_seg, const float* seg_sumsq,
+                                   const float* hyper, hipStream_t stream) {
+  LAFS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && chunk_seg && seg_flags && seg_step && seg_sumsq && hyper, "null operand");
+  LAFS_CHECK_ARG(n_chunks > 0 && n_chunks < (1ll << 31) && n_seg > 0, "bad sizes");
+  hipLaunchKernelGGL(seg_step_kernel, dim3(ceil_div(n_seg, 256)), dim3(256), 0, stream, seg_flags, seg_step, n_seg, hyper);
+  hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3((unsigned)n_chunks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, teacher,
+                     (bf16_t*)param_bf16, (bf16_t*)teacher_bf16, chunk_seg, seg_flags, seg_step, seg_sumsq, hyper);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
+  LAFS_CHECK_ARG(src && dst && n > 0, "bad operand");
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, (bf16_t*)dst, (size_t)n);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_transpose_cast_bf16(const float* src, int rows, int cols, void* dst, int ld_dst, hipStream_t stream) {
+  LAFS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_dst >= rows, "bad operand");
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0, stream, src, rows, cols,
+                     (bf16_t*)dst, ld_dst);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}

@@ -1,0 +1,157 @@
+"""Tensor-level wrappers over the C ABI (torch is only the owner of device memory and streams here).
+
+Every function launches hand-written HIP kernels from liblafs_hip.so on torch's current stream; nothing in this
+module computes on the host or falls back to ATen math.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+bf16 = torch.bfloat16
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.LafsHipError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise _lib.LafsHipError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if t.dim() >= 2 and t.stride(-1) != 1:
+        raise _lib.LafsHipError(f"{name}: last dimension must be contiguous")
+
+
+def _ld(t):
+    return t.stride(0) if t.dim() >= 2 else t.numel()
+
+
+def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=None, seq_scale=None, row2seq=None,
+            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None):
+    """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*)."""
+    _chk(A, bf16, "A"); _chk(B, bf16, "B")
+    M, K = A.shape
+    N = B.shape[0] if n_cols is None else n_cols
+    f32_out = epilogue in (_lib.EPI_RESID_F32, _lib.EPI_F32, _lib.EPI_ATOMIC_F32, _lib.EPI_EMBED_F32)
+    if out is None:
+        rows = M if out_rows is None else out_rows
+        out = (torch.zeros if epilogue == _lib.EPI_ATOMIC_F32 else torch.empty)(
+            rows, N, device=A.device, dtype=torch.float32 if f32_out else bf16)
+    _chk(out, torch.float32 if f32_out else bf16, "out")
+    if epilogue == _lib.EPI_BF16_GELU and out2 is None:
+        out2 = torch.empty(M, N, device=A.device, dtype=bf16)
+    a = _lib.GemmNTArgs()
+    a.A, a.lda, a.B, a.ldb = A.data_ptr(), _ld(A), B.data_ptr(), _ld(B)
+    a.M, a.N, a.K, a.epilogue = M, N, K, epilogue
+    a.C, a.ldc = out.data_ptr(), _ld(out)
+    if out2 is not None:
+        _chk(out2, bf16, "out2"); a.C2, a.ldc2 = out2.data_ptr(), _ld(out2)
+    if bias is not None:
+        _chk(bias, torch.float32, "bias"); a.bias = bias.data_ptr()
+    if resid is not None:
+        _chk(resid, torch.float32, "resid"); a.resid, a.ldr = resid.data_ptr(), _ld(resid)
+    if seq_scale is not None:
+        _chk(seq_scale, torch.float32, "seq_scale"); _chk(row2seq, torch.int32, "row2seq")
+        a.seq_scale, a.row2seq = seq_scale.data_ptr(), row2seq.data_ptr()
+    if aux is not None:
+        _chk(aux, bf16, "aux"); a.aux, a.ldaux = aux.data_ptr(), _ld(aux)
+    if pos is not None:
+        _chk(pos, torch.float32, "pos"); a.pos, a.npatch = pos.data_ptr(), npatch
+    a.splits = splits
+    call("lafs_gemm_nt", C.byref(a))
+    return (out, out2) if epilogue == _lib.EPI_BF16_GELU else out
+
+
+def gemm_tn_acc(A, B, Cacc, splits=0):
+    """Cacc[N1,N2] (f32) += A[M,N1]^T @ B[M,N2]."""
+    _chk(A, bf16, "A"); _chk(B, bf16, "B"); _chk(Cacc, torch.float32, "C")
+    M, N1 = A.shape
+    N2 = B.shape[1]
+    call("lafs_gemm_tn_acc", _p(A), _ld(A), _p(B), _ld(B), _p(Cacc), _ld(Cacc), M, N1, N2, splits)
+    return Cacc
+
+
+def colsum_bf16_acc(X, out):
+    _chk(X, bf16, "X"); _chk(out, torch.float32, "out")
+    call("lafs_colsum_bf16_acc", _p(X), _ld(X), X.shape[0], X.shape[1], _p(out))
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, want_bf16=True, want_f32=False):
+    _chk(x, torch.float32, "x")
+    rows, D = x.shape
+    y = torch.empty(rows, D, device=x.device, dtype=bf16) if want_bf16 else None
+    yf = torch.empty(rows, D, device=x.device, dtype=torch.float32) if want_f32 else None
+    stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+    call("lafs_layernorm_fwd", _p(x), _ld(x), _p(gamma), _p(beta), eps, _p(y), D, _p(yf), D, _p(stats), rows, D)
+    return y, yf, stats
+
+
+def layernorm_bwd(dy, x, stats, gamma, g_io, dgamma, dbeta, accumulate=True, gb_out=None, seq_scale=None, row2seq=None):
+    """dy: bf16 or f32 [rows, D].  g_io (f32) receives (accumulates) dx; returns g_io."""
+    rows, D = x.shape
+    dy_b = dy if dy.dtype == bf16 else None
+    dy_f = dy if dy.dtype == torch.float32 else None
+    call("lafs_layernorm_bwd", _p(dy_b), D if dy_b is None else _ld(dy_b), _p(dy_f), D if dy_f is None else _ld(dy_f),
+         _p(x), _ld(x), _p(stats), _p(gamma), _p(g_io), _ld(g_io), 1 if accumulate else 0,
+         _p(gb_out), D if gb_out is None else _ld(gb_out), _p(seq_scale), _p(row2seq), _p(dgamma), _p(dbeta), rows, D)
+    return g_io
+
+
+def scale_cast_bf16(g, seq_scale=None, row2seq=None, out=None):
+    rows, D = g.shape
+    if out is None:
+        out = torch.empty(rows, D, device=g.device, dtype=bf16)
+    call("lafs_scale_cast_bf16", _p(g), _ld(g), _p(out), _ld(out), _p(seq_scale), _p(row2seq), rows, D)
+    return out
+
+
+def attention_fwd(qkv, cu_seqlens, max_len, heads, scale):
+    _chk(qkv, bf16, "qkv"); _chk(cu_seqlens, torch.int32, "cu_seqlens")
+    T = qkv.shape[0]
+    inner = heads * 64
+    out = torch.empty(T, inner, device=qkv.device, dtype=bf16)
+    lse = torch.empty(T, heads, device=qkv.device, dtype=torch.float32)
+    call("lafs_attention_fwd", _p(qkv), _ld(qkv), _p(cu_seqlens), cu_seqlens.numel() - 1, max_len, heads, scale,
+         _p(out), inner, _p(lse))
+    return out, lse
+
+
+def attention_bwd(qkv, out, dout, lse, cu_seqlens, max_len, heads, scale):
+    _chk(dout, bf16, "dout")
+    T = qkv.shape[0]
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(T, heads, device=qkv.device, dtype=torch.float32)
+    call("lafs_attention_bwd", _p(qkv), _ld(qkv), _p(out), _ld(out), _p(dout), _ld(dout), _p(lse), _p(delta),
+         _p(cu_seqlens), cu_seqlens.numel() - 1, T, max_len, heads, scale, _p(dqkv), _ld(dqkv))
+    return dqkv
+
+
+def patchify(img, order=_lib.PATCH_ORDER_CHW):
+    _chk(img, torch.float32, "img")
+    B, _, S, _ = img.shape
+    out = torch.empty(B * (S // 8) ** 2, 192, device=img.device, dtype=bf16)
+    call("lafs_patchify", _p(img.contiguous()), B, S, order, _p(out))
+    return out
+
+
+def dino_loss_fwd_bwd(student, teacher, center, ncrops, student_temp, teacher_temp, K=None, grad=None, grad_bf16=True,
+                      grad_scale=1.0):
+    """Returns (loss[1] f32, grad [rows, ld] bf16|f32).  student/teacher may be padded (ld >= K)."""
+    _chk(student, torch.float32, "student"); _chk(teacher, torch.float32, "teacher")
+    rows, ld = student.shape[0], _ld(student)
+    K = student.shape[1] if K is None else K
+    B = rows // ncrops
+    ws = torch.empty(_lib.lib().lafs_dino_loss_workspace(ncrops, B, K), device=student.device, dtype=torch.float32)
+    loss = torch.empty(1, device=student.device, dtype=torch.float32)
+    if grad is None:
+        grad = torch.zeros(rows, ld, device=student.device, dtype=bf16 if grad_bf16 else torch.float32)
+    call("lafs_dino_loss_fwd_bwd", _p(student), _p(teacher), ld, _p(center), ncrops, B, K, student_temp, teacher_temp,
+         _p(loss), _p(grad), _ld(grad), 1 if grad.dtype == bf16 else 0, grad_scale, _p(ws))
+    return loss, grad

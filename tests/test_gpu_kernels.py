@@ -1,0 +1,145 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against fp32 CPU math on the same inputs."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from lafs_cvpr2024_amd import _lib, ops  # noqa: E402
+
+DEV = "cuda"
+bf16 = torch.bfloat16
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def rnd_bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(bf16)
+
+
+def test_lds_transpose_read_model():
+    """lane l, slot j must receive element (l>>4)*64 + j*16 + (l&15) of a lane-linear ramp."""
+    src = torch.arange(512, dtype=torch.int16, device=DEV)
+    out = torch.zeros(256, dtype=torch.int16, device=DEV)
+    _lib.call("lafs_debug_tr16", C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()))
+    got = out.cpu().view(64, 4)
+    exp = torch.tensor([[(l >> 4) * 64 + j * 16 + (l & 15) for j in range(4)] for l in range(64)], dtype=torch.int16)
+    assert torch.equal(got, exp), f"transpose-read model mismatch:\n{got[:20]}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (197 * 3, 1152, 384), (640, 1000, 256)])
+def test_gemm_nt_epilogues(M, N, K):
+    A, B = rnd_bf(M, K, seed=1), rnd_bf(N, K, scale=0.1, seed=2)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    ref = A.float() @ B.float().t() + bias
+    Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd)
+    assert relerr(out.float(), ref) < 1e-2
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_F32, bias=bd)
+    assert relerr(out, ref) < 2e-5 * math.sqrt(K)
+    u, a = ops.gemm_nt(Ad, Bd, _lib.EPI_BF16_GELU, bias=bd)
+    assert relerr(u.float(), ref) < 1e-2 and relerr(a.float(), F.gelu(ref)) < 1e-2
+    # residual + per-sequence DropPath scale
+    nseq = 7
+    row2seq = (torch.arange(M) * nseq // M).int()
+    sc = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9, 0.0, 1.0 / 0.9, 1.0 / 0.9, 1.0 / 0.9])
+    resid = torch.randn(M, N, generator=torch.Generator().manual_seed(4))
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=resid.to(DEV), seq_scale=sc.to(DEV), row2seq=row2seq.to(DEV))
+    assert relerr(out, resid + sc[row2seq.long()].unsqueeze(1) * ref) < 1e-4
+    # dGELU
+    aux = rnd_bf(M, N, seed=5)
+    x = aux.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV))
+    assert relerr(out.float(), (A.float() @ B.float().t()) * x.grad) < 1e-2
+    # split-K atomics
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_ATOMIC_F32, splits=2)
+    assert relerr(out, A.float() @ B.float().t()) < 2e-5 * math.sqrt(K)
+
+
+def test_gemm_nt_embed_epilogue():
+    nseq, npatch, D = 3, 36, 128
+    A, B = rnd_bf(nseq * npatch, 192, seed=1), rnd_bf(D, 192, scale=0.1, seed=2)
+    bias, pos = torch.randn(D), torch.randn(npatch + 1, D)
+    out = torch.zeros(nseq * (npatch + 1), D, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), _lib.EPI_EMBED_F32, bias=bias.to(DEV), pos=pos.to(DEV), npatch=npatch, out=out)
+    ref = torch.zeros(nseq, npatch + 1, D)
+    ref[:, 1:] = (A.float() @ B.float().t() + bias).view(nseq, npatch, D) + pos[1:]
+    assert relerr(out, ref.view(-1, D)) < 1e-4
+
+
+@pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (1000, 384, 1152), (777, 200, 72), (640, 1000, 256)])
+def test_gemm_tn(M, N1, N2):
+    A, B = rnd_bf(M, N1, seed=1), rnd_bf(M, N2, seed=2)
+    Cd = torch.zeros(N1, N2, device=DEV)
+    ops.gemm_tn_acc(A.to(DEV), B.to(DEV), Cd)
+    ref = A.float().t() @ B.float()
+    assert relerr(Cd, ref) < 2e-5 * math.sqrt(M)
+    ops.gemm_tn_acc(A.to(DEV), B.to(DEV), Cd, splits=3)                 # accumulates
+    assert relerr(Cd, 2 * ref) < 2e-5 * math.sqrt(M)
+
+
+@pytest.mark.parametrize("rows,D", [(50, 64), (1000, 384), (333, 192), (64, 768), (7, 2048)])
+def test_layernorm_fwd_bwd(rows, D):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(rows, D, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    xr = x.clone().requires_grad_(True); gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), gr, br, 1e-6)
+    y, yf, stats = ops.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, want_f32=True)
+    assert relerr(yf, yr) < 1e-5 and relerr(y.float(), yr) < 1e-2
+    dy = rnd_bf(rows, D, seed=9)
+    yr.backward(dy.float())
+    g0 = torch.randn(rows, D, generator=g)
+    nseq = 5
+    row2seq = (torch.arange(rows) * nseq // rows).int()
+    sc = torch.tensor([1.0, 0.0, 2.0, 1.0, 0.5])
+    g_io = g0.clone().to(DEV)
+    dgam, dbet = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    gb = torch.empty(rows, D, device=DEV, dtype=bf16)
+    ops.layernorm_bwd(dy.to(DEV), x.to(DEV), stats, gamma.to(DEV), g_io, dgam, dbet, accumulate=True, gb_out=gb,
+                      seq_scale=sc.to(DEV), row2seq=row2seq.to(DEV))
+    assert relerr(g_io, g0 + xr.grad) < 1e-5
+    assert relerr(dgam, gr.grad) < 1e-4 and relerr(dbet, br.grad) < 1e-4
+    assert relerr(gb.float(), sc[row2seq.long()].unsqueeze(1) * (g0 + xr.grad)) < 1e-2
+
+
+def _attn_ref(qkv, cu, heads, scale):
+    inner = heads * 64
+    outs = []
+    for s in range(len(cu) - 1):
+        x = qkv[cu[s]:cu[s + 1]]
+        n = x.shape[0]
+        q, k, v = (x[:, i * inner:(i + 1) * inner].view(n, heads, 64).transpose(0, 1) for i in range(3))
+        a = (q @ k.transpose(-1, -2) * scale).softmax(-1)
+        outs.append((a @ v).transpose(0, 1).reshape(n, inner))
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize("lens,heads", [([197, 197], 2), ([37] * 5, 3), ([16, 1, 37, 48, 33], 1), ([100, 77], 2),
+                                        ([197, 150], 6), ([256, 200], 1)])
+def test_attention_fwd_bwd(lens, heads):
+    cu = [0]
+    for n in lens:
+        cu.append(cu[-1] + n)
+    T, inner = cu[-1], heads * 64
+    qkv = rnd_bf(T, 3 * inner, seed=11)
+    scale = 64 ** -0.5
+    xr = qkv.float().requires_grad_(True)
+    ref = _attn_ref(xr, cu, heads, scale)
+    cud = torch.tensor(cu, dtype=torch.int32, device=DEV)
+    out, lse = ops.attention_fwd(qkv.to(DEV), cud, max(lens), heads, scale)
+    assert relerr(out.float(), ref) < 1.5e-2
+    dout = rnd_bf(T, inner, seed=12)
+    ref.backward(dout.float())
+    dqkv = ops.attention_bwd(qkv.to(DEV), out, dout.to(DEV), lse, cud, max(lens), heads, scale)
+    for i, name in enumerate("qkv"):
+        e = relerr(dqkv[:, i * inner:(i + 1) * inner].float(), xr.grad[:, i * inner:(i + 1) * inner])
+        assert e < 3e-2, f"d{name}: {e}"
