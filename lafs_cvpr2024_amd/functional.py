@@ -1,0 +1,252 @@
+"""Kernel-level forward/backward passes of the hot-path models over ParamArena buffers (no autograd, no ATen math).
+
+These functions are the single implementation used by the drop-in nn.Modules (through torch.autograd.Function
+wrappers) and by the fused, hipGraph-captured training engine.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib
+from . import ops
+from .ops import _p, call
+
+bf16 = torch.bfloat16
+f32 = torch.float32
+
+
+# ----------------------------------------------------------------------------------------------- packed geometry
+@dataclass
+class PackedGeometry:
+    """Token packing of several equal-resolution crop groups into one [n_tok, D] batch."""
+    groups: tuple                       # ((n_images, side), ...)
+    patch: int = 8
+    device: object = None
+    n_seq: int = 0
+    n_tok: int = 0
+    max_len: int = 0
+    tok_start: list = field(default_factory=list)     # first token row of each group
+    seq_start: list = field(default_factory=list)     # first sequence index of each group
+    cu_seqlens: torch.Tensor = None
+    row2seq: torch.Tensor = None
+
+    def __post_init__(self):
+        cu, r2s, tok, seq = [0], [], 0, 0
+        for n_img, side in self.groups:
+            n = (side // self.patch) ** 2 + 1
+            self.tok_start.append(tok)
+            self.seq_start.append(seq)
+            for _ in range(n_img):
+                cu.append(cu[-1] + n)
+            r2s.append(torch.arange(seq, seq + n_img, dtype=torch.int32).repeat_interleave(n))
+            tok += n_img * n
+            seq += n_img
+            self.max_len = max(self.max_len, n)
+        self.n_seq, self.n_tok = seq, tok
+        self.cu_seqlens = torch.tensor(cu, dtype=torch.int32, device=self.device)
+        self.row2seq = torch.cat(r2s).to(self.device)
+
+    def npatch(self, gi):
+        return (self.groups[gi][1] // self.patch) ** 2
+
+
+_GEOM_CACHE = {}
+
+
+def geometry(groups, device, patch=8):
+    key = (tuple(groups), str(device), patch)
+    if key not in _GEOM_CACHE:
+        _GEOM_CACHE[key] = PackedGeometry(tuple(groups), patch, device)
+    return _GEOM_CACHE[key]
+
+
+# ----------------------------------------------------------------------------------------------- trunk descriptor
+@dataclass
+class TrunkSpec:
+    """Where one pre-LN transformer trunk lives inside an arena (names are arena keys)."""
+    dim: int
+    heads: int
+    mlp: int
+    depth: int
+    ln_eps: float
+    attn_scale: float
+    block_names: list                   # per block: dict(ln1_g=..., w_qkv=..., b_qkv=None|name, ...)
+
+    @property
+    def inner(self):
+        return self.heads * 64
+
+
+def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=None, with_grad=True):
+    """Build the C descriptor (keeps the ctypes block array alive on the returned object)."""
+    blocks = (_lib.BlockOffsets * spec.depth)()
+    for i, nm in enumerate(spec.block_names):
+        b = blocks[i]
+        for f in ("ln1_g", "ln1_b", "w_qkv", "w_proj", "b_proj", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2"):
+            setattr(b, f, arena.offsets[nm[f]])
+        b.b_qkv = arena.offsets[nm["b_qkv"]] if nm.get("b_qkv") else -1
+        for f in ("w_qkv", "w_proj", "w_fc1", "w_fc2"):
+            setattr(b, f + "_t", arena.t_offsets[nm[f]])
+    d = _lib.TrunkDesc()
+    d.dim, d.inner, d.heads, d.mlp, d.depth = spec.dim, spec.inner, spec.heads, spec.mlp, spec.depth
+    d.ln_eps, d.attn_scale = spec.ln_eps, spec.attn_scale
+    d.n_tok, d.n_seq, d.max_len = geom.n_tok, geom.n_seq, geom.max_len
+    d.cu_seqlens, d.row2seq = geom.cu_seqlens.data_ptr(), geom.row2seq.data_ptr()
+    d.drop_scales = drop_scales.data_ptr() if drop_scales is not None else None
+    d.master, d.shadow, d.shadow_t = arena.master.data_ptr(), arena.shadow.data_ptr(), arena.shadow_t.data_ptr()
+    d.grad = arena.grad.data_ptr() if (with_grad and arena.grad is not None) else None
+    d.blocks = C.cast(blocks, C.POINTER(_lib.BlockOffsets))
+    d._keep = (blocks, drop_scales, geom, arena)
+    return d
+
+
+def trunk_workspace(desc, save, device):
+    n = _lib.lib().lafs_trunk_workspace_bytes(C.byref(desc), 1 if save else 0)
+    if n < 0:
+        raise _lib.LafsHipError("lafs_trunk_workspace_bytes: " + _lib.lib().lafs_last_error().decode())
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+# ----------------------------------------------------------------------------------------------- ViT (DINO/timm style)
+@dataclass
+class ViTSpec:
+    trunk: TrunkSpec
+    prefix: str                         # arena key prefix of the VisionTransformer ('' or 'backbone.')
+    patch_order: int = _lib.PATCH_ORDER_CHW
+    w_patch: str = "patch_embed.proj.weight"
+    b_patch: str = "patch_embed.proj.bias"
+    cls: str = "cls_token"
+    final_g: str = "norm.weight"
+    final_b: str = "norm.bias"
+
+
+class ViTState:
+    """Buffers kept between forward and backward of one packed ViT pass."""
+    __slots__ = ("geom", "desc", "ws", "x_in", "patches", "cls_rows", "stats", "feat")
+
+
+def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, drop_scales=None, save=True,
+                ws=None, x_in=None, x_out=None):
+    """imgs: list of fp32 NCHW tensors (one per group); pos_tokens: list of fp32 [npatch+1, D] per group.
+    Returns (feat f32 [n_seq, D], state)."""
+    D = spec.trunk.dim
+    dev = imgs[0].device
+    pre = spec.prefix
+    st = ViTState()
+    st.geom = geom
+    st.desc = make_trunk_desc(arena, spec.trunk, geom, drop_scales, with_grad=save)
+    st.ws = ws if ws is not None else trunk_workspace(st.desc, save, dev)
+    st.x_in = x_in if x_in is not None else torch.empty(geom.n_tok, D, device=dev, dtype=f32)
+    if x_out is None:
+        x_out = torch.empty(geom.n_tok, D, device=dev, dtype=f32)
+    st.patches = []
+    wpe = arena.bf(pre + spec.w_patch).view(D, -1)
+    for gi, img in enumerate(imgs):
+        n_img, np_ = geom.groups[gi][0], geom.npatch(gi)
+        pt = ops.patchify(img, spec.patch_order)
+        rows = st.x_in[geom.tok_start[gi]: geom.tok_start[gi] + n_img * (np_ + 1)]
+        ops.gemm_nt(pt, wpe, _lib.EPI_EMBED_F32, bias=arena.view(arena.master, pre + spec.b_patch),
+                    pos=pos_tokens[gi], npatch=np_, out=rows)
+        call("lafs_embed_cls", _p(arena.view(arena.master, pre + spec.cls)), _p(pos_tokens[gi]), _p(rows), D, n_img, np_, D)
+        st.patches.append(pt if save else None)
+    call("lafs_trunk_forward", C.byref(st.desc), _p(st.x_in), _p(x_out), _p(st.ws), 1 if save else 0)
+    st.cls_rows = torch.empty(geom.n_seq, D, device=dev, dtype=f32)
+    call("lafs_gather_cls", _p(x_out), D, _p(geom.cu_seqlens), geom.n_seq, D, _p(st.cls_rows))
+    _, feat, st.stats = ops.layernorm_fwd(st.cls_rows, arena.view(arena.master, pre + spec.final_g),
+                                          arena.view(arena.master, pre + spec.final_b), spec.trunk.ln_eps,
+                                          want_bf16=False, want_f32=True)
+    st.feat = feat
+    return feat, st, x_out
+
+
+def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, layer_slices=None, on_slice_done=None):
+    """dfeat f32 [n_seq, D].  Accumulates every parameter gradient into arena.grad EXCEPT the position table:
+    returns the list of dpos f32 [npatch+1, D] per group (the bicubic resampling lives in torch)."""
+    geom, D, pre = st.geom, spec.trunk.dim, spec.prefix
+    dev = dfeat.device
+    gv = lambda n: arena.view(arena.grad, pre + n)
+    dcls_rows = torch.empty(geom.n_seq, D, device=dev, dtype=f32)
+    ops.layernorm_bwd(dfeat.contiguous(), st.cls_rows, st.stats, arena.view(arena.master, pre + spec.final_g), dcls_rows,
+                      gv(spec.final_g), gv(spec.final_b), accumulate=False)
+    g = g_buf if g_buf is not None else torch.empty(geom.n_tok, D, device=dev, dtype=f32)
+    g.zero_()
+    call("lafs_scatter_cls", _p(dcls_rows), _p(geom.cu_seqlens), geom.n_seq, D, _p(g), D)
+    depth = spec.trunk.depth
+    slices = layer_slices or [(depth, 0)]
+    for hi, lo in slices:
+        call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo)
+        if on_slice_done is not None:
+            on_slice_done(hi, lo)
+    dpos = []
+    for gi in range(len(geom.groups)):
+        n_img, np_ = geom.groups[gi][0], geom.npatch(gi)
+        rows = g[geom.tok_start[gi]: geom.tok_start[gi] + n_img * (np_ + 1)]
+        gp = torch.empty(n_img * np_, D, device=dev, dtype=bf16)
+        dp = torch.zeros(np_ + 1, D, device=dev, dtype=f32)
+        call("lafs_embed_bwd", _p(rows), D, n_img, np_, D, _p(gp), _p(dp), _p(gv(spec.cls)))
+        ops.colsum_bf16_acc(gp, gv(spec.b_patch))
+        ops.gemm_tn_acc(gp, st.patches[gi], gv(spec.w_patch).view(D, -1))
+        dpos.append(dp)
+    return dpos
+
+
+# ----------------------------------------------------------------------------------------------- DINO head
+class HeadState:
+    __slots__ = ("x_bf", "u1", "a1", "u2", "a2", "z", "zn", "inv_z", "wn", "wn_t", "inv_v", "logits", "K", "Kpad")
+
+
+def head_forward(arena, prefix, x, K, save=True, logits=None):
+    """DINOHead: x f32 [n, in_dim] -> logits f32 [n, Kpad] (columns >= K are zero)."""
+    n = x.shape[0]
+    dev = x.device
+    st = HeadState()
+    st.K, st.Kpad = K, (K + 127) // 128 * 128
+    m = lambda k: arena.view(arena.master, prefix + k)
+    st.x_bf = ops.scale_cast_bf16(x.contiguous())
+    st.u1, st.a1 = ops.gemm_nt(st.x_bf, arena.bf(prefix + "mlp.0.weight"), _lib.EPI_BF16_GELU, bias=m("mlp.0.bias"))
+    st.u2, st.a2 = ops.gemm_nt(st.a1, arena.bf(prefix + "mlp.2.weight"), _lib.EPI_BF16_GELU, bias=m("mlp.2.bias"))
+    st.z = ops.gemm_nt(st.a2, arena.bf(prefix + "mlp.4.weight"), _lib.EPI_F32, bias=m("mlp.4.bias"))
+    Db = st.z.shape[1]
+    st.zn = torch.empty(n, Db, device=dev, dtype=bf16)
+    st.inv_z = torch.empty(n, device=dev, dtype=f32)
+    call("lafs_l2norm_fwd", _p(st.z), Db, _p(st.zn), Db, _p(st.inv_z), n, Db)
+    st.wn = torch.empty(st.Kpad, Db, device=dev, dtype=bf16)
+    st.wn_t = torch.empty(Db, st.Kpad, device=dev, dtype=bf16) if save else None
+    st.inv_v = torch.empty(K, device=dev, dtype=f32)
+    call("lafs_weightnorm_fwd", _p(m("last_layer.weight_v")), _p(m("last_layer.weight_g")), K, st.Kpad, Db, _p(st.wn),
+         _p(st.wn_t), st.Kpad, _p(st.inv_v))
+    if logits is None:
+        logits = torch.empty(n, st.Kpad, device=dev, dtype=f32)
+    ops.gemm_nt(st.zn, st.wn, _lib.EPI_F32, out=logits, n_cols=st.Kpad)
+    st.logits = logits
+    return logits, st
+
+
+def head_backward(arena, prefix, st: HeadState, dlogits_bf, train_g=False):
+    """dlogits_bf: bf16 [n, Kpad] (pad columns zero).  Accumulates into arena.grad; returns dx f32 [n, in_dim]."""
+    n, dev = dlogits_bf.shape[0], dlogits_bf.device
+    K, Kpad = st.K, st.Kpad
+    Db = st.z.shape[1]
+    m = lambda k: arena.view(arena.master, prefix + k)
+    gv = lambda k: arena.view(arena.grad, prefix + k)
+    p2 = lambda k: arena.params[arena.names.index(prefix + k)].shape
+    dzn = ops.gemm_nt(dlogits_bf, st.wn_t, _lib.EPI_ATOMIC_F32, splits=max(1, min(64, Kpad // 1024)))
+    dwn = torch.zeros(Kpad, Db, device=dev, dtype=f32)
+    ops.gemm_tn_acc(dlogits_bf, st.zn, dwn, splits=1)
+    dg = gv("last_layer.weight_g") if train_g else None
+    call("lafs_weightnorm_bwd", _p(dwn), _p(m("last_layer.weight_v")), _p(m("last_layer.weight_g")), _p(st.inv_v), K, Db,
+         _p(gv("last_layer.weight_v")), _p(dg), 1)
+    dz = torch.empty(n, Db, device=dev, dtype=f32)
+    call("lafs_l2norm_bwd", _p(st.z), Db, _p(dzn), Db, _p(st.inv_z), _p(dz), Db, n, Db)
+    dz_bf = ops.scale_cast_bf16(dz)
+    ops.colsum_bf16_acc(dz_bf, gv("mlp.4.bias"))
+    ops.gemm_tn_acc(dz_bf, st.a2, gv("mlp.4.weight").view(p2("mlp.4.weight")))
+    du2 = ops.gemm_nt(dz_bf, arena.tview(prefix + "mlp.4.weight"), _lib.EPI_DGELU_BF16, aux=st.u2)
+    ops.colsum_bf16_acc(du2, gv("mlp.2.bias"))
+    ops.gemm_tn_acc(du2, st.a1, gv("mlp.2.weight").view(p2("mlp.2.weight")))
+    du1 = ops.gemm_nt(du2, arena.tview(prefix + "mlp.2.weight"), _lib.EPI_DGELU_BF16, aux=st.u1)
+    ops.colsum_bf16_acc(du1, gv("mlp.0.bias"))
+    ops.gemm_tn_acc(du1, st.x_bf, gv("mlp.0.weight").view(p2("mlp.0.weight")))
+    return ops.gemm_nt(du1, arena.tview(prefix + "mlp.0.weight"), _lib.EPI_F32)
