@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""LAFS pre-training step benchmark on MI355X (BASELINE.json metric: face-crops/sec/node).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config C2/C3): ViT-S/8 student+teacher, DINO head K=100000, 2 global 112x112 + 8 local 48x48 synthetic
+crops, batch 64 per GPU, drop_path 0.1, epoch >= 1 (last layer unfrozen), bf16 MFMA GEMMs with fp32 accumulate /
+residual stream / optimizer.  One "step" = teacher fwd + student fwd + DINO loss + backward + RCCL gradient/center
+all-reduce + per-tensor clip + AdamW + teacher EMA + center EMA, inputs resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMG = {"vit_small": 113.3e9, "vit_tiny": None}
+
+
+def step_flops(arch_dims, B, n_local, K):
+    """Algorithmic FLOPs of one step per GPU: 2*MAC, backward = 2x forward for the student."""
+    D, depth, heads = arch_dims
+    mlp = 4 * D
+    per_tok_layer = 2 * (D * 3 * D + D * D + 2 * D * mlp)
+    def crop(n_tok):
+        return depth * (per_tok_layer * n_tok + 4 * n_tok * n_tok * D) + 2 * 192 * D * (n_tok - 1)
+    head = 2 * (D * 2048 + 2048 * 2048 + 2048 * 256 + 256 * K)
+    g, l = crop(197), crop(37)
+    student = 3 * (2 * g + n_local * l + (2 + n_local) * head)
+    teacher = 2 * g + 2 * head
+    return B * (student + teacher)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--arch", default="vit_small")
+    ap.add_argument("--out-dim", type=int, default=100000)
+    ap.add_argument("--local-crops", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    return ap.parse_args()
+
+
+def dominant_kernel_roofline(device, iters=30):
+    """The dominant kernel of the step is the 128x128 MFMA GEMM; its heaviest instance is the student MLP fc1
+    (M = 64*(2*197+8*37) = 44160 tokens, N = 1536, K = 384, bias+GELU epilogue writing u and gelu(u)).  Timed with HIP
+    events on the stream it is launched on."""
+    from lafs_cvpr2024_amd import _lib, ops
+    M, N, K = 44160, 1536, 384
+    A = torch.randn(M, K, device=device).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=device) * 0.02).to(torch.bfloat16)
+    b = torch.zeros(N, device=device)
+    u = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    a = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    for _ in range(3):
+        ops.gemm_nt(A, W, _lib.EPI_BF16_GELU, bias=b, out=u, out2=a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops.gemm_nt(A, W, _lib.EPI_BF16_GELU, bias=b, out=u, out2=a)
+    e1.record()
+    torch.cuda.synchronize()
+    dur = e0.elapsed_time(e1) / iters * 1e-3
+    flops = 2.0 * M * N * K
+    peak = 2500.0
+    ach = flops / dur / 1e12
+    return {"bound": "mfma", "kernel": "gemm_nt_kernel<BF16_GELU> M=44160 N=1536 K=384", "achieved": round(ach, 1),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+            "avg_launch_us": round(dur * 1e6, 2)}
+
+
+def cpu_baseline(arch_dims, n_local, K, batch):
+    """The oracle (fp32 torch-CPU restatement, parity-locked to the reference's golden vectors) timed on the host cores
+    on a bounded sample of the same workload: ONE step of the same model/crop geometry at a small batch."""
+    from oracle import dino, step as ostep, vit as ovit
+    D, depth, heads = arch_dims
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = ovit.ViTConfig(patch_size=8, embed_dim=D, depth=depth, num_heads=heads, img_size=224)
+    st = ostep.LafsState(cfg, out_dim=K, seed=0)
+    g = torch.Generator().manual_seed(0)
+    crops = [torch.randn(batch, 3, 112, 112, generator=g).clamp(-1, 1) for _ in range(2)] + \
+            [torch.randn(batch, 3, 48, 48, generator=g).clamp(-1, 1) for _ in range(n_local)]
+    t0 = time.time()
+    r = ostep.lafs_step(st, crops, epoch=1, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04)
+    dt = time.time() - t0
+    return {"value": round(batch * (2 + n_local) / dt, 3), "unit": "face-crops/s", "cores": cores, "kind": "port",
+            "sample": f"1 step of the same model/crops at batch {batch} (fp32, torch CPU, {dt:.1f} s), loss {float(r['loss']):.4f}"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from lafs_cvpr2024_amd import vision_transformer as vits
+    from lafs_cvpr2024_amd.dino_loss import DINOLoss
+    from lafs_cvpr2024_amd.engine import LafsPretrainEngine
+    from lafs_cvpr2024_amd.utils import MultiCropWrapper, cosine_scheduler
+
+    if args.roofline_only:
+        print(json.dumps({"roofline": dominant_kernel_roofline(device, iters=200)}))
+        return
+
+    dims = {"vit_small": (384, 12, 6), "vit_tiny": (192, 12, 3), "vit_base": (768, 12, 12)}[args.arch]
+    torch.manual_seed(0)
+    B, K, nl = args.batch, args.out_dim, args.local_crops
+    student = MultiCropWrapper(vits.__dict__[args.arch](patch_size=8, drop_path_rate=0.1),
+                               vits.DINOHead(dims[0], K, use_bn=False, norm_last_layer=True))
+    teacher = MultiCropWrapper(vits.__dict__[args.arch](patch_size=8), vits.DINOHead(dims[0], K, use_bn=False))
+    teacher.load_state_dict(student.state_dict())
+    crit = DINOLoss(K, 2 + nl, 0.07, 0.04, 30, 41)
+    eng = LafsPretrainEngine(student, teacher, crit, B, n_local=nl, clip_grad=3.0, freeze_last_layer=1,
+                             use_graph=not args.no_graph, device=device)
+    g = torch.Generator(device=device).manual_seed(rank)
+    eng.in_global_all.copy_(torch.randn(eng.in_global_all.shape, device=device, generator=g).clamp_(-1, 1))
+    eng.in_local_all.copy_(torch.randn(eng.in_local_all.shape, device=device, generator=g).clamp_(-1, 1))
+
+    niter = 1000
+    lr_s = cosine_scheduler(5e-4 * B * world / 256., 1e-6, 41, niter, warmup_epochs=10)
+    wd_s = cosine_scheduler(0.04, 0.4, 41, niter)
+    mom_s = cosine_scheduler(0.996, 1, 41, niter)
+    epoch = 1
+    tt = float(crit.teacher_temp_schedule[epoch])
+
+    def one(it):
+        return eng.step(lr=float(lr_s[it]), wd=float(wd_s[it]), momentum=float(mom_s[it]), teacher_temp=tt, epoch=epoch)
+
+    it0 = epoch * niter
+    for i in range(args.warmup):
+        one(it0 + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one(it0 + args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_v = float(loss.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        crops = world * B * (2 + nl)
+        fl = step_flops(dims, B, nl, K)
+        out = {
+            "metric": "face-crops/sec/node (ViT-S LAFS pretrain, 2g+8l crops)", "value": round(crops / (ms * 1e-3), 1),
+            "unit": "face-crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.arch}/8 LAFS pretrain step, 2 global 112x112 + {nl} local 48x48 crops, "
+                                   f"batch {B}/GPU, out_dim {K}, drop_path 0.1, dp{world}",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+            "images_per_s": round(world * B / (ms * 1e-3), 1),
+            "step_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
+            "step_mfma_frac": round(fl / (ms * 1e-3) / 2.5e15, 4),
+            "final_loss": round(loss_v, 4),
+        }
+        out["roofline"] = dominant_kernel_roofline(device)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims, nl, K, args.cpu_batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,7 +51,7 @@ enum {
 typedef struct lafs_gemm_nt_args {
   const void* A; int lda;          /* bf16 [M, K]                                  */
   const void* B; int ldb;          /* bf16 [N, K]  (nn.Linear weight layout)       */
-  int M, N, K;                     /* K % 64 == 0                                  */
+  int M, N, K;                     /* K % 32 == 0                                  */
   int epilogue;                    /* LAFS_EPI_*                                   */
   void* C; int ldc;                /* bf16 or f32 [M, N]                           */
   void* C2; int ldc2;              /* second output (BF16_GELU)                    */
@@ -154,13 +154,15 @@ int lafs_weightnorm_bwd(const float* dw, const float* v, const float* g, const f
  *   loss = 1/n_terms * sum_{i in {0,1}, v != i} mean_b [ lse(s_v/tau_s) - <q_i, s_v/tau_s> ]
  *   dL/ds_v = 1/(n_terms * B * tau_s) * sum_{i != v} (p_v - q_i)
  * student f32 [ncrops*B, ld], teacher f32 [2*B, ld], center f32 [K]; grad bf16 or f32 [ncrops*B, ldg].
- * workspace f32: lafs_dino_loss_workspace(ncrops, B, K) floats.
+ * workspace f32: lafs_dino_loss_workspace(ncrops, B, K) floats.  dev_temps (optional, device f32[2] =
+ * {student_temp, teacher_temp}) overrides the two host values so that a captured hipGraph follows the
+ * teacher-temperature schedule.
  * ------------------------------------------------------------------------------------------------ */
 int64_t lafs_dino_loss_workspace(int ncrops, int B, int K);
 int lafs_dino_loss_fwd_bwd(const float* student, const float* teacher, int ld, const float* center, int ncrops,
                            int B, int K, float student_temp, float teacher_temp, float* loss_out,
                            void* grad, int ldg, int grad_is_bf16, float grad_scale, float* workspace,
-                           hipStream_t stream);
+                           const float* dev_temps, hipStream_t stream);
 /* colsum(f32)[k] = sum_rows teacher[r, k]   (lafs_train.py:674; all-reduced by the caller) */
 int lafs_colsum_f32(const float* x, int ld, int rows, int K, float* out, hipStream_t stream);
 /* center = center*m + colsum/(rows_total) * (1-m)   (lafs_train.py:676-679) */

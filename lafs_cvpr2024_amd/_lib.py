@@ -68,7 +68,7 @@ _PROTOS = {
     "lafs_l2norm_bwd": [vp, i32, vp, i32, vp, vp, i32, i32, i32],
     "lafs_weightnorm_fwd": [vp, vp, i32, i32, i32, vp, vp, i32, vp],
     "lafs_weightnorm_bwd": [vp, vp, vp, vp, i32, i32, vp, vp, i32],
-    "lafs_dino_loss_fwd_bwd": [vp, vp, i32, vp, i32, i32, i32, f32, f32, vp, vp, i32, i32, f32, vp],
+    "lafs_dino_loss_fwd_bwd": [vp, vp, i32, vp, i32, i32, i32, f32, f32, vp, vp, i32, i32, f32, vp, vp],
     "lafs_colsum_f32": [vp, i32, i32, i32, vp],
     "lafs_center_ema": [vp, vp, i32, f32, f32],
     "lafs_grad_sumsq": [vp, vp, i64, vp, vp],
@@ -97,6 +97,9 @@ def lib():
     """Load (once) and return the ctypes handle; raises LafsHipError when the library is absent."""
     global _lib
     if _lib is None:
+        # torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's): it must be mapped FIRST so that this
+        # library binds to the very same HIP runtime instance (streams and device pointers are shared with torch).
+        import torch  # noqa: F401
         if not os.path.isfile(LIB_PATH):
             raise LafsHipError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
                                "there is no CPU fallback")

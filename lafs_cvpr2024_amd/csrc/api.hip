@@ -27,6 +27,7 @@ __global__ void debug_tr16_kernel(const short* in, short* out) {
   out[l * 4 + 0] = v[0]; out[l * 4 + 1] = v[1]; out[l * 4 + 2] = v[2]; out[l * 4 + 3] = v[3];
 }
 extern "C" int lafs_debug_tr16(const void* in, void* out, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   hipLaunchKernelGGL(debug_tr16_kernel, dim3(1), dim3(64), 0, stream, (const short*)in, (short*)out);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;

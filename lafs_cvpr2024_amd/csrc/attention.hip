@@ -19,6 +19,8 @@
 //   R (row fragments, ds_read_b128): 16-byte chunk c of row r stored at chunk c ^ (r & 7)
 //   T (transpose reads):             8-byte unit u of row r stored at unit  u ^ ((r >> 1) & 3)
 // Both are conflict-free for their access pattern.
+#include <mutex>
+#include <set>
 #include "common.hpp"
 #include "lafs_hip.h"
 
@@ -391,10 +393,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 
 template <typename K>
 int launch_attn(K kernel, int n_pairs, int ppb, size_t lds, const AttnArgs& a, hipStream_t s) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) {
-    lafs_set_error("attention: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
-    return (int)e;
+  // raise the dynamic-LDS limit once per kernel instantiation (not a stream operation; kept out of graph capture)
+  static std::mutex mu;
+  static std::set<const void*> done;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    const void* key = reinterpret_cast<const void*>(kernel);
+    if (done.find(key) == done.end()) {
+      hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        lafs_set_error("attention: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e));
+        return (int)e;
+      }
+      done.insert(key);
+    }
   }
   hipLaunchKernelGGL(kernel, dim3(ceil_div(n_pairs, ppb)), dim3(256), lds, s, a);
   LAFS_LAUNCH_CHECK();
@@ -427,6 +439,7 @@ int dispatch_len(int which, int max_len, const AttnArgs& a, hipStream_t s) {
 
 extern "C" int lafs_attention_fwd(const void* qkv, int ldqkv, const int32_t* cu_seqlens, int n_seq, int max_len, int heads,
                                   float scale, void* out_bf16, int ldo, float* lse, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(qkv && cu_seqlens && out_bf16 && lse, "null operand");
   LAFS_CHECK_ARG(n_seq > 0 && heads > 0 && max_len > 0 && max_len <= 256, "sequence length must be in 1..256");
   LAFS_CHECK_ARG(ldqkv % 8 == 0 && ldo % 8 == 0, "row strides must be multiples of 8 elements");
@@ -439,6 +452,7 @@ extern "C" int lafs_attention_fwd(const void* qkv, int ldqkv, const int32_t* cu_
 extern "C" int lafs_attention_bwd(const void* qkv, int ldqkv, const void* out_bf16, int ldo, const void* dout_bf16, int lddo,
                                   const float* lse, float* delta, const int32_t* cu_seqlens, int n_seq, int n_tok, int max_len,
                                   int heads, float scale, void* dqkv, int lddqkv, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(qkv && out_bf16 && dout_bf16 && lse && delta && cu_seqlens && dqkv, "null operand");
   LAFS_CHECK_ARG(n_seq > 0 && n_tok > 0 && heads > 0 && max_len > 0 && max_len <= 256, "sequence length must be in 1..256");
   LAFS_CHECK_ARG(ldqkv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0, "row strides must be multiples of 8");

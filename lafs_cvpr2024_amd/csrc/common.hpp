@@ -24,6 +24,8 @@ extern "C" void lafs_set_error(const char* fmt, ...);
       return LAFS_ESHAPE;                                                             \
     }                                                                                 \
   } while (0)
+// hipGetLastError is sticky per thread: drop whatever an earlier, unrelated runtime call left behind
+#define LAFS_CLEAR_ERROR() (void)hipGetLastError()
 #define LAFS_LAUNCH_CHECK()                                                           \
   do {                                                                                \
     hipError_t e_ = hipGetLastError();                                                \
@@ -46,10 +48,18 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-// ---- exact (erf) GELU, as nn.GELU() default ----
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// ---- erf GELU (nn.GELU() default).  erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, one v_exp + one v_rcp):
+// the library erff costs ~5x more VALU work and made the GELU epilogue the longest phase of the fc1 GEMM. ----
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float y = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }

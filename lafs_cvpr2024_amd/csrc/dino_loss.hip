@@ -20,8 +20,10 @@ __device__ __forceinline__ void online(float& m, float& s, float v) {
 
 // stats[row] = {max, lse} of (x[row,:] - center) * inv_temp   (center may be NULL)
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int ld, const float* __restrict__ center,
-                                                       float inv_temp, int K, float* __restrict__ stats) {
+                                                       float inv_temp, const float* __restrict__ dtemp, int K,
+                                                       float* __restrict__ stats) {
   __shared__ float sm[4], ss[4];
+  if (dtemp != nullptr) inv_temp = 1.0f / dtemp[0];
   const int row = blockIdx.x;
   const float* xr = x + (size_t)row * ld;
   float m = -INFINITY, s = 0.f;
@@ -63,8 +65,10 @@ template <bool GRAD_BF16>
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ student, const float* __restrict__ teacher, int ld,
                                                        const float* __restrict__ center, int ncrops, int B, int K, float its,
                                                        float itt, const float* __restrict__ s_stats, const float* __restrict__ t_stats,
-                                                       void* __restrict__ grad, int ldg, float coef, float* __restrict__ dots) {
+                                                       void* __restrict__ grad, int ldg, float coef, float* __restrict__ dots,
+                                                       const float* __restrict__ dtemps) {
   __shared__ float part[MAXC][4];
+  if (dtemps != nullptr) { coef = coef / (its * dtemps[0]); its = 1.0f / dtemps[0]; itt = 1.0f / dtemps[1]; }
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int k = chunk * CHUNK + threadIdx.x * 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -171,7 +175,8 @@ extern "C" int64_t lafs_dino_loss_workspace(int ncrops, int B, int K) {
 extern "C" int lafs_dino_loss_fwd_bwd(const float* student, const float* teacher, int ld, const float* center, int ncrops,
                                       int B, int K, float student_temp, float teacher_temp, float* loss_out,
                                       void* grad, int ldg, int grad_is_bf16, float grad_scale, float* workspace,
-                                      hipStream_t stream) {
+                                      const float* dev_temps, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(student && teacher && center && loss_out && grad && workspace, "null operand");
   LAFS_CHECK_ARG(ncrops >= 2 && ncrops <= MAXC && B > 0 && K > 0, "ncrops must be in 2..16");
   LAFS_CHECK_ARG(ld % 4 == 0 && ldg % 4 == 0 && ld >= K && ldg >= K, "row strides must be multiples of 4 and >= K");
@@ -180,21 +185,24 @@ extern "C" int lafs_dino_loss_fwd_bwd(const float* student, const float* teacher
   float* t_stats = s_stats + 2 * (size_t)ncrops * B;
   float* dots = t_stats + 2 * (size_t)2 * B;
   const float its = 1.0f / student_temp, itt = 1.0f / teacher_temp;
-  hipLaunchKernelGGL(row_stats_kernel, dim3(ncrops * B), dim3(256), 0, stream, student, ld, (const float*)nullptr, its, K, s_stats);
-  hipLaunchKernelGGL(row_stats_kernel, dim3(2 * B), dim3(256), 0, stream, teacher, ld, center, itt, K, t_stats);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(ncrops * B), dim3(256), 0, stream, student, ld, (const float*)nullptr, its,
+                     dev_temps, K, s_stats);
+  hipLaunchKernelGGL(row_stats_kernel, dim3(2 * B), dim3(256), 0, stream, teacher, ld, center, itt,
+                     dev_temps ? dev_temps + 1 : nullptr, K, t_stats);
   const float coef = grad_scale / ((float)(2 * ncrops - 2) * (float)B * student_temp);
   if (grad_is_bf16)
     hipLaunchKernelGGL(loss_grad_kernel<true>, dim3(nchunks, B), dim3(256), 0, stream, student, teacher, ld, center, ncrops, B, K, its,
-                       itt, s_stats, t_stats, grad, ldg, coef, dots);
+                       itt, s_stats, t_stats, grad, ldg, coef, dots, dev_temps);
   else
     hipLaunchKernelGGL(loss_grad_kernel<false>, dim3(nchunks, B), dim3(256), 0, stream, student, teacher, ld, center, ncrops, B, K, its,
-                       itt, s_stats, t_stats, grad, ldg, coef, dots);
+                       itt, s_stats, t_stats, grad, ldg, coef, dots, dev_temps);
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, s_stats, dots, ncrops, B, nchunks, loss_out);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
 
 extern "C" int lafs_colsum_f32(const float* x, int ld, int rows, int K, float* out, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && out && rows > 0 && K > 0 && ld % 4 == 0, "bad operand");
   hipLaunchKernelGGL(colsum_f32_kernel, dim3(ceil_div(ceil_div(K, 4), 256)), dim3(256), 0, stream, x, ld, rows, K, out);
   LAFS_LAUNCH_CHECK();
@@ -202,6 +210,7 @@ extern "C" int lafs_colsum_f32(const float* x, int ld, int rows, int K, float* o
 }
 
 extern "C" int lafs_center_ema(float* center, const float* colsum, int K, float inv_rows_total, float momentum, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(center && colsum && K > 0, "bad operand");
   hipLaunchKernelGGL(center_ema_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, stream, center, colsum, K, inv_rows_total, momentum);
   LAFS_LAUNCH_CHECK();

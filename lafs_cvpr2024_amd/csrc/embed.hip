@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void scatter_cls_kernel(const float* __restric
 }  // namespace
 
 extern "C" int lafs_patchify(const float* img, int B, int S, int order, void* patches, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(img && patches && B > 0 && S > 0 && S % 8 == 0, "image side must be a multiple of the 8-pixel patch");
   const int total = B * S * (S / 8);
   if (order == LAFS_PATCH_ORDER_CHW)
@@ -103,6 +104,7 @@ extern "C" int lafs_patchify(const float* img, int B, int S, int order, void* pa
 
 extern "C" int lafs_embed_cls(const float* cls, const float* pos, float* tokens, int ldt, int n_seq, int npatch, int D,
                               hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(cls && pos && tokens && n_seq > 0 && npatch > 0 && D > 0, "bad operand");
   hipLaunchKernelGGL(embed_cls_kernel, dim3(ceil_div(n_seq * D, 256)), dim3(256), 0, stream, cls, pos, tokens, ldt, n_seq, npatch, D);
   LAFS_LAUNCH_CHECK();
@@ -111,6 +113,7 @@ extern "C" int lafs_embed_cls(const float* cls, const float* pos, float* tokens,
 
 extern "C" int lafs_embed_bwd(const float* g, int ldg, int n_seq, int npatch, int D, void* gp, float* dpos, float* dcls,
                               hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g && dpos && n_seq > 0 && npatch > 0 && D > 0 && D % 4 == 0 && ldg % 4 == 0, "bad operand");
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(ceil_div((npatch + 1) * (D / 4), 256)), dim3(256), 0, stream, g, ldg, n_seq, npatch, D,
                      (bf16_t*)gp, dpos, dcls);
@@ -120,6 +123,7 @@ extern "C" int lafs_embed_bwd(const float* g, int ldg, int n_seq, int npatch, in
 
 extern "C" int lafs_gather_cls(const float* x, int ldx, const int32_t* cu_seqlens, int n_seq, int D, float* out_f32,
                                hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && cu_seqlens && out_f32 && n_seq > 0 && D > 0, "bad operand");
   hipLaunchKernelGGL(gather_cls_kernel, dim3(ceil_div(n_seq * D, 256)), dim3(256), 0, stream, x, ldx, cu_seqlens, n_seq, D, out_f32);
   LAFS_LAUNCH_CHECK();
@@ -128,6 +132,7 @@ extern "C" int lafs_gather_cls(const float* x, int ldx, const int32_t* cu_seqlen
 
 extern "C" int lafs_scatter_cls(const float* src, const int32_t* cu_seqlens, int n_seq, int D, float* g, int ldg,
                                 hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(src && cu_seqlens && g && n_seq > 0 && D > 0, "bad operand");
   hipLaunchKernelGGL(scatter_cls_kernel, dim3(ceil_div(n_seq * D, 256)), dim3(256), 0, stream, src, cu_seqlens, n_seq, D, g, ldg);
   LAFS_LAUNCH_CHECK();

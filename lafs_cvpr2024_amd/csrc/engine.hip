@@ -97,6 +97,7 @@ extern "C" int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save
 
 extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, float* x_out, void* workspace,
                                   int save_for_backward, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   RUN(check_desc(d));
   LAFS_CHECK_ARG(x_in && x_out && workspace, "null buffer");
   const Carve c = carve(d, workspace, save_for_backward);
@@ -128,6 +129,7 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
 
 extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
                                    int layer_lo, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   RUN(check_desc(d));
   LAFS_CHECK_ARG(x_in && g && workspace && d->shadow_t && d->grad, "null buffer");
   LAFS_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= d->depth, "bad layer range");

@@ -159,6 +159,7 @@ int isqrt_exact(int n) {
 extern "C" int lafs_margin_softmax_ce(float* cos, int ld, int B, int C, const int32_t* y1, const int32_t* y2, float lam,
                                       float s, float m, int margin_type, float loss_scale, float* loss_out, float* row_ws,
                                       hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(cos && y1 && y2 && loss_out && row_ws && B > 0 && C > 0 && ld >= C, "bad operand");
   LAFS_CHECK_ARG(margin_type == 0 || margin_type == 1, "margin_type must be 0 (CosFace) or 1 (ArcFace)");
   hipLaunchKernelGGL(margin_ce_kernel, dim3(B), dim3(256), 0, stream, cos, ld, C, y1, y2, lam, s, m, margin_type, loss_scale / (float)B,
@@ -169,6 +170,7 @@ extern "C" int lafs_margin_softmax_ce(float* cos, int ld, int B, int C, const in
 }
 
 extern "C" int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(src_u8 && dst && B > 0 && S > 0, "bad operand");
   const size_t per = (size_t)3 * S * S;
   size_t blocks = ((size_t)B * per + 255) / 256;
@@ -179,6 +181,7 @@ extern "C" int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, in
 }
 
 extern "C" int lafs_patch_gather_fwd(const float* img, const float* theta, int B, int S, int n, float* mosaic, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   const int r = isqrt_exact(n);
   LAFS_CHECK_ARG(img && theta && mosaic && B > 0 && S > 0 && r > 0, "n must be a perfect square");
   hipLaunchKernelGGL(gather_fwd_kernel, dim3(n, B), dim3(64), 0, stream, img, theta, S, n, r, mosaic);
@@ -188,6 +191,7 @@ extern "C" int lafs_patch_gather_fwd(const float* img, const float* theta, int B
 
 extern "C" int lafs_patch_gather_bwd(const float* img, const float* theta, const float* dmosaic, int B, int S, int n,
                                      float* dtheta, float* dimg, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   const int r = isqrt_exact(n);
   LAFS_CHECK_ARG(img && theta && dmosaic && dtheta && B > 0 && S > 0 && r > 0, "n must be a perfect square");
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(n, B), dim3(64), 0, stream, img, theta, dmosaic, S, n, r, dtheta, dimg);

@@ -39,49 +39,72 @@ struct NTArgs {
   const float* pos; int npatch;
 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int BM = 128, BN = 128;
+constexpr int NT_BK = 32;                          // k-depth of one pipeline stage
+constexpr int NT_NS = 3;                           // LDS ring depth (stages in flight: NS-1)
+constexpr int NT_STAGE = (BM + BN) * NT_BK * 2;    // 16 KiB: A tile then B tile
+constexpr int TILE_BYTES = 128 * 64 * 2;           // TN kernel operand tile
 
-__device__ __forceinline__ int nt_perm(int r) {   // LDS row -> weight row inside the 128-row tile
-  return (r & 64) + ((r >> 2) & 3) * 16 + ((r >> 4) & 3) * 4 + (r & 3);
+// LDS row -> weight row inside the 128-row tile.  MFMA row slot s = (rho & 15) of column-group j = (rho >> 4) & 3 ends
+// up in lane group g = s >> 2, register r = s & 3.  VPL = how many CONSECUTIVE output columns one lane should own so
+// that the 4 lane groups of a row write one contiguous 64-byte segment per store instruction:
+//   VPL 4 (fp32 outputs): column = j*16 + g*4 + r          (identity)
+//   VPL 8 (bf16 outputs): column = (j>>1)*32 + g*8 + (j&1)*4 + r
+template <int VPL>
+__device__ __forceinline__ int nt_perm(int rho) {
+  const int j = (rho >> 4) & 3, g = (rho >> 2) & 3, r = rho & 3;
+  if (VPL == 4) return rho;
+  return (rho & 64) + (j >> 1) * 32 + g * 8 + (j & 1) * 4 + r;
+}
+template <int EPI> struct EpiTraits {
+  static constexpr bool f32_out = (EPI == LAFS_EPI_RESID_F32 || EPI == LAFS_EPI_F32 || EPI == LAFS_EPI_ATOMIC_F32 || EPI == LAFS_EPI_EMBED_F32);
+  static constexpr int VPL = f32_out ? 4 : 8;
+};
+// 64-byte LDS rows (BK = 32): logical 16-byte chunk c of row r lives at chunk c ^ ((-(r >> 2)) & 3), which makes the
+// ds_read_b128 fragment reads (row = lane & 15, chunk = lane >> 4) conflict-free in every 16-lane service group.
+__device__ __forceinline__ int nt_swz(int row) { return (-(row >> 2)) & 3; }
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// XCD-aware, bijective block -> tile map: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a
+// contiguous run of tiles so that the n-tiles of one m-tile (same A rows) hit the same L2.
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(NTArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NT_NS * NT_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = blockIdx.z * p.klen;
   const int kend = min(p.K, kbeg + p.klen);
-  const int nk = (kend - kbeg) / BK;
+  const int nk = (kend - kbeg) / NT_BK;
 
-  // ---- per-thread staging coordinates: 4 x 16-byte chunks of A and of B per k-step ----
-  const bf16_t* ga[4]; const bf16_t* gb[4]; int soff[4];
+  // ---- async global -> LDS staging (LDS-DMA): each thread moves 2 x 16 B of A and 2 x 16 B of B per stage.  The LDS
+  // image is lane-linear (wave base + lane*16), so the XOR swizzle is applied to the SOURCE column instead. ----
+  const bf16_t* ga[2]; const bf16_t* gb[2]; int ldsoff[2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i, row = c >> 3, ch = c & 7;
+  for (int i = 0; i < 2; ++i) {
+    const int q = i * 256 + tid, row = q >> 2, ch = (q & 3) ^ nt_swz(row);
     ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + kbeg + ch * 8;
-    gb[i] = p.B + (size_t)min(n0 + nt_perm(row), p.N - 1) * p.ldb + kbeg + ch * 8;
-    soff[i] = row * 128 + ((ch ^ (row & 7)) << 4);
+    gb[i] = p.B + (size_t)min(n0 + nt_perm<EpiTraits<EPI>::VPL>(row), p.N - 1) * p.ldb + kbeg + ch * 8;
+    ldsoff[i] = (i * 256 + wave * 64) * 16;           // wave-uniform
   }
-  uint4 ra[4], rb[4];
-  auto gload = [&](int t) {
+  auto issue = [&](int t) {
+    unsigned char* st = smem + (t % NT_NS) * NT_STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const uint4*>(ga[i] + t * BK);
-      rb[i] = *reinterpret_cast<const uint4*>(gb[i] + t * BK);
-    }
-  };
-  auto sstore = [&](int buf) {
-    unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-    unsigned char* sb = sa + TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sa + soff[i]) = ra[i];
-      *reinterpret_cast<uint4*>(sb + soff[i]) = rb[i];
+    for (int i = 0; i < 2; ++i) {
+      glds16(ga[i] + t * NT_BK, st + ldsoff[i]);
+      glds16(gb[i] + t * NT_BK, st + BM * NT_BK * 2 + ldsoff[i]);
     }
   };
 
@@ -92,43 +115,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
-  if (nk > 0) { gload(0); sstore(0); }
-  __syncthreads();
-  int cur = 0;
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra_ = wr * 64 + i * 16 + frow, rb_ = wc * 64 + i * 16 + frow;
+    aoff[i] = ra_ * 64 + ((fq ^ nt_swz(ra_)) << 4);
+    boff[i] = BM * NT_BK * 2 + rb_ * 64 + ((fq ^ nt_swz(rb_)) << 4);
+  }
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) gload(t + 1);
-    const unsigned char* sa = smem + cur * 2 * TILE_BYTES;
-    const unsigned char* sb = sa + TILE_BYTES;
+    // stage t has landed once at most the 4 loads of stage t+1 are still in flight (loads retire in order)
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                    // everyone's part of stage t landed; stage (t-1)%NS is free again
+    if (t + 2 < nk) issue(t + 2);
+    const unsigned char* st = smem + (t % NT_NS) * NT_STAGE;
+    bf16x8_t fa[4], fb[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ra_ = wr * 64 + i * 16 + frow;
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + ra_ * 128 + (((kk * 4 + fq) ^ (ra_ & 7)) << 4));
-        const int rb_ = wc * 64 + i * 16 + frow;
-        fb[i] = *reinterpret_cast<const bf16x8_t*>(sb + rb_ * 128 + (((kk * 4 + fq) ^ (rb_ & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = mfma16(fb[j], fa[i], acc[j][i]);
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i]);
+      fb[i] = *reinterpret_cast<const bf16x8_t*>(st + boff[i]);
     }
-    if (t + 1 < nk) sstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = mfma16(fb[j], fa[i], acc[j][i]);
   }
 
-  // ---- epilogue: lane owns rows m = m0 + wr*64 + i*16 + (lane&15), columns nb .. nb+15 ----
-  const int nb = n0 + wc * 64 + fq * 16;
-  if (nb >= p.N) return;
-  const bool full = (nb + 16 <= p.N);
+  // ---- epilogue: lane owns rows m = m0 + wr*64 + i*16 + (lane&15) and, per row, NG groups of VPL consecutive columns:
+  // group q starts at n0 + wc*64 + q*4*VPL + fq*VPL; register e = j*4 + r of the row is element e % VPL of group e / VPL.
+  constexpr int VPL = EpiTraits<EPI>::VPL, NG = 16 / VPL;
+  const int ncol0 = n0 + wc * 64 + fq * VPL;
   float bias[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) bias[e] = 0.f;
   if (p.bias != nullptr && EPI != EPI_ATOMIC_F32 && EPI != EPI_DGELU_BF16) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) if (full || nb + e < p.N) bias[e] = p.bias[nb + e];
+    for (int e = 0; e < 16; ++e) {
+      const int n = ncol0 + (e / VPL) * 4 * VPL + (e % VPL);
+      if (n < p.N) bias[e] = p.bias[n];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -139,61 +166,76 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTArgs p) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[j][i][r] + bias[j * 4 + r];
-
-    if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_DGELU_BF16) {
-      if (EPI == EPI_DGELU_BF16) {
-        const bf16_t* ax = p.aux + (size_t)m * p.ldaux + nb;
+    float sc = 1.0f;
+    size_t orow = (size_t)m;
+    int tpos = 0;
+    if (EPI == EPI_RESID_F32 && p.seq_scale != nullptr) sc = p.seq_scale[p.row2seq[m]];
+    if (EPI == EPI_EMBED_F32) {
+      const int b = m / p.npatch;
+      tpos = m - b * p.npatch + 1;
+      orow = (size_t)m + b + 1;                         // one cls row in front of every sequence
+    }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) if (full || nb + e < p.N) v[e] *= gelu_grad_f(bf2f(ax[e]));
-      }
-      bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nb;
-      bf16_t* c2 = (EPI == EPI_BF16_GELU) ? reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + nb : nullptr;
-      if (full) {
-        uint32_t w[8];
+    for (int q = 0; q < NG; ++q) {
+      const int n = ncol0 + q * 4 * VPL;
+      if (n >= p.N) continue;
+      const bool full = (n + VPL <= p.N);
+      float* w = v + q * VPL;
+      if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_DGELU_BF16) {        // VPL == 8: one 16-byte store
+        if (EPI == EPI_DGELU_BF16) {
+          const bf16_t* ax = p.aux + (size_t)m * p.ldaux + n;
+          if (full) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(ax);
+            w[0] *= gelu_grad_f(bf_lo(a4.x)); w[1] *= gelu_grad_f(bf_hi(a4.x)); w[2] *= gelu_grad_f(bf_lo(a4.y)); w[3] *= gelu_grad_f(bf_hi(a4.y));
+            w[4] *= gelu_grad_f(bf_lo(a4.z)); w[5] *= gelu_grad_f(bf_hi(a4.z)); w[6] *= gelu_grad_f(bf_lo(a4.w)); w[7] *= gelu_grad_f(bf_hi(a4.w));
+          } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) w[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-        reinterpret_cast<uint4*>(c)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        reinterpret_cast<uint4*>(c)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        if (EPI == EPI_BF16_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = pack_bf2(gelu_f(v[2 * e]), gelu_f(v[2 * e + 1]));
-          reinterpret_cast<uint4*>(c2)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-          reinterpret_cast<uint4*>(c2)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (nb + e < p.N) {
-            c[e] = f2bf(v[e]);
-            if (EPI == EPI_BF16_GELU) c2[e] = f2bf(gelu_f(v[e]));
+            for (int e = 0; e < VPL; ++e) if (n + e < p.N) w[e] *= gelu_grad_f(bf2f(ax[e]));
           }
-      }
-    } else if (EPI == EPI_ATOMIC_F32) {
-      float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nb;
+        }
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+        if (full) {
+          *reinterpret_cast<uint4*>(c) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+        } else {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) if (full || nb + e < p.N) atomicAdd(c + e, v[e]);
-    } else {
-      size_t orow = (size_t)m;
-      if (EPI == EPI_RESID_F32) {
-        const float s = (p.seq_scale != nullptr) ? p.seq_scale[p.row2seq[m]] : 1.0f;
-        const float* rs = p.resid + (size_t)m * p.ldr + nb;
+          for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(w[e]);
+        }
+        if (EPI == EPI_BF16_GELU) {
+          bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n;
+          if (full) {
+            *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(gelu_f(w[0]), gelu_f(w[1])), pack_bf2(gelu_f(w[2]), gelu_f(w[3])),
+                                                       pack_bf2(gelu_f(w[4]), gelu_f(w[5])), pack_bf2(gelu_f(w[6]), gelu_f(w[7])));
+          } else {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) if (full || nb + e < p.N) v[e] = rs[e] + s * v[e];
-      } else if (EPI == EPI_EMBED_F32) {
-        const int b = m / p.npatch, t = m - b * p.npatch;
-        orow = (size_t)m + b + 1;                       // one cls row in front of every sequence
-        const float* ps = p.pos + (size_t)(t + 1) * p.N + nb;
+            for (int e = 0; e < VPL; ++e) if (n + e < p.N) c2[e] = f2bf(gelu_f(w[e]));
+          }
+        }
+      } else if (EPI == EPI_ATOMIC_F32) {
+        float* c = reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) if (full || nb + e < p.N) v[e] += ps[e];
-      }
-      float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + nb;
-      if (full) {
+        for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) atomicAdd(c + e, w[e]);
+      } else {                                                                        // VPL == 4: one float4
+        if (EPI == EPI_RESID_F32) {
+          const float* rs = p.resid + (size_t)m * p.ldr + n;
+          if (full) {
+            const float4 r4 = *reinterpret_cast<const float4*>(rs);
+            w[0] = r4.x + sc * w[0]; w[1] = r4.y + sc * w[1]; w[2] = r4.z + sc * w[2]; w[3] = r4.w + sc * w[3];
+          } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          reinterpret_cast<float4*>(c)[e] = make_float4(v[4 * e], v[4 * e + 1], v[4 * e + 2], v[4 * e + 3]);
-      } else {
+            for (int e = 0; e < VPL; ++e) if (n + e < p.N) w[e] = rs[e] + sc * w[e];
+          }
+        } else if (EPI == EPI_EMBED_F32) {
+          const float* ps = p.pos + (size_t)tpos * p.N + n;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) if (nb + e < p.N) c[e] = v[e];
+          for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) w[e] += ps[e];
+        }
+        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+        if (full) {
+          *reinterpret_cast<float4*>(c) = make_float4(w[0], w[1], w[2], w[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = w[e];
+        }
       }
     }
   }
@@ -311,9 +353,10 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
 }  // namespace
 
 extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g != nullptr && g->A && g->B && g->C, "null operand");
   LAFS_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0, "empty problem");
-  LAFS_CHECK_ARG(g->K % 64 == 0, "K must be a multiple of 64");
+  LAFS_CHECK_ARG(g->K % 32 == 0, "K must be a multiple of 32");
   LAFS_CHECK_ARG(g->lda % 8 == 0 && g->ldb % 8 == 0, "lda/ldb must be multiples of 8 elements (16-byte rows)");
   NTArgs a;
   a.A = (const bf16_t*)g->A; a.B = (const bf16_t*)g->B;
@@ -326,9 +369,9 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   a.klen = g->K;
   if (g->epilogue == LAFS_EPI_ATOMIC_F32) {
     splits = g->splits > 0 ? g->splits : 1;
-    const int ksteps = g->K / 64;
+    const int ksteps = g->K / 32;
     splits = splits > ksteps ? ksteps : splits;
-    a.klen = ceil_div(ksteps, splits) * 64;
+    a.klen = ceil_div(ksteps, splits) * 32;
     splits = ceil_div(g->K, a.klen);
   }
   const bool vec_ok = (g->ldc % 8 == 0);
@@ -358,6 +401,7 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
 
 extern "C" int lafs_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* C, int ldc,
                                 int M, int N1, int N2, int splits, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(A && B && C, "null operand");
   LAFS_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0, "empty problem");
   LAFS_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && N1 % 8 == 0 && N2 % 8 == 0, "N1/N2/lda/ldb must be multiples of 8");

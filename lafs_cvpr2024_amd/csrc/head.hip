@@ -149,6 +149,7 @@ __global__ __launch_bounds__(256) void weightnorm_bwd_kernel(const float* __rest
 }  // namespace
 
 extern "C" int lafs_l2norm_fwd(const float* x, int ldx, void* y_bf16, int ldy, float* inv_norm, int rows, int D, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && y_bf16 && inv_norm && rows > 0 && D > 0 && D % 4 == 0 && D <= 1024, "D must be a multiple of 4 and <= 1024");
   hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, x, ldx, (bf16_t*)y_bf16, ldy, inv_norm, rows, D);
   LAFS_LAUNCH_CHECK();
@@ -157,6 +158,7 @@ extern "C" int lafs_l2norm_fwd(const float* x, int ldx, void* y_bf16, int ldy, f
 
 extern "C" int lafs_l2norm_bwd(const float* x, int ldx, const float* dy, int lddy, const float* inv_norm, float* dx, int lddx,
                                int rows, int D, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && dy && inv_norm && dx && rows > 0 && D > 0 && D % 4 == 0 && D <= 1024, "D must be a multiple of 4 and <= 1024");
   hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, x, ldx, dy, lddy, inv_norm, dx, lddx, rows, D);
   LAFS_LAUNCH_CHECK();
@@ -165,6 +167,7 @@ extern "C" int lafs_l2norm_bwd(const float* x, int ldx, const float* dy, int ldd
 
 extern "C" int lafs_weightnorm_fwd(const float* v, const float* g, int K, int Kpad, int D, void* w, void* w_t, int ldwt,
                                    float* inv_norm, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(v && g && w && inv_norm && K > 0 && Kpad >= K && D > 0 && D % 4 == 0 && D <= 1024, "bad operand");
   LAFS_CHECK_ARG(w_t == nullptr || (D <= 256 && Kpad % 8 == 0 && ldwt % 8 == 0 && ldwt >= Kpad), "w_t needs D <= 256 and 8-aligned Kpad/ldwt");
   hipLaunchKernelGGL(weightnorm_fwd_kernel, dim3(ceil_div(Kpad, 64)), dim3(256), 0, stream, v, g, K, Kpad, D, (bf16_t*)w, (bf16_t*)w_t,
@@ -175,6 +178,7 @@ extern "C" int lafs_weightnorm_fwd(const float* v, const float* g, int K, int Kp
 
 extern "C" int lafs_weightnorm_bwd(const float* dw, const float* v, const float* g, const float* inv_norm, int K, int D,
                                    float* dv, float* dg, int accumulate, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(dw && v && g && inv_norm && dv && K > 0 && D > 0 && D % 4 == 0 && D <= 1024, "bad operand");
   hipLaunchKernelGGL(weightnorm_bwd_kernel, dim3(ceil_div(K, 4)), dim3(256), 0, stream, dw, v, g, inv_norm, K, D, dv, dg, accumulate);
   LAFS_LAUNCH_CHECK();

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 extern "C" int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps,
                                   void* y_bf16, int ldy, float* y_f32, int ldyf, float* stats, int rows, int D,
                                   hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && gamma && beta && stats && (y_bf16 || y_f32), "null operand");
   LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
   LAFS_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldyf % 4 == 0, "row strides must be multiples of 4");
@@ -190,6 +191,7 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
                                   const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
                                   void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
                                   float* dgamma, float* dbeta, int rows, int D, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG((dy_bf16 || dy_f32) && x && stats && gamma && g_io && dgamma && dbeta, "null operand");
   LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
   LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
@@ -205,6 +207,7 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
 
 extern "C" int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb, const float* seq_scale,
                                     const int32_t* row2seq, int rows, int D, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g && gb && rows > 0 && D > 0 && D % 4 == 0, "bad operand");
   LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
   const size_t total = (size_t)rows * (D / 4);
@@ -216,6 +219,7 @@ extern "C" int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb,
 }
 
 extern "C" int lafs_colsum_bf16_acc(const void* X, int ldx, int M, int N, float* out, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(X && out && M > 0 && N > 0, "bad operand");
   hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(N, 64), ceil_div(M, 256)), dim3(256), 0, stream,
                      (const bf16_t*)X, ldx, M, N, out);

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 
 extern "C" int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, const float* hyper,
                                float* seg_sumsq, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(grad && chunk_seg && hyper && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31), "bad operand");
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)n_chunks), dim3(256), 0, stream, grad, chunk_seg, hyper, seg_sumsq);
   LAFS_LAUNCH_CHECK();
@@ -127,6 +128,7 @@ extern "C" int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_a
                                    void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t n_chunks,
                                    const int32_t* seg_flags, int32_t* seg_step, int n_seg, const float* seg_sumsq,
                                    const float* hyper, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && chunk_seg && seg_flags && seg_step && seg_sumsq && hyper, "null operand");
   LAFS_CHECK_ARG(n_chunks > 0 && n_chunks < (1ll << 31) && n_seg > 0, "bad sizes");
   hipLaunchKernelGGL(seg_step_kernel, dim3(ceil_div(n_seg, 256)), dim3(256), 0, stream, seg_flags, seg_step, n_seg, hyper);
@@ -137,6 +139,7 @@ extern "C" int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_a
 }
 
 extern "C" int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(src && dst && n > 0, "bad operand");
   int64_t blocks = (n + 1023) / 1024;
   if (blocks > 8192) blocks = 8192;
@@ -146,6 +149,7 @@ extern "C" int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_
 }
 
 extern "C" int lafs_transpose_cast_bf16(const float* src, int rows, int cols, void* dst, int ld_dst, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_dst >= rows, "bad operand");
   hipLaunchKernelGGL(transpose_cast_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0, stream, src, rows, cols,
                      (bf16_t*)dst, ld_dst);

@@ -1,0 +1,233 @@
+"""Fused LAFS pre-training step (reference lafs_train.py:513-613) for one MI355X rank.
+
+    teacher fwd (global crops) -> student fwd (all crops, one packed pass) -> fused DINO loss fwd+bwd ->
+    head bwd -> [RCCL all-reduce of head grads + center sum, overlapped with] trunk bwd -> [all-reduce trunk grads] ->
+    per-tensor clip + AdamW + teacher EMA + bf16 shadow refresh (one launch) -> center EMA
+
+Everything between the brackets is captured once into hipGraphs (static buffers, hyper-parameters in a device
+buffer that is refreshed by one async H2D copy per step), so a step costs three graph launches instead of ~1500
+kernel launches from Python.  Collectives stay outside the graphs and run through torch.distributed ("nccl" = RCCL).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, functional as Fn, ops
+from .arena import ParamArena
+from .ops import _p, call
+from .vision_transformer import VisionTransformer, attach_arena, _is_matrix_for_dgrad
+
+f32, bf16 = torch.float32, torch.bfloat16
+
+
+def _interp_matrix(grid_src, grid_dst, device):
+    """Dense matrix of torch's bicubic F.interpolate from a g x g grid to an r x r grid with the reference's
+    scale_factor = (r + 0.1) / g (vision_transformer.py:184-191): a fixed linear map, built once by pushing the
+    identity through the same torch op, so pos tokens (and their gradient) become one small matmul."""
+    n = grid_src * grid_src
+    eye = torch.eye(n, device=device).view(1, n, grid_src, grid_src)
+    sf = (grid_dst + 0.1) / grid_src
+    out = torch.nn.functional.interpolate(eye, scale_factor=(sf, sf), mode="bicubic")
+    assert out.shape[-1] == grid_dst and out.shape[-2] == grid_dst
+    return out.view(n, grid_dst * grid_dst).t().contiguous()            # [r*r, g*g]
+
+
+class LafsPretrainEngine:
+    def __init__(self, student, teacher, dino_loss, batch_size, n_local=8, global_size=112, local_size=48,
+                 clip_grad=3.0, freeze_last_layer=1, use_graph=True, device=None, grad_slices=2):
+        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        self.student, self.teacher, self.dino_loss = student, teacher, dino_loss
+        self.B, self.n_local, self.ncrops = batch_size, n_local, 2 + n_local
+        self.clip_grad, self.freeze_last_layer = float(clip_grad or 0.0), freeze_last_layer
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        vit_s, vit_t = student.backbone, teacher.backbone
+        if not isinstance(vit_s, VisionTransformer):
+            raise _lib.LafsHipError("LafsPretrainEngine drives the HIP VisionTransformer backbone")
+        self.sa = attach_arena(student, self.device)
+        self.ta = getattr(teacher, "_lafs_arena", None)
+        if self.ta is None:
+            for p in teacher.parameters():
+                p.requires_grad = False
+            self.ta = ParamArena(teacher, self.device, with_grad=False, transposed=None)
+            object.__setattr__(teacher, "_lafs_arena", self.ta)
+            for name, m in teacher.named_modules():
+                if hasattr(m, "_bind_arena"):
+                    m._bind_arena(self.ta, name + "." if name else "")
+        if self.sa.names != self.ta.names or self.sa.size != self.ta.size:
+            raise _lib.LafsHipError("student and teacher must have identical parameter layouts")
+        dino_loss.to(self.device)
+        self.K = student.head.out_dim
+        self.Kpad = (self.K + 127) // 128 * 128
+        B, D = batch_size, vit_s.embed_dim
+        self.geom_s = Fn.geometry([(2 * B, global_size), (n_local * B, local_size)] if n_local else [(2 * B, global_size)], self.device)
+        self.geom_t = Fn.geometry([(2 * B, global_size)], self.device)
+        self.spec_s, self.spec_t = vit_s._spec, vit_t._spec
+        self.head_prefix_s, self.head_prefix_t = student.head._prefix, teacher.head._prefix
+        # bicubic resampling matrices for the stored position table
+        g = int(math.isqrt(vit_s.pos_embed.shape[1] - 1))
+        self.grids = [global_size // 8] + ([local_size // 8] if n_local else [])
+        self.interp = [None if r == g else _interp_matrix(g, r, self.device) for r in self.grids]
+        # static buffers
+        dev = self.device
+        self.hyper = torch.zeros(_lib.HP_COUNT, device=dev, dtype=f32)
+        self.hyper_host = torch.zeros(_lib.HP_COUNT, dtype=f32).pin_memory()
+        self.temps = torch.zeros(2, device=dev, dtype=f32)
+        self.temps_host = torch.zeros(2, dtype=f32).pin_memory()
+        self.logits_s = torch.zeros(self.ncrops * B, self.Kpad, device=dev, dtype=f32)
+        self.logits_t = torch.zeros(2 * B, self.Kpad, device=dev, dtype=f32)
+        self.dlogits = torch.zeros(self.ncrops * B, self.Kpad, device=dev, dtype=bf16)
+        self.loss = torch.zeros(1, device=dev, dtype=f32)
+        self.loss_ws = torch.empty(_lib.lib().lafs_dino_loss_workspace(self.ncrops, B, self.K), device=dev, dtype=f32)
+        self.colsum = torch.zeros(self.K, device=dev, dtype=f32)
+        self.in_global_all = torch.zeros(2 * B, 3, global_size, global_size, device=dev)
+        self.in_local_all = torch.zeros(max(n_local, 1) * B, 3, local_size, local_size, device=dev)
+        self.in_global = list(self.in_global_all.split(B))
+        self.in_local = list(self.in_local_all.split(B))[:n_local]
+        # gradient ranges for the two all-reduces: [trunk | head]
+        self.head_start = min(o for n, o in self.sa.offsets.items() if n.startswith(self.head_prefix_s))
+        self.depth = vit_s.depth
+        n_sl = max(1, min(grad_slices, self.depth))
+        cuts = [round(self.depth * i / n_sl) for i in range(n_sl, -1, -1)]
+        self.layer_slices = [(cuts[i], cuts[i + 1]) for i in range(n_sl)]
+        self.use_graph = use_graph
+        self._graphs = None
+        self._st = {}
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ pieces (all capturable)
+    def _pos_tokens(self, arena, spec):
+        pe = arena.view(arena.master, spec.prefix + "pos_embed").view(-1, spec.trunk.dim)
+        out = []
+        for M in self.interp:
+            out.append(pe if M is None else torch.cat((pe[:1], M @ pe[1:])))
+        return out
+
+    def _seg_forward(self):
+        sa, ta, B = self.sa, self.ta, self.B
+        sa.grad.zero_()
+        # teacher: two global views, no activations kept
+        pos_t = self._pos_tokens(ta, self.spec_t)[:1]
+        feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, None, save=False)
+        Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self.logits_t)
+        # student: all views in one packed pass
+        vit = self.student.backbone
+        drop = vit._sample_drop_scales(self.geom_s) if vit.training else None
+        imgs = [self.in_global_all] + ([self.in_local_all] if self.n_local else [])
+        feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s), drop, save=True)
+        _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self.logits_s)
+        # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
+        ops.dino_loss_fwd_bwd(self.logits_s, self.logits_t, self.dino_loss.center.view(-1), self.ncrops,
+                              float(self.dino_loss.student_temp), 0.04, K=self.K, grad=self.dlogits, ws=self.loss_ws,
+                              loss=self.loss, dev_temps=self.temps)
+        call("lafs_colsum_f32", _p(self.logits_t), self.Kpad, 2 * B, self.K, _p(self.colsum))
+        train_g = self.student.head.last_layer.weight_g.requires_grad
+        dfeat = Fn.head_backward(sa, self.head_prefix_s, st_h, self.dlogits, train_g=train_g)
+        self._st = dict(vit=st_v, dfeat=dfeat)
+
+    def _seg_trunk_backward(self):
+        sa = self.sa
+        dpos = Fn.vit_backward(sa, self.spec_s, self._st["vit"], self._st["dfeat"], layer_slices=self.layer_slices)
+        gpe = sa.view(sa.grad, self.spec_s.prefix + "pos_embed").view(-1, self.spec_s.trunk.dim)
+        for M, dp in zip(self.interp, dpos):
+            if M is None:
+                gpe += dp
+            else:
+                gpe[:1] += dp[:1]
+                gpe[1:] += M.t() @ dp[1:]
+
+    def _seg_update(self):
+        sa, ta = self.sa, self.ta
+        call("lafs_center_ema", _p(self.dino_loss.center), _p(self.colsum), self.K, 1.0 / (2 * self.B * self.world),
+             float(self.dino_loss.center_momentum))
+        sa.seg_sumsq.zero_()
+        call("lafs_grad_sumsq", _p(sa.grad), _p(sa.chunk_seg), sa.n_chunks, _p(self.hyper), _p(sa.seg_sumsq))
+        call("lafs_clip_adamw_ema", _p(sa.master), _p(sa.grad), _p(sa.exp_avg), _p(sa.exp_avg_sq), _p(ta.master),
+             _p(sa.shadow), _p(ta.shadow), _p(sa.chunk_seg), sa.n_chunks, _p(sa.seg_flags), _p(sa.seg_step), sa.n_seg,
+             _p(sa.seg_sumsq), _p(self.hyper))
+        sa.refresh_transposed()
+
+    # ------------------------------------------------------------------ step
+    def _capture(self):
+        segs = [self._seg_forward, self._seg_trunk_backward, self._seg_update]
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                       # warm-up outside capture (lazy inits, caches)
+            for f in segs:
+                f()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graphs, pool = [], None
+        for f in segs:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                f()
+            pool = g.pool()
+            graphs.append(g)
+        self._graphs = graphs
+
+    def set_inputs(self, crops):
+        """crops: list of 2 global + n_local local NCHW tensors (any device); copied into the static input buffers."""
+        for dst, src in zip(self.in_global + self.in_local, crops):
+            dst.copy_(src, non_blocking=True)
+
+    def step(self, crops=None, *, lr, wd, momentum, teacher_temp, epoch, beta1=0.9, beta2=0.999, eps=1e-8):
+        """One optimisation step.  Returns the device scalar loss (no host sync)."""
+        if crops is not None:
+            self.set_inputs(crops)
+        h = self.hyper_host
+        h[_lib.HP_LR], h[_lib.HP_WD], h[_lib.HP_BETA1], h[_lib.HP_BETA2], h[_lib.HP_EPS] = lr, wd, beta1, beta2, eps
+        h[_lib.HP_CLIP], h[_lib.HP_EMA_M] = self.clip_grad, momentum
+        h[_lib.HP_FREEZE_LAST] = 1.0 if epoch < self.freeze_last_layer else 0.0
+        h[_lib.HP_GRAD_SCALE] = 1.0 / self.world            # DDP mean of the summed gradients
+        self.hyper.copy_(h, non_blocking=True)
+        self.temps_host[0], self.temps_host[1] = float(self.dino_loss.student_temp), teacher_temp
+        self.temps.copy_(self.temps_host, non_blocking=True)
+        if self.use_graph and self._graphs is None:
+            saved = self._snapshot()
+            self._capture()
+            self._restore(saved)
+            self.hyper.copy_(h, non_blocking=True)
+        run = (lambda i, f: self._graphs[i].replay()) if self.use_graph else (lambda i, f: f())
+        run(0, self._seg_forward)
+        works = []
+        if self.world > 1:
+            works.append(dist.all_reduce(self.sa.grad[self.head_start:], async_op=True))
+            works.append(dist.all_reduce(self.colsum, async_op=True))
+        run(1, self._seg_trunk_backward)
+        if self.world > 1:
+            works.append(dist.all_reduce(self.sa.grad[:self.head_start], async_op=True))
+            for w in works:
+                w.wait()
+        run(2, self._seg_update)
+        self.step_count += 1
+        return self.loss
+
+    # warm-up/capture executes real optimisation steps on whatever is in the buffers: snapshot and restore the state
+    def _snapshot(self):
+        sa, ta = self.sa, self.ta
+        return [t.clone() for t in (sa.master, sa.exp_avg, sa.exp_avg_sq, sa.seg_step, ta.master, self.dino_loss.center)], \
+            torch.cuda.get_rng_state(self.device)
+
+    def _restore(self, saved):
+        tensors, rng = saved
+        sa, ta = self.sa, self.ta
+        for dst, src in zip((sa.master, sa.exp_avg, sa.exp_avg_sq, sa.seg_step, ta.master, self.dino_loss.center), tensors):
+            dst.copy_(src)
+        sa.refresh_shadows()
+        ta.refresh_shadows()
+        torch.cuda.set_rng_state(rng, self.device)
+
+    # ------------------------------------------------------------------ checkpoint helpers (reference layout)
+    def optimizer_state_dict(self):
+        sa = self.sa
+        return {"lafs_arena": {"exp_avg": sa.exp_avg.cpu(), "exp_avg_sq": sa.exp_avg_sq.cpu(), "seg_step": sa.seg_step.cpu(),
+                               "names": list(sa.names)}}
+
+    def load_optimizer_state_dict(self, sd):
+        a = sd.get("lafs_arena")
+        if a is None or a["names"] != list(self.sa.names):
+            print("=> optimizer state in checkpoint is not a lafs arena state; moments start from zero")
+            return
+        self.sa.exp_avg.copy_(a["exp_avg"]); self.sa.exp_avg_sq.copy_(a["exp_avg_sq"]); self.sa.seg_step.copy_(a["seg_step"])

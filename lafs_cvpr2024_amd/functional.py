@@ -88,7 +88,7 @@ def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=No
             setattr(b, f, arena.offsets[nm[f]])
         b.b_qkv = arena.offsets[nm["b_qkv"]] if nm.get("b_qkv") else -1
         for f in ("w_qkv", "w_proj", "w_fc1", "w_fc2"):
-            setattr(b, f + "_t", arena.t_offsets[nm[f]])
+            setattr(b, f + "_t", arena.t_offsets.get(nm[f], 0))      # teacher arenas keep no W^T (forward only)
     d = _lib.TrunkDesc()
     d.dim, d.inner, d.heads, d.mlp, d.depth = spec.dim, spec.inner, spec.heads, spec.mlp, spec.depth
     d.ln_eps, d.attn_scale = spec.ln_eps, spec.attn_scale

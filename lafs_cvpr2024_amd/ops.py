@@ -142,16 +142,18 @@ def patchify(img, order=_lib.PATCH_ORDER_CHW):
 
 
 def dino_loss_fwd_bwd(student, teacher, center, ncrops, student_temp, teacher_temp, K=None, grad=None, grad_bf16=True,
-                      grad_scale=1.0):
+                      grad_scale=1.0, ws=None, loss=None, dev_temps=None):
     """Returns (loss[1] f32, grad [rows, ld] bf16|f32).  student/teacher may be padded (ld >= K)."""
     _chk(student, torch.float32, "student"); _chk(teacher, torch.float32, "teacher")
     rows, ld = student.shape[0], _ld(student)
     K = student.shape[1] if K is None else K
     B = rows // ncrops
-    ws = torch.empty(_lib.lib().lafs_dino_loss_workspace(ncrops, B, K), device=student.device, dtype=torch.float32)
-    loss = torch.empty(1, device=student.device, dtype=torch.float32)
+    if ws is None:
+        ws = torch.empty(_lib.lib().lafs_dino_loss_workspace(ncrops, B, K), device=student.device, dtype=torch.float32)
+    if loss is None:
+        loss = torch.empty(1, device=student.device, dtype=torch.float32)
     if grad is None:
         grad = torch.zeros(rows, ld, device=student.device, dtype=bf16 if grad_bf16 else torch.float32)
     call("lafs_dino_loss_fwd_bwd", _p(student), _p(teacher), ld, _p(center), ncrops, B, K, student_temp, teacher_temp,
-         _p(loss), _p(grad), _ld(grad), 1 if grad.dtype == bf16 else 0, grad_scale, _p(ws))
+         _p(loss), _p(grad), _ld(grad), 1 if grad.dtype == bf16 else 0, grad_scale, _p(ws), _p(dev_temps))
     return loss, grad

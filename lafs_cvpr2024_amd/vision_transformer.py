@@ -134,6 +134,7 @@ class VisionTransformer(nn.Module):
         object.__setattr__(self, "_arena", arena)
         self._spec = Fn.ViTSpec(trunk=trunk, prefix=prefix)
         self._hook = torch.zeros(1, device=arena.device, requires_grad=True)
+        self._keep_prob = 1.0 - torch.tensor(self.drop_path_rates, device=arena.device, dtype=torch.float32).view(-1, 1, 1)
 
     def _ensure_arena(self):
         if self._arena is None:
@@ -145,7 +146,7 @@ class VisionTransformer(nn.Module):
         (reference drop_path, vision_transformer.py:27-35): [depth, 2, n_seq] f32, or None when all rates are 0."""
         if not any(self.drop_path_rates):
             return None
-        keep = 1.0 - torch.tensor(self.drop_path_rates, device=self._arena.device, dtype=torch.float32).view(-1, 1, 1)
+        keep = self._keep_prob                       # device tensor made at bind time (no H2D inside graph capture)
         u = torch.rand(self.depth, 2, geom.n_seq, device=self._arena.device)
         return (torch.floor(keep + u) / keep).contiguous()
 

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the hot kernels at the C2 shapes (ViT-S, B=64: 44160 student tokens).  GPU box only."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lafs_cvpr2024_amd import _lib, ops
+
+dev = "cuda"
+bf = torch.bfloat16
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def nt(M, N, K, epi, name):
+    A = torch.randn(M, K, device=dev).to(bf); B = (torch.randn(N, K, device=dev) * .02).to(bf)
+    bias = torch.zeros(N, device=dev)
+    kw = {}
+    f32 = epi in (_lib.EPI_RESID_F32, _lib.EPI_F32)
+    out = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else bf)
+    byts = (M * K + N * K) * 2 + M * N * (4 if f32 else 2)
+    if epi == _lib.EPI_BF16_GELU:
+        kw["out2"] = torch.empty(M, N, device=dev, dtype=bf); byts += M * N * 2
+    if epi == _lib.EPI_RESID_F32:
+        kw["resid"] = torch.randn(M, N, device=dev); byts += M * N * 4
+    if epi == _lib.EPI_DGELU_BF16:
+        kw["aux"] = torch.randn(M, N, device=dev).to(bf); byts += M * N * 2
+    t = timeit(lambda: ops.gemm_nt(A, B, epi, bias=None if epi == _lib.EPI_DGELU_BF16 else bias, out=out, **kw))
+    print(f"NT {name:22s} M={M:6d} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s  {byts/t/1e9:7.0f} GB/s")
+
+
+def tn(M, N1, N2, name):
+    A = torch.randn(M, N1, device=dev).to(bf); B = torch.randn(M, N2, device=dev).to(bf)
+    C = torch.zeros(N1, N2, device=dev)
+    t = timeit(lambda: ops.gemm_tn_acc(A, B, C))
+    print(f"TN {name:22s} M={M:6d} N1={N1:4d} N2={N2:5d}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TF/s  {(M*(N1+N2)*2)/t/1e9:7.0f} GB/s")
+
+
+T = 44160
+nt(T, 1152, 384, _lib.EPI_BF16, "qkv fwd")
+nt(T, 384, 384, _lib.EPI_RESID_F32, "proj fwd")
+nt(T, 1536, 384, _lib.EPI_BF16_GELU, "fc1 fwd")
+nt(T, 384, 1536, _lib.EPI_RESID_F32, "fc2 fwd")
+nt(T, 1536, 384, _lib.EPI_DGELU_BF16, "fc2 dgrad")
+nt(T, 384, 1536, _lib.EPI_BF16, "fc1 dgrad")
+nt(T, 384, 384, _lib.EPI_BF16, "proj dgrad")
+nt(T, 384, 1152, _lib.EPI_BF16, "qkv dgrad")
+nt(640, 100096, 256, _lib.EPI_F32, "last layer")
+nt(4096, 4096, 4096, _lib.EPI_BF16, "square 4k")
+tn(T, 384, 1536, "fc2 wgrad")
+tn(T, 1536, 384, "fc1 wgrad")
+tn(T, 384, 384, "proj wgrad")
+tn(T, 1152, 384, "qkv wgrad")
+tn(640, 100096, 256, "last wgrad")
