@@ -30,6 +30,8 @@ int lafs_version(void);
 /* Diagnostic: lane l of one wave issues ds_read_b64_tr_b16 at LDS byte 8*l over in(i16)[512]; out(i16)[256] gets
  * the 4 values each lane received.  Pins the LDS-transpose-read model used by the attention / wgrad kernels. */
 int lafs_debug_tr16(const void* in, void* out, hipStream_t stream);
+/* Diagnostic flags for timing experiments only (results become wrong); never set on the product path. */
+int lafs_debug_set(int flags);
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* lafs_last_error(void);
 
@@ -68,9 +70,10 @@ typedef struct lafs_gemm_nt_args {
 int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
 
 /* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
- * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0. */
+ * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0.
+ * colsum_a (optional f32 [N1]) += column sums of A: the bias gradient db = sum_m dY[m,:] rides along for free. */
 int lafs_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* C, int ldc,
-                     int M, int N1, int N2, int splits, hipStream_t stream);
+                     int M, int N1, int N2, int splits, float* colsum_a, hipStream_t stream);
 
 /* out(f32)[n] += sum_m X(bf16)[m, n]   (bias gradients). */
 int lafs_colsum_bf16_acc(const void* X, int ldx, int M, int N, float* out, hipStream_t stream);

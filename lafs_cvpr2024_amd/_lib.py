@@ -52,7 +52,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "lafs_debug_tr16": [vp, vp],
     "lafs_gemm_nt": [C.POINTER(GemmNTArgs)],
-    "lafs_gemm_tn_acc": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32],
+    "lafs_gemm_tn_acc": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
     "lafs_layernorm_fwd": [vp, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32],
     "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32],
@@ -84,6 +84,7 @@ _PROTOS = {
 }
 _NO_STREAM = {
     "lafs_version": ([], i32),
+    "lafs_debug_set": ([i32], i32),
     "lafs_last_error": ([], C.c_char_p),
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),

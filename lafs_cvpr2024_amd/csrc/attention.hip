@@ -18,7 +18,10 @@
 // LDS layouts for a [rows][64] bf16 tile (128-byte rows):
 //   R (row fragments, ds_read_b128): 16-byte chunk c of row r stored at chunk c ^ (r & 7)
 //   T (transpose reads):             8-byte unit u of row r stored at unit  u ^ ((r >> 1) & 3)
-// Both are conflict-free for their access pattern.
+//   F (both, used by the backward):  8-byte unit u of row r stored at unit  u ^ F(r), F = x0 | x1<<1 | x1<<2 | x0<<3 with
+//                                    x = (r >> 1) & 3; a row fragment is then ONE ds_read_b128 at chunk c ^ (F >> 1) whose
+//                                    two 8-byte halves arrive swapped when F & 1 (undone with 4 v_cndmask).
+// All three are conflict-free for their access patterns (tools/lds_bank_sim.py).
 #include <mutex>
 #include <set>
 #include "common.hpp"
@@ -38,8 +41,13 @@ __device__ __forceinline__ bf16x8_t pack_frag(const float* v) {
   return __builtin_bit_cast(bf16x8_t, w);
 }
 
+__device__ __forceinline__ int lds_f(int row) {
+  const int x = (row >> 1) & 3;
+  return (x & 1) | ((x >> 1) << 1) | ((x >> 1) << 2) | ((x & 1) << 3);
+}
+
 // Stage `rows_pad` rows x 64 columns (bf16) starting at src (row stride ld elements) into LDS; rows >= len are zero.
-// LAYOUT 0 = R, 1 = T.  `nthreads` cooperating threads, this thread's index `lt`.
+// LAYOUT 0 = R, 1 = T, 2 = F.  `nthreads` cooperating threads, this thread's index `lt`.
 template <int LAYOUT>
 __device__ __forceinline__ void stage_tile(unsigned char* dst, const bf16_t* src, int ld, int len, int rows_pad, int lt,
                                            int nthreads) {
@@ -49,6 +57,10 @@ __device__ __forceinline__ void stage_tile(unsigned char* dst, const bf16_t* src
     if (row < len) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
     if (LAYOUT == 0) {
       *reinterpret_cast<uint4*>(dst + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
+    } else if (LAYOUT == 2) {
+      const int f = lds_f(row);
+      if (f & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+      *reinterpret_cast<uint4*>(dst + row * 128 + ((ch ^ (f >> 1)) << 4)) = v;
     } else {
       const int x = (row >> 1) & 3;
       if (x & 1) v = make_uint4(v.z, v.w, v.x, v.y);          // units 2ch,2ch+1 swap places under ^1
@@ -69,6 +81,23 @@ __device__ __forceinline__ bf16x8_t tfrag(const unsigned char* tile, int ta, int
   const int ra = ta * 16 + g * 4 + (p >> 2), rb = tb * 16 + g * 4 + (p >> 2);
   s16x4_t lo = lds_read_tr16(tile + ra * 128 + ((unit ^ ((ra >> 1) & 3)) << 3));
   s16x4_t hi = lds_read_tr16(tile + rb * 128 + ((unit ^ ((rb >> 1) & 3)) << 3));
+  return to_frag(lo, hi);
+}
+
+// row fragment from an F tile (swap = F(row) & 1 is the same for every 16-row tile: it only depends on lane & 15)
+__device__ __forceinline__ bf16x8_t rfrag_f(const unsigned char* tile, int row, int chunk, bool swap) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+  u32x4_t v = *reinterpret_cast<const u32x4_t*>(tile + row * 128 + ((chunk ^ (lds_f(row) >> 1)) << 4));
+  u32x4_t w = {swap ? v[2] : v[0], swap ? v[3] : v[1], swap ? v[0] : v[2], swap ? v[1] : v[3]};
+  return __builtin_bit_cast(bf16x8_t, w);
+}
+// transposed fragment from an F tile (same contract as tfrag)
+__device__ __forceinline__ bf16x8_t tfrag_f(const unsigned char* tile, int ta, int tb, int dt, int lane) {
+  const int g = lane >> 4, p = lane & 15;
+  const int unit = (p & 3) * 4 + dt;
+  const int ra = ta * 16 + g * 4 + (p >> 2), rb = tb * 16 + g * 4 + (p >> 2);
+  s16x4_t lo = lds_read_tr16(tile + ra * 128 + ((unit ^ lds_f(ra)) << 3));
+  s16x4_t hi = lds_read_tr16(tile + rb * 128 + ((unit ^ lds_f(rb)) << 3));
   return to_frag(lo, hi);
 }
 
@@ -196,7 +225,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-// LDS per pair: K (R), K (T), V (R)
+// LDS per pair: K (F: row fragments and transpose reads), V (R)
 template <int NT, int PPB>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -213,10 +242,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
       const int seq = pair / a.heads, h = pair % a.heads;
       const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
       const bf16_t* base = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
-      unsigned char* s0 = smem + pl * 3 * TILE;
-      stage_tile<0>(s0, base + inner, a.ldqkv, len, NT * 16, lt, TPP);
-      stage_tile<1>(s0 + TILE, base + inner, a.ldqkv, len, NT * 16, lt, TPP);
-      stage_tile<0>(s0 + 2 * TILE, base + 2 * inner, a.ldqkv, len, NT * 16, lt, TPP);
+      unsigned char* s0 = smem + pl * 2 * TILE;
+      stage_tile<2>(s0, base + inner, a.ldqkv, len, NT * 16, lt, TPP);
+      stage_tile<0>(s0 + TILE, base + 2 * inner, a.ldqkv, len, NT * 16, lt, TPP);
     }
   }
   __syncthreads();
@@ -227,9 +255,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     const int seq = pair / a.heads, h = pair % a.heads;
     const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
     if (qt * 16 >= len) continue;
-    const unsigned char* KsR = smem + pl * 3 * TILE;
-    const unsigned char* KsT = KsR + TILE;
-    const unsigned char* VsR = KsR + 2 * TILE;
+    const unsigned char* KsF = smem + pl * 2 * TILE;
+    const unsigned char* VsR = KsF + TILE;
+    const bool swp = (lds_f(c16) & 1) != 0;
     const int q = qt * 16 + c16;
     const int qc = min(q, len - 1);
     const bf16_t* qp = a.qkv + (size_t)(tok0 + qc) * a.ldqkv + h * 64 + g * 8;
@@ -251,8 +279,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         if (t < NT) {
           const int krow = t * 16 + c16;
           f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(rfrag(KsR, krow, g), qf0, s);
-          s = mfma16(rfrag(KsR, krow, 4 + g), qf1, s);
+          s = mfma16(rfrag_f(KsF, krow, g, swp), qf0, s);
+          s = mfma16(rfrag_f(KsF, krow, 4 + g, swp), qf1, s);
           dp = mfma16(rfrag(VsR, krow, g), df0, dp);
           dp = mfma16(rfrag(VsR, krow, 4 + g), df1, dp);
 #pragma unroll
@@ -269,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
       const bf16x8_t dsf = pack_frag(ds);
       const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tfrag(KsT, t0, t1, dt, lane), dsf, dq[dt]);
+      for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tfrag_f(KsF, t0, t1, dt, lane), dsf, dq[dt]);
     }
     if (q < len) {
       uint32_t w[8];
@@ -286,11 +314,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-// LDS per pair: Q (R), Q (T), dO (R), dO (T)
+// LDS per pair: Q (F), dO (F), then lse[NT*16] and delta[NT*16] (f32)
 template <int NT, int PPB>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TILE = NT * 16 * 128;
+  constexpr int PAIR_BYTES = 2 * TILE + 2 * NT * 16 * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c16 = lane & 15;
   const int inner = a.heads * 64;
@@ -304,11 +333,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
       const bf16_t* qb = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
       const bf16_t* db = a.dout + (size_t)tok0 * a.lddo + h * 64;
-      unsigned char* s0 = smem + pl * 4 * TILE;
-      stage_tile<0>(s0, qb, a.ldqkv, len, NT * 16, lt, TPP);
-      stage_tile<1>(s0 + TILE, qb, a.ldqkv, len, NT * 16, lt, TPP);
-      stage_tile<0>(s0 + 2 * TILE, db, a.lddo, len, NT * 16, lt, TPP);
-      stage_tile<1>(s0 + 3 * TILE, db, a.lddo, len, NT * 16, lt, TPP);
+      unsigned char* s0 = smem + pl * PAIR_BYTES;
+      stage_tile<2>(s0, qb, a.ldqkv, len, NT * 16, lt, TPP);
+      stage_tile<2>(s0 + TILE, db, a.lddo, len, NT * 16, lt, TPP);
+      float* lsd = reinterpret_cast<float*>(s0 + 2 * TILE);
+      for (int r = lt; r < NT * 16; r += TPP) {
+        const bool ok = r < len;
+        lsd[r] = ok ? a.lse[(size_t)(tok0 + r) * a.heads + h] : 0.f;
+        lsd[NT * 16 + r] = ok ? a.delta[(size_t)(tok0 + r) * a.heads + h] : 0.f;
+      }
     }
   }
   __syncthreads();
@@ -319,10 +352,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     const int seq = pair / a.heads, h = pair % a.heads;
     const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
     if (kt * 16 >= len) continue;
-    const unsigned char* QsR = smem + pl * 4 * TILE;
-    const unsigned char* QsT = QsR + TILE;
-    const unsigned char* DsR = QsR + 2 * TILE;
-    const unsigned char* DsT = QsR + 3 * TILE;
+    const unsigned char* QsF = smem + pl * PAIR_BYTES;
+    const unsigned char* DsF = QsF + TILE;
+    const float* lsd = reinterpret_cast<const float*>(QsF + 2 * TILE);
+    const bool swp = (lds_f(c16) & 1) != 0;
     const int key = kt * 16 + c16;
     const int kc = min(key, len - 1);
     const bf16_t* kp = a.qkv + (size_t)(tok0 + kc) * a.ldqkv + inner + h * 64 + g * 8;
@@ -343,16 +376,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
         if (qt < NT) {
           const int qrow = qt * 16 + c16;
           f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(rfrag(QsR, qrow, g), kf0, s);
-          s = mfma16(rfrag(QsR, qrow, 4 + g), kf1, s);
-          dp = mfma16(rfrag(DsR, qrow, g), vf0, dp);
-          dp = mfma16(rfrag(DsR, qrow, 4 + g), vf1, dp);
+          s = mfma16(rfrag_f(QsF, qrow, g, swp), kf0, s);
+          s = mfma16(rfrag_f(QsF, qrow, 4 + g, swp), kf1, s);
+          dp = mfma16(rfrag_f(DsF, qrow, g, swp), vf0, dp);
+          dp = mfma16(rfrag_f(DsF, qrow, 4 + g, swp), vf1, dp);
+          const float4 l4 = *reinterpret_cast<const float4*>(lsd + qt * 16 + g * 4);
+          const float4 d4 = *reinterpret_cast<const float4*>(lsd + NT * 16 + qt * 16 + g * 4);
+          const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + g * 4 + r;
-            const int qc = min(q, len - 1);
-            const float lse_q = a.lse[(size_t)(tok0 + qc) * a.heads + h];
-            const float del_q = a.delta[(size_t)(tok0 + qc) * a.heads + h];
+            const float lse_q = lq[r], del_q = dq4[r];
             const float p = (q < len && key_ok) ? __expf(s[r] * a.scale - lse_q) : 0.f;
             pv[tt * 4 + r] = p;
             ds[tt * 4 + r] = p * (dp[r] - del_q) * a.scale;
@@ -366,8 +400,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = mfma16(tfrag(DsT, t0, t1, dt, lane), pf, dv[dt]);
-        dk[dt] = mfma16(tfrag(QsT, t0, t1, dt, lane), dsf, dk[dt]);
+        dv[dt] = mfma16(tfrag_f(DsF, t0, t1, dt, lane), pf, dv[dt]);
+        dk[dt] = mfma16(tfrag_f(QsF, t0, t1, dt, lane), dsf, dk[dt]);
       }
     }
     if (key_ok) {
@@ -419,8 +453,8 @@ int dispatch(int which, const AttnArgs& a, hipStream_t s) {
   const int n_pairs = a.n_seq * a.heads;
   const size_t tile = (size_t)NT * 16 * 128;
   if (which == 0) return launch_attn(attn_fwd_kernel<NT, PPB>, n_pairs, PPB, PPB * 2 * tile, a, s);
-  if (which == 1) return launch_attn(attn_bwd_dq_kernel<NT, PPB>, n_pairs, PPB, PPB * 3 * tile, a, s);
-  return launch_attn(attn_bwd_dkv_kernel<NT, PPB>, n_pairs, PPB, PPB * 4 * tile, a, s);
+  if (which == 1) return launch_attn(attn_bwd_dq_kernel<NT, PPB>, n_pairs, PPB, PPB * 2 * tile, a, s);
+  return launch_attn(attn_bwd_dkv_kernel<NT, PPB>, n_pairs, PPB, PPB * (2 * tile + 2 * NT * 16 * 4), a, s);
 }
 
 int dispatch_len(int which, int max_len, const AttnArgs& a, hipStream_t s) {

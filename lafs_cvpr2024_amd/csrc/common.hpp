@@ -52,15 +52,15 @@ __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 
 // the library erff costs ~5x more VALU work and made the GELU epilogue the longest phase of the fc1 GEMM. ----
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);                       // v_rcp_f32 (1 ulp)
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-  const float y = 1.0f - poly * __expf(-ax * ax);
+  const float y = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);  // v_exp_f32
   return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
   const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  const float pdf = 0.39894228040143268f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
   return cdf + x * pdf;
 }
 

@@ -146,23 +146,19 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const LayerBuf& b = c.layers[l];
     const float* x0 = (l == 0) ? x_in : b.x0;
     // ---- MLP branch ----
-    RUN(lafs_colsum_bf16_acc(s.gb, D, T, D, gr + o.b_fc2, stream));
-    RUN(lafs_gemm_tn_acc(s.gb, D, b.a, M, gr + o.w_fc2, M, T, D, M, 0, stream));
+    RUN(lafs_gemm_tn_acc(s.gb, D, b.a, M, gr + o.w_fc2, M, T, D, M, 0, gr + o.b_fc2, stream));
     RUN(gemm(s.gb, D, sht + o.w_fc2_t, D, T, M, D, LAFS_EPI_DGELU_BF16, s.du, M, nullptr, stream, nullptr, 0, nullptr, 0, nullptr,
              nullptr, b.u, M));
-    RUN(lafs_colsum_bf16_acc(s.du, M, T, M, gr + o.b_fc1, stream));
-    RUN(lafs_gemm_tn_acc(s.du, M, b.h2, D, gr + o.w_fc1, D, T, M, D, 0, stream));
+    RUN(lafs_gemm_tn_acc(s.du, M, b.h2, D, gr + o.w_fc1, D, T, M, D, 0, gr + o.b_fc1, stream));
     RUN(gemm(s.du, M, sht + o.w_fc1_t, M, T, D, M, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, b.x1, D, b.st2, d->master + o.ln2_g, g, D, 1, s.gb, D, scale(l, 0), d->row2seq,
                            gr + o.ln2_g, gr + o.ln2_b, T, D, stream));
     // ---- attention branch ----
-    RUN(lafs_colsum_bf16_acc(s.gb, D, T, D, gr + o.b_proj, stream));
-    RUN(lafs_gemm_tn_acc(s.gb, D, b.o, I, gr + o.w_proj, I, T, D, I, 0, stream));
+    RUN(lafs_gemm_tn_acc(s.gb, D, b.o, I, gr + o.w_proj, I, T, D, I, 0, gr + o.b_proj, stream));
     RUN(gemm(s.gb, D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
     RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens, d->n_seq, T, d->max_len, d->heads,
                            d->attn_scale, s.dqkv, 3 * I, stream));
-    if (o.b_qkv >= 0) RUN(lafs_colsum_bf16_acc(s.dqkv, 3 * I, T, 3 * I, gr + o.b_qkv, stream));
-    RUN(lafs_gemm_tn_acc(s.dqkv, 3 * I, b.h1, D, gr + o.w_qkv, D, T, 3 * I, D, 0, stream));
+    RUN(lafs_gemm_tn_acc(s.dqkv, 3 * I, b.h1, D, gr + o.w_qkv, D, T, 3 * I, D, 0, o.b_qkv >= 0 ? gr + o.b_qkv : nullptr, stream));
     RUN(gemm(s.dqkv, 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     const bool more = l > 0;
     RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, x0, D, b.st1, d->master + o.ln1_g, g, D, 1, more ? s.gb : nullptr, D,

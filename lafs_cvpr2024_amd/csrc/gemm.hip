@@ -37,6 +37,7 @@ struct NTArgs {
   const float* seq_scale; const int* row2seq;
   const bf16_t* aux; int ldaux;
   const float* pos; int npatch;
+  int dbg;                          // timing ablations (lafs_debug_set): 16 = no epilogue stores, 32 = no MFMA/ds_read
 };
 
 constexpr int BM = 128, BN = 128;
@@ -76,35 +77,48 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(NTArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NT_NS * NT_STAGE];
+// WM = wave rows: 2 -> 128x128 tile, 256 threads; 4 -> 256x128 tile, 512 threads (one third less L2->LDS traffic per
+// flop).  BK = k-depth of a pipeline stage: 32 (3-stage ring, 64-byte row pieces) or 64 (2-stage ring, full 128-byte
+// cache lines per row piece).
+template <int BK> __device__ __forceinline__ int nt_swzk(int row) { return BK == 32 ? nt_swz(row) : (row & 7); }
+
+template <int EPI, int WM, int BK>
+__global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2)) void gemm_nt_kernel(NTArgs p) {
+  constexpr int THREADS = WM * 128, BMT = WM * 64;
+  constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
+  constexpr int ROWB = BK * 2;                        // bytes per LDS row
+  constexpr int STAGE = (BMT + BN) * ROWB;
+  constexpr int NSTG = (BK == 32) ? 3 : 2;
+  constexpr int NA = (BMT * CPR) / THREADS;           // 16-byte A chunks per thread per stage
+  constexpr int NB = (BN * CPR) / THREADS;            // 16-byte B chunks per thread per stage
+  constexpr int NMAX = NA > NB ? NA : NB;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BMT, n0 = tn * BN;
   const int kbeg = blockIdx.z * p.klen;
   const int kend = min(p.K, kbeg + p.klen);
-  const int nk = (kend - kbeg) / NT_BK;
+  const int nk = (kend - kbeg) / BK;
 
-  // ---- async global -> LDS staging (LDS-DMA): each thread moves 2 x 16 B of A and 2 x 16 B of B per stage.  The LDS
-  // image is lane-linear (wave base + lane*16), so the XOR swizzle is applied to the SOURCE column instead. ----
-  const bf16_t* ga[2]; const bf16_t* gb[2]; int ldsoff[2];
+  // ---- async global -> LDS staging (LDS-DMA).  The LDS image is lane-linear (wave base + lane*16), so the XOR
+  // swizzle is applied to the SOURCE column instead. ----
+  const bf16_t* ga[NA]; const bf16_t* gb[NB]; int ldsoff[NMAX];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = i * 256 + tid, row = q >> 2, ch = (q & 3) ^ nt_swz(row);
-    ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + kbeg + ch * 8;
-    gb[i] = p.B + (size_t)min(n0 + nt_perm<EpiTraits<EPI>::VPL>(row), p.N - 1) * p.ldb + kbeg + ch * 8;
-    ldsoff[i] = (i * 256 + wave * 64) * 16;           // wave-uniform
+  for (int i = 0; i < NMAX; ++i) {
+    const int q = i * THREADS + tid, row = q / CPR, ch = (q % CPR) ^ nt_swzk<BK>(row);
+    if (i < NA) ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + kbeg + ch * 8;
+    if (i < NB) gb[i] = p.B + (size_t)min(n0 + nt_perm<EpiTraits<EPI>::VPL>(row), p.N - 1) * p.ldb + kbeg + ch * 8;
+    ldsoff[i] = (i * THREADS + wave * 64) * 16;       // wave-uniform
   }
   auto issue = [&](int t) {
-    unsigned char* st = smem + (t % NT_NS) * NT_STAGE;
+    unsigned char* st = smem + (t % NSTG) * STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      glds16(ga[i] + t * NT_BK, st + ldsoff[i]);
-      glds16(gb[i] + t * NT_BK, st + BM * NT_BK * 2 + ldsoff[i]);
+    for (int i = 0; i < NMAX; ++i) {
+      if (i < NA) glds16(ga[i] + t * BK, st + ldsoff[i]);
+      if (i < NB) glds16(gb[i] + t * BK, st + BMT * ROWB + ldsoff[i]);
     }
   };
 
@@ -115,38 +129,64 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(NTArgs p) {
     for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
-  int aoff[4], boff[4];
+  int arow[4], brow[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra_ = wr * 64 + i * 16 + frow, rb_ = wc * 64 + i * 16 + frow;
-    aoff[i] = ra_ * 64 + ((fq ^ nt_swz(ra_)) << 4);
-    boff[i] = BM * NT_BK * 2 + rb_ * 64 + ((fq ^ nt_swz(rb_)) << 4);
-  }
-  if (nk > 0) issue(0);
-  if (nk > 1) issue(1);
-  for (int t = 0; t < nk; ++t) {
-    // stage t has landed once at most the 4 loads of stage t+1 are still in flight (loads retire in order)
-    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                    // everyone's part of stage t landed; stage (t-1)%NS is free again
-    if (t + 2 < nk) issue(t + 2);
-    const unsigned char* st = smem + (t % NT_NS) * NT_STAGE;
-    bf16x8_t fa[4], fb[4];
+  for (int i = 0; i < 4; ++i) { arow[i] = wr * 64 + i * 16 + frow; brow[i] = wc * 64 + i * 16 + frow; }
+
+  auto compute = [&](int t) {
+    if (p.dbg & 32) return;
+    const unsigned char* st = smem + (t % NSTG) * STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      fa[i] = *reinterpret_cast<const bf16x8_t*>(st + aoff[i]);
-      fb[i] = *reinterpret_cast<const bf16x8_t*>(st + boff[i]);
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *reinterpret_cast<const bf16x8_t*>(st + arow[i] * ROWB + (((kk * 4 + fq) ^ nt_swzk<BK>(arow[i])) << 4));
+        fb[i] = *reinterpret_cast<const bf16x8_t*>(st + BMT * ROWB + brow[i] * ROWB + (((kk * 4 + fq) ^ nt_swzk<BK>(brow[i])) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = mfma16(fb[j], fa[i], acc[j][i]);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = mfma16(fb[j], fa[i], acc[j][i]);
+  };
+
+  if (NSTG == 3) {
+    if (nk > 0) issue(0);
+    if (nk > 1) issue(1);
+    for (int t = 0; t < nk; ++t) {
+      // stage t has landed once at most the NA+NB loads of stage t+1 are still in flight (loads retire in order)
+      if (t + 1 < nk) {
+        if (NA + NB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                  // everyone's part of stage t landed; stage (t-1)%3 is free again
+      if (t + 2 < nk) issue(t + 2);
+      compute(t);
+    }
+  } else {
+    if (nk > 0) issue(0);
+    for (int t = 0; t < nk; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                  // stage t landed everywhere; the other buffer is free again
+      if (t + 1 < nk) issue(t + 1);
+      compute(t);
+    }
   }
 
   // ---- epilogue: lane owns rows m = m0 + wr*64 + i*16 + (lane&15) and, per row, NG groups of VPL consecutive columns:
   // group q starts at n0 + wc*64 + q*4*VPL + fq*VPL; register e = j*4 + r of the row is element e % VPL of group e / VPL.
   constexpr int VPL = EpiTraits<EPI>::VPL, NG = 16 / VPL;
   const int ncol0 = n0 + wc * 64 + fq * VPL;
+  if (p.dbg & 16) {                                    // ablation: keep the accumulators live, store nothing
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(acc[j][i]));
+    return;
+  }
   float bias[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) bias[e] = 0.f;
@@ -200,9 +240,11 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(NTArgs p) {
 #pragma unroll
           for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(w[e]);
         }
-        if (EPI == EPI_BF16_GELU) {
+        if (EPI == EPI_BF16_GELU && !(p.dbg & 64)) {
           bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n;
-          if (full) {
+          if (full && (p.dbg & 128)) {
+            *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+          } else if (full) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(gelu_f(w[0]), gelu_f(w[1])), pack_bf2(gelu_f(w[2]), gelu_f(w[3])),
                                                        pack_bf2(gelu_f(w[4]), gelu_f(w[5])), pack_bf2(gelu_f(w[6]), gelu_f(w[7])));
           } else {
@@ -243,90 +285,115 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(NTArgs p) {
 
 // ------------------------------------------------------------------------------------------------ TN
 struct TNArgs {
-  const bf16_t* A; const bf16_t* B; float* C;
-  int M, N1, N2, lda, ldb, ldc, mlen;
+  const bf16_t* A; const bf16_t* B; float* C; float* colsum;
+  int M, N1, N2, lda, ldb, ldc, mlen, mode, splits, tiles;
 };
 
+constexpr int TN_BM = 32;                          // reduction rows per pipeline stage
+constexpr int TN_STAGE = 2 * TN_BM * 256;          // 16 KiB: A rows then B rows (128 bf16 = 256 B each)
+
+// XOR applied to the 8-byte unit index (0..31) of a 256-byte row so that ds_read_b64_tr_b16 of 4 consecutive rows x
+// 4 units is conflict-free for both 16-lane groups sharing an LDS cycle (rows r..r+3 and r+8..r+11).
 __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 2; }
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(TNArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NT_NS * TN_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int n1_0 = blockIdx.y * 128, n2_0 = blockIdx.x * 128;
-  const int mbeg = blockIdx.z * p.mlen;
-  const int mend = min(p.M, mbeg + p.mlen);
-  const int nk = (mend - mbeg + 63) / 64;
-
-  int srow[4], sch[4], soff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i;
-    srow[i] = c >> 4; sch[i] = c & 15;
-    soff[i] = srow[i] * 256 + ((sch[i] ^ (tn_f(srow[i]) >> 1)) << 4);
+  // 1-D grid.  All output tiles of one M-slice run on the SAME XCD (blocks b, b+8, ... share an L2), back to back, so
+  // the slice's rows are fetched from HBM once and re-read by the other tiles out of that L2.
+  int zslice, tile;
+  if (p.splits % 8 == 0) {
+    const int j = blockIdx.x >> 3;
+    zslice = (blockIdx.x & 7) + 8 * (j / p.tiles);
+    tile = j % p.tiles;
+  } else {
+    zslice = blockIdx.x / p.tiles;
+    tile = blockIdx.x % p.tiles;
   }
-  uint4 ra[4], rb[4];
-  auto gload = [&](int t) {
+  const int tiles_n2 = (p.N2 + 127) >> 7;
+  const int n1_0 = (tile / tiles_n2) * 128, n2_0 = (tile % tiles_n2) * 128;
+  const int mbeg = zslice * p.mlen;
+  const int mend = min(p.M, mbeg + p.mlen);
+  const int nk = (mend - mbeg + TN_BM - 1) / TN_BM;
+  const bool do_colsum = (p.colsum != nullptr) && n2_0 == 0 && wn == 0;
+
+  // LDS-DMA staging: the image is lane-linear, so the unit swizzle goes on the source column.  Rows past the end of
+  // the slice are clamped to a valid row here and zeroed in LDS before use (last stage only).
+  const bf16_t* ga[2]; const bf16_t* gb[2]; int ldsoff[2], srow[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mbeg + t * 64 + srow[i];
-      const int ca = n1_0 + sch[i] * 8, cb = n2_0 + sch[i] * 8;
-      ra[i] = (m < mend && ca < p.N1) ? *reinterpret_cast<const uint4*>(p.A + (size_t)m * p.lda + ca) : make_uint4(0, 0, 0, 0);
-      rb[i] = (m < mend && cb < p.N2) ? *reinterpret_cast<const uint4*>(p.B + (size_t)m * p.ldb + cb) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto sstore = [&](int buf) {
-    unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-    unsigned char* sb = sa + TILE_BYTES;
+  for (int i = 0; i < 2; ++i) {
+    const int q = i * 256 + tid, row = q >> 4, ch = (q & 15) ^ (tn_f(row) >> 1);
+    srow[i] = row;
+    const int ca = n1_0 + ch * 8, cb = n2_0 + ch * 8;
+    ga[i] = p.A + (ca < p.N1 ? ca : 0);
+    gb[i] = p.B + (cb < p.N2 ? cb : 0);
+    ldsoff[i] = (i * 256 + wave * 64) * 16;
+  }
+  auto issue = [&](int t) {
+    unsigned char* st = smem + (t % NT_NS) * TN_STAGE;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4*>(sa + soff[i]) = ra[i];
-      *reinterpret_cast<uint4*>(sb + soff[i]) = rb[i];
+    for (int i = 0; i < 2; ++i) {
+      const int m = min(mbeg + t * TN_BM + srow[i], mend - 1);
+      glds16(ga[i] + (size_t)m * p.lda, st + ldsoff[i]);
+      glds16(gb[i] + (size_t)m * p.ldb, st + TN_BM * 256 + ldsoff[i]);
     }
   };
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[4][4], accs[4];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < 4; ++a) {
+    accs[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
   const int g = lane >> 4, pl = lane & 15;
-  if (nk > 0) { gload(0); sstore(0); }
-  __syncthreads();
-  int cur = 0;
+  const int r0 = g * 8 + (pl >> 2), r1 = r0 + 4;
+  int offa0[4], offa1[4], offb0[4], offb1[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+    const int ua = wm * 16 + x * 4 + (pl & 3), ub = wn * 16 + x * 4 + (pl & 3);
+    offa0[x] = r0 * 256 + ((ua ^ tn_f(r0)) << 3);
+    offa1[x] = r1 * 256 + ((ua ^ tn_f(r1)) << 3);
+    offb0[x] = TN_BM * 256 + r0 * 256 + ((ub ^ tn_f(r0)) << 3);
+    offb1[x] = TN_BM * 256 + r1 * 256 + ((ub ^ tn_f(r1)) << 3);
+  }
+  if (nk > 0) issue(0);
+  if (nk > 1) issue(1);
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) gload(t + 1);
-    const unsigned char* sa = smem + cur * 2 * TILE_BYTES;
-    const unsigned char* sb = sa + TILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8_t fa[4], fb[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) {
-        s16x4_t lo_a, hi_a, lo_b, hi_b;
-        {
-          const int r0 = kk * 32 + g * 8 + (pl >> 2), r1 = r0 + 4;
-          const int ua = wm * 16 + x * 4 + (pl & 3), ub = wn * 16 + x * 4 + (pl & 3);
-          lo_a = lds_read_tr16(sa + r0 * 256 + ((ua ^ tn_f(r0)) << 3));
-          hi_a = lds_read_tr16(sa + r1 * 256 + ((ua ^ tn_f(r1)) << 3));
-          lo_b = lds_read_tr16(sb + r0 * 256 + ((ub ^ tn_f(r0)) << 3));
-          hi_b = lds_read_tr16(sb + r1 * 256 + ((ub ^ tn_f(r1)) << 3));
-        }
-        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-        s16x8_t va = __builtin_shufflevector(lo_a, hi_a, 0, 1, 2, 3, 4, 5, 6, 7);
-        s16x8_t vb = __builtin_shufflevector(lo_b, hi_b, 0, 1, 2, 3, 4, 5, 6, 7);
-        fa[x] = __builtin_bit_cast(bf16x8_t, va);
-        fb[x] = __builtin_bit_cast(bf16x8_t, vb);
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nk) issue(t + 2);
+    unsigned char* st = smem + (t % NT_NS) * TN_STAGE;
+    const int valid = mend - (mbeg + t * TN_BM);
+    if (valid < TN_BM) {                              // ragged tail: clear the rows that were clamped
+      for (int q = tid; q < 2 * TN_BM * 16; q += 256) {
+        const int row = (q >> 4) % TN_BM;
+        if (row >= valid) *reinterpret_cast<uint4*>(st + q * 16) = make_uint4(0, 0, 0, 0);
       }
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+      __syncthreads();
     }
-    if (t + 1 < nk) sstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    bf16x8_t fa[4], fb[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      s16x8_t va = __builtin_shufflevector(lds_read_tr16(st + offa0[x]), lds_read_tr16(st + offa1[x]), 0, 1, 2, 3, 4, 5, 6, 7);
+      s16x8_t vb = __builtin_shufflevector(lds_read_tr16(st + offb0[x]), lds_read_tr16(st + offb1[x]), 0, 1, 2, 3, 4, 5, 6, 7);
+      fa[x] = __builtin_bit_cast(bf16x8_t, va);
+      fb[x] = __builtin_bit_cast(bf16x8_t, vb);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+    if (do_colsum) {                                  // column sums of A (bias gradient) ride along as A^T * ones
+#pragma unroll
+      for (int a = 0; a < 4; ++a) accs[a] = mfma16(fa[a], ones, accs[a]);
+    }
   }
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -337,15 +404,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TNArgs p) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int n2 = n2_0 + wn * 64 + b * 16 + pl;
-        if (n2 < p.N2) atomicAdd(p.C + (size_t)n1 * p.ldc + n2, acc[a][b][r]);
+        if (n2 < p.N2) {
+          if (p.mode == 0) atomicAdd(p.C + (size_t)n1 * p.ldc + n2, acc[a][b][r]);
+          else p.C[(size_t)n1 * p.ldc + n2] = acc[a][b][r];          // timing experiment only (lafs_debug_set)
+        }
       }
+      if (do_colsum && pl == 0) atomicAdd(p.colsum + n1, accs[a][r]);
     }
 }
 
+int g_debug_flags = 0;
+
 template <int EPI>
 int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
-  const int tiles = ceil_div(a.M, BM) * ceil_div(a.N, BN);
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, dim3(tiles, 1, splits), dim3(256), 0, s, a);
+  // tile height: 256 rows when that does not cost whole extra rounds of workgroups (512 resident slots vs 768)
+  const int tn = ceil_div(a.N, BN);
+  const long t2 = (long)ceil_div(a.M, 128) * tn * splits, t4 = (long)ceil_div(a.M, 256) * tn * splits;
+  const double c2 = (double)((t2 + 767) / 768), c4 = 1.7 * (double)((t4 + 511) / 512);
+  int wm = (c4 < c2 && a.M >= 512) ? 4 : 2;
+  if (g_debug_flags & 2) wm = 2;
+  if (g_debug_flags & 4) wm = 4;
+  const bool bk64 = (g_debug_flags & 8) && a.klen % 64 == 0;
+  if (wm == 4) {
+    if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 64>), dim3((unsigned)t4 / splits, 1, splits), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32>), dim3((unsigned)t4 / splits, 1, splits), dim3(512), 0, s, a);
+  } else {
+    if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64>), dim3((unsigned)t2 / splits, 1, splits), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 32>), dim3((unsigned)t2 / splits, 1, splits), dim3(256), 0, s, a);
+  }
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -364,7 +450,7 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   a.C = g->C; a.ldc = g->ldc; a.C2 = g->C2; a.ldc2 = g->ldc2;
   a.bias = g->bias; a.resid = g->resid; a.ldr = g->ldr;
   a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
-  a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux; a.pos = g->pos; a.npatch = g->npatch;
+  a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux; a.pos = g->pos; a.npatch = g->npatch; a.dbg = g_debug_flags;
   int splits = 1;
   a.klen = g->K;
   if (g->epilogue == LAFS_EPI_ATOMIC_F32) {
@@ -400,23 +486,29 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
 }
 
 extern "C" int lafs_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* C, int ldc,
-                                int M, int N1, int N2, int splits, hipStream_t stream) {
+                                int M, int N1, int N2, int splits, float* colsum_a, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(A && B && C, "null operand");
   LAFS_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0, "empty problem");
   LAFS_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && N1 % 8 == 0 && N2 % 8 == 0, "N1/N2/lda/ldb must be multiples of 8");
   TNArgs a;
-  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
-  a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  const int msteps = ceil_div(M, 64);
-  if (splits <= 0) {                       // aim for ~4 workgroups per CU
-    const int tiles = ceil_div(N1, 128) * ceil_div(N2, 128);
-    splits = ceil_div(1024, tiles);
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.colsum = colsum_a;
+  a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.mode = g_debug_flags & 1;
+  const int msteps = ceil_div(M, TN_BM);
+  const int tiles = ceil_div(N1, 128) * ceil_div(N2, 128);
+  if (splits <= 0) {                       // ~2 workgroups per CU, slices in multiples of 8 (one run of slices per XCD)
+    splits = ceil_div(512, tiles);
+    if (splits > 4) splits = (splits + 7) & ~7;
   }
   if (splits > msteps) splits = msteps;
-  a.mlen = ceil_div(msteps, splits) * 64;
-  splits = ceil_div(M, a.mlen);
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(ceil_div(N2, 128), ceil_div(N1, 128), splits), dim3(256), 0, stream, a);
+  a.mlen = ceil_div(msteps, splits) * TN_BM;
+  if (splits % 8 != 0) splits = ceil_div(M, a.mlen);       // (empty trailing slices are harmless for the x8 layout)
+  a.splits = splits; a.tiles = tiles;
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 0, stream, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
+
+// Diagnostic knob for timing experiments (bit 0: TN GEMM stores instead of atomics -> WRONG results).  Never set by
+// the product path.
+extern "C" int lafs_debug_set(int flags) { g_debug_flags = flags; return LAFS_OK; }

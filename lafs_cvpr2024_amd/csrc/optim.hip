@@ -11,17 +11,32 @@
 
 namespace {
 
+// Each workgroup walks SUMSQ_SPAN consecutive chunks and only touches the per-tensor accumulator when the tensor
+// changes (or at the end): the 25k chunks of the DINO last layer would otherwise serialise 25k same-address atomics.
+constexpr int SUMSQ_SPAN = 32;
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ grad, const int* __restrict__ chunk_seg,
-                                                   const float* __restrict__ hyper, float* __restrict__ seg_sumsq) {
+                                                   long n_chunks, const float* __restrict__ hyper, float* __restrict__ seg_sumsq) {
   __shared__ float red[4];
-  const size_t base = (size_t)blockIdx.x * LAFS_CHUNK + threadIdx.x * 4;
-  const float4 g = *reinterpret_cast<const float4*>(grad + base);
   const float gs = hyper[LAFS_HP_GRAD_SCALE];
-  float s = (g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w) * gs * gs;
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(seg_sumsq + chunk_seg[blockIdx.x], red[0] + red[1] + red[2] + red[3]);
+  const long c0 = (long)blockIdx.x * SUMSQ_SPAN;
+  const long c1 = c0 + SUMSQ_SPAN < n_chunks ? c0 + SUMSQ_SPAN : n_chunks;
+  float s = 0.f;
+  int seg = chunk_seg[c0];
+  auto flush = [&](int sg) {
+    float t = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(seg_sumsq + sg, (red[0] + red[1] + red[2] + red[3]) * gs * gs);
+    __syncthreads();
+    s = 0.f;
+  };
+  for (long c = c0; c < c1; ++c) {
+    const int sg = chunk_seg[c];
+    if (sg != seg) { flush(seg); seg = sg; }
+    const float4 g = *reinterpret_cast<const float4*>(grad + c * LAFS_CHUNK + threadIdx.x * 4);
+    s += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+  }
+  flush(seg);
 }
 
 __global__ __launch_bounds__(256) void seg_step_kernel(const int* __restrict__ seg_flags, int* __restrict__ seg_step, int n_seg,
@@ -119,7 +134,8 @@ extern "C" int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int6
                                float* seg_sumsq, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(grad && chunk_seg && hyper && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31), "bad operand");
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)n_chunks), dim3(256), 0, stream, grad, chunk_seg, hyper, seg_sumsq);
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)((n_chunks + SUMSQ_SPAN - 1) / SUMSQ_SPAN)), dim3(256), 0, stream, grad, chunk_seg,
+                     (long)n_chunks, hyper, seg_sumsq);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -186,8 +186,7 @@ def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, layer_sl
         gp = torch.empty(n_img * np_, D, device=dev, dtype=bf16)
         dp = torch.zeros(np_ + 1, D, device=dev, dtype=f32)
         call("lafs_embed_bwd", _p(rows), D, n_img, np_, D, _p(gp), _p(dp), _p(gv(spec.cls)))
-        ops.colsum_bf16_acc(gp, gv(spec.b_patch))
-        ops.gemm_tn_acc(gp, st.patches[gi], gv(spec.w_patch).view(D, -1))
+        ops.gemm_tn_acc(gp, st.patches[gi], gv(spec.w_patch).view(D, -1), colsum=gv(spec.b_patch))
         dpos.append(dp)
     return dpos
 
@@ -241,12 +240,9 @@ def head_backward(arena, prefix, st: HeadState, dlogits_bf, train_g=False):
     dz = torch.empty(n, Db, device=dev, dtype=f32)
     call("lafs_l2norm_bwd", _p(st.z), Db, _p(dzn), Db, _p(st.inv_z), _p(dz), Db, n, Db)
     dz_bf = ops.scale_cast_bf16(dz)
-    ops.colsum_bf16_acc(dz_bf, gv("mlp.4.bias"))
-    ops.gemm_tn_acc(dz_bf, st.a2, gv("mlp.4.weight").view(p2("mlp.4.weight")))
+    ops.gemm_tn_acc(dz_bf, st.a2, gv("mlp.4.weight").view(p2("mlp.4.weight")), colsum=gv("mlp.4.bias"))
     du2 = ops.gemm_nt(dz_bf, arena.tview(prefix + "mlp.4.weight"), _lib.EPI_DGELU_BF16, aux=st.u2)
-    ops.colsum_bf16_acc(du2, gv("mlp.2.bias"))
-    ops.gemm_tn_acc(du2, st.a1, gv("mlp.2.weight").view(p2("mlp.2.weight")))
+    ops.gemm_tn_acc(du2, st.a1, gv("mlp.2.weight").view(p2("mlp.2.weight")), colsum=gv("mlp.2.bias"))
     du1 = ops.gemm_nt(du2, arena.tview(prefix + "mlp.2.weight"), _lib.EPI_DGELU_BF16, aux=st.u1)
-    ops.colsum_bf16_acc(du1, gv("mlp.0.bias"))
-    ops.gemm_tn_acc(du1, st.x_bf, gv("mlp.0.weight").view(p2("mlp.0.weight")))
+    ops.gemm_tn_acc(du1, st.x_bf, gv("mlp.0.weight").view(p2("mlp.0.weight")), colsum=gv("mlp.0.bias"))
     return ops.gemm_nt(du1, arena.tview(prefix + "mlp.0.weight"), _lib.EPI_F32)

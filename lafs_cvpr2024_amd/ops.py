@@ -68,12 +68,12 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     return (out, out2) if epilogue == _lib.EPI_BF16_GELU else out
 
 
-def gemm_tn_acc(A, B, Cacc, splits=0):
-    """Cacc[N1,N2] (f32) += A[M,N1]^T @ B[M,N2]."""
+def gemm_tn_acc(A, B, Cacc, splits=0, colsum=None):
+    """Cacc[N1,N2] (f32) += A[M,N1]^T @ B[M,N2]; optional colsum[N1] (f32) += column sums of A (bias gradient)."""
     _chk(A, bf16, "A"); _chk(B, bf16, "B"); _chk(Cacc, torch.float32, "C")
     M, N1 = A.shape
     N2 = B.shape[1]
-    call("lafs_gemm_tn_acc", _p(A), _ld(A), _p(B), _ld(B), _p(Cacc), _ld(Cacc), M, N1, N2, splits)
+    call("lafs_gemm_tn_acc", _p(A), _ld(A), _p(B), _ld(B), _p(Cacc), _ld(Cacc), M, N1, N2, splits, _p(colsum))
     return Cacc
 
 

@@ -82,8 +82,10 @@ def test_gemm_tn(M, N1, N2):
     ops.gemm_tn_acc(A.to(DEV), B.to(DEV), Cd)
     ref = A.float().t() @ B.float()
     assert relerr(Cd, ref) < 2e-5 * math.sqrt(M)
-    ops.gemm_tn_acc(A.to(DEV), B.to(DEV), Cd, splits=3)                 # accumulates
+    cs = torch.zeros(N1, device=DEV)
+    ops.gemm_tn_acc(A.to(DEV), B.to(DEV), Cd, splits=3, colsum=cs)      # accumulates; bias gradient rides along
     assert relerr(Cd, 2 * ref) < 2e-5 * math.sqrt(M)
+    assert relerr(cs, A.float().sum(0)) < 2e-5 * math.sqrt(M)
 
 
 @pytest.mark.parametrize("rows,D", [(50, 64), (1000, 384), (333, 192), (64, 768), (7, 2048)])

@@ -60,3 +60,47 @@ tn(T, 1536, 384, "fc1 wgrad")
 tn(T, 384, 384, "proj wgrad")
 tn(T, 1152, 384, "qkv wgrad")
 tn(640, 100096, 256, "last wgrad")
+
+print("--- NT tile height 128 (flag 2) vs 256 (flag 4)")
+for flag in (2, 4, 10, 12):
+    _lib.lib().lafs_debug_set(flag)
+    nt(T, 1152, 384, _lib.EPI_BF16, f"qkv fwd wm{flag}")
+    nt(T, 384, 384, _lib.EPI_RESID_F32, f"proj fwd wm{flag}")
+    nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd wm{flag}")
+    nt(T, 1536, 384, _lib.EPI_BF16, f"fc1 plain wm{flag}")
+    nt(T, 384, 1536, _lib.EPI_RESID_F32, f"fc2 fwd wm{flag}")
+    nt(T, 1536, 384, _lib.EPI_DGELU_BF16, f"fc2 dgrad wm{flag}")
+    nt(T, 384, 1536, _lib.EPI_BF16, f"fc1 dgrad wm{flag}")
+    nt(T, 384, 1152, _lib.EPI_BF16, f"qkv dgrad wm{flag}")
+    nt(25216, 1152, 384, _lib.EPI_BF16, f"qkv fwd teacher wm{flag}")
+    nt(4096, 4096, 4096, _lib.EPI_BF16, f"square 4k wm{flag}")
+_lib.lib().lafs_debug_set(0)
+
+print("--- NT ablations: 0 full, 16 no stores, 32 no mfma, 48 loads only")
+for flag in (0, 16, 32, 48):
+    _lib.lib().lafs_debug_set(flag)
+    nt(T, 1152, 384, _lib.EPI_BF16, f"qkv fwd abl{flag}")
+    nt(T, 384, 1536, _lib.EPI_BF16, f"fc1 dgrad abl{flag}")
+    nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd abl{flag}")
+_lib.lib().lafs_debug_set(0)
+
+print("--- fc1 GELU epilogue: separate u/a buffers vs one interleaved [T, 2*mlp] buffer")
+def gelu_variants():
+    M, N, K = T, 1536, 384
+    A = torch.randn(M, K, device=dev).to(bf); B = (torch.randn(N, K, device=dev) * .02).to(bf); bias = torch.zeros(N, device=dev)
+    u = torch.empty(M, N, device=dev, dtype=bf); a = torch.empty(M, N, device=dev, dtype=bf)
+    t = timeit(lambda: ops.gemm_nt(A, B, _lib.EPI_BF16_GELU, bias=bias, out=u, out2=a))
+    print(f"   separate buffers      : {t*1e6:7.1f} us")
+    ua = torch.empty(M, 2 * N, device=dev, dtype=bf)
+    t = timeit(lambda: ops.gemm_nt(A, B, _lib.EPI_BF16_GELU, bias=bias, out=ua[:, :N], out2=ua[:, N:]))
+    print(f"   interleaved rows      : {t*1e6:7.1f} us")
+    pad = torch.empty(M * N + 4096 + 64, device=dev, dtype=bf)
+    a2 = pad[4096 + 64: 4096 + 64 + M * N].view(M, N) if (4096 + 64) % 8 == 0 else a
+    t = timeit(lambda: ops.gemm_nt(A, B, _lib.EPI_BF16_GELU, bias=bias, out=u, out2=a2))
+    print(f"   separate, a shifted 8K: {t*1e6:7.1f} us")
+gelu_variants()
+print("--- fc1 GELU ablations: 64 = no second store, 128 = second store without gelu math")
+for flag in (0, 64, 128):
+    _lib.lib().lafs_debug_set(flag)
+    nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd abl{flag}")
+_lib.lib().lafs_debug_set(0)
