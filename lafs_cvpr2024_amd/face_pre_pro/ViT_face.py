@@ -1,0 +1,242 @@
+"""Drop-in surface of the reference's ``face_pre_pro/ViT_face.py`` for the symbols on the hot path
+(SURVEY.md section 8b): ``CosFace``, ``ViT_face_landmark_patch8`` (Part-fViT) and
+``extract_patches_pytorch_gridsample`` -- same constructor / forward signatures and state_dict keys, running on the
+gfx950 HIP kernels.  Experiment variants the entry points never instantiate are not provided.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, functional as Fn, ops
+from ..ops import _p, call
+from ..vision_transformer import attach_arena
+
+f32, bf16 = torch.float32, torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------------- landmark gather
+class _PatchGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, imgs, landmarks, n):
+        B, _, S, _ = imgs.shape
+        r = int(math.isqrt(n))
+        img = imgs.contiguous().float()
+        th = landmarks[:, :n].contiguous().float()
+        out = torch.empty(B, 3, 8 * r, 8 * r, device=imgs.device, dtype=f32)
+        call("lafs_patch_gather_fwd", _p(img), _p(th), B, S, n, _p(out))
+        ctx.save_for_backward(img, th)
+        ctx.n, ctx.full_n = n, landmarks.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, th = ctx.saved_tensors
+        B, _, S, _ = img.shape
+        dth = torch.empty_like(th)
+        dimg = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
+        call("lafs_patch_gather_bwd", _p(img), _p(th), _p(dout.contiguous().float()), B, S, ctx.n, _p(dth), _p(dimg))
+        if ctx.full_n != ctx.n:
+            full = torch.zeros(B, ctx.full_n, 2, device=th.device, dtype=f32)
+            full[:, :ctx.n] = dth
+            dth = full
+        return dimg, dth, None
+
+
+def extract_patches_pytorch_gridsample(imgs, landmarks, patch_shape=None, num_landm=49):
+    """8x8 bilinear patches around ``landmarks`` (x, y in pixels) assembled into a sqrt(n) x sqrt(n) mosaic
+    (reference face_pre_pro/ViT_face.py:1615-1656: n sequential grid_sample calls) as ONE kernel launch,
+    differentiable with respect to the landmarks and the image.  Only 8x8 patches (the LAFS configuration)."""
+    if patch_shape is not None and (int(patch_shape[0]) != 8 or int(patch_shape[1]) != 8):
+        raise NotImplementedError("the HIP gather kernel is specialised for 8x8 patches")
+    if imgs.shape[1] != 3:
+        raise NotImplementedError("3-channel images only")
+    return _PatchGather.apply(imgs, landmarks, int(num_landm))
+
+
+# ------------------------------------------------------------------------------------------------- margin head
+class _CosFaceFunction(torch.autograd.Function):
+    """s * (cos(x, W) - m * y).  cos is an MFMA GEMM over row-normalised bf16 operands; the normalisations are HIP
+    row kernels.  (The training engine fuses margin + softmax + CE instead: lafs_margin_softmax_ce.)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, label, s, m):
+        B, D = x.shape
+        C = weight.shape[0]
+        Cpad = (C + 127) // 128 * 128
+        dev = x.device
+        xn = torch.empty(B, D, device=dev, dtype=bf16); inv_x = torch.empty(B, device=dev, dtype=f32)
+        x32 = x.contiguous().float()
+        call("lafs_l2norm_fwd", _p(x32), D, _p(xn), D, _p(inv_x), B, D)
+        wn = torch.empty(Cpad, D, device=dev, dtype=bf16); inv_w = torch.empty(C, device=dev, dtype=f32)
+        ones = torch.ones(C, device=dev, dtype=f32)
+        w32 = weight.contiguous().float()
+        call("lafs_weightnorm_fwd", _p(w32), _p(ones), C, Cpad, D, _p(wn), None, Cpad, _p(inv_w))
+        cos = ops.gemm_nt(xn, wn, _lib.EPI_F32, n_cols=Cpad)[:, :C]
+        if label.dim() > 1:
+            y = label.to(f32)
+        else:
+            y = torch.zeros(B, C, device=dev, dtype=f32).scatter_(1, label.view(-1, 1).long(), 1.0)
+        ctx.save_for_backward(x32, w32, xn, wn, inv_x, inv_w, ones)
+        ctx.s, ctx.C, ctx.Cpad = s, C, Cpad
+        return s * (cos - m * y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x32, w32, xn, wn, inv_x, inv_w, ones = ctx.saved_tensors
+        B, D = x32.shape
+        C, Cpad = ctx.C, ctx.Cpad
+        dev = x32.device
+        dcos = torch.zeros(B, Cpad, device=dev, dtype=bf16)
+        dcos[:, :C] = (dout * ctx.s).to(bf16)
+        # d(xn) = dcos @ wn  (contraction over classes -> split-K), d(wn) = dcos^T @ xn
+        wn_t = wn.t().contiguous()
+        dxn = ops.gemm_nt(dcos, wn_t, _lib.EPI_ATOMIC_F32, splits=max(1, min(64, Cpad // 1024)))
+        dwn = torch.zeros(Cpad, D, device=dev, dtype=f32)
+        ops.gemm_tn_acc(dcos, xn, dwn, splits=1)
+        dx = torch.empty(B, D, device=dev, dtype=f32)
+        call("lafs_l2norm_bwd", _p(x32), D, _p(dxn), D, _p(inv_x), _p(dx), D, B, D)
+        dw = torch.empty(C, D, device=dev, dtype=f32)
+        call("lafs_weightnorm_bwd", _p(dwn), _p(w32), _p(ones), _p(inv_w), C, D, _p(dw), None, 0)
+        return dx, dw, None, None, None
+
+
+class CosFace(nn.Module):
+    """CosFace margin head (reference face_pre_pro/ViT_face.py:26-96): out = s * (cos(x, W) - m * label), where label is a
+    class-index vector or a dense soft target (the mixup branch).  ``device_id`` must be None (the reference's
+    single-process model-parallel branch is dead code: both entry points pass GPU_ID=None)."""
+
+    def __init__(self, in_features, out_features, device_id, s=64.0, m=0.4):
+        super().__init__()
+        if device_id is not None:
+            raise NotImplementedError("device_id model parallelism is not part of the hot path (always None in the reference)")
+        if in_features % 64:
+            raise NotImplementedError("in_features must be a multiple of 64 for the MFMA GEMM")
+        self.in_features, self.out_features, self.device_id, self.s, self.m = in_features, out_features, device_id, s, m
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        nn.init.xavier_uniform_(self.weight)
+
+    def forward(self, input, label):
+        return _CosFaceFunction.apply(input, self.weight, label, float(self.s), float(self.m))
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(in_features = {self.in_features}, out_features = {self.out_features}, s = {self.s}, m = {self.m})"
+
+
+# ------------------------------------------------------------------------------------------------- Part-fViT
+class _Holder(nn.Module):
+    pass
+
+
+class _PartFViTFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, hook, x, pos):
+        save = any(ctx.needs_input_grad)
+        n_img = x.shape[0]
+        n = x.shape[1] if x.dim() == 3 else (x.shape[-1] // 8) ** 2
+        side = 8 * int(math.isqrt(n))
+        if (side // 8) ** 2 != n:
+            raise _lib.LafsHipError("the packed engine needs a square number of patches per image")
+        geom = Fn.geometry([(n_img, side)], x.device)
+        drop = model._sample_drop_scales(geom) if model.training else None
+        feat, st, _ = Fn.vit_forward(model._arena, model._spec, geom, [x.contiguous().float()], [pos.detach().contiguous()],
+                                     drop, save=save)
+        ctx.model, ctx.st = model, (st if save else None)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        model, st = ctx.model, ctx.st
+        dpos = Fn.vit_backward(model._arena, model._spec, st, dfeat)
+        return None, None, None, dpos[0]
+
+
+class ViT_face_landmark_patch8(nn.Module):
+    """Part-fViT (reference face_pre_pro/ViT_face.py:560-795): pre-LN ViT with bias-free qkv, attention scale dim**-0.5,
+    ``heads * 64`` inner width, DropPath 0.1 on every residual branch, LayerNorm head; 4-D images or 3-D [B, n, 192]
+    patch vectors.  ``with_land=True`` (the MobileNetV3 landmark branch) and non-zero dropout are not in this build."""
+
+    def __init__(self, *, loss_type, GPU_ID, num_class, image_size, patch_size, dim, depth, heads, mlp_dim, pool='cls',
+                 num_patches=None, channels=3, dim_head=64, dropout=0., emb_dropout=0., fp16=True, with_land=False,
+                 use_standcoord=False, Random_prob=False, shuffle=False, drop_path_rate=0.1):
+        super().__init__()
+        if patch_size != 8 or channels != 3 or dim_head != 64:
+            raise NotImplementedError("HIP kernels are specialised for 3x8x8 patches and head_dim 64")
+        if with_land or use_standcoord:
+            raise NotImplementedError("landmark CNN branch (MobileNetV3 'stn') is the next row of SURVEY.md 8(f); "
+                                      "feed landmark mosaics from extract_patches_pytorch_gridsample instead")
+        if dropout or emb_dropout:
+            raise NotImplementedError("element dropout is not implemented in the fused epilogues (parity mode uses rate 0)")
+        if pool != 'cls':
+            raise NotImplementedError("only cls pooling is on the hot path")
+        if num_patches is None:
+            num_patches = (image_size // patch_size) ** 2
+        self.patch_size, self.fp16, self.num_patches = patch_size, fp16, num_patches
+        self.row_num = int(math.sqrt(num_patches))
+        self.with_land, self.pool, self.loss_type, self.GPU_ID = with_land, pool, loss_type, GPU_ID
+        self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, mlp_dim
+        self.drop_path_rate = drop_path_rate
+        inner = heads * dim_head
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
+        self.patch_to_embedding = nn.Linear(channels * patch_size ** 2, dim)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.transformer = _Holder()
+        layers = []
+        for _ in range(depth):
+            att = _Holder(); att.fn = _Holder(); att.fn.norm = nn.LayerNorm(dim); att.fn.fn = _Holder()
+            att.fn.fn.to_qkv = nn.Linear(dim, inner * 3, bias=False)
+            att.fn.fn.to_out = nn.Sequential(nn.Linear(inner, dim), nn.Dropout(dropout))
+            ff = _Holder(); ff.fn = _Holder(); ff.fn.norm = nn.LayerNorm(dim); ff.fn.fn = _Holder()
+            ff.fn.fn.net = nn.Sequential(nn.Linear(dim, mlp_dim), nn.GELU(), nn.Dropout(dropout), nn.Linear(mlp_dim, dim), nn.Dropout(dropout))
+            layers.append(nn.ModuleList([att, ff]))
+        self.transformer.layers = nn.ModuleList(layers)
+        self.mlp_head = nn.Sequential(nn.LayerNorm(dim))
+        if loss_type == 'None':
+            pass
+        elif loss_type == 'CosFace':
+            self.loss = CosFace(in_features=dim, out_features=num_class, device_id=GPU_ID, m=0.4)
+        else:
+            raise NotImplementedError(f"loss_type {loss_type!r}: only 'CosFace' and 'None' exist in the reference")
+        self.theta = 0
+        self._arena, self._spec, self._hook = None, None, None
+
+    def _bind_arena(self, arena, prefix):
+        names = []
+        for i in range(self.depth):
+            a, f = f"{prefix}transformer.layers.{i}.0.fn.", f"{prefix}transformer.layers.{i}.1.fn."
+            names.append(dict(ln1_g=a + "norm.weight", ln1_b=a + "norm.bias", w_qkv=a + "fn.to_qkv.weight", b_qkv=None,
+                              w_proj=a + "fn.to_out.0.weight", b_proj=a + "fn.to_out.0.bias",
+                              ln2_g=f + "norm.weight", ln2_b=f + "norm.bias",
+                              w_fc1=f + "fn.net.0.weight", b_fc1=f + "fn.net.0.bias",
+                              w_fc2=f + "fn.net.3.weight", b_fc2=f + "fn.net.3.bias"))
+        trunk = Fn.TrunkSpec(dim=self.dim, heads=self.heads, mlp=self.mlp_dim, depth=self.depth, ln_eps=1e-5,
+                             attn_scale=self.dim ** -0.5, block_names=names)      # scale quirk: model dim (ref :145)
+        object.__setattr__(self, "_arena", arena)
+        self._spec = Fn.ViTSpec(trunk=trunk, prefix=prefix, patch_order=_lib.PATCH_ORDER_HWC,
+                                w_patch="patch_to_embedding.weight", b_patch="patch_to_embedding.bias", cls="cls_token",
+                                final_g="mlp_head.0.weight", final_b="mlp_head.0.bias")
+        self._hook = torch.zeros(1, device=arena.device, requires_grad=True)
+
+    def _sample_drop_scales(self, geom):
+        """Residual_droppath: the same rate on both branches of every layer (reference :106-112)."""
+        if not self.drop_path_rate:
+            return None
+        keep = 1.0 - self.drop_path_rate
+        u = torch.rand(self.depth, 2, geom.n_seq, device=self._arena.device)
+        return (torch.floor(keep + u) / keep).contiguous()
+
+    def forward_embedding(self, x):
+        if self._arena is None:
+            attach_arena(self)
+        self._arena.ensure_fresh()
+        n = x.shape[1] if x.dim() == 3 else (x.shape[-1] // 8) ** 2
+        pos = self.pos_embedding[0, :n + 1]
+        return _PartFViTFunction.apply(self, self._hook, x, pos)
+
+    def forward(self, x, label=None, mask=None, visualize=False, save_token=False, opt=None, keep_num=None, glo_diff=False):
+        if mask is not None or save_token:
+            raise NotImplementedError("attention masks / token dumps are not on the training hot path")
+        emb = self.forward_embedding(x)
+        if label is not None:
+            return self.loss(emb, label), self.theta
+        return (emb, self.theta) if visualize else emb

@@ -145,7 +145,10 @@ def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, dr
     wpe = arena.bf(pre + spec.w_patch).view(D, -1)
     for gi, img in enumerate(imgs):
         n_img, np_ = geom.groups[gi][0], geom.npatch(gi)
-        pt = ops.patchify(img, spec.patch_order)
+        if img.dim() == 3:                                # already '(p1 p2 c)' patch vectors [n_img, n, 192] (3-D input path)
+            pt = ops.scale_cast_bf16(img.reshape(-1, img.shape[-1]).contiguous().float())
+        else:
+            pt = ops.patchify(img, spec.patch_order)
         rows = st.x_in[geom.tok_start[gi]: geom.tok_start[gi] + n_img * (np_ + 1)]
         ops.gemm_nt(pt, wpe, _lib.EPI_EMBED_F32, bias=arena.view(arena.master, pre + spec.b_patch),
                     pos=pos_tokens[gi], npatch=np_, out=rows)
