@@ -1,0 +1,112 @@
+"""Fused Part-fViT + CosFace fine-tune micro-step (reference train_largescale.py:785-891) on the HIP kernels.
+
+    u8 batch -> (x/255*2-1) + batch mixup (one kernel) -> Part-fViT trunk -> L2-normalised embedding x L2-normalised class
+    centres (MFMA GEMM) -> fused margin + softmax + soft-target CE (the dense [B, C] mixup target is never built: it has
+    <= 2 non-zeros per row) -> backward -> every `acc_step` micro-steps: AdamW over the flat arena.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, functional as Fn, ops
+from .face_pre_pro.ViT_face import ViT_face_landmark_patch8
+from .ops import _p, call
+from .vision_transformer import attach_arena
+
+f32, bf16 = torch.float32, torch.bfloat16
+
+
+class FinetuneEngine:
+    def __init__(self, backbone: ViT_face_landmark_patch8, batch_size, acc_step=3, mixup_alpha=0.2, mixup_prob=0.1,
+                 s=64.0, m=0.4, margin_type=0, image_size=112, device=None):
+        if not isinstance(backbone, ViT_face_landmark_patch8) or not hasattr(backbone, "loss"):
+            raise _lib.LafsHipError("FinetuneEngine drives ViT_face_landmark_patch8(loss_type='CosFace')")
+        if batch_size % 8:
+            raise _lib.LafsHipError("FinetuneEngine needs a batch size that is a multiple of 8 (16-byte rows in the class-gradient GEMM)")
+        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        self.model, self.B, self.acc_step = backbone, batch_size, acc_step
+        self.mixup_alpha, self.mixup_prob = mixup_alpha, mixup_prob
+        self.s, self.m, self.margin_type = float(s), float(m), margin_type
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.arena = attach_arena(backbone, self.device)
+        self.C = backbone.loss.out_features
+        self.Cpad = (self.C + 127) // 128 * 128
+        self.D = backbone.dim
+        self.geom = Fn.geometry([(batch_size, image_size)], self.device)
+        dev = self.device
+        self.hyper = torch.zeros(_lib.HP_COUNT, device=dev, dtype=f32)
+        self.ones = torch.ones(self.C, device=dev, dtype=f32)
+        self.x = torch.empty(batch_size, 3, image_size, image_size, device=dev, dtype=f32)
+        self.cos = torch.empty(batch_size, self.Cpad, device=dev, dtype=f32)
+        self.dcos = torch.zeros(batch_size, self.Cpad, device=dev, dtype=bf16)
+        self.wn = torch.empty(self.Cpad, self.D, device=dev, dtype=bf16)
+        self.inv_w = torch.empty(self.C, device=dev, dtype=f32)
+        self.dwn = torch.zeros(self.Cpad, self.D, device=dev, dtype=f32)
+        self.loss = torch.zeros(1, device=dev, dtype=f32)
+        self.row_ws = torch.empty(batch_size, device=dev, dtype=f32)
+        self.micro = 0
+
+    def draw_lambda(self):
+        if np.random.rand() < self.mixup_prob:
+            return float(np.random.beta(self.mixup_alpha, self.mixup_alpha))
+        return 1.0
+
+    def micro_step(self, inputs_u8, labels, lam=None):
+        """One forward/backward on a uint8 NCHW batch.  Gradients accumulate in the arena (loss pre-divided by acc_step)."""
+        a, m, B, D, dev = self.arena, self.model, self.B, self.D, self.device
+        a.ensure_fresh()
+        lam = self.draw_lambda() if lam is None else float(lam)
+        call("lafs_mixup_normalize", _p(inputs_u8.contiguous()), _p(self.x), B, self.x.shape[-1], lam)
+        y1 = labels.to(dev, torch.int32).contiguous()
+        y2 = y1.flip(0).contiguous()
+        pos = a.view(a.master, m._spec.prefix + "pos_embedding").view(-1, D)[: self.geom.npatch(0) + 1]
+        drop = m._sample_drop_scales(self.geom) if m.training else None
+        emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [self.x], [pos], drop, save=True)
+        # cosine logits
+        xn = torch.empty(B, D, device=dev, dtype=bf16); inv_x = torch.empty(B, device=dev, dtype=f32)
+        call("lafs_l2norm_fwd", _p(emb), D, _p(xn), D, _p(inv_x), B, D)
+        wname = m._spec.prefix + "loss.weight"
+        call("lafs_weightnorm_fwd", _p(a.view(a.master, wname)), _p(self.ones), self.C, self.Cpad, D, _p(self.wn), None, self.Cpad,
+             _p(self.inv_w))
+        ops.gemm_nt(xn, self.wn, _lib.EPI_F32, out=self.cos, n_cols=self.Cpad)
+        # margin + softmax + soft-target CE, forward and d/dcos in place
+        call("lafs_margin_softmax_ce", _p(self.cos), self.Cpad, B, self.C, _p(y1), _p(y2), lam, self.s, self.m, self.margin_type,
+             1.0 / self.acc_step, _p(self.loss), _p(self.row_ws))
+        ops.scale_cast_bf16(self.cos, out=self.dcos)
+        # d(emb_n) = dcos @ Wn (reduction over the classes), d(Wn) = dcos^T @ emb_n (reduction over the batch)
+        dxn = torch.zeros(B, D, device=dev, dtype=f32)
+        ops.gemm_tn_acc(self.dcos.t().contiguous(), self.wn, dxn)
+        self.dwn.zero_()
+        ops.gemm_tn_acc(self.dcos, xn, self.dwn, splits=1)
+        call("lafs_weightnorm_bwd", _p(self.dwn), _p(a.view(a.master, wname)), _p(self.ones), _p(self.inv_w), self.C, D,
+             _p(a.view(a.grad, wname)), None, 1)
+        demb = torch.empty(B, D, device=dev, dtype=f32)
+        call("lafs_l2norm_bwd", _p(emb), D, _p(dxn), D, _p(inv_x), _p(demb), D, B, D)
+        dpos = Fn.vit_backward(a, m._spec, st, demb)
+        a.view(a.grad, m._spec.prefix + "pos_embedding").view(-1, D)[: dpos[0].shape[0]] += dpos[0]
+        self.micro += 1
+        return self.loss
+
+    def optimizer_step(self, lr, weight_decay=0.1, beta1=0.9, beta2=0.999, eps=1e-8):
+        """AdamW over every tensor (decay only on >= 2-D tensors, train_largescale.py:122-173); all-reduces the flat gradient
+        first when running data-parallel (the reference's DDP does it on every micro-step, :676-677)."""
+        a = self.arena
+        if self.world > 1:
+            dist.all_reduce(a.grad)
+        h = torch.zeros(_lib.HP_COUNT, dtype=f32)
+        h[_lib.HP_LR], h[_lib.HP_WD], h[_lib.HP_BETA1], h[_lib.HP_BETA2], h[_lib.HP_EPS] = lr, weight_decay, beta1, beta2, eps
+        h[_lib.HP_CLIP], h[_lib.HP_EMA_M], h[_lib.HP_FREEZE_LAST], h[_lib.HP_GRAD_SCALE] = 0.0, 0.0, 0.0, 1.0 / self.world
+        self.hyper.copy_(h)
+        call("lafs_clip_adamw_ema", _p(a.master), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq), None, _p(a.shadow), None,
+             _p(a.chunk_seg), a.n_chunks, _p(a.seg_flags), _p(a.seg_step), a.n_seg, _p(a.seg_sumsq), _p(self.hyper))
+        a.refresh_transposed()
+        a.zero_grad()
+
+    def step(self, inputs_u8, labels, lr, weight_decay=0.1):
+        """micro_step + optimizer step every acc_step micro-steps (train_largescale.py:842-891)."""
+        loss = self.micro_step(inputs_u8, labels)
+        if self.micro % self.acc_step == 0:
+            self.optimizer_step(lr, weight_decay)
+        return loss
