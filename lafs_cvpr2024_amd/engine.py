@@ -16,6 +16,7 @@ import torch.distributed as dist
 
 from . import _lib, functional as Fn, ops
 from .arena import ParamArena
+from .distributed import FlatReducer
 from .ops import _p, call
 from .vision_transformer import VisionTransformer, attach_arena, _is_matrix_for_dgrad
 
@@ -91,6 +92,7 @@ class LafsPretrainEngine:
         n_sl = max(1, min(grad_slices, self.depth))
         cuts = [round(self.depth * i / n_sl) for i in range(n_sl, -1, -1)]
         self.layer_slices = [(cuts[i], cuts[i + 1]) for i in range(n_sl)]
+        self.reducer = FlatReducer()
         self.use_graph = use_graph
         self._graphs = None
         self._st = {}
@@ -191,15 +193,12 @@ class LafsPretrainEngine:
             self.hyper.copy_(h, non_blocking=True)
         run = (lambda i, f: self._graphs[i].replay()) if self.use_graph else (lambda i, f: f())
         run(0, self._seg_forward)
-        works = []
-        if self.world > 1:
-            works.append(dist.all_reduce(self.sa.grad[self.head_start:], async_op=True))
-            works.append(dist.all_reduce(self.colsum, async_op=True))
+        # head gradients + center sums go out over RCCL while the trunk backward runs; the trunk range follows it
+        self.reducer.launch(self.sa.grad[self.head_start:])
+        self.reducer.launch(self.colsum)
         run(1, self._seg_trunk_backward)
-        if self.world > 1:
-            works.append(dist.all_reduce(self.sa.grad[:self.head_start], async_op=True))
-            for w in works:
-                w.wait()
+        self.reducer.launch(self.sa.grad[:self.head_start])
+        self.reducer.wait_all()
         run(2, self._seg_update)
         self.step_count += 1
         return self.loss

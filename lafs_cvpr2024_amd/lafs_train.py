@@ -1,0 +1,187 @@
+"""LAFS / DINO pre-training entry point with the reference's flags, launch contract and checkpoint layout
+(reference lafs_train.py:30-122 flags, :156-471 train_lafs, :474-623 train_one_epoch), driving the fused HIP engine.
+
+Launch (one process per GPU, RCCL):
+    python -m torch.distributed.run --nproc-per-node=N --master-addr 127.0.0.1 lafs_train.py --arch vit_small ...
+
+Differences from the reference, all forced by its own breakage or by scope:
+  * --arch choices are the ViT family (the reference's default 'mynet' is not in its own `choices`, its xcit choices
+    need network access, and its vit_* path crashes on an undefined landmarkcnn);
+  * the data pipeline (MXNet recordio + PIL augmentations + landmark CNN) is out of scope: `--data synthetic` feeds the
+    crop shapes the landmark gather emits (2 x 112^2 + n x 48^2), or pass any Dataset through `train_lafs(args, dataset=...)`
+    yielding lists of 2 + n crops;
+  * the optimizer is the engine's fused per-tensor-clip + AdamW (the reference's default and only used one).
+"""
+import argparse
+import datetime
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import utils
+from . import vision_transformer as vits
+from .dino_loss import DINOLoss
+from .engine import LafsPretrainEngine
+from .vision_transformer import DINOHead
+
+__all__ = ["DINOLoss", "get_args_parser", "train_lafs", "train_one_epoch", "SyntheticCrops"]
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser('LAFS', add_help=False)
+    p.add_argument('--arch', default='vit_small', type=str, choices=['vit_tiny', 'vit_small', 'vit_base'])
+    p.add_argument('--patch_size', default=8, type=int)
+    p.add_argument('--out_dim', default=100000, type=int)
+    p.add_argument('--norm_last_layer', default=True, type=utils.bool_flag)
+    p.add_argument('--momentum_teacher', default=0.996, type=float)
+    p.add_argument('--use_bn_in_head', default=False, type=utils.bool_flag)
+    p.add_argument('--warmup_teacher_temp', default=0.07, type=float)
+    p.add_argument('--teacher_temp', default=0.04, type=float)
+    p.add_argument('--warmup_teacher_temp_epochs', default=30, type=int)
+    p.add_argument('--use_fp16', type=utils.bool_flag, default=True, help="kept for CLI compatibility: the HIP path always "
+                   "multiplies in bf16 with fp32 accumulation and needs no loss scaling")
+    p.add_argument('--weight_decay', type=float, default=0.04)
+    p.add_argument('--weight_decay_end', type=float, default=0.4)
+    p.add_argument('--clip_grad', type=float, default=3.0)
+    p.add_argument('--batch_size_per_gpu', default=64, type=int)
+    p.add_argument('--epochs', default=41, type=int)
+    p.add_argument('--freeze_last_layer', default=1, type=int)
+    p.add_argument("--lr", default=0.0005, type=float)
+    p.add_argument("--warmup_epochs", default=10, type=int)
+    p.add_argument('--min_lr', type=float, default=1e-6)
+    p.add_argument('--optimizer', default='adamw', type=str, choices=['adamw'])
+    p.add_argument('--drop_path_rate', type=float, default=0.1)
+    p.add_argument('--local_crops_number', type=int, default=8)
+    p.add_argument('--data', default='synthetic', type=str, help="'synthetic' (landmark-crop shaped random tensors)")
+    p.add_argument('--steps_per_epoch', default=100, type=int, help="iterations per epoch for --data synthetic")
+    p.add_argument('--output_dir', default=".", type=str)
+    p.add_argument('--saveckp_freq', default=10, type=int)
+    p.add_argument('--seed', default=0, type=int)
+    p.add_argument('--use_graph', default=True, type=utils.bool_flag, help="capture the step into hipGraphs")
+    p.add_argument("--dist_url", default="env://", type=str)
+    p.add_argument("--local_rank", default=0, type=int)
+    return p
+
+
+class SyntheticCrops:
+    """Random crops with the geometry the landmark gather emits: 2 global 3x112x112 + n local 3x48x48 in [-1, 1]."""
+
+    def __init__(self, steps, batch, n_local, device, seed):
+        self.steps, self.batch, self.n_local, self.device = steps, batch, n_local, device
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            g = [torch.randn(self.batch, 3, 112, 112, device=self.device, generator=self.gen).clamp_(-1, 1) for _ in range(2)]
+            l = [torch.randn(self.batch, 3, 48, 48, device=self.device, generator=self.gen).clamp_(-1, 1) for _ in range(self.n_local)]
+            yield g + l, None
+
+
+def train_lafs(args, dataset=None):
+    utils.init_distributed_mode(args)
+    utils.fix_random_seeds(args.seed)
+    print("\n".join("%s: %s" % (k, str(v)) for k, v in sorted(dict(vars(args)).items())))
+    device = torch.device("cuda", args.gpu)
+    world = utils.get_world_size()
+
+    # ---- student / teacher: MultiCropWrapper(backbone, DINOHead), as reference lafs_train.py:200-356 ----
+    student_b = vits.__dict__[args.arch](patch_size=args.patch_size, drop_path_rate=args.drop_path_rate)
+    teacher_b = vits.__dict__[args.arch](patch_size=args.patch_size)
+    embed_dim = student_b.embed_dim
+    student = utils.MultiCropWrapper(student_b, DINOHead(embed_dim, args.out_dim, use_bn=args.use_bn_in_head,
+                                                         norm_last_layer=args.norm_last_layer))
+    teacher = utils.MultiCropWrapper(teacher_b, DINOHead(embed_dim, args.out_dim, args.use_bn_in_head))
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad = False
+    dino_loss = DINOLoss(args.out_dim, args.local_crops_number + 2, args.warmup_teacher_temp, args.teacher_temp,
+                         args.warmup_teacher_temp_epochs, args.epochs)
+    engine = LafsPretrainEngine(student, teacher, dino_loss, args.batch_size_per_gpu, n_local=args.local_crops_number,
+                                clip_grad=args.clip_grad, freeze_last_layer=args.freeze_last_layer, use_graph=args.use_graph,
+                                device=device)
+    print(f"Student and Teacher are built: they are both {args.arch} networks.")
+
+    data_loader = dataset if dataset is not None else SyntheticCrops(args.steps_per_epoch, args.batch_size_per_gpu,
+                                                                      args.local_crops_number, device,
+                                                                      args.seed + utils.get_rank())
+    n_it = len(data_loader)
+    # ---- schedules (reference :411-424) ----
+    lr_schedule = utils.cosine_scheduler(args.lr * (args.batch_size_per_gpu * world) / 256., args.min_lr, args.epochs, n_it,
+                                         warmup_epochs=args.warmup_epochs)
+    wd_schedule = utils.cosine_scheduler(args.weight_decay, args.weight_decay_end, args.epochs, n_it)
+    momentum_schedule = utils.cosine_scheduler(args.momentum_teacher, 1, args.epochs, n_it)
+
+    # ---- resume (reference :428-438; checkpoint keys :451-460) ----
+    to_restore = {"epoch": 0}
+    ckpt = os.path.join(args.output_dir, "checkpoint.pth")
+    if os.path.isfile(ckpt):
+        _load_checkpoint(ckpt, student, teacher, dino_loss, engine, to_restore)
+    start_epoch = to_restore["epoch"]
+
+    start = time.time()
+    print("Starting LAFS training !")
+    for epoch in range(start_epoch, args.epochs):
+        stats = train_one_epoch(engine, dino_loss, data_loader, lr_schedule, wd_schedule, momentum_schedule, epoch, args)
+        save_dict = {
+            'student': {"module." + k: v for k, v in student.state_dict().items()},     # DDP-style prefix, as the reference saves
+            'teacher': teacher.state_dict(),
+            'optimizer': engine.optimizer_state_dict(),
+            'epoch': epoch + 1,
+            'args': args,
+            'dino_loss': dino_loss.state_dict(),
+        }
+        utils.save_on_master(save_dict, ckpt)
+        if args.saveckp_freq and epoch % args.saveckp_freq == 0:
+            utils.save_on_master(save_dict, os.path.join(args.output_dir, f'checkpoint{epoch:04}.pth'))
+        if utils.is_main_process():
+            with (Path(args.output_dir) / "log.txt").open("a") as f:
+                f.write(json.dumps({**{f'train_{k}': v for k, v in stats.items()}, 'epoch': epoch}) + "\n")
+    print('Training time {}'.format(str(datetime.timedelta(seconds=int(time.time() - start)))))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def _load_checkpoint(path, student, teacher, dino_loss, engine, run_variables):
+    print("Found checkpoint at {}".format(path))
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    strip = lambda sd: {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+    print("=> student:", student.load_state_dict(strip(ck["student"]), strict=False))
+    print("=> teacher:", teacher.load_state_dict(strip(ck["teacher"]), strict=False))
+    if "dino_loss" in ck:
+        dino_loss.load_state_dict(ck["dino_loss"])
+    if "optimizer" in ck:
+        engine.load_optimizer_state_dict(ck["optimizer"])
+    engine.sa.refresh_shadows(); engine.ta.refresh_shadows()
+    run_variables["epoch"] = ck.get("epoch", 0)
+
+
+def train_one_epoch(engine, dino_loss, data_loader, lr_schedule, wd_schedule, momentum_schedule, epoch, args):
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    header = 'Epoch: [{}/{}]'.format(epoch, args.epochs)
+    tt = float(dino_loss.teacher_temp_schedule[epoch])
+    n = len(data_loader)
+    for it, (images, _) in enumerate(metric_logger.log_every(data_loader, 100, header)):
+        it = n * epoch + it
+        loss = engine.step(images, lr=float(lr_schedule[it]), wd=float(wd_schedule[it]), momentum=float(momentum_schedule[it]),
+                           teacher_temp=tt, epoch=epoch)
+        if it % 20 == 0:                                   # the only host sync: loss sanity check (reference :585-587 does it every step)
+            lv = float(loss.item())
+            if not math.isfinite(lv):
+                print("Loss is {}, stopping training".format(lv), force=True)
+                sys.exit(1)
+            metric_logger.update(loss=lv)
+        metric_logger.update(lr=float(lr_schedule[it]))
+        metric_logger.update(wd=float(wd_schedule[it]))
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}

@@ -1,0 +1,100 @@
+"""Supervised Part-fViT + CosFace fine-tuning loop (reference train_largescale.py:317-963) on the HIP fine-tune engine.
+
+Kept from the reference: flags that define the step (batch size, epochs, lr rescale `lr * bs * world / 512`, weight decay
+0.1, mixup alpha/prob, acc_step=3 from supervised_config.py:37, warm-up(5 epochs)+cosine(eta_min 1e-6) LR, loading
+`ckpt['teacher']` of an SSL checkpoint with the 'encoder.|backbone.|module.' prefixes stripped and strict=False).
+Out of scope here: MXNet recordio datasets, RandAugment, LFW/CFP/AgeDB evaluation,
+tensorboard; `--data synthetic` feeds uint8 batches of the right shape.
+"""
+import argparse
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import utils
+from .face_pre_pro.ViT_face import ViT_face_landmark_patch8
+from .finetune_engine import FinetuneEngine
+
+
+def get_config(args):
+    """The few supervised_config.py entries that define the step."""
+    return dict(acc_step=3, SEED=1337, INPUT_SIZE=[112, 112], EMBEDDING_SIZE=768, WARMUP_EPOCH=5)
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser("Part-fViT fine-tuning", add_help=False)
+    p.add_argument("--batch_size", "-b", default=128, type=int)
+    p.add_argument("--epochs", "-e", default=34, type=int)
+    p.add_argument("--lr", default=3e-4, type=float)
+    p.add_argument("--weight_decay", default=0.1, type=float)
+    p.add_argument("--head", default="CosFace", type=str, choices=["CosFace"])
+    p.add_argument("--num_class", default=205990, type=int)
+    p.add_argument("--mixup", default=0.2, type=float)
+    p.add_argument("--mixup-prob", dest="mixup_prob", default=0.1, type=float)
+    p.add_argument("--drop_path", default=0.1, type=float)
+    p.add_argument("--model_dir", default="", type=str, help="LAFS checkpoint whose ['teacher'] weights initialise the backbone")
+    p.add_argument("--data", default="synthetic", type=str)
+    p.add_argument("--steps_per_epoch", default=100, type=int)
+    p.add_argument("--outdir", "-o", default=".", type=str)
+    p.add_argument("--dist_url", default="env://", type=str)
+    p.add_argument("--local_rank", default=0, type=int)
+    return p
+
+
+def warmup_cosine(base_lr, epoch_float, warmup_epochs, total_epochs, eta_min=1e-6):
+    """GradualWarmupScheduler(multiplier=1) + CosineAnnealingLR (train_largescale.py:728-733); the `warmup_scheduler` package is
+    not vendored by the reference, so this follows its documented behaviour (parity unpinned)."""
+    if epoch_float < warmup_epochs:
+        return base_lr * epoch_float / warmup_epochs
+    t, T = epoch_float - warmup_epochs, max(total_epochs - warmup_epochs, 1)
+    return eta_min + 0.5 * (base_lr - eta_min) * (1 + math.cos(math.pi * t / T))
+
+
+def load_ssl_teacher(backbone, path):
+    """Initialise from ckpt['teacher'] with the prefixes stripped, strict=False (train_largescale.py:639-657)."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    sd = ck.get("teacher", ck)
+    clean = {}
+    for k, v in sd.items():
+        for pre in ("module.", "backbone.", "encoder."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        clean[k] = v
+    print("=> loaded SSL teacher:", backbone.load_state_dict(clean, strict=False))
+
+
+def main(args):
+    utils.init_distributed_mode(args)
+    cfg = get_config(args)
+    utils.fix_random_seeds(cfg["SEED"])
+    device = torch.device("cuda", args.gpu)
+    world = utils.get_world_size()
+    backbone = ViT_face_landmark_patch8(loss_type=args.head, GPU_ID=None, num_class=args.num_class, image_size=112, patch_size=8,
+                                        dim=768, depth=12, heads=11, mlp_dim=2048, dropout=0.0, emb_dropout=0.0,
+                                        with_land=False, drop_path_rate=args.drop_path)
+    if args.model_dir:
+        load_ssl_teacher(backbone, args.model_dir)
+    engine = FinetuneEngine(backbone, args.batch_size, acc_step=cfg["acc_step"], mixup_alpha=args.mixup, mixup_prob=args.mixup_prob,
+                            device=device)
+    base_lr = args.lr * args.batch_size * world / 512.0                     # train_largescale.py:472
+    n_it = args.steps_per_epoch
+    gen = torch.Generator(device=device).manual_seed(cfg["SEED"] + utils.get_rank())
+    t0 = time.time()
+    for epoch in range(args.epochs):
+        for it in range(n_it):
+            x = torch.randint(0, 256, (args.batch_size, 3, 112, 112), device=device, dtype=torch.uint8, generator=gen)
+            y = torch.randint(0, args.num_class, (args.batch_size,), device=device, generator=gen)
+            lr = warmup_cosine(base_lr, epoch + it / n_it, cfg["WARMUP_EPOCH"], args.epochs)
+            loss = engine.step(x, y, lr=lr, weight_decay=args.weight_decay)
+            if it % 50 == 0:
+                print(f"Epoch {epoch} it {it}/{n_it} loss {float(loss.item()):.4f} lr {lr:.3e} "
+                      f"{(epoch * n_it + it + 1) * args.batch_size * world / (time.time() - t0):.1f} samples/s")
+        if utils.is_main_process():
+            torch.save({"module." + k: v for k, v in backbone.state_dict().items()},
+                       os.path.join(args.outdir, f"Backbone_VIT_Epoch_{epoch + 1}.pth"))    # IJB loader expects 'module.' (IJB_evaluation.py:126)
+    if dist.is_initialized():
+        dist.destroy_process_group()

@@ -1,0 +1,58 @@
+"""world_size = 2 on CPU (gloo): the data-parallel semantics of the LAFS step -- gradient mean and center all-reduce --
+through the same FlatReducer the engine uses, checked against a single-process run on the full batch."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import step as ostep, vit as ovit
+
+
+def _make(seed=0):
+    cfg = ovit.ViTConfig(patch_size=8, embed_dim=64, depth=1, num_heads=1, img_size=112)
+    return cfg, ostep.LafsState(cfg, out_dim=256, seed=seed, hidden_dim=64, bottleneck_dim=32)
+
+
+def _crops(B):
+    g = torch.Generator().manual_seed(7)
+    return [torch.randn(B, 3, 112, 112, generator=g).clamp(-1, 1) for _ in range(2)] + [torch.randn(B, 3, 48, 48, generator=g).clamp(-1, 1)]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from lafs_cvpr2024_amd.distributed import FlatReducer, center_from_colsum, world_size
+    assert world_size() == world
+    red = FlatReducer()
+
+    def all_reduce(t):                       # the engine's reducer: async SUM launches, one wait
+        red.launch(t); red.wait_all()
+
+    cfg, st = _make()
+    full = _crops(4)
+    mine = [c[rank * 2:(rank + 1) * 2] for c in full]
+    r = ostep.lafs_step(st, mine, epoch=1, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, world_size=world, all_reduce=all_reduce)
+    # center through the helper == oracle's update_center
+    colsum = r["teacher_out"].sum(0, keepdim=True); all_reduce(colsum)
+    c2 = center_from_colsum(torch.zeros(1, 256), colsum, r["teacher_out"].shape[0], 0.9)
+    assert torch.allclose(c2, st.center, atol=1e-7)
+    if rank == 0:
+        torch.save({"student": st.student, "center": st.center, "loss": r["loss"]}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_full_batch(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    port = 29600 + os.getpid() % 200
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    cfg, st = _make()
+    ostep.lafs_step(st, _crops(4), epoch=1, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05)
+    torch.testing.assert_close(got["center"], st.center, rtol=1e-5, atol=1e-7)
+    errs = torch.cat([(got["student"][k] - v).abs().flatten() for k, v in st.student.items()])
+    # identical up to fp32 summation order, except Adam's amplification where the gradient is round-off
+    assert float(errs.median()) < 1e-7 and float((errs > 1e-5).float().mean()) < 0.02 and float(errs.max()) < 2.5e-3
