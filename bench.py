@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
-    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=32)
     return ap.parse_args()
 
 
@@ -88,7 +88,9 @@ def cpu_baseline(arch_dims, n_local, K, batch):
     on a bounded sample of the same workload: ONE step of the same model/crop geometry at a small batch."""
     from oracle import dino, step as ostep, vit as ovit
     D, depth, heads = arch_dims
-    cores = os.cpu_count() or 1
+    # torch's CPU GEMMs stop scaling (and collapse when oversubscribed) beyond a few dozen threads at these sizes:
+    # measured on the GPU box host, 32 threads is the fastest setting (256 threads is 100x slower)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     cfg = ovit.ViTConfig(patch_size=8, embed_dim=D, depth=depth, num_heads=heads, img_size=224)
     st = ostep.LafsState(cfg, out_dim=K, seed=0)

@@ -228,9 +228,11 @@ int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, float* x_out
                        int save_for_backward, hipStream_t stream);
 /* g(f32) [n_tok, dim]: dL/dx_out on entry, dL/dx_in on exit.  Parameter gradients are ACCUMULATED into d->grad.
  * Blocks layer_hi-1 .. layer_lo run; pass (depth, 0) for the whole trunk, or walk it in slices to start the
- * gradient all-reduce of finished blocks early. */
+ * gradient all-reduce of finished blocks early.  wgrad_stream (optional, may be NULL or == stream): the weight-gradient
+ * GEMMs are enqueued there and overlap the dgrad / attention / LayerNorm chain on `stream` (forked and joined with
+ * events, so the call is still hipGraph-capturable and complete on `stream` when it returns to stream order). */
 int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
-                        int layer_lo, hipStream_t stream);
+                        int layer_lo, hipStream_t wgrad_stream, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fine-tune path (train_largescale.py): margin-softmax head, mixup, landmark patch gather

@@ -76,7 +76,7 @@ _PROTOS = {
     "lafs_cast_bf16": [vp, vp, i64],
     "lafs_transpose_cast_bf16": [vp, i32, i32, vp, i32],
     "lafs_trunk_forward": [C.POINTER(TrunkDesc), vp, vp, vp, i32],
-    "lafs_trunk_backward": [C.POINTER(TrunkDesc), vp, vp, vp, i32, i32],
+    "lafs_trunk_backward": [C.POINTER(TrunkDesc), vp, vp, vp, i32, i32, vp],
     "lafs_margin_softmax_ce": [vp, i32, i32, i32, vp, vp, f32, f32, f32, i32, f32, vp, vp],
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],

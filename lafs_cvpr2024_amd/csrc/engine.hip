@@ -17,8 +17,8 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct LayerBuf {
   float* x0; float* st1; bf16_t* h1; bf16_t* qkv; float* lse; bf16_t* o; float* x1; float* st2; bf16_t* h2; bf16_t* u; bf16_t* a;
 };
-struct Scratch {
-  bf16_t* gb; bf16_t* du; bf16_t* dh; bf16_t* d_o; bf16_t* dqkv; float* delta;
+struct Scratch {             // [2]: alternate by layer parity so the wgrad stream may lag one layer behind
+  bf16_t* gbm[2]; bf16_t* gba[2]; bf16_t* du[2]; bf16_t* dqkv[2]; bf16_t* dh; bf16_t* d_o; float* delta;
 };
 struct Carve {
   std::vector<LayerBuf> layers;   // depth entries when saving, 1 otherwise (reused)
@@ -51,11 +51,14 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
   }
   c.xalt = save ? nullptr : (float*)take(T * D * 4);
   if (save) {
-    c.s.gb = (bf16_t*)take(T * D * 2);
-    c.s.du = (bf16_t*)take(T * M * 2);
+    for (int q = 0; q < 2; ++q) {
+      c.s.gbm[q] = (bf16_t*)take(T * D * 2);
+      c.s.gba[q] = (bf16_t*)take(T * D * 2);
+      c.s.du[q] = (bf16_t*)take(T * M * 2);
+      c.s.dqkv[q] = (bf16_t*)take(T * 3 * I * 2);
+    }
     c.s.dh = (bf16_t*)take(T * D * 2);
     c.s.d_o = (bf16_t*)take(T * I * 2);
-    c.s.dqkv = (bf16_t*)take(T * 3 * I * 2);
     c.s.delta = (float*)take(T * H * 4);
   } else {
     c.s = Scratch{};
@@ -127,42 +130,75 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   return LAFS_OK;
 }
 
+// Events for the two-stream backward (weight gradients run on `wgrad_stream` concurrently with the dgrad / attention /
+// LayerNorm chain).  Lazily created, reused on every call; the only process-wide state of the library.
+static std::vector<hipEvent_t>& event_pool(size_t n) {
+  static std::vector<hipEvent_t> pool;
+  while (pool.size() < n) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
+    pool.push_back(e);
+  }
+  return pool;
+}
+
 extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
-                                   int layer_lo, hipStream_t stream) {
+                                   int layer_lo, hipStream_t wgrad_stream, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   RUN(check_desc(d));
   LAFS_CHECK_ARG(x_in && g && workspace && d->shadow_t && d->grad, "null buffer");
   LAFS_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= d->depth, "bad layer range");
   const Carve c = carve(d, workspace, 1);
   const int T = d->n_tok, D = d->dim, I = d->inner, M = d->mlp;
-  const bf16_t* sh = reinterpret_cast<const bf16_t*>(d->shadow);
   const bf16_t* sht = reinterpret_cast<const bf16_t*>(d->shadow_t);
   float* gr = d->grad;
   const Scratch& s = c.s;
+  const bool two = (wgrad_stream != nullptr) && (wgrad_stream != stream);
+  hipStream_t s2 = two ? wgrad_stream : stream;
+  const int nl = layer_hi - layer_lo;
+  std::vector<hipEvent_t>& ev = event_pool(two ? (size_t)5 * nl + 1 : 0);
+  LAFS_CHECK_ARG(!two || ev.size() >= (size_t)5 * nl + 1, "could not create HIP events");
+  int evi = 0;
+  auto fork = [&]() {                      // work enqueued on s2 after this sees everything enqueued on `stream` so far
+    if (!two) return;
+    hipEvent_t e = ev[evi++];
+    hipEventRecord(e, stream);
+    hipStreamWaitEvent(s2, e, 0);
+  };
+  std::vector<hipEvent_t> done(d->depth, nullptr);
   auto scale = [&](int l, int br) { return d->drop_scales ? d->drop_scales + ((size_t)l * 2 + br) * d->n_seq : nullptr; };
-  RUN(lafs_scale_cast_bf16(g, D, s.gb, D, scale(layer_hi - 1, 1), d->row2seq, T, D, stream));
+  RUN(lafs_scale_cast_bf16(g, D, s.gbm[(layer_hi - 1) & 1], D, scale(layer_hi - 1, 1), d->row2seq, T, D, stream));
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const lafs_block_offsets& o = d->blocks[l];
     const LayerBuf& b = c.layers[l];
     const float* x0 = (l == 0) ? x_in : b.x0;
+    const int p = l & 1;
+    if (two && l + 2 < layer_hi) hipStreamWaitEvent(stream, done[l + 2], 0);     // parity buffers free again
     // ---- MLP branch ----
-    RUN(lafs_gemm_tn_acc(s.gb, D, b.a, M, gr + o.w_fc2, M, T, D, M, 0, gr + o.b_fc2, stream));
-    RUN(gemm(s.gb, D, sht + o.w_fc2_t, D, T, M, D, LAFS_EPI_DGELU_BF16, s.du, M, nullptr, stream, nullptr, 0, nullptr, 0, nullptr,
+    fork();
+    RUN(lafs_gemm_tn_acc(s.gbm[p], D, b.a, M, gr + o.w_fc2, M, T, D, M, 0, gr + o.b_fc2, s2));
+    RUN(gemm(s.gbm[p], D, sht + o.w_fc2_t, D, T, M, D, LAFS_EPI_DGELU_BF16, s.du[p], M, nullptr, stream, nullptr, 0, nullptr, 0, nullptr,
              nullptr, b.u, M));
-    RUN(lafs_gemm_tn_acc(s.du, M, b.h2, D, gr + o.w_fc1, D, T, M, D, 0, gr + o.b_fc1, stream));
-    RUN(gemm(s.du, M, sht + o.w_fc1_t, M, T, D, M, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
-    RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, b.x1, D, b.st2, d->master + o.ln2_g, g, D, 1, s.gb, D, scale(l, 0), d->row2seq,
+    fork();
+    RUN(lafs_gemm_tn_acc(s.du[p], M, b.h2, D, gr + o.w_fc1, D, T, M, D, 0, gr + o.b_fc1, s2));
+    RUN(gemm(s.du[p], M, sht + o.w_fc1_t, M, T, D, M, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
+    RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, b.x1, D, b.st2, d->master + o.ln2_g, g, D, 1, s.gba[p], D, scale(l, 0), d->row2seq,
                            gr + o.ln2_g, gr + o.ln2_b, T, D, stream));
     // ---- attention branch ----
-    RUN(lafs_gemm_tn_acc(s.gb, D, b.o, I, gr + o.w_proj, I, T, D, I, 0, gr + o.b_proj, stream));
-    RUN(gemm(s.gb, D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
+    fork();
+    RUN(lafs_gemm_tn_acc(s.gba[p], D, b.o, I, gr + o.w_proj, I, T, D, I, 0, gr + o.b_proj, s2));
+    RUN(gemm(s.gba[p], D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
     RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens, d->n_seq, T, d->max_len, d->heads,
-                           d->attn_scale, s.dqkv, 3 * I, stream));
-    RUN(lafs_gemm_tn_acc(s.dqkv, 3 * I, b.h1, D, gr + o.w_qkv, D, T, 3 * I, D, 0, o.b_qkv >= 0 ? gr + o.b_qkv : nullptr, stream));
-    RUN(gemm(s.dqkv, 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
+                           d->attn_scale, s.dqkv[p], 3 * I, stream));
+    fork();
+    RUN(lafs_gemm_tn_acc(s.dqkv[p], 3 * I, b.h1, D, gr + o.w_qkv, D, T, 3 * I, D, 0, o.b_qkv >= 0 ? gr + o.b_qkv : nullptr, s2));
+    if (two) { done[l] = ev[evi++]; hipEventRecord(done[l], s2); }
+    RUN(gemm(s.dqkv[p], 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     const bool more = l > 0;
-    RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, x0, D, b.st1, d->master + o.ln1_g, g, D, 1, more ? s.gb : nullptr, D,
+    RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, x0, D, b.st1, d->master + o.ln1_g, g, D, 1, more ? s.gbm[(l - 1) & 1] : nullptr, D,
                            more ? scale(l - 1, 1) : nullptr, d->row2seq, gr + o.ln1_g, gr + o.ln1_b, T, D, stream));
   }
+  if (two) hipStreamWaitEvent(stream, done[layer_lo], 0);                        // join (s2 is in-order)
+  LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

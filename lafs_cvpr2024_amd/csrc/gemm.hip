@@ -417,14 +417,17 @@ int g_debug_flags = 0;
 
 template <int EPI>
 int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
-  // tile height: 256 rows when that does not cost whole extra rounds of workgroups (512 resident slots vs 768)
+  // Shape heuristics from tools/bench_kernels.py on MI355X (ViT-S/B shapes):
+  //  * wide outputs (N >= 1024) on many rows: 256x128 tiles (less L2->LDS traffic per flop, 16 resident waves/CU);
+  //  * long reductions (K >= 1024): 64-deep stages (full 128-byte lines per row piece) in a 2-stage ring.
   const int tn = ceil_div(a.N, BN);
   const long t2 = (long)ceil_div(a.M, 128) * tn * splits, t4 = (long)ceil_div(a.M, 256) * tn * splits;
-  const double c2 = (double)((t2 + 767) / 768), c4 = 1.7 * (double)((t4 + 511) / 512);
-  int wm = (c4 < c2 && a.M >= 512) ? 4 : 2;
+  bool bk64 = (a.klen % 64 == 0) && a.klen >= 1024 && splits == 1;
+  int wm = (!bk64 && a.N >= 1024 && a.M >= 4096) ? 4 : 2;
   if (g_debug_flags & 2) wm = 2;
   if (g_debug_flags & 4) wm = 4;
-  const bool bk64 = (g_debug_flags & 8) && a.klen % 64 == 0;
+  if (g_debug_flags & 8) bk64 = (a.klen % 64 == 0);
+  if (g_debug_flags & 2) bk64 = bk64 && (g_debug_flags & 8);
   if (wm == 4) {
     if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 64>), dim3((unsigned)t4 / splits, 1, splits), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32>), dim3((unsigned)t4 / splits, 1, splits), dim3(512), 0, s, a);

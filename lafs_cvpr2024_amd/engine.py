@@ -93,6 +93,7 @@ class LafsPretrainEngine:
         cuts = [round(self.depth * i / n_sl) for i in range(n_sl, -1, -1)]
         self.layer_slices = [(cuts[i], cuts[i + 1]) for i in range(n_sl)]
         self.reducer = FlatReducer()
+        self.side_stream = torch.cuda.Stream(device=self.device)      # teacher forward / weight-gradient GEMMs
         self.use_graph = use_graph
         self._graphs = None
         self._st = {}
@@ -109,16 +110,20 @@ class LafsPretrainEngine:
     def _seg_forward(self):
         sa, ta, B = self.sa, self.ta, self.B
         sa.grad.zero_()
-        # teacher: two global views, no activations kept
-        pos_t = self._pos_tokens(ta, self.spec_t)[:1]
-        feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, None, save=False)
-        Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self.logits_t)
+        # teacher (two global views, no activations kept) runs on the side stream, concurrently with the student
+        cur = torch.cuda.current_stream()
+        self.side_stream.wait_stream(cur)
+        with torch.cuda.stream(self.side_stream):
+            pos_t = self._pos_tokens(ta, self.spec_t)[:1]
+            feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, None, save=False)
+            Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self.logits_t)
         # student: all views in one packed pass
         vit = self.student.backbone
         drop = vit._sample_drop_scales(self.geom_s) if vit.training else None
         imgs = [self.in_global_all] + ([self.in_local_all] if self.n_local else [])
         feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s), drop, save=True)
         _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self.logits_s)
+        cur.wait_stream(self.side_stream)
         # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
         ops.dino_loss_fwd_bwd(self.logits_s, self.logits_t, self.dino_loss.center.view(-1), self.ncrops,
                               float(self.dino_loss.student_temp), 0.04, K=self.K, grad=self.dlogits, ws=self.loss_ws,
@@ -130,7 +135,8 @@ class LafsPretrainEngine:
 
     def _seg_trunk_backward(self):
         sa = self.sa
-        dpos = Fn.vit_backward(sa, self.spec_s, self._st["vit"], self._st["dfeat"], layer_slices=self.layer_slices)
+        dpos = Fn.vit_backward(sa, self.spec_s, self._st["vit"], self._st["dfeat"], layer_slices=self.layer_slices,
+                               wgrad_stream=self.side_stream)
         gpe = sa.view(sa.grad, self.spec_s.prefix + "pos_embed").view(-1, self.spec_s.trunk.dim)
         for M, dp in zip(self.interp, dpos):
             if M is None:

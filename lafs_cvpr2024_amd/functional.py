@@ -164,7 +164,7 @@ def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, dr
     return feat, st, x_out
 
 
-def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, layer_slices=None, on_slice_done=None):
+def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, layer_slices=None, on_slice_done=None, wgrad_stream=None):
     """dfeat f32 [n_seq, D].  Accumulates every parameter gradient into arena.grad EXCEPT the position table:
     returns the list of dpos f32 [npatch+1, D] per group (the bicubic resampling lives in torch)."""
     geom, D, pre = st.geom, spec.trunk.dim, spec.prefix
@@ -179,7 +179,8 @@ def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, layer_sl
     depth = spec.trunk.depth
     slices = layer_slices or [(depth, 0)]
     for hi, lo in slices:
-        call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo)
+        ws2 = C.c_void_p(wgrad_stream.cuda_stream) if wgrad_stream is not None else None
+        call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo, ws2)
         if on_slice_done is not None:
             on_slice_done(hi, lo)
     dpos = []

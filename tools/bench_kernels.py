@@ -104,3 +104,9 @@ for flag in (0, 64, 128):
     _lib.lib().lafs_debug_set(flag)
     nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd abl{flag}")
 _lib.lib().lafs_debug_set(0)
+print("--- loads-only ablation across tile variants (flag 48 + {0: 128x128 bk32, 4: 256x128 bk32, 8: 128x128 bk64, 12: 256x128 bk64})")
+for flag in (48, 52, 56, 60):
+    _lib.lib().lafs_debug_set(flag)
+    nt(T, 1152, 384, _lib.EPI_BF16, f"qkv fwd loads f{flag}")
+    nt(T, 384, 1536, _lib.EPI_BF16, f"fc1 dgrad loads f{flag}")
+_lib.lib().lafs_debug_set(0)
