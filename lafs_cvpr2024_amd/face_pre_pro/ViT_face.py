@@ -240,3 +240,62 @@ class ViT_face_landmark_patch8(nn.Module):
         if label is not None:
             return self.loss(emb, label), self.theta
         return (emb, self.theta) if visualize else emb
+
+
+# ------------------------------------------------------------------------------------------------- landmark CNN wrapper
+class face_landmark_4simmin_glo_loc(nn.Module):
+    """Frozen landmark regressor of the LAFS step (reference face_pre_pro/ViT_face.py:1218-1409): MobileNetV3 trunk ->
+    mean pool -> Linear(160, 2*r*r) -> per-sample min-max to [0, 111] px -> optional N(0, 5^2) px jitter -> optional random
+    choice of 36 landmarks (with replacement) -> 8x8 bilinear patch gather from ``x_Aug`` into a mosaic image.
+    The CNN runs on stock PyTorch-ROCm; the gather is the single-launch HIP kernel.  Random draws are made on the CPU
+    generator in the reference's order (randn for the jitter, then randint for the selection) and moved to the device."""
+
+    def __init__(self, *, loss_type, GPU_ID, num_class, image_size, patch_size, dim, depth, heads, mlp_dim, pool='cls',
+                 num_patches=None, channels=3, dim_head=64, dropout=0., emb_dropout=0., fp16=True):
+        super().__init__()
+        from .mobilenet import MobileNetV3_backbone
+        if num_patches is None:
+            num_patches = (image_size // patch_size) ** 2
+        if patch_size != 8:
+            raise NotImplementedError("the HIP gather kernel is specialised for 8x8 patches")
+        self.patch_size, self.fp16, self.num_patches, self.dim = patch_size, fp16, num_patches, dim
+        self.row_num = int(math.sqrt(num_patches))
+        self.stn = MobileNetV3_backbone(mode='large')
+        self.output_layer = nn.Sequential(nn.Dropout(p=0.5), nn.Linear(160, self.row_num * self.row_num * 2))
+        self.global_token = nn.Sequential(nn.Dropout(p=0.5), nn.Linear(160, dim))
+        self.patch_shape = torch.tensor([patch_size, patch_size])
+        self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
+        self.patch_to_embedding = nn.Linear(channels * patch_size ** 2, dim)
+        self.cls_token = nn.Parameter(torch.randn(1, 1, dim))
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, dim))
+        nn.init.trunc_normal_(self.mask_token, std=.02, a=-.02, b=.02)
+        self.loss_type, self.GPU_ID, self.num_features, self.in_chans = loss_type, GPU_ID, dim, channels
+        self.theta = 0
+
+    def landmarks(self, x):
+        """[B,3,S,S] -> theta [B, r*r, 2] in pixels (x, y), min-max scaled per sample (reference :1338-1355)."""
+        t = self.output_layer(self.stn(x).mean(dim=(-2, -1)))
+        tmax, tmin = t.max(dim=1, keepdim=True)[0], t.min(dim=1, keepdim=True)[0]
+        return ((t - tmin) / (tmax - tmin) * 111).view(-1, self.row_num * self.row_num, 2)
+
+    def forward(self, x, x_Aug=None, keep_num=None, patch_shape=None, Random_prob=False, return_prob=False, ran_sample=False,
+                random_coor=False, return_land=False):
+        if random_coor:
+            num_land = 25 if ran_sample else self.row_num * self.row_num
+            theta = (torch.rand(x.shape[0], num_land, 2) * 111.0).to(x.device)
+        else:
+            S = x.shape[-2]
+            num_land = self.num_patches if (S == 112 and self.num_patches in (144, 196)) else (S // self.patch_size) ** 2
+            theta = self.landmarks(x)
+            if Random_prob:
+                theta = theta + (torch.randn(theta.shape) * 5).to(theta.device)
+                if not return_prob:
+                    b, c, _ = theta.shape
+                    num_land = 36 if ran_sample else self.row_num * self.row_num
+                    idx = torch.randint(0, c, (b, num_land, 1)).to(theta.device).repeat(1, 1, 2)
+                    theta = torch.gather(theta, 1, idx)
+            self.theta = theta
+        if return_land:
+            return theta, x
+        src = x if x_Aug is None else x_Aug
+        return theta, extract_patches_pytorch_gridsample(src, theta[:, :num_land], patch_shape=self.patch_shape, num_landm=num_land)

@@ -36,3 +36,28 @@ def golden():
 
 def has_gpu():
     return torch.cuda.is_available()
+
+
+def det_fill(module):
+    """Fill every tensor of a module's state_dict with a closed-form pattern that depends only on its key and shape
+    (used by tools/make_golden.py on the reference model and by the tests on this build's model: same keys -> same weights)."""
+    import zlib
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            n = v.numel()
+            ph = (zlib.crc32(k.encode()) % 1000) / 1000.0
+            t = torch.sin(torch.arange(n, dtype=torch.float64) * 0.618 + ph * 6.283)
+            fan = max(v[0].numel() if v.dim() > 1 else 1, 1)
+            if k.endswith("running_var"):
+                val = 1.0 + 0.2 * t
+            elif k.endswith("running_mean"):
+                val = 0.05 * t
+            elif v.dim() == 1 and k.endswith("weight"):
+                val = 1.0 + 0.1 * t
+            elif v.dim() == 1:
+                val = 0.05 * t
+            else:
+                val = t * (1.5 / fan ** 0.5)
+            v.copy_(val.view(v.shape).to(v.dtype))

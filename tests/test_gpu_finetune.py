@@ -110,3 +110,32 @@ def test_finetune_micro_step_against_oracle(lam):
     d = (named["patch_to_embedding.weight"].detach() - w0).abs().max().item()
     assert 0.5e-3 < d < 2.5e-3, d
     assert float(eng.arena.grad.abs().max()) == 0.0
+
+
+def test_f9_landmark_cnn_wrapper_matches_reference():
+    """Frozen MobileNetV3 landmark regressor + min-max + jitter + random-36 selection + HIP gather vs the reference
+    (weights: the same closed-form fill on both sides, conftest.det_fill)."""
+    from conftest import det_fill
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
+    fx = load_golden("f9_landmark_cnn")
+    lc = face_landmark_4simmin_glo_loc(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=64, depth=1,
+                                       heads=1, mlp_dim=64)
+    assert sorted(lc.state_dict().keys()) == [str(k) for k in fx["keys"]]
+    det_fill(lc)
+    lc = lc.to(DEV).eval()
+    x, xa = fx["x"].to(DEV), fx["x_aug"].to(DEV)
+    with torch.no_grad():
+        th, mo = lc(x, x_Aug=xa, Random_prob=False)
+        assert th.shape == (2, 196, 2) and mo.shape == (2, 3, 112, 112)
+        torch.testing.assert_close(th.cpu(), fx["theta_plain"], rtol=1e-3, atol=2e-2)        # pixels in [0, 111]
+        # the gather itself is exact given the same landmarks
+        torch.manual_seed(123); th_b, mo_b = lc(x, x_Aug=xa, Random_prob=True, return_prob=True)
+        torch.manual_seed(124); th_c, mo_c = lc(x, x_Aug=xa, Random_prob=True, ran_sample=True)
+    torch.testing.assert_close(th_b.cpu(), fx["theta_jitter"], rtol=1e-3, atol=2e-2)
+    assert th_c.shape == (2, 36, 2) and mo_c.shape == (2, 3, 48, 48)
+    torch.testing.assert_close(th_c.cpu(), fx["theta_local"], rtol=1e-3, atol=2e-2)
+    # mosaics: feed the REFERENCE landmarks so the comparison isolates the gather
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import extract_patches_pytorch_gridsample as gather
+    for th_ref, mo_ref, n in ((fx["theta_plain"], fx["mosaic_plain"], 196), (fx["theta_local"], fx["mosaic_local"], 36)):
+        out = gather(xa, th_ref.to(DEV), num_landm=n)
+        torch.testing.assert_close(out.cpu(), mo_ref, rtol=1e-4, atol=1e-4)

@@ -236,6 +236,25 @@ def main():
         (out * w).sum().backward()
         save(f"f8_gather_n{n}", img=img, theta=th, w=w, out=out, gtheta=th.grad, gimg=img.grad)
 
+    # ---------------------------------------------------------------- F9 landmark CNN wrapper (frozen, eval)
+    # 2.8 M parameters are too many to ship: both sides fill every tensor of the (identical) state_dict with the same
+    # closed-form pattern (tests/conftest.det_fill), so only inputs and outputs are stored.
+    print("F9 landmark cnn")
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    from conftest import det_fill
+    torch.manual_seed(9)
+    lc = ref_face.face_landmark_4simmin_glo_loc(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8,
+                                                dim=64, depth=1, heads=1, mlp_dim=64)
+    det_fill(lc)
+    lc.eval()
+    x9 = torch.randn(2, 3, 112, 112).clamp(-1, 1); xa9 = torch.randn(2, 3, 112, 112).clamp(-1, 1)
+    with torch.no_grad():
+        th_a, mo_a = lc(x9, x_Aug=xa9, Random_prob=False)
+        torch.manual_seed(123); th_b, mo_b = lc(x9, x_Aug=xa9, Random_prob=True, return_prob=True, random_coor=False)
+        torch.manual_seed(124); th_c, mo_c = lc(x9, x_Aug=xa9, Random_prob=True, ran_sample=True, random_coor=False)
+    save("f9_landmark_cnn", x=x9, x_aug=xa9, theta_plain=th_a, mosaic_plain=mo_a, theta_jitter=th_b, mosaic_jitter=mo_b,
+         theta_local=th_c, mosaic_local=mo_c, keys=np.array(sorted(lc.state_dict().keys())))
+
     # ---------------------------------------------------------------- F10 CosFace
     print("F10 cosface")
     torch.manual_seed(10)
