@@ -75,6 +75,7 @@ _PROTOS = {
     "lafs_clip_adamw_ema": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp],
     "lafs_cast_bf16": [vp, vp, i64],
     "lafs_transpose_cast_bf16": [vp, i32, i32, vp, i32],
+    "lafs_transpose_cast_table": [vp, vp, vp, vp, i32, i32],
     "lafs_trunk_forward": [C.POINTER(TrunkDesc), vp, vp, vp, i32],
     "lafs_trunk_backward": [C.POINTER(TrunkDesc), vp, vp, vp, i32, i32, vp],
     "lafs_margin_softmax_ce": [vp, i32, i32, i32, vp, vp, f32, f32, f32, i32, f32, vp, vp],

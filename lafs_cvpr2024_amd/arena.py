@@ -102,11 +102,22 @@ class ParamArena:
         self._versions = self._version_key()
 
     def refresh_transposed(self):
-        for name, toff in self.t_offsets.items():
-            p = self.params[self.names.index(name)]
-            rows, cols = p.shape[0], p.numel() // p.shape[0]
-            src = self.view(self.master, name)
-            call("lafs_transpose_cast_bf16", _p(src), rows, cols, _p(self.shadow_t[toff:]), rows)
+        """All W^T shadows in one launch (table-driven 32x32 tile transpose)."""
+        if not self.t_offsets:
+            return
+        if getattr(self, "_t_table", None) is None:
+            rows_, starts, n = [], [0], 0
+            for name, toff in self.t_offsets.items():
+                p = self.params[self.names.index(name)]
+                r, c = p.shape[0], p.numel() // p.shape[0]
+                rows_ += [self.offsets[name], r, c, toff]
+                n += ((r + 31) // 32) * ((c + 31) // 32)
+                starts.append(n)
+            self._t_table = torch.tensor(rows_, dtype=torch.int64, device=self.device)
+            self._t_starts = torch.tensor(starts, dtype=torch.int32, device=self.device)
+            self._t_n = (len(self.t_offsets), n)
+        call("lafs_transpose_cast_table", _p(self.master), _p(self.shadow_t), _p(self._t_table), _p(self._t_starts),
+             self._t_n[0], self._t_n[1])
 
     def ensure_fresh(self):
         """Re-derive the shadows if someone modified a parameter through torch (load_state_dict, .copy_ ...)."""

@@ -46,26 +46,41 @@ __device__ __forceinline__ int lds_f(int row) {
   return (x & 1) | ((x >> 1) << 1) | ((x >> 1) << 2) | ((x & 1) << 3);
 }
 
-// Stage `rows_pad` rows x 64 columns (bf16) starting at src (row stride ld elements) into LDS; rows >= len are zero.
-// LAYOUT 0 = R, 1 = T, 2 = F.  `nthreads` cooperating threads, this thread's index `lt`.
+// Stage ROWS rows x 64 columns (bf16) starting at src (row stride ld elements) into LDS; rows >= len are zero.
+// LAYOUT 0 = R, 1 = T, 2 = F.  NTHR cooperating threads, this thread's index `lt`.  All global loads are issued before the
+// first LDS store (a load->store loop serialises ~7 HBM round trips per tile and dominated the kernel).
 template <int LAYOUT>
-__device__ __forceinline__ void stage_tile(unsigned char* dst, const bf16_t* src, int ld, int len, int rows_pad, int lt,
-                                           int nthreads) {
-  for (int idx = lt; idx < rows_pad * 8; idx += nthreads) {
-    const int row = idx >> 3, ch = idx & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < len) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
-    if (LAYOUT == 0) {
-      *reinterpret_cast<uint4*>(dst + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
-    } else if (LAYOUT == 2) {
-      const int f = lds_f(row);
-      if (f & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-      *reinterpret_cast<uint4*>(dst + row * 128 + ((ch ^ (f >> 1)) << 4)) = v;
-    } else {
-      const int x = (row >> 1) & 3;
-      if (x & 1) v = make_uint4(v.z, v.w, v.x, v.y);          // units 2ch,2ch+1 swap places under ^1
-      *reinterpret_cast<uint4*>(dst + row * 128 + ((ch ^ (x >> 1)) << 4)) = v;
+__device__ __forceinline__ void lds_put(unsigned char* dst, int row, int ch, uint4 v) {
+  if (LAYOUT == 0) {
+    *reinterpret_cast<uint4*>(dst + row * 128 + ((ch ^ (row & 7)) << 4)) = v;
+  } else if (LAYOUT == 2) {
+    const int f = lds_f(row);
+    if (f & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+    *reinterpret_cast<uint4*>(dst + row * 128 + ((ch ^ (f >> 1)) << 4)) = v;
+  } else {
+    const int x = (row >> 1) & 3;
+    if (x & 1) v = make_uint4(v.z, v.w, v.x, v.y);          // units 2ch,2ch+1 swap places under ^1
+    *reinterpret_cast<uint4*>(dst + row * 128 + ((ch ^ (x >> 1)) << 4)) = v;
+  }
+}
+template <int LA, int LB, int ROWS, int NTHR>
+__device__ __forceinline__ void stage_pair(unsigned char* dA, const bf16_t* sA, int ldA, unsigned char* dB, const bf16_t* sB, int ldB,
+                                           int len, int lt) {
+  constexpr int IT = (ROWS * 8 + NTHR - 1) / NTHR;
+  uint4 va[IT], vb[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int idx = lt + i * NTHR, row = idx >> 3, ch = idx & 7;
+    va[i] = make_uint4(0, 0, 0, 0); vb[i] = make_uint4(0, 0, 0, 0);
+    if (idx < ROWS * 8 && row < len) {
+      va[i] = *reinterpret_cast<const uint4*>(sA + (size_t)row * ldA + ch * 8);
+      vb[i] = *reinterpret_cast<const uint4*>(sB + (size_t)row * ldB + ch * 8);
     }
+  }
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int idx = lt + i * NTHR, row = idx >> 3, ch = idx & 7;
+    if (idx < ROWS * 8) { lds_put<LA>(dA, row, ch, va[i]); lds_put<LB>(dB, row, ch, vb[i]); }
   }
 }
 
@@ -109,8 +124,8 @@ struct AttnArgs {
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NT, int PPB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+template <int NT, int PPB, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TILE = NT * 16 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -118,19 +133,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int inner = a.heads * 64;
   const int n_pairs = a.n_seq * a.heads;
   {
-    constexpr int TPP = 256 / PPB;
+    constexpr int TPP = (NW * 64) / PPB;
     const int pl = tid / TPP, lt = tid % TPP;
     const int pair = blockIdx.x * PPB + pl;
     if (pair < n_pairs) {
       const int seq = pair / a.heads, h = pair % a.heads;
       const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
       const bf16_t* base = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
-      stage_tile<0>(smem + pl * 2 * TILE, base + inner, a.ldqkv, len, NT * 16, lt, TPP);
-      stage_tile<1>(smem + pl * 2 * TILE + TILE, base + 2 * inner, a.ldqkv, len, NT * 16, lt, TPP);
+      stage_pair<0, 1, NT * 16, TPP>(smem + pl * 2 * TILE, base + inner, a.ldqkv, smem + pl * 2 * TILE + TILE, base + 2 * inner,
+                                     a.ldqkv, len, lt);
     }
   }
   __syncthreads();
-  for (int item = wave; item < PPB * NT; item += 4) {
+  for (int item = wave; item < PPB * NT; item += NW) {
     const int pl = item % PPB, qt = item / PPB;
     const int pair = blockIdx.x * PPB + pl;
     if (pair >= n_pairs) continue;
@@ -146,17 +161,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 
     f32x4_t st[NT];
     float mx = -INFINITY;
+    const float c2 = a.scale * 1.4426950408889634f;          // scores kept in the log2 domain: p = exp2(s*c2 - max)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4_t s = {0.f, 0.f, 0.f, 0.f};
       const int krow = t * 16 + c16;
       s = mfma16(rfrag(Ks, krow, g), qf0, s);
       s = mfma16(rfrag(Ks, krow, 4 + g), qf1, s);
+      if (t * 16 + 16 <= len) {                               // wave-uniform: only a ragged last tile pays for the mask
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = t * 16 + g * 4 + r;
-        s[r] = (key < len) ? s[r] * a.scale : -INFINITY;
-        mx = fmaxf(mx, s[r]);
+        for (int r = 0; r < 4; ++r) { s[r] *= c2; mx = fmaxf(mx, s[r]); }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s[r] = (t * 16 + g * 4 + r < len) ? s[r] * c2 : -INFINITY;
+          mx = fmaxf(mx, s[r]);
+        }
       }
       st[t] = s;
     }
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = __expf(st[t][r] - mx);
+        const float e = __builtin_amdgcn_exp2f(st[t][r] - mx);
         st[t][r] = e;
         sum += e;
       }
@@ -201,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       bf16_t* op = a.out + (size_t)(tok0 + q) * a.ldo + h * 64 + g * 16;
       reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
       reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-      if (g == 0) a.lse[(size_t)(tok0 + q) * a.heads + h] = mx + __logf(sum);
+      if (g == 0) a.lse[(size_t)(tok0 + q) * a.heads + h] = (mx + __log2f(sum)) * 0.6931471805599453f;   // natural log-sum-exp
     }
   }
 }
@@ -226,8 +246,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // LDS per pair: K (F: row fragments and transpose reads), V (R)
-template <int NT, int PPB>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int NT, int PPB, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TILE = NT * 16 * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -235,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   const int inner = a.heads * 64;
   const int n_pairs = a.n_seq * a.heads;
   {
-    constexpr int TPP = 256 / PPB;
+    constexpr int TPP = (NW * 64) / PPB;
     const int pl = tid / TPP, lt = tid % TPP;
     const int pair = blockIdx.x * PPB + pl;
     if (pair < n_pairs) {
@@ -243,12 +263,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
       const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
       const bf16_t* base = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
       unsigned char* s0 = smem + pl * 2 * TILE;
-      stage_tile<2>(s0, base + inner, a.ldqkv, len, NT * 16, lt, TPP);
-      stage_tile<0>(s0 + TILE, base + 2 * inner, a.ldqkv, len, NT * 16, lt, TPP);
+      stage_pair<2, 0, NT * 16, TPP>(s0, base + inner, a.ldqkv, s0 + TILE, base + 2 * inner, a.ldqkv, len, lt);
     }
   }
   __syncthreads();
-  for (int item = wave; item < PPB * NT; item += 4) {
+  for (int item = wave; item < PPB * NT; item += NW) {
     const int pl = item % PPB, qt = item / PPB;
     const int pair = blockIdx.x * PPB + pl;
     if (pair >= n_pairs) continue;
@@ -285,8 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
           dp = mfma16(rfrag(VsR, krow, 4 + g), df1, dp);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int key = t * 16 + g * 4 + r;
-            const float p = (key < len) ? __expf(s[r] * a.scale - lse_q) : 0.f;
+            const float p = (t * 16 + g * 4 + r < len) ? __expf(s[r] * a.scale - lse_q) : 0.f;
             ds[tt * 4 + r] = p * (dp[r] - del_q) * a.scale;
           }
         } else {
@@ -315,8 +333,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 // LDS per pair: Q (F), dO (F), then lse[NT*16] and delta[NT*16] (f32)
-template <int NT, int PPB>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+template <int NT, int PPB, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TILE = NT * 16 * 128;
   constexpr int PAIR_BYTES = 2 * TILE + 2 * NT * 16 * 4;
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int inner = a.heads * 64;
   const int n_pairs = a.n_seq * a.heads;
   {
-    constexpr int TPP = 256 / PPB;
+    constexpr int TPP = (NW * 64) / PPB;
     const int pl = tid / TPP, lt = tid % TPP;
     const int pair = blockIdx.x * PPB + pl;
     if (pair < n_pairs) {
@@ -334,8 +352,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       const bf16_t* qb = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
       const bf16_t* db = a.dout + (size_t)tok0 * a.lddo + h * 64;
       unsigned char* s0 = smem + pl * PAIR_BYTES;
-      stage_tile<2>(s0, qb, a.ldqkv, len, NT * 16, lt, TPP);
-      stage_tile<2>(s0 + TILE, db, a.lddo, len, NT * 16, lt, TPP);
+      stage_pair<2, 2, NT * 16, TPP>(s0, qb, a.ldqkv, s0 + TILE, db, a.lddo, len, lt);
       float* lsd = reinterpret_cast<float*>(s0 + 2 * TILE);
       for (int r = lt; r < NT * 16; r += TPP) {
         const bool ok = r < len;
@@ -345,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
     }
   }
   __syncthreads();
-  for (int item = wave; item < PPB * NT; item += 4) {
+  for (int item = wave; item < PPB * NT; item += NW) {
     const int pl = item % PPB, kt = item / PPB;
     const int pair = blockIdx.x * PPB + pl;
     if (pair >= n_pairs) continue;
@@ -386,8 +403,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = qt * 16 + g * 4 + r;
-            const float lse_q = lq[r], del_q = dq4[r];
-            const float p = (q < len && key_ok) ? __expf(s[r] * a.scale - lse_q) : 0.f;
+            const float del_q = dq4[r];
+            const float p = (q < len && key_ok) ? __expf(s[r] * a.scale - lq[r]) : 0.f;
             pv[tt * 4 + r] = p;
             ds[tt * 4 + r] = p * (dp[r] - del_q) * a.scale;
           }
@@ -426,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
 }
 
 template <typename K>
-int launch_attn(K kernel, int n_pairs, int ppb, size_t lds, const AttnArgs& a, hipStream_t s) {
+int launch_attn(K kernel, int n_pairs, int ppb, int threads, size_t lds, const AttnArgs& a, hipStream_t s) {
   // raise the dynamic-LDS limit once per kernel instantiation (not a stream operation; kept out of graph capture)
   static std::mutex mu;
   static std::set<const void*> done;
@@ -442,7 +459,7 @@ int launch_attn(K kernel, int n_pairs, int ppb, size_t lds, const AttnArgs& a, h
       done.insert(key);
     }
   }
-  hipLaunchKernelGGL(kernel, dim3(ceil_div(n_pairs, ppb)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kernel, dim3(ceil_div(n_pairs, ppb)), dim3(threads), lds, s, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -450,11 +467,13 @@ int launch_attn(K kernel, int n_pairs, int ppb, size_t lds, const AttnArgs& a, h
 // which: 0 = fwd (2 tiles/pair), 1 = dq (3), 2 = dkv (4)
 template <int NT, int PPB>
 int dispatch(int which, const AttnArgs& a, hipStream_t s) {
+  // 8 waves per workgroup for long sequences: 13 query/key tiles spread over 8 waves (2 rounds) instead of 4 (4 rounds)
+  constexpr int NW = 4;          // measured: 8 waves/workgroup is slower (36.7 vs 31.0 us fwd at 128 x 197)
   const int n_pairs = a.n_seq * a.heads;
   const size_t tile = (size_t)NT * 16 * 128;
-  if (which == 0) return launch_attn(attn_fwd_kernel<NT, PPB>, n_pairs, PPB, PPB * 2 * tile, a, s);
-  if (which == 1) return launch_attn(attn_bwd_dq_kernel<NT, PPB>, n_pairs, PPB, PPB * 2 * tile, a, s);
-  return launch_attn(attn_bwd_dkv_kernel<NT, PPB>, n_pairs, PPB, PPB * (2 * tile + 2 * NT * 16 * 4), a, s);
+  if (which == 0) return launch_attn(attn_fwd_kernel<NT, PPB, NW>, n_pairs, PPB, NW * 64, PPB * 2 * tile, a, s);
+  if (which == 1) return launch_attn(attn_bwd_dq_kernel<NT, PPB, NW>, n_pairs, PPB, NW * 64, PPB * 2 * tile, a, s);
+  return launch_attn(attn_bwd_dkv_kernel<NT, PPB, NW>, n_pairs, PPB, NW * 64, PPB * (2 * tile + 2 * NT * 16 * 4), a, s);
 }
 
 int dispatch_len(int which, int max_len, const AttnArgs& a, hipStream_t s) {

@@ -37,13 +37,14 @@ extern "C" void lafs_set_error(const char* fmt, ...);
 
 // ---- bf16 <-> fp32 (round to nearest even) ----
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16 through the native __bf16 type: on gfx950 the compiler lowers this to v_cvt_pk_bf16_f32 (round to nearest
+// even, two values per instruction) -- the hand-rolled integer rounding cost ~5 VALU per value and made the attention
+// kernels and GEMM epilogues VALU-issue bound.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }

@@ -54,23 +54,28 @@ __global__ __launch_bounds__(256) void embed_cls_kernel(const float* __restrict_
   tok[(size_t)s * (npatch + 1) * ldt + d] = cls[d] + pos[d];
 }
 
-// thread per (token t in 0..np, 4 channels): loops over sequences
+// grid (column-quad chunks, sequence chunks of EB_SEQ): thread = (token t, 4 channels); each workgroup sums its sequence
+// chunk in registers and adds it to dpos with one atomic per element (n_seq/EB_SEQ adds per address).
+constexpr int EB_SEQ = 16;
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, int ldg, int n_seq, int npatch, int D,
                                                        bf16_t* __restrict__ gp, float* __restrict__ dpos, float* __restrict__ dcls) {
   const int per = D >> 2;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= (npatch + 1) * per) return;
   const int t = i / per, c = (i % per) * 4;
+  const int s0 = blockIdx.y * EB_SEQ, s1 = min(n_seq, s0 + EB_SEQ);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int s = 0; s < n_seq; ++s) {
+  for (int s = s0; s < s1; ++s) {
     const float4 v = *reinterpret_cast<const float4*>(g + ((size_t)s * (npatch + 1) + t) * ldg + c);
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     if (t > 0 && gp != nullptr)
       *reinterpret_cast<uint2*>(gp + ((size_t)s * npatch + (t - 1)) * D + c) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
   }
   float* dp = dpos + (size_t)t * D + c;
-  dp[0] += acc.x; dp[1] += acc.y; dp[2] += acc.z; dp[3] += acc.w;
-  if (t == 0 && dcls != nullptr) { dcls[c] += acc.x; dcls[c + 1] += acc.y; dcls[c + 2] += acc.z; dcls[c + 3] += acc.w; }
+  atomicAdd(dp, acc.x); atomicAdd(dp + 1, acc.y); atomicAdd(dp + 2, acc.z); atomicAdd(dp + 3, acc.w);
+  if (t == 0 && dcls != nullptr) {
+    atomicAdd(dcls + c, acc.x); atomicAdd(dcls + c + 1, acc.y); atomicAdd(dcls + c + 2, acc.z); atomicAdd(dcls + c + 3, acc.w);
+  }
 }
 
 __global__ __launch_bounds__(256) void gather_cls_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ cu,
@@ -115,7 +120,7 @@ extern "C" int lafs_embed_bwd(const float* g, int ldg, int n_seq, int npatch, in
                               hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g && dpos && n_seq > 0 && npatch > 0 && D > 0 && D % 4 == 0 && ldg % 4 == 0, "bad operand");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(ceil_div((npatch + 1) * (D / 4), 256)), dim3(256), 0, stream, g, ldg, n_seq, npatch, D,
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(ceil_div((npatch + 1) * (D / 4), 256), ceil_div(n_seq, EB_SEQ)), dim3(256), 0, stream, g, ldg, n_seq, npatch, D,
                      (bf16_t*)gp, dpos, dcls);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;

@@ -162,8 +162,8 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   auto fork = [&]() {                      // work enqueued on s2 after this sees everything enqueued on `stream` so far
     if (!two) return;
     hipEvent_t e = ev[evi++];
-    hipEventRecord(e, stream);
-    hipStreamWaitEvent(s2, e, 0);
+    (void)hipEventRecord(e, stream);
+    (void)hipStreamWaitEvent(s2, e, 0);
   };
   std::vector<hipEvent_t> done(d->depth, nullptr);
   auto scale = [&](int l, int br) { return d->drop_scales ? d->drop_scales + ((size_t)l * 2 + br) * d->n_seq : nullptr; };
@@ -173,7 +173,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const LayerBuf& b = c.layers[l];
     const float* x0 = (l == 0) ? x_in : b.x0;
     const int p = l & 1;
-    if (two && l + 2 < layer_hi) hipStreamWaitEvent(stream, done[l + 2], 0);     // parity buffers free again
+    if (two && l + 2 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 2], 0);     // parity buffers free again
     // ---- MLP branch ----
     fork();
     RUN(lafs_gemm_tn_acc(s.gbm[p], D, b.a, M, gr + o.w_fc2, M, T, D, M, 0, gr + o.b_fc2, s2));
@@ -192,13 +192,13 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
                            d->attn_scale, s.dqkv[p], 3 * I, stream));
     fork();
     RUN(lafs_gemm_tn_acc(s.dqkv[p], 3 * I, b.h1, D, gr + o.w_qkv, D, T, 3 * I, D, 0, o.b_qkv >= 0 ? gr + o.b_qkv : nullptr, s2));
-    if (two) { done[l] = ev[evi++]; hipEventRecord(done[l], s2); }
+    if (two) { done[l] = ev[evi++]; (void)hipEventRecord(done[l], s2); }
     RUN(gemm(s.dqkv[p], 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     const bool more = l > 0;
     RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, x0, D, b.st1, d->master + o.ln1_g, g, D, 1, more ? s.gbm[(l - 1) & 1] : nullptr, D,
                            more ? scale(l - 1, 1) : nullptr, d->row2seq, gr + o.ln1_g, gr + o.ln1_b, T, D, stream));
   }
-  if (two) hipStreamWaitEvent(stream, done[layer_lo], 0);                        // join (s2 is in-order)
+  if (two) (void)hipStreamWaitEvent(stream, done[layer_lo], 0);                        // join (s2 is in-order)
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -164,6 +164,42 @@ extern "C" int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_
   return LAFS_OK;
 }
 
+// table[4*i + {0,1,2,3}] = {src offset (elements into master), rows, cols, dst offset (elements into shadow_t)};
+// tile_start[i] = first 32x32-tile index of matrix i (prefix sum), tile_start[n] = total tiles.
+__global__ __launch_bounds__(256) void transpose_cast_table_kernel(const float* __restrict__ master, bf16_t* __restrict__ shadow_t,
+                                                                  const long* __restrict__ table, const int* __restrict__ tile_start,
+                                                                  int n_mat) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = n_mat;                                  // binary search: which matrix owns this tile
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const long* e = table + 4 * lo;
+  const int rows = (int)e[1], cols = (int)e[2];
+  const float* src = master + e[0];
+  bf16_t* dst = shadow_t + e[3];
+  const int local = blockIdx.x - tile_start[lo], tcols = (cols + 31) >> 5;
+  const int c0 = (local % tcols) * 32, r0 = (local / tcols) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < cols && r < rows) dst[(size_t)c * rows + r] = f2bf(tile[tx][j]);
+  }
+}
+
+extern "C" int lafs_transpose_cast_table(const float* master, void* shadow_t, const int64_t* table, const int32_t* tile_start,
+                                         int n_mat, int n_tiles, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(master && shadow_t && table && tile_start && n_mat > 0 && n_tiles > 0, "bad operand");
+  hipLaunchKernelGGL(transpose_cast_table_kernel, dim3(n_tiles), dim3(256), 0, stream, master, (bf16_t*)shadow_t, (const long*)table,
+                     tile_start, n_mat);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
 extern "C" int lafs_transpose_cast_bf16(const float* src, int rows, int cols, void* dst, int ld_dst, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_dst >= rows, "bad operand");

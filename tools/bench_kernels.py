@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the hot kernels at the C2 shapes (ViT-S, B=64: 44160 student tokens).  GPU box only."""
-import sys, os
+"""Micro-benchmarks of the hot kernels at the C2 shapes (ViT-S, B=64: 44160 student tokens).  GPU box only.
+usage: python tools/bench_kernels.py [nt] [tn] [attn] [ablate] [tiles]      (default: nt tn attn)"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from lafs_cvpr2024_amd import _lib, ops
 
-dev = "cuda"
-bf = torch.bfloat16
+dev, bf, T = "cuda", torch.bfloat16, 44160
+which = set(sys.argv[1:]) or {"nt", "tn", "attn"}
 
 
 def timeit(fn, iters=20):
@@ -34,79 +37,54 @@ def nt(M, N, K, epi, name):
     if epi == _lib.EPI_DGELU_BF16:
         kw["aux"] = torch.randn(M, N, device=dev).to(bf); byts += M * N * 2
     t = timeit(lambda: ops.gemm_nt(A, B, epi, bias=None if epi == _lib.EPI_DGELU_BF16 else bias, out=out, **kw))
-    print(f"NT {name:22s} M={M:6d} N={N:5d} K={K:5d}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s  {byts/t/1e9:7.0f} GB/s")
+    print(f"NT {name:24s} M={M:6d} N={N:6d} K={K:5d}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s  {byts/t/1e9:7.0f} GB/s")
 
 
-def tn(M, N1, N2, name):
+def tn(M, N1, N2, name, splits=0):
     A = torch.randn(M, N1, device=dev).to(bf); B = torch.randn(M, N2, device=dev).to(bf)
     C = torch.zeros(N1, N2, device=dev)
-    t = timeit(lambda: ops.gemm_tn_acc(A, B, C))
-    print(f"TN {name:22s} M={M:6d} N1={N1:4d} N2={N2:5d}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TF/s  {(M*(N1+N2)*2)/t/1e9:7.0f} GB/s")
+    t = timeit(lambda: ops.gemm_tn_acc(A, B, C, splits=splits))
+    print(f"TN {name:24s} M={M:6d} N1={N1:6d} N2={N2:5d}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TF/s  {(M*(N1+N2)*2)/t/1e9:7.0f} GB/s")
 
 
-T = 44160
-nt(T, 1152, 384, _lib.EPI_BF16, "qkv fwd")
-nt(T, 384, 384, _lib.EPI_RESID_F32, "proj fwd")
-nt(T, 1536, 384, _lib.EPI_BF16_GELU, "fc1 fwd")
-nt(T, 384, 1536, _lib.EPI_RESID_F32, "fc2 fwd")
-nt(T, 1536, 384, _lib.EPI_DGELU_BF16, "fc2 dgrad")
-nt(T, 384, 1536, _lib.EPI_BF16, "fc1 dgrad")
-nt(T, 384, 384, _lib.EPI_BF16, "proj dgrad")
-nt(T, 384, 1152, _lib.EPI_BF16, "qkv dgrad")
-nt(640, 100096, 256, _lib.EPI_F32, "last layer")
-nt(4096, 4096, 4096, _lib.EPI_BF16, "square 4k")
-tn(T, 384, 1536, "fc2 wgrad")
-tn(T, 1536, 384, "fc1 wgrad")
-tn(T, 384, 384, "proj wgrad")
-tn(T, 1152, 384, "qkv wgrad")
-tn(640, 100096, 256, "last wgrad")
+SHAPES = [(T, 1152, 384, _lib.EPI_BF16, "qkv fwd"), (T, 384, 384, _lib.EPI_RESID_F32, "proj fwd"),
+          (T, 1536, 384, _lib.EPI_BF16_GELU, "fc1 fwd"), (T, 384, 1536, _lib.EPI_RESID_F32, "fc2 fwd"),
+          (T, 1536, 384, _lib.EPI_DGELU_BF16, "fc2 dgrad"), (T, 384, 1536, _lib.EPI_BF16, "fc1 dgrad"),
+          (T, 384, 384, _lib.EPI_BF16, "proj dgrad"), (T, 384, 1152, _lib.EPI_BF16, "qkv dgrad"),
+          (640, 100096, 256, _lib.EPI_F32, "last layer"), (4096, 4096, 4096, _lib.EPI_BF16, "square 4k")]
 
-print("--- NT tile height 128 (flag 2) vs 256 (flag 4)")
-for flag in (2, 4, 10, 12):
-    _lib.lib().lafs_debug_set(flag)
-    nt(T, 1152, 384, _lib.EPI_BF16, f"qkv fwd wm{flag}")
-    nt(T, 384, 384, _lib.EPI_RESID_F32, f"proj fwd wm{flag}")
-    nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd wm{flag}")
-    nt(T, 1536, 384, _lib.EPI_BF16, f"fc1 plain wm{flag}")
-    nt(T, 384, 1536, _lib.EPI_RESID_F32, f"fc2 fwd wm{flag}")
-    nt(T, 1536, 384, _lib.EPI_DGELU_BF16, f"fc2 dgrad wm{flag}")
-    nt(T, 384, 1536, _lib.EPI_BF16, f"fc1 dgrad wm{flag}")
-    nt(T, 384, 1152, _lib.EPI_BF16, f"qkv dgrad wm{flag}")
-    nt(25216, 1152, 384, _lib.EPI_BF16, f"qkv fwd teacher wm{flag}")
-    nt(4096, 4096, 4096, _lib.EPI_BF16, f"square 4k wm{flag}")
-_lib.lib().lafs_debug_set(0)
-
-print("--- NT ablations: 0 full, 16 no stores, 32 no mfma, 48 loads only")
-for flag in (0, 16, 32, 48):
-    _lib.lib().lafs_debug_set(flag)
-    nt(T, 1152, 384, _lib.EPI_BF16, f"qkv fwd abl{flag}")
-    nt(T, 384, 1536, _lib.EPI_BF16, f"fc1 dgrad abl{flag}")
-    nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd abl{flag}")
-_lib.lib().lafs_debug_set(0)
-
-print("--- fc1 GELU epilogue: separate u/a buffers vs one interleaved [T, 2*mlp] buffer")
-def gelu_variants():
-    M, N, K = T, 1536, 384
-    A = torch.randn(M, K, device=dev).to(bf); B = (torch.randn(N, K, device=dev) * .02).to(bf); bias = torch.zeros(N, device=dev)
-    u = torch.empty(M, N, device=dev, dtype=bf); a = torch.empty(M, N, device=dev, dtype=bf)
-    t = timeit(lambda: ops.gemm_nt(A, B, _lib.EPI_BF16_GELU, bias=bias, out=u, out2=a))
-    print(f"   separate buffers      : {t*1e6:7.1f} us")
-    ua = torch.empty(M, 2 * N, device=dev, dtype=bf)
-    t = timeit(lambda: ops.gemm_nt(A, B, _lib.EPI_BF16_GELU, bias=bias, out=ua[:, :N], out2=ua[:, N:]))
-    print(f"   interleaved rows      : {t*1e6:7.1f} us")
-    pad = torch.empty(M * N + 4096 + 64, device=dev, dtype=bf)
-    a2 = pad[4096 + 64: 4096 + 64 + M * N].view(M, N) if (4096 + 64) % 8 == 0 else a
-    t = timeit(lambda: ops.gemm_nt(A, B, _lib.EPI_BF16_GELU, bias=bias, out=u, out2=a2))
-    print(f"   separate, a shifted 8K: {t*1e6:7.1f} us")
-gelu_variants()
-print("--- fc1 GELU ablations: 64 = no second store, 128 = second store without gelu math")
-for flag in (0, 64, 128):
-    _lib.lib().lafs_debug_set(flag)
-    nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd abl{flag}")
-_lib.lib().lafs_debug_set(0)
-print("--- loads-only ablation across tile variants (flag 48 + {0: 128x128 bk32, 4: 256x128 bk32, 8: 128x128 bk64, 12: 256x128 bk64})")
-for flag in (48, 52, 56, 60):
-    _lib.lib().lafs_debug_set(flag)
-    nt(T, 1152, 384, _lib.EPI_BF16, f"qkv fwd loads f{flag}")
-    nt(T, 384, 1536, _lib.EPI_BF16, f"fc1 dgrad loads f{flag}")
-_lib.lib().lafs_debug_set(0)
+if "nt" in which:
+    for M, N, K, e, n in SHAPES:
+        nt(M, N, K, e, n)
+if "tn" in which:
+    tn(T, 384, 1536, "fc2 wgrad"); tn(T, 1536, 384, "fc1 wgrad"); tn(T, 384, 384, "proj wgrad"); tn(T, 1152, 384, "qkv wgrad")
+    tn(640, 100096, 256, "last wgrad")
+if "tiles" in which:
+    print("--- NT tile variants: flag 2 = 128x128 bk32, 4 = 256x128 bk32, 10 = 128x128 bk64, 12 = 256x128 bk64")
+    for flag in (2, 4, 10, 12):
+        _lib.lib().lafs_debug_set(flag)
+        for M, N, K, e, n in SHAPES[:8]:
+            nt(M, N, K, e, f"{n} f{flag}")
+    _lib.lib().lafs_debug_set(0)
+if "ablate" in which:
+    print("--- NT ablations: 0 full, 16 no stores, 32 no mfma, 48 loads only, 64 no second (GELU) store")
+    for flag in (0, 16, 32, 48, 64):
+        _lib.lib().lafs_debug_set(flag)
+        nt(T, 1152, 384, _lib.EPI_BF16, f"qkv fwd abl{flag}")
+        nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd abl{flag}")
+    _lib.lib().lafs_debug_set(1)
+    print("--- TN with plain stores instead of atomics (flag 1)")
+    tn(T, 384, 1536, "fc2 wgrad")
+    _lib.lib().lafs_debug_set(0)
+if "attn" in which:
+    print("--- attention (student shapes: 128 seqs x 197 and 512 x 37, 6 heads)")
+    for nseq, n in ((128, 197), (512, 37)):
+        heads = 6
+        cu = torch.arange(0, (nseq + 1) * n, n, dtype=torch.int32, device=dev)
+        qkv = torch.randn(nseq * n, 3 * heads * 64, device=dev).to(bf)
+        out, lse = ops.attention_fwd(qkv, cu, n, heads, 0.125)
+        dout = torch.randn(nseq * n, heads * 64, device=dev).to(bf)
+        tf = timeit(lambda: ops.attention_fwd(qkv, cu, n, heads, 0.125))
+        tb = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, cu, n, heads, 0.125))
+        fl = 4 * nseq * heads * n * n * 64
+        print(f"   {nseq:4d} x {n:3d}: fwd {tf*1e6:7.1f} us ({fl/tf/1e12:6.1f} TF/s)   bwd {tb*1e6:7.1f} us ({2.5*fl/tb/1e12:6.1f} TF/s)")
