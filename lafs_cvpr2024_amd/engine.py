@@ -59,6 +59,10 @@ class LafsPretrainEngine:
         if self.sa.names != self.ta.names or self.sa.size != self.ta.size:
             raise _lib.LafsHipError("student and teacher must have identical parameter layouts")
         dino_loss.to(self.device)
+        if self.world > 1:                       # DDP's initial parameter broadcast (reference lafs_train.py:375)
+            for t in (self.sa.master, self.ta.master, dino_loss.center):
+                dist.broadcast(t, 0)
+            self.sa.refresh_shadows(); self.ta.refresh_shadows()
         self.K = student.head.out_dim
         self.Kpad = (self.K + 127) // 128 * 128
         B, D = batch_size, vit_s.embed_dim
@@ -89,9 +93,10 @@ class LafsPretrainEngine:
         # gradient ranges for the two all-reduces: [trunk | head]
         self.head_start = min(o for n, o in self.sa.offsets.items() if n.startswith(self.head_prefix_s))
         self.depth = vit_s.depth
-        n_sl = max(1, min(grad_slices, self.depth))
-        cuts = [round(self.depth * i / n_sl) for i in range(n_sl, -1, -1)]
-        self.layer_slices = [(cuts[i], cuts[i + 1]) for i in range(n_sl)]
+        # the trunk backward is cut in two graph segments so that the upper blocks' gradients are already on the wire
+        # (RCCL) while the lower blocks are still being computed
+        self.mid = self.depth // 2 if grad_slices > 1 else 0
+        self.mid_start = self.sa.offsets[f"{self.spec_s.prefix}blocks.{self.mid}.norm1.weight"] if self.mid > 0 else 0
         self.reducer = FlatReducer()
         self.side_stream = torch.cuda.Stream(device=self.device)      # teacher forward / weight-gradient GEMMs
         self.use_graph = use_graph
@@ -133,10 +138,17 @@ class LafsPretrainEngine:
         dfeat = Fn.head_backward(sa, self.head_prefix_s, st_h, self.dlogits, train_g=train_g)
         self._st = dict(vit=st_v, dfeat=dfeat)
 
-    def _seg_trunk_backward(self):
+    def _seg_trunk_backward_hi(self):
+        """Upper half of the trunk (final norm + blocks depth-1 .. mid)."""
+        self._st["g"] = Fn.vit_backward_begin(self.sa, self.spec_s, self._st["vit"], self._st["dfeat"])
+        Fn.vit_backward_layers(self._st["vit"], self._st["g"], self.depth, self.mid, wgrad_stream=self.side_stream)
+
+    def _seg_trunk_backward_lo(self):
+        """Lower half (blocks mid-1 .. 0), patch embedding, position table."""
         sa = self.sa
-        dpos = Fn.vit_backward(sa, self.spec_s, self._st["vit"], self._st["dfeat"], layer_slices=self.layer_slices,
-                               wgrad_stream=self.side_stream)
+        if self.mid > 0:
+            Fn.vit_backward_layers(self._st["vit"], self._st["g"], self.mid, 0, wgrad_stream=self.side_stream)
+        dpos = Fn.vit_backward_end(sa, self.spec_s, self._st["vit"], self._st["g"])
         gpe = sa.view(sa.grad, self.spec_s.prefix + "pos_embed").view(-1, self.spec_s.trunk.dim)
         for M, dp in zip(self.interp, dpos):
             if M is None:
@@ -158,7 +170,7 @@ class LafsPretrainEngine:
 
     # ------------------------------------------------------------------ step
     def _capture(self):
-        segs = [self._seg_forward, self._seg_trunk_backward, self._seg_update]
+        segs = [self._seg_forward, self._seg_trunk_backward_hi, self._seg_trunk_backward_lo, self._seg_update]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                       # warm-up outside capture (lazy inits, caches)
@@ -199,13 +211,17 @@ class LafsPretrainEngine:
             self.hyper.copy_(h, non_blocking=True)
         run = (lambda i, f: self._graphs[i].replay()) if self.use_graph else (lambda i, f: f())
         run(0, self._seg_forward)
-        # head gradients + center sums go out over RCCL while the trunk backward runs; the trunk range follows it
+        # head gradients + center sums go out over RCCL while the trunk backward runs; each half of the trunk follows as
+        # soon as its graph segment has been enqueued (arena order: [embed | blocks 0..depth-1 | norm | head])
         self.reducer.launch(self.sa.grad[self.head_start:])
         self.reducer.launch(self.colsum)
-        run(1, self._seg_trunk_backward)
-        self.reducer.launch(self.sa.grad[:self.head_start])
+        run(1, self._seg_trunk_backward_hi)
+        self.reducer.launch(self.sa.grad[self.mid_start:self.head_start])
+        run(2, self._seg_trunk_backward_lo)
+        if self.mid_start > 0:
+            self.reducer.launch(self.sa.grad[:self.mid_start])
         self.reducer.wait_all()
-        run(2, self._seg_update)
+        run(3, self._seg_update)
         self.step_count += 1
         return self.loss
 

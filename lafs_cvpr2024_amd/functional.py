@@ -164,9 +164,8 @@ def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, dr
     return feat, st, x_out
 
 
-def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, layer_slices=None, on_slice_done=None, wgrad_stream=None):
-    """dfeat f32 [n_seq, D].  Accumulates every parameter gradient into arena.grad EXCEPT the position table:
-    returns the list of dpos f32 [npatch+1, D] per group (the bicubic resampling lives in torch)."""
+def vit_backward_begin(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None):
+    """Final-LayerNorm backward on the cls rows and scatter into the (zeroed) residual-gradient buffer.  Returns g."""
     geom, D, pre = st.geom, spec.trunk.dim, spec.prefix
     dev = dfeat.device
     gv = lambda n: arena.view(arena.grad, pre + n)
@@ -176,13 +175,21 @@ def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, layer_sl
     g = g_buf if g_buf is not None else torch.empty(geom.n_tok, D, device=dev, dtype=f32)
     g.zero_()
     call("lafs_scatter_cls", _p(dcls_rows), _p(geom.cu_seqlens), geom.n_seq, D, _p(g), D)
-    depth = spec.trunk.depth
-    slices = layer_slices or [(depth, 0)]
-    for hi, lo in slices:
-        ws2 = C.c_void_p(wgrad_stream.cuda_stream) if wgrad_stream is not None else None
-        call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo, ws2)
-        if on_slice_done is not None:
-            on_slice_done(hi, lo)
+    return g
+
+
+def vit_backward_layers(st: ViTState, g, hi, lo, wgrad_stream=None):
+    """Blocks hi-1 .. lo of the trunk backward (weight-gradient GEMMs optionally on `wgrad_stream`)."""
+    ws2 = C.c_void_p(wgrad_stream.cuda_stream) if wgrad_stream is not None else None
+    call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo, ws2)
+
+
+def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g):
+    """Token-assembly / patch-embedding backward.  Returns the list of dpos f32 [npatch+1, D] per group (the bicubic
+    resampling of the position table lives in torch)."""
+    geom, D, pre = st.geom, spec.trunk.dim, spec.prefix
+    dev = g.device
+    gv = lambda n: arena.view(arena.grad, pre + n)
     dpos = []
     for gi in range(len(geom.groups)):
         n_img, np_ = geom.groups[gi][0], geom.npatch(gi)
@@ -193,6 +200,14 @@ def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, layer_sl
         ops.gemm_tn_acc(gp, st.patches[gi], gv(spec.w_patch).view(D, -1), colsum=gv(spec.b_patch))
         dpos.append(dp)
     return dpos
+
+
+def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, wgrad_stream=None):
+    """dfeat f32 [n_seq, D].  Accumulates every parameter gradient into arena.grad EXCEPT the position table, whose
+    per-group gradients are returned."""
+    g = vit_backward_begin(arena, spec, st, dfeat, g_buf)
+    vit_backward_layers(st, g, spec.trunk.depth, 0, wgrad_stream)
+    return vit_backward_end(arena, spec, st, g)
 
 
 # ----------------------------------------------------------------------------------------------- DINO head
