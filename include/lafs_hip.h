@@ -248,6 +248,18 @@ int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, v
 int lafs_margin_softmax_ce(float* cos, int ld, int B, int C, const int32_t* y1, const int32_t* y2, float lam,
                            float s, float m, int margin_type, float loss_scale, float* loss_out, float* row_ws,
                            hipStream_t stream);
+/* Class-sharded margin softmax (PartialFC; PARITY UNPINNED: absent from the reference, ViT_face.py:645-649 is a commented
+ * import; semantics follow InsightFace partial_fc_v2).  cos(f32) [B, ld] over this rank's S (sampled) class centres;
+ * y_local(i32)[B] = local index of the target or -1.  Three passes with the cross-rank statistics exchanged in between
+ * (all-reduce MAX of rowmax, all-reduce SUM of rowsum and target_logit):  z = margin logits;
+ *   rowmax[b] = max_k z ;  rowsum[b] = sum_k exp(z - gmax[b]), target_logit[b] = z_target or 0 ;
+ *   grad (in place) cos <- grad_scale * (exp(z - gmax)/Z - onehot) * dz/dcos. */
+int lafs_shard_margin_rowmax(const float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
+                             int margin_type, float* rowmax, hipStream_t stream);
+int lafs_shard_margin_rowsum(const float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
+                             int margin_type, const float* gmax, float* rowsum, float* target_logit, hipStream_t stream);
+int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m, int margin_type,
+                           const float* gmax, const float* Z, float grad_scale, hipStream_t stream);
 /* x(f32) [B,3,S,S]: x = lam*x + (1-lam)*flip_batch(x) in place, from u8 or f32 source with (x/255*2-1) folded in. */
 int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, hipStream_t stream);
 /* Landmark patch gather (face_pre_pro/ViT_face.py:1615-1656): img f32 [B,3,S,S], theta f32 [B,n,2] (x,y pixels) ->

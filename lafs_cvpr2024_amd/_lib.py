@@ -79,6 +79,9 @@ _PROTOS = {
     "lafs_trunk_forward": [C.POINTER(TrunkDesc), vp, vp, vp, i32],
     "lafs_trunk_backward": [C.POINTER(TrunkDesc), vp, vp, vp, i32, i32, vp],
     "lafs_margin_softmax_ce": [vp, i32, i32, i32, vp, vp, f32, f32, f32, i32, f32, vp, vp],
+    "lafs_shard_margin_rowmax": [vp, i32, i32, i32, vp, f32, f32, i32, vp],
+    "lafs_shard_margin_rowsum": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, vp],
+    "lafs_shard_margin_grad": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, f32],
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],
     "lafs_patch_gather_bwd": [vp, vp, vp, i32, i32, i32, vp, vp],

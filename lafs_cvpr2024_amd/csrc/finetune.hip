@@ -148,6 +148,57 @@ __global__ __launch_bounds__(64) void gather_bwd_kernel(const float* __restrict_
   }
 }
 
+// ---- class-sharded margin softmax (PartialFC): three row passes with the cross-rank statistics exchanged in between ----
+// y[b] = local index of the row's target class inside this shard, or -1 when another rank owns it.
+__global__ __launch_bounds__(256) void shard_rowmax_kernel(const float* __restrict__ cosv, int ld, int S, const int* __restrict__ y,
+                                                          float s, float m, int type, float* __restrict__ rowmax) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* row = cosv + (size_t)b * ld;
+  const int t = y[b];
+  float mx = -INFINITY;
+  for (int k = threadIdx.x; k < S; k += 256) mx = fmaxf(mx, margin_logit(row[k], k == t ? 1.f : 0.f, s, m, type));
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) rowmax[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// rowsum[b] = sum_k exp(z_k - gmax[b]);  tgt[b] = z_target (0 when the target lives on another rank)
+__global__ __launch_bounds__(256) void shard_rowsum_kernel(const float* __restrict__ cosv, int ld, int S, const int* __restrict__ y,
+                                                          float s, float m, int type, const float* __restrict__ gmax,
+                                                          float* __restrict__ rowsum, float* __restrict__ tgt) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float* row = cosv + (size_t)b * ld;
+  const int t = y[b];
+  const float g = gmax[b];
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < S; k += 256) acc += __expf(margin_logit(row[k], k == t ? 1.f : 0.f, s, m, type) - g);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    rowsum[b] = red[0] + red[1] + red[2] + red[3];
+    tgt[b] = (t >= 0) ? margin_logit(row[t], 1.f, s, m, type) : 0.f;
+  }
+}
+
+// in place: cos -> dL/dcos = gscale * (exp(z - gmax)/Z - onehot) * dz/dcos
+__global__ __launch_bounds__(256) void shard_grad_kernel(float* __restrict__ cosv, int ld, int S, const int* __restrict__ y, float s,
+                                                        float m, int type, const float* __restrict__ gmax,
+                                                        const float* __restrict__ Z, float gscale) {
+  const int b = blockIdx.x;
+  float* row = cosv + (size_t)b * ld;
+  const int t = y[b];
+  const float g = gmax[b], iz = 1.0f / Z[b];
+  for (int k = threadIdx.x; k < S; k += 256) {
+    const float c = row[k], yk = (k == t) ? 1.f : 0.f;
+    const float z = margin_logit(c, yk, s, m, type);
+    row[k] = gscale * (__expf(z - g) * iz - yk) * margin_dlogit(c, yk, s, m, type);
+  }
+}
+
 int isqrt_exact(int n) {
   int r = 0;
   while ((r + 1) * (r + 1) <= n) ++r;
@@ -195,6 +246,35 @@ extern "C" int lafs_patch_gather_bwd(const float* img, const float* theta, const
   const int r = isqrt_exact(n);
   LAFS_CHECK_ARG(img && theta && dmosaic && dtheta && B > 0 && S > 0 && r > 0, "n must be a perfect square");
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(n, B), dim3(64), 0, stream, img, theta, dmosaic, S, n, r, dtheta, dimg);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_shard_margin_rowmax(const float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
+                                        int margin_type, float* rowmax, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(cos && y_local && rowmax && B > 0 && S > 0 && ld >= S, "bad operand");
+  hipLaunchKernelGGL(shard_rowmax_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, s, m, margin_type, rowmax);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_shard_margin_rowsum(const float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
+                                        int margin_type, const float* gmax, float* rowsum, float* target_logit,
+                                        hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(cos && y_local && gmax && rowsum && target_logit && B > 0 && S > 0 && ld >= S, "bad operand");
+  hipLaunchKernelGGL(shard_rowsum_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, s, m, margin_type, gmax, rowsum,
+                     target_logit);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
+                                      int margin_type, const float* gmax, const float* Z, float grad_scale, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(cos && y_local && gmax && Z && B > 0 && S > 0 && ld >= S, "bad operand");
+  hipLaunchKernelGGL(shard_grad_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, s, m, margin_type, gmax, Z, grad_scale);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

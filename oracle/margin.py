@@ -61,3 +61,32 @@ def partial_fc_reference(emb, weight, labels, s=64.0, m=0.4):
     reference: only a commented import, ViT_face.py:645-649)."""
     logits = cosface_logits(emb, weight, labels, s, m)
     return F.cross_entropy(logits, labels.long())
+
+
+def partial_fc_sharded(emb_local, labels_local, weight_shard, class_start, s=64.0, m=0.4,
+                       all_gather=None, all_reduce_max=None, all_reduce_sum=None):
+    """Class-sharded CosFace + CE with the distributed softmax of InsightFace partial_fc_v2
+    (DistCrossEntropy), sample_rate = 1.  PARITY UNPINNED (see partial_fc_reference).
+    The three callables perform the cross-rank exchange (identity when None).  Returns the
+    mean loss over the GLOBAL batch and d loss / d emb restricted to this shard's classes for
+    ALL rows (the caller reduce-scatters it)."""
+    ident = lambda t: t
+    all_gather = all_gather or ident
+    all_reduce_max = all_reduce_max or ident
+    all_reduce_sum = all_reduce_sum or ident
+    E = all_gather(emb_local).detach().requires_grad_(True)
+    L = all_gather(labels_local).long()
+    n_local = weight_shard.shape[0]
+    cos = F.linear(F.normalize(E), F.normalize(weight_shard))
+    own = (L >= class_start) & (L < class_start + n_local)
+    y = torch.zeros_like(cos)
+    y[own, (L - class_start)[own]] = 1.0
+    z = s * (cos - m * y)
+    gmax = all_reduce_max(z.detach().max(dim=1).values)
+    ez = torch.exp(z - gmax[:, None])
+    Z = all_reduce_sum(ez.detach().sum(dim=1))
+    tgt = all_reduce_sum((z.detach() * y).sum(dim=1))
+    loss = (torch.log(Z) + gmax - tgt).mean()
+    dz = (ez.detach() / Z[:, None] - y) / E.shape[0]
+    z.backward(dz)
+    return loss, E.grad

@@ -56,3 +56,55 @@ def test_two_rank_step_equals_single_process_full_batch(tmp_path):
     errs = torch.cat([(got["student"][k] - v).abs().flatten() for k, v in st.student.items()])
     # identical up to fp32 summation order, except Adam's amplification where the gradient is round-off
     assert float(errs.median()) < 1e-7 and float((errs > 1e-5).float().mean()) < 0.02 and float(errs.max()) < 2.5e-3
+
+
+def _pfc_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from lafs_cvpr2024_amd.partial_fc import shard_range
+    from oracle import margin
+    g = torch.Generator().manual_seed(3)
+    C, D, B = 37, 16, 4
+    Wfull = torch.randn(C, D, generator=g)
+    emb = torch.randn(world * B, D, generator=g)
+    lab = torch.randint(0, C, (world * B,), generator=g)
+    start, n = shard_range(C, rank, world)
+
+    def gather(t):
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t.contiguous())
+        return torch.cat(parts)
+
+    def rmax(t):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX); return t
+
+    def rsum(t):
+        dist.all_reduce(t); return t
+
+    loss, dE = margin.partial_fc_sharded(emb[rank * B:(rank + 1) * B], lab[rank * B:(rank + 1) * B], Wfull[start:start + n], start,
+                                         all_gather=gather, all_reduce_max=rmax, all_reduce_sum=rsum)
+    dist.all_reduce(dE)                       # gloo has no reduce_scatter: all-reduce and slice (same sum)
+    mine = dE[rank * B:(rank + 1) * B]
+    torch.save({"loss": loss, "demb": mine}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partial_fc_two_shards_equal_unsharded(tmp_path):
+    """The class-sharded softmax exchange (MAX, SUM, SUM; reduce-scatter of dE) reproduces the unsharded CosFace + CE."""
+    from oracle import margin
+    out = str(tmp_path / "pfc")
+    port = 29850 + os.getpid() % 100
+    mp.spawn(_pfc_worker, args=(2, port, out), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(3)
+    C, D, B = 37, 16, 4
+    Wfull = torch.randn(C, D, generator=g)
+    emb = torch.randn(2 * B, D, generator=g).requires_grad_(True)
+    lab = torch.randint(0, C, (2 * B,), generator=g)
+    ref = margin.partial_fc_reference(emb, Wfull, lab)
+    ref.backward()
+    for r in range(2):
+        got = torch.load(out + f".{r}", weights_only=False)
+        torch.testing.assert_close(got["loss"], ref.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got["demb"], emb.grad[r * B:(r + 1) * B], rtol=1e-4, atol=1e-6)

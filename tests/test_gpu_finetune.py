@@ -139,3 +139,40 @@ def test_f9_landmark_cnn_wrapper_matches_reference():
     for th_ref, mo_ref, n in ((fx["theta_plain"], fx["mosaic_plain"], 196), (fx["theta_local"], fx["mosaic_local"], 36)):
         out = gather(xa, th_ref.to(DEV), num_landm=n)
         torch.testing.assert_close(out.cpu(), mo_ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("margin_type,m", [(0, 0.4), (1, 0.5)])
+@pytest.mark.parametrize("rate", [1.0, 0.25])
+def test_partial_fc_single_rank_matches_unsharded_oracle(margin_type, m, rate):
+    """PartialFC (parity unpinned: self-check against the unsharded oracle).  At sample_rate 1 the loss and
+    both gradients equal CosFace/ArcFace + CE over all classes; at rate < 1 they equal the same loss restricted to the
+    sampled centres (positives always kept)."""
+    import torch.nn.functional as F
+    from lafs_cvpr2024_amd.partial_fc import PartialFC
+    from oracle import margin
+    torch.manual_seed(0)
+    C, D, B = 1000, 64, 16
+    pfc = PartialFC(D, C, B, sample_rate=rate, s=64.0, m=m, margin_type=margin_type, device="cuda", seed=0)
+    emb = torch.randn(B, D, device="cuda")
+    lab = torch.randint(0, C, (B,), device="cuda")
+    gen_state = pfc.gen.get_state()
+    loss, demb = pfc.forward_backward(emb, lab)
+    pfc.gen.set_state(gen_state)
+    from lafs_cvpr2024_amd.partial_fc import sample_classes
+    index, y = sample_classes(lab, 0, C, pfc.num_sample, pfc.gen)
+    assert index.numel() == (C if rate == 1.0 else max(int(rate * C), 1))
+    Wc = pfc.weight.detach().cpu().clone().requires_grad_(True)
+    e = emb.cpu().clone().requires_grad_(True)
+    idx, yl = index.cpu(), y.cpu().long()
+    fn = margin.cosface_logits if margin_type == 0 else margin.arcface_logits
+    ref = F.cross_entropy(fn(e, Wc[idx], yl, 64.0, m), yl)
+    ref.backward()
+    # bf16 MFMA operands for the cosine and the two gradient GEMMs: tolerance at the tensor scale
+    assert abs(float(loss) - float(ref)) < 2e-2 * max(1.0, abs(float(ref)))
+    scale = float(e.grad.abs().max())
+    assert float((demb.cpu() - e.grad).abs().max()) < 3e-2 * scale
+    gw = pfc.arena.view(pfc.arena.grad, "weight", (C, D)).cpu()
+    assert float((gw - Wc.grad).abs().max()) < 3e-2 * float(Wc.grad.abs().max())
+    w0 = pfc.weight.detach().clone()
+    pfc.optimizer_step(lr=1e-3)
+    assert float((pfc.weight.detach() - w0).abs().max()) > 0 and float(pfc.arena.grad.abs().max()) == 0.0

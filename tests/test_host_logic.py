@@ -53,3 +53,28 @@ def test_finetune_lr_schedule_shape():
     assert warmup_cosine(1e-3, 0.0, 5, 34) == 0.0 and abs(warmup_cosine(1e-3, 5.0, 5, 34) - 1e-3) < 1e-12
     assert abs(warmup_cosine(1e-3, 34.0, 5, 34) - 1e-6) < 1e-12
     assert warmup_cosine(1e-3, 2.5, 5, 34) == ooptim.warmup_cosine_lr(1e-3, 2.5, 5, 34)
+
+
+def test_partial_fc_shard_range_and_sampling():
+    """PartialFC host logic (InsightFace partial_fc_v2 semantics): the shards tile the class range, positives always
+    survive the negative sampling, and the remapped labels point at the right sampled centre."""
+    from lafs_cvpr2024_amd.partial_fc import sample_classes, shard_range
+    for C, W in ((10, 3), (2059906, 8), (7, 7), (100, 1)):
+        spans = [shard_range(C, r, W) for r in range(W)]
+        assert spans[0][0] == 0 and sum(n for _, n in spans) == C
+        for (s0, n0), (s1, _) in zip(spans, spans[1:]):
+            assert s0 + n0 == s1
+    g = torch.Generator().manual_seed(0)
+    labels = torch.tensor([5, 17, 17, 3, 40, 29, 11, 5])
+    start, n_local = 10, 20                                   # this rank owns classes [10, 30)
+    index, y = sample_classes(labels, start, n_local, 6, g)
+    assert index.numel() == 6 and torch.equal(index, index.sort()[0]) and index.unique().numel() == 6
+    own = (labels >= start) & (labels < start + n_local)
+    assert torch.equal(y[~own], torch.full((int((~own).sum()),), -1, dtype=torch.int32))
+    assert torch.equal(index[y[own].long()] + start, labels[own])
+    # more positives than the sample budget: only the positives are kept
+    index2, y2 = sample_classes(labels, start, n_local, 2, g)
+    assert torch.equal(index2 + start, torch.tensor([11, 17, 29]))
+    # sample_rate 1: identity
+    index3, y3 = sample_classes(labels, start, n_local, n_local, g)
+    assert torch.equal(index3, torch.arange(n_local)) and torch.equal(y3[own].long(), labels[own] - start)
