@@ -142,19 +142,27 @@ class _PartFViTFunction(torch.autograd.Function):
         feat, st, _ = Fn.vit_forward(model._arena, model._spec, geom, [x.contiguous().float()], [pos.detach().contiguous()],
                                      drop, save=save)
         ctx.model, ctx.st = model, (st if save else None)
+        ctx.x_dim = x.dim()
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         model, st = ctx.model, ctx.st
-        dpos = Fn.vit_backward(model._arena, model._spec, st, dfeat)
-        return None, None, None, dpos[0]
+        if not ctx.needs_input_grad[2]:
+            dpos = Fn.vit_backward(model._arena, model._spec, st, dfeat)
+            return None, None, None, dpos[0]
+        # landmark branch: the patch vectors themselves are differentiable (reference ViT_face.py:679-711)
+        dpos, dx = Fn.vit_backward(model._arena, model._spec, st, dfeat, want_dx=True)
+        dx = dx[0] if ctx.x_dim == 3 else Fn.unpatchify_grad(dx[0], model._spec.patch_order)
+        return None, None, dx, dpos[0]
 
 
 class ViT_face_landmark_patch8(nn.Module):
     """Part-fViT (reference face_pre_pro/ViT_face.py:560-795): pre-LN ViT with bias-free qkv, attention scale dim**-0.5,
     ``heads * 64`` inner width, DropPath 0.1 on every residual branch, LayerNorm head; 4-D images or 3-D [B, n, 192]
-    patch vectors.  ``with_land=True`` (the MobileNetV3 landmark branch) and non-zero dropout are not in this build."""
+    patch vectors.  ``with_land=True`` adds the trainable MobileNetV3 landmark regressor (``stn`` + ``output_layer``, stock
+    PyTorch-ROCm / MIOpen) whose landmarks drive the single-launch HIP patch gather; gradients flow back through the patch
+    embedding and the gather into theta (reference :679-711).  Non-zero element dropout is not in this build."""
 
     def __init__(self, *, loss_type, GPU_ID, num_class, image_size, patch_size, dim, depth, heads, mlp_dim, pool='cls',
                  num_patches=None, channels=3, dim_head=64, dropout=0., emb_dropout=0., fp16=True, with_land=False,
@@ -162,9 +170,8 @@ class ViT_face_landmark_patch8(nn.Module):
         super().__init__()
         if patch_size != 8 or channels != 3 or dim_head != 64:
             raise NotImplementedError("HIP kernels are specialised for 3x8x8 patches and head_dim 64")
-        if with_land or use_standcoord:
-            raise NotImplementedError("landmark CNN branch (MobileNetV3 'stn') is the next row of SURVEY.md 8(f); "
-                                      "feed landmark mosaics from extract_patches_pytorch_gridsample instead")
+        if use_standcoord:
+            raise NotImplementedError("use_standcoord (fixed grid + jitter) is never enabled by the reference's entry points")
         if dropout or emb_dropout:
             raise NotImplementedError("element dropout is not implemented in the fused epilogues (parity mode uses rate 0)")
         if pool != 'cls':
@@ -174,6 +181,11 @@ class ViT_face_landmark_patch8(nn.Module):
         self.patch_size, self.fp16, self.num_patches = patch_size, fp16, num_patches
         self.row_num = int(math.sqrt(num_patches))
         self.with_land, self.pool, self.loss_type, self.GPU_ID = with_land, pool, loss_type, GPU_ID
+        if with_land:                                     # reference :577-602
+            from .mobilenet import MobileNetV3_backbone
+            self.stn = MobileNetV3_backbone(mode='large')
+            self.output_layer = nn.Sequential(nn.Dropout(p=0.5), nn.Linear(160, self.row_num * self.row_num * 2))
+        self.patch_shape = torch.tensor([patch_size, patch_size])
         self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, mlp_dim
         self.drop_path_rate = drop_path_rate
         inner = heads * dim_head
@@ -233,9 +245,23 @@ class ViT_face_landmark_patch8(nn.Module):
         pos = self.pos_embedding[0, :n + 1]
         return _PartFViTFunction.apply(self, self._hook, x, pos)
 
+    def landmarks(self, x):
+        """[B,3,112,112] -> theta [B, r*r, 2] in pixels: CNN -> mean pool -> Dropout(0.5)+Linear(160, 2*r*r) -> per-sample
+        min-max to [0, 111] (reference :680-706).  Differentiable (torch autograd over MIOpen convolutions)."""
+        t = self.output_layer(self.stn(x).mean(dim=(-2, -1)))
+        tmax, tmin = t.max(dim=1, keepdim=True)[0], t.min(dim=1, keepdim=True)[0]
+        return ((t - tmin) / (tmax - tmin) * 111).view(-1, self.row_num * self.row_num, 2)
+
     def forward(self, x, label=None, mask=None, visualize=False, save_token=False, opt=None, keep_num=None, glo_diff=False):
         if mask is not None or save_token:
             raise NotImplementedError("attention masks / token dumps are not on the training hot path")
+        if self._arena is None:
+            attach_arena(self)
+        if self.with_land and x.dim() == 4:
+            num_land = keep_num if keep_num is not None else self.row_num * self.row_num
+            theta = self.landmarks(x)
+            self.theta = theta
+            x = extract_patches_pytorch_gridsample(x, theta[:, :num_land], patch_shape=self.patch_shape, num_landm=num_land)
         emb = self.forward_embedding(x)
         if label is not None:
             return self.loss(emb, label), self.theta

@@ -184,13 +184,19 @@ def vit_backward_layers(st: ViTState, g, hi, lo, wgrad_stream=None):
     call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo, ws2)
 
 
-def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g):
+def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g, want_dx=False):
     """Token-assembly / patch-embedding backward.  Returns the list of dpos f32 [npatch+1, D] per group (the bicubic
-    resampling of the position table lives in torch)."""
+    resampling of the position table lives in torch); with ``want_dx`` also the gradient of the patch vectors
+    f32 [n_img, npatch, 192] per group (the landmark branch of Part-fViT differentiates through the patches,
+    reference face_pre_pro/ViT_face.py:679-711)."""
     geom, D, pre = st.geom, spec.trunk.dim, spec.prefix
     dev = g.device
     gv = lambda n: arena.view(arena.grad, pre + n)
-    dpos = []
+    dpos, dx = [], []
+    wt = None
+    if want_dx:                                           # W_patch^T bf16 [192, D]: B operand of dP = dTok @ W_patch
+        wt = torch.empty(192, D, device=dev, dtype=bf16)
+        call("lafs_transpose_cast_bf16", _p(arena.view(arena.master, pre + spec.w_patch)), D, 192, _p(wt), D)
     for gi in range(len(geom.groups)):
         n_img, np_ = geom.groups[gi][0], geom.npatch(gi)
         rows = g[geom.tok_start[gi]: geom.tok_start[gi] + n_img * (np_ + 1)]
@@ -199,15 +205,26 @@ def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g):
         call("lafs_embed_bwd", _p(rows), D, n_img, np_, D, _p(gp), _p(dp), _p(gv(spec.cls)))
         ops.gemm_tn_acc(gp, st.patches[gi], gv(spec.w_patch).view(D, -1), colsum=gv(spec.b_patch))
         dpos.append(dp)
-    return dpos
+        if want_dx:
+            dx.append(ops.gemm_nt(gp, wt, _lib.EPI_F32).view(n_img, np_, 192))
+    return (dpos, dx) if want_dx else dpos
 
 
-def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, wgrad_stream=None):
+def unpatchify_grad(dpatch, order):
+    """Patch-vector gradient [B, n, 192] -> image gradient [B, 3, 8r, 8r] (pure re-indexing; the inverse of lafs_patchify)."""
+    B, n, _ = dpatch.shape
+    r = int(math.isqrt(n))
+    if order == _lib.PATCH_ORDER_HWC:                     # '(p1 p2 c)'
+        return dpatch.view(B, r, r, 8, 8, 3).permute(0, 5, 1, 3, 2, 4).reshape(B, 3, 8 * r, 8 * r)
+    return dpatch.view(B, r, r, 3, 8, 8).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 8 * r, 8 * r)
+
+
+def vit_backward(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None, wgrad_stream=None, want_dx=False):
     """dfeat f32 [n_seq, D].  Accumulates every parameter gradient into arena.grad EXCEPT the position table, whose
-    per-group gradients are returned."""
+    per-group gradients are returned (plus the patch-vector gradients when ``want_dx``)."""
     g = vit_backward_begin(arena, spec, st, dfeat, g_buf)
     vit_backward_layers(st, g, spec.trunk.depth, 0, wgrad_stream)
-    return vit_backward_end(arena, spec, st, g)
+    return vit_backward_end(arena, spec, st, g, want_dx)
 
 
 # ----------------------------------------------------------------------------------------------- DINO head

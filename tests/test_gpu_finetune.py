@@ -176,3 +176,33 @@ def test_partial_fc_single_rank_matches_unsharded_oracle(margin_type, m, rate):
     w0 = pfc.weight.detach().clone()
     pfc.optimizer_step(lr=1e-3)
     assert float((pfc.weight.detach() - w0).abs().max()) > 0 and float(pfc.arena.grad.abs().max()) == 0.0
+
+
+def test_f13_partfvit_with_trainable_landmark_branch():
+    """ViT_face_landmark_patch8(with_land=True) as train_largescale.py builds it (:432,556): CNN -> theta -> HIP gather ->
+    Part-fViT, and the backward through the patch embedding and the gather into the CNN, against the reference
+    (eval mode; identical closed-form weights on both sides)."""
+    from conftest import det_fill
+    fx = load_golden("f13_partfvit_land")
+    m = ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=128, depth=2,
+                                 heads=3, mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=True)
+    det_fill(m)
+    attach_arena(m, DEV)
+    m.eval()
+    e = m(fx["x"].to(DEV))
+    torch.testing.assert_close(m.theta.detach().cpu(), fx["theta"], rtol=1e-3, atol=2e-2)
+    assert rel_l2(e, fx["e"]) < 2e-2
+    (e * fx["w"].to(DEV)).sum().backward()
+    params = dict(m.named_parameters())
+    bad = {}
+    for k, g in sub(fx, "g.").items():
+        err = rel_l2(params[k].grad, g)
+        if err > 8e-2:
+            bad[k] = err
+    assert not bad, bad
+    # every tensor the reference gives a gradient gets one here, with a matching norm
+    ref = dict(zip([str(k) for k in fx["gnorm_keys"]], fx["gnorms"].tolist()))
+    got = {k: float(p.grad.norm()) for k, p in params.items() if p.grad is not None and float(p.grad.abs().max()) > 0}
+    assert set(ref) <= set(got) | {k for k, v in ref.items() if v == 0.0}
+    off = {k: (got[k], v) for k, v in ref.items() if v > 0 and abs(got[k] - v) > 0.1 * v}
+    assert not off, off

@@ -57,7 +57,12 @@ def npy(t):
     return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
 
 
+ONLY = os.environ.get("LAFS_GOLDEN_ONLY", "")       # e.g. "f13": rewrite only the fixtures whose name starts with it
+
+
 def save(name, **arrays):
+    if ONLY and not name.startswith(ONLY):
+        return
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
@@ -285,6 +290,26 @@ def main():
     np.random.seed(11)
     np.random.rand(); lam = float(np.random.beta(0.2, 0.2))
     save("f11_mixup", x_in=x_in, y=ym, x_out=xo, target=yo, lam=np.float64(lam))
+    # ---------------------------------------------------------------- F13 Part-fViT with the trainable landmark branch
+    # (train_largescale.py:432,556: with_land=True).  eval mode (BatchNorm running statistics, Dropout/DropPath off) so the
+    # pass is deterministic; weights via det_fill on both sides; gradients reach the CNN through theta.
+    print("F13 part-fvit with_land")
+    torch.manual_seed(13)
+    pl = ref_face.ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8,
+                                           dim=128, depth=2, heads=3, mlp_dim=256, dropout=0.0, emb_dropout=0.0,
+                                           with_land=True)
+    det_fill(pl)
+    pl.eval()
+    x13 = torch.randn(2, 3, 112, 112).clamp(-1, 1)
+    w13 = torch.randn(2, 128)
+    e13 = pl(x13)
+    (e13 * w13).sum().backward()
+    g13 = {k: p.grad for k, p in pl.named_parameters() if p.grad is not None}
+    keep = ["output_layer.1.weight", "output_layer.1.bias", "stn.features.0.0.weight", "stn.features.15.conv.7.weight",
+            "patch_to_embedding.weight", "pos_embedding", "transformer.layers.0.0.fn.fn.to_qkv.weight"]
+    save("f13_partfvit_land", x=x13, w=w13, e=e13, theta=pl.theta,
+         gnorm_keys=np.array(sorted(g13.keys())), gnorms=np.array([float(g13[k].norm()) for k in sorted(g13.keys())]),
+         **{"g." + k: g13[k] for k in keep})
     print("done")
 
 
