@@ -63,7 +63,15 @@ class FinetuneEngine:
         y2 = y1.flip(0).contiguous()
         pos = a.view(a.master, m._spec.prefix + "pos_embedding").view(-1, D)[: self.geom.npatch(0) + 1]
         drop = m._sample_drop_scales(self.geom) if m.training else None
-        emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [self.x], [pos], drop, save=True)
+        img_in, theta = self.x, None
+        if m.with_land:
+            # trainable landmark regressor (torch autograd over MIOpen) -> one-launch patch gather (ViT_face.py:679-711)
+            theta = m.landmarks(self.x)
+            m.theta = theta
+            th = theta.detach().contiguous()
+            img_in = torch.empty_like(self.x)
+            call("lafs_patch_gather_fwd", _p(self.x), _p(th), B, self.x.shape[-1], th.shape[1], _p(img_in))
+        emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [pos], drop, save=True)
         # cosine logits
         xn = torch.empty(B, D, device=dev, dtype=bf16); inv_x = torch.empty(B, device=dev, dtype=f32)
         call("lafs_l2norm_fwd", _p(emb), D, _p(xn), D, _p(inv_x), B, D)
@@ -84,7 +92,14 @@ class FinetuneEngine:
              _p(a.view(a.grad, wname)), None, 1)
         demb = torch.empty(B, D, device=dev, dtype=f32)
         call("lafs_l2norm_bwd", _p(emb), D, _p(dxn), D, _p(inv_x), _p(demb), D, B, D)
-        dpos = Fn.vit_backward(a, m._spec, st, demb)
+        if m.with_land:
+            dpos, dx = Fn.vit_backward(a, m._spec, st, demb, want_dx=True)
+            dmosaic = Fn.unpatchify_grad(dx[0], m._spec.patch_order).contiguous()
+            dth = torch.empty_like(th)
+            call("lafs_patch_gather_bwd", _p(self.x), _p(th), _p(dmosaic), B, self.x.shape[-1], th.shape[1], _p(dth), None)
+            theta.backward(dth)                          # into stn.* / output_layer.* gradients (views of the arena)
+        else:
+            dpos = Fn.vit_backward(a, m._spec, st, demb)
         a.view(a.grad, m._spec.prefix + "pos_embedding").view(-1, D)[: dpos[0].shape[0]] += dpos[0]
         self.micro += 1
         return self.loss

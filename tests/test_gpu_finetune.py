@@ -206,3 +206,31 @@ def test_f13_partfvit_with_trainable_landmark_branch():
     assert set(ref) <= set(got) | {k for k, v in ref.items() if v == 0.0}
     off = {k: (got[k], v) for k, v in ref.items() if v > 0 and abs(got[k] - v) > 0.1 * v}
     assert not off, off
+
+
+def test_finetune_engine_with_landmark_branch_matches_module_path():
+    """FinetuneEngine on the with_land=True model (the train_largescale.py configuration) == the autograd module path
+    (pinned to the reference by F13 and F10) on the same batch: loss and the gradients that flow through theta."""
+    import torch.nn.functional as F
+    from conftest import det_fill
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    B, C = 8, 1000
+    mk = lambda: ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=C, image_size=112, patch_size=8, dim=128,
+                                          depth=2, heads=3, mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=True,
+                                          drop_path_rate=0.0)
+    torch.manual_seed(6)
+    u8 = torch.randint(0, 256, (B, 3, 112, 112), dtype=torch.uint8, device=DEV)
+    labels = torch.tensor([3, 999, 17, 3, 500, 0, 42, 999], device=DEV)
+    keys = ("output_layer.1.weight", "stn.features.0.0.weight", "stn.features.15.conv.7.weight", "patch_to_embedding.weight",
+            "loss.weight")
+    m1 = mk(); det_fill(m1); m1.eval()
+    eng = FinetuneEngine(m1, B, acc_step=1, device=DEV)
+    loss1 = float(eng.micro_step(u8, labels, lam=1.0).item())
+    g1 = {k: dict(m1.named_parameters())[k].grad.clone() for k in keys}
+    m2 = mk(); det_fill(m2); attach_arena(m2, DEV); m2.eval()
+    logits, _ = m2(u8.float() / 255 * 2 - 1, labels)
+    loss2 = F.cross_entropy(logits, labels)
+    loss2.backward()
+    assert abs(loss1 - float(loss2)) < 5e-3 * abs(float(loss2)), (loss1, float(loss2))
+    bad = {k: rel_l2(g1[k], dict(m2.named_parameters())[k].grad) for k in keys}
+    assert all(v < 5e-2 for v in bad.values()), bad
