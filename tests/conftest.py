@@ -61,3 +61,4 @@ def det_fill(module):
             else:
                 val = t * (1.5 / fan ** 0.5)
             v.copy_(val.view(v.shape).to(v.dtype))
+

@@ -186,7 +186,9 @@ def test_f13_partfvit_with_trainable_landmark_branch():
     fx = load_golden("f13_partfvit_land")
     m = ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=128, depth=2,
                                  heads=3, mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=True)
-    det_fill(m)
+    det_fill(m.stn); det_fill(m.output_layer)
+    missing, unexpected = m.load_state_dict(sub(fx, "p."), strict=False)
+    assert not unexpected and all(k.startswith(("stn.", "output_layer.")) for k in missing)
     attach_arena(m, DEV)
     m.eval()
     e = m(fx["x"].to(DEV))
@@ -223,11 +225,11 @@ def test_finetune_engine_with_landmark_branch_matches_module_path():
     labels = torch.tensor([3, 999, 17, 3, 500, 0, 42, 999], device=DEV)
     keys = ("output_layer.1.weight", "stn.features.0.0.weight", "stn.features.15.conv.7.weight", "patch_to_embedding.weight",
             "loss.weight")
-    m1 = mk(); det_fill(m1); m1.eval()
+    m1 = mk(); det_fill(m1.stn); det_fill(m1.output_layer); m1.eval()
     eng = FinetuneEngine(m1, B, acc_step=1, device=DEV)
     loss1 = float(eng.micro_step(u8, labels, lam=1.0).item())
     g1 = {k: dict(m1.named_parameters())[k].grad.clone() for k in keys}
-    m2 = mk(); det_fill(m2); attach_arena(m2, DEV); m2.eval()
+    m2 = mk(); m2.load_state_dict(m1.state_dict()); attach_arena(m2, DEV); m2.eval()
     logits, _ = m2(u8.float() / 255 * 2 - 1, labels)
     loss2 = F.cross_entropy(logits, labels)
     loss2.backward()

@@ -185,3 +185,14 @@ def test_f11_mixup_batch_mode():
     x, tgt = margin.mixup_batch(fx["x_in"].clone(), fx["y"], 50, lam)
     close(x, fx["x_out"], 1e-6, 1e-7)
     close(tgt, fx["target"], 1e-6, 1e-7)
+
+
+def test_f13_oracle_gather_plus_partfvit_matches_reference_landmark_branch():
+    """with_land=True forward of the reference (CNN -> theta -> gather -> Part-fViT) from its own theta: the oracle's
+    gather + trunk reproduce the embedding (the CNN itself is stock PyTorch on both sides)."""
+    from oracle import gather, partfvit
+    fx = load_golden("f13_partfvit_land")
+    cfg = partfvit.PartFViTConfig(patch_size=8, dim=128, depth=2, heads=3, mlp_dim=256, num_patches=196)
+    mosaic = gather.extract_patches(fx["x"], fx["theta"])
+    e = partfvit.forward_embedding(sub(fx, "p."), mosaic, cfg)
+    torch.testing.assert_close(e, fx["e"], rtol=1e-4, atol=1e-5)

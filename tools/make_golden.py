@@ -292,13 +292,13 @@ def main():
     save("f11_mixup", x_in=x_in, y=ym, x_out=xo, target=yo, lam=np.float64(lam))
     # ---------------------------------------------------------------- F13 Part-fViT with the trainable landmark branch
     # (train_largescale.py:432,556: with_land=True).  eval mode (BatchNorm running statistics, Dropout/DropPath off) so the
-    # pass is deterministic; weights via det_fill on both sides; gradients reach the CNN through theta.
+    # pass is deterministic; gradients reach the CNN through theta.
     print("F13 part-fvit with_land")
     torch.manual_seed(13)
     pl = ref_face.ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8,
                                            dim=128, depth=2, heads=3, mlp_dim=256, dropout=0.0, emb_dropout=0.0,
                                            with_land=True)
-    det_fill(pl)
+    det_fill(pl.stn); det_fill(pl.output_layer)     # the 2.8 M-parameter CNN: closed form; the trunk: seeded init, stored
     pl.eval()
     x13 = torch.randn(2, 3, 112, 112).clamp(-1, 1)
     w13 = torch.randn(2, 128)
@@ -309,7 +309,8 @@ def main():
             "patch_to_embedding.weight", "pos_embedding", "transformer.layers.0.0.fn.fn.to_qkv.weight"]
     save("f13_partfvit_land", x=x13, w=w13, e=e13, theta=pl.theta,
          gnorm_keys=np.array(sorted(g13.keys())), gnorms=np.array([float(g13[k].norm()) for k in sorted(g13.keys())]),
-         **{"g." + k: g13[k] for k in keep})
+         **{"g." + k: g13[k] for k in keep},
+         **{"p." + k: v for k, v in pl.state_dict().items() if not k.startswith(("stn.", "output_layer."))})
     print("done")
 
 
