@@ -262,6 +262,12 @@ int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_lo
                            const float* gmax, const float* Z, float grad_scale, hipStream_t stream);
 /* x(f32) [B,3,S,S]: x = lam*x + (1-lam)*flip_batch(x) in place, from u8 or f32 source with (x/255*2-1) folded in. */
 int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, hipStream_t stream);
+/* Landmark post-processing (face_pre_pro/ViT_face.py:1347-1378, 698-706): t f32 [B, 2*n_full] raw regressor output ->
+ * theta f32 [B, n_out, 2] pixels:  theta = (t - min_b)/(max_b - min_b)*111  (+ noise_scale * noise[B, n_full, 2], the
+ * N(0,1)*5 px jitter), landmark k of the output = landmark sel[b,k] of the input (random choice with replacement) or k
+ * when sel is NULL. */
+int lafs_landmark_theta(const float* t, int B, int n_full, const float* noise, float noise_scale, const int32_t* sel, int n_out,
+                        float* theta, hipStream_t stream);
 /* Landmark patch gather (face_pre_pro/ViT_face.py:1615-1656): img f32 [B,3,S,S], theta f32 [B,n,2] (x,y pixels) ->
  * mosaic f32 [B,3,8r,8r], r = sqrt(n). */
 int lafs_patch_gather_fwd(const float* img, const float* theta, int B, int S, int n, float* mosaic, hipStream_t stream);

@@ -82,6 +82,7 @@ _PROTOS = {
     "lafs_shard_margin_rowmax": [vp, i32, i32, i32, vp, f32, f32, i32, vp],
     "lafs_shard_margin_rowsum": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, vp],
     "lafs_shard_margin_grad": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, f32],
+    "lafs_landmark_theta": [vp, i32, i32, vp, f32, vp, i32, vp],
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],
     "lafs_patch_gather_bwd": [vp, vp, vp, i32, i32, i32, vp, vp],

@@ -199,6 +199,31 @@ __global__ __launch_bounds__(256) void shard_grad_kernel(float* __restrict__ cos
   }
 }
 
+// ---- landmark post-processing: raw regressor output -> pixel landmarks (face_pre_pro/ViT_face.py:1347-1378) ----
+// one workgroup per image: per-sample min-max to [0,111], + noise_scale * noise, optional selection (with replacement)
+__global__ __launch_bounds__(256) void landmark_theta_kernel(const float* __restrict__ t, int n_full, const float* __restrict__ noise,
+                                                             float noise_scale, const int* __restrict__ sel, int n_out,
+                                                             float* __restrict__ theta) {
+  __shared__ float rmin[4], rmax[4];
+  const int b = blockIdx.x, L = 2 * n_full;
+  const float* row = t + (size_t)b * L;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int k = threadIdx.x; k < L; k += 256) { const float v = row[k]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+  mx = wave_max(mx); mn = -wave_max(-mn);
+  if ((threadIdx.x & 63) == 0) { rmin[threadIdx.x >> 6] = mn; rmax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  mn = fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3]));
+  mx = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+  const float range = mx - mn;
+  for (int k = threadIdx.x; k < 2 * n_out; k += 256) {
+    const int lm = sel ? sel[(size_t)b * n_out + (k >> 1)] : (k >> 1);
+    const int src = 2 * lm + (k & 1);
+    float v = (row[src] - mn) / range * 111.0f;
+    if (noise) v += noise_scale * noise[(size_t)b * L + src];
+    theta[(size_t)b * 2 * n_out + k] = v;
+  }
+}
+
 int isqrt_exact(int n) {
   int r = 0;
   while ((r + 1) * (r + 1) <= n) ++r;
@@ -275,6 +300,16 @@ extern "C" int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const in
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(cos && y_local && gmax && Z && B > 0 && S > 0 && ld >= S, "bad operand");
   hipLaunchKernelGGL(shard_grad_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, s, m, margin_type, gmax, Z, grad_scale);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_landmark_theta(const float* t, int B, int n_full, const float* noise, float noise_scale, const int32_t* sel,
+                                   int n_out, float* theta, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(t && theta && B > 0 && n_full > 0 && n_out > 0, "bad operand");
+  LAFS_CHECK_ARG(sel != nullptr || n_out <= n_full, "n_out > n_full needs a selection");
+  hipLaunchKernelGGL(landmark_theta_kernel, dim3(B), dim3(256), 0, stream, t, n_full, noise, noise_scale, sel, n_out, theta);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

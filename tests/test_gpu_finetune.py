@@ -236,3 +236,47 @@ def test_finetune_engine_with_landmark_branch_matches_module_path():
     assert abs(loss1 - float(loss2)) < 5e-3 * abs(float(loss2)), (loss1, float(loss2))
     bad = {k: rel_l2(g1[k], dict(m2.named_parameters())[k].grad) for k in keys}
     assert all(v < 5e-2 for v in bad.values()), bad
+
+
+def test_landmark_frontend_matches_module_calls():
+    """LandmarkFrontEnd (1 CNN pass + 2 theta launches + 2 gather launches on a side stream) == the three
+    face_landmark_4simmin_glo_loc calls of lafs_train.py:535-567 (module path pinned to the reference by F9) given the same
+    jitter noise and landmark selection."""
+    import types
+    from conftest import det_fill
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
+    from lafs_cvpr2024_amd.landmark_frontend import LandmarkFrontEnd
+    B, nl = 2, 3
+    lc = face_landmark_4simmin_glo_loc(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=64, depth=1,
+                                       heads=1, mlp_dim=64)
+    det_fill(lc)
+    lc = lc.to(DEV).eval()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    views = [torch.randn(B, 3, 112, 112, device=DEV, generator=g).clamp(-1, 1) for _ in range(2 * (2 + nl))]
+    noise = torch.randn((2 + nl) * B, 196, 2, device=DEV, generator=g)
+    sel = torch.randint(0, 196, (nl * B, 36), device=DEV, generator=g, dtype=torch.int32)
+    eng = types.SimpleNamespace(in_global_all=torch.zeros(2 * B, 3, 112, 112, device=DEV),
+                                in_local_all=torch.zeros(nl * B, 3, 48, 48, device=DEV))
+    fe = LandmarkFrontEnd(lc, B, n_local=nl, device=DEV)
+    fe(views, eng, noise=noise, sel=sel)
+    fe(torch.stack(views), eng, noise=noise, sel=sel)            # stacked input, second round trip through the staging buffers
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        for i in range(2):
+            th = lc.landmarks(views[2 * i]) + 5 * noise[i * B:(i + 1) * B]
+            ref = extract_patches_pytorch_gridsample(views[2 * i + 1], th, num_landm=196)
+            torch.testing.assert_close(fe.theta_g[i * B:(i + 1) * B], th, rtol=1e-4, atol=5e-3)
+            torch.testing.assert_close(eng.in_global_all[i * B:(i + 1) * B], ref, rtol=1e-3, atol=2e-2)
+        for j in range(nl):
+            rows = slice((2 + j) * B, (3 + j) * B)
+            th = lc.landmarks(views[4 + 2 * j]) + 5 * noise[rows]
+            th = torch.gather(th, 1, sel[j * B:(j + 1) * B].long()[:, :, None].repeat(1, 1, 2))
+            ref = extract_patches_pytorch_gridsample(views[5 + 2 * j], th, num_landm=36)
+            torch.testing.assert_close(fe.theta_l[j * B:(j + 1) * B], th, rtol=1e-4, atol=5e-3)
+            torch.testing.assert_close(eng.in_local_all[j * B:(j + 1) * B], ref, rtol=1e-3, atol=2e-2)
+    # device-drawn jitter / selection: right statistics, landmarks stay a perturbed subset of the clean ones
+    fe(views, eng)
+    torch.cuda.synchronize()
+    clean = lc.landmarks(views[0]).detach()
+    d = fe.theta_g[:B] - clean
+    assert 3.5 < float(d.std()) < 6.5 and abs(float(d.mean())) < 1.0
