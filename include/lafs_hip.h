@@ -64,6 +64,9 @@ typedef struct lafs_gemm_nt_args {
   const void* aux; int ldaux;      /* bf16 [M, N] pre-activation (DGELU_BF16)      */
   const float* pos; int npatch;    /* f32 [npatch+1, N] (EMBED_F32)                */
   int splits;                      /* ATOMIC_F32: number of K slices (>=1)         */
+  float drop_p; uint32_t drop_seed; /* element dropout (0 = off): on the linear's output before the residual add
+                                      (RESID_F32), on GELU(u) (BF16_GELU: C2 only), and its backward (DGELU_BF16).
+                                      Counter-based mask of (drop_seed, row, col): see lafs_debug_dropout_mask.       */
 } lafs_gemm_nt_args;
 
 /* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue. */
@@ -74,6 +77,13 @@ int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
  * colsum_a (optional f32 [N1]) += column sums of A: the bias gradient db = sum_m dY[m,:] rides along for free. */
 int lafs_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* C, int ldc,
                      int M, int N1, int N2, int splits, float* colsum_a, hipStream_t stream);
+/* Same contraction, accumulated into per-XCD images: part(f32) [LAFS_N_XCD][...], image x at part + x*part_stride.  Every
+ * XCD adds into its own image with L2-local atomics (no cross-XCD traffic); fold with lafs_reduce_partials.  The images must
+ * be zero before the first accumulation (lafs_reduce_partials leaves them zeroed). */
+int lafs_gemm_tn_part(const void* A, int lda, const void* B, int ldb, float* part, int ldc, int64_t part_stride,
+                      int M, int N1, int N2, int splits, float* colsum_a, hipStream_t stream);
+/* out(f32)[i] += sum_x part[x*part_stride + i], then part[...] = 0;  n, part_stride multiples of 4. */
+int lafs_reduce_partials(float* part, int64_t part_stride, int n_part, int64_t n, float* out, hipStream_t stream);
 
 /* out(f32)[n] += sum_m X(bf16)[m, n]   (bias gradients). */
 int lafs_colsum_bf16_acc(const void* X, int ldx, int M, int N, float* out, hipStream_t stream);
@@ -94,11 +104,21 @@ int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, const float*
 int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf, const float* x, int ldx,
                        const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
                        void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
-                       float* dgamma, float* dbeta, int rows, int D, hipStream_t stream);
+                       float* dgamma, float* dbeta, int rows, int D, float drop_p, uint32_t drop_seed,
+                       hipStream_t stream);
 
 /* gb(bf16)[r,:] = bf16(seq_scale[row2seq[r]] * g(f32)[r,:])  (seq_scale NULL -> plain cast). */
 int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb, const float* seq_scale,
-                         const int32_t* row2seq, int rows, int D, hipStream_t stream);
+                         const int32_t* row2seq, int rows, int D,
+                         float drop_p, uint32_t drop_seed, hipStream_t stream);
+/* Element dropout (nn.Dropout of Part-fViT, face_pre_pro/ViT_face.py:131-133,150-153,614).  The mask is a pure function
+ * of (drop_seed, row, col, n_cols): factor(r,c) = mix32(r*n_cols + c, seed) >= drop_p*2^32 ? 1/(1-drop_p) : 0, so a
+ * backward kernel regenerates the forward's mask from the same seed; drop_p = 0 disables it.  In lafs_layernorm_bwd and
+ * lafs_scale_cast_bf16 the factor multiplies gb_out (the gradient entering a dropped-out branch output).
+ * lafs_dropout_f32: x(f32)[rows, D] *= factor in place (embedding dropout, forward and backward).
+ * lafs_debug_dropout_mask: out(f32)[rows, cols] = factor (tests feed it to the oracle). */
+int lafs_dropout_f32(float* x, int ldx, int rows, int D, float drop_p, uint32_t drop_seed, hipStream_t stream);
+int lafs_debug_dropout_mask(int rows, int cols, float drop_p, uint32_t drop_seed, float* out, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-head attention over variable-length sequences, head_dim = 64
@@ -179,6 +199,7 @@ int lafs_center_ema(float* center, const float* colsum, int K, float inv_rows_to
  * bit1 = "last_layer" (skipped while frozen), bit2 = trainable.  Hyper-parameters live in a device f32[16]:
  * {lr, wd, beta1, beta2, eps, clip, ema_m, freeze_last_layer(0/1), grad_scale, ...}.
  * ------------------------------------------------------------------------------------------------ */
+#define LAFS_N_XCD 8          /* XCDs (L2 domains) of an MI355X */
 #define LAFS_CHUNK 1024
 enum { LAFS_SEG_DECAY = 1, LAFS_SEG_LAST_LAYER = 2, LAFS_SEG_TRAINABLE = 4 };
 enum { LAFS_HP_LR = 0, LAFS_HP_WD, LAFS_HP_BETA1, LAFS_HP_BETA2, LAFS_HP_EPS, LAFS_HP_CLIP, LAFS_HP_EMA_M,
@@ -219,6 +240,9 @@ typedef struct lafs_trunk_desc {
   const int32_t* cu_seqlens;      /* device i32 [n_seq+1] */
   const int32_t* row2seq;         /* device i32 [n_tok]   */
   const float* drop_scales;       /* device f32 [depth, 2, n_seq] or NULL */
+  float dropout_p;                /* element dropout after to_out / after GELU / after fc2 (Part-fViT); 0 = off.  Site s of
+                                     layer l uses seed dropout_seed + 3*l + s (s: 0 to_out, 1 GELU, 2 fc2)                 */
+  uint32_t dropout_seed;
   const float* master; const void* shadow; const void* shadow_t; float* grad;
   const lafs_block_offsets* blocks;   /* HOST array [depth] */
 } lafs_trunk_desc;

@@ -21,7 +21,7 @@ class GemmNTArgs(C.Structure):
                 ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int),
                 ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
                 ("aux", C.c_void_p), ("ldaux", C.c_int), ("pos", C.c_void_p), ("npatch", C.c_int),
-                ("splits", C.c_int)]
+                ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
 
 
 class BlockOffsets(C.Structure):
@@ -35,6 +35,7 @@ class TrunkDesc(C.Structure):
                 ("ln_eps", C.c_float), ("attn_scale", C.c_float),
                 ("n_tok", C.c_int), ("n_seq", C.c_int), ("max_len", C.c_int),
                 ("cu_seqlens", C.c_void_p), ("row2seq", C.c_void_p), ("drop_scales", C.c_void_p),
+                ("dropout_p", C.c_float), ("dropout_seed", C.c_uint32),
                 ("master", C.c_void_p), ("shadow", C.c_void_p), ("shadow_t", C.c_void_p), ("grad", C.c_void_p),
                 ("blocks", C.POINTER(BlockOffsets))]
 
@@ -46,17 +47,21 @@ SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE = 1, 2, 4
 HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE = range(9)
 HP_COUNT = 16
 
-vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
 # name -> argument types (the trailing hipStream_t is appended automatically); all return int unless listed
 _PROTOS = {
     "lafs_debug_tr16": [vp, vp],
     "lafs_gemm_nt": [C.POINTER(GemmNTArgs)],
     "lafs_gemm_tn_acc": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
+    "lafs_gemm_tn_part": [vp, i32, vp, i32, vp, i32, i64, i32, i32, i32, i32, vp],
+    "lafs_reduce_partials": [vp, i64, i32, i64, vp],
     "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
     "lafs_layernorm_fwd": [vp, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32],
-    "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32],
-    "lafs_scale_cast_bf16": [vp, i32, vp, i32, vp, vp, i32, i32],
+    "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, u32],
+    "lafs_scale_cast_bf16": [vp, i32, vp, i32, vp, vp, i32, i32, f32, u32],
+    "lafs_dropout_f32": [vp, i32, i32, i32, f32, u32],
+    "lafs_debug_dropout_mask": [i32, i32, f32, u32, vp],
     "lafs_attention_fwd": [vp, i32, vp, i32, i32, i32, f32, vp, i32, vp],
     "lafs_attention_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, i32],
     "lafs_patchify": [vp, i32, i32, i32, vp],

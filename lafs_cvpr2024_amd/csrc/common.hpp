@@ -65,6 +65,29 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// ---- element dropout (nn.Dropout of Part-fViT, face_pre_pro/ViT_face.py:131-133,150-153,614): counter-based mask, so
+// the backward kernels regenerate exactly the forward's mask from (seed, row, col) instead of storing it.
+// keep <=> mix32(row * n_cols + col, seed) >= thresh, thresh = p * 2^32; kept values are scaled by 1/(1-p).
+struct DropCfg { unsigned thresh; unsigned seed; float scale; };        // thresh == 0: disabled
+__device__ __forceinline__ unsigned drop_mix32(unsigned idx, unsigned seed) {
+  unsigned x = idx * 0x9E3779B1u ^ seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ float drop_mult(const DropCfg& d, unsigned idx) {
+  return drop_mix32(idx, d.seed) >= d.thresh ? d.scale : 0.f;
+}
+inline DropCfg make_drop(float p, unsigned seed) {
+  DropCfg d;
+  if (!(p > 0.f)) { d.thresh = 0; d.seed = 0; d.scale = 1.f; return d; }
+  const double t = (double)p * 4294967296.0;
+  d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+  if (d.thresh == 0) d.thresh = 1;
+  d.seed = seed * 0x632BE5ABu + 0x7F4A7C15u;
+  d.scale = 1.0f / (1.0f - p);
+  return d;
+}
+
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

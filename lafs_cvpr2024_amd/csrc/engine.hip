@@ -72,6 +72,7 @@ int check_desc(const lafs_trunk_desc* d) {
   LAFS_CHECK_ARG(d->dim > 0 && d->dim % 64 == 0 && d->mlp % 64 == 0 && d->inner == d->heads * 64, "dims must be multiples of 64");
   LAFS_CHECK_ARG(d->depth > 0 && d->n_tok > 0 && d->n_seq > 0 && d->max_len > 0 && d->max_len <= 256, "bad geometry");
   LAFS_CHECK_ARG(d->cu_seqlens && d->row2seq && d->master && d->shadow && d->blocks, "null pointer in descriptor");
+  LAFS_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "dropout_p must be in [0, 1)");
   return LAFS_OK;
 }
 
@@ -83,8 +84,10 @@ int check_desc(const lafs_trunk_desc* d) {
 
 int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
          hipStream_t s, void* C2 = nullptr, int ldc2 = 0, const float* resid = nullptr, int ldr = 0,
-         const float* seq_scale = nullptr, const int32_t* row2seq = nullptr, const void* aux = nullptr, int ldaux = 0) {
+         const float* seq_scale = nullptr, const int32_t* row2seq = nullptr, const void* aux = nullptr, int ldaux = 0,
+         float drop_p = 0.f, uint32_t drop_seed = 0) {
   lafs_gemm_nt_args g = {};
+  g.drop_p = drop_p; g.drop_seed = drop_seed;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.epilogue = epi;
   g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.seq_scale = seq_scale; g.row2seq = row2seq; g.aux = aux; g.ldaux = ldaux; g.splits = 1;
@@ -119,12 +122,15 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
     RUN(lafs_layernorm_fwd(cur, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1, D, nullptr, 0, b.st1, T, D, stream));
     RUN(gemm(b.h1, D, sh + o.w_qkv, D, T, 3 * I, D, LAFS_EPI_BF16, b.qkv, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, stream));
     RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, stream));
+    const float dp = d->dropout_p;
+    const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
     RUN(gemm(b.o, I, sh + o.w_proj, I, T, D, I, LAFS_EPI_RESID_F32, b.x1, D, d->master + o.b_proj, stream, nullptr, 0, cur, D, sa,
-             d->row2seq));
+             d->row2seq, nullptr, 0, dp, ds + 0));
     RUN(lafs_layernorm_fwd(b.x1, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2, D, nullptr, 0, b.st2, T, D, stream));
-    RUN(gemm(b.h2, D, sh + o.w_fc1, D, T, M, D, LAFS_EPI_BF16_GELU, b.u, M, d->master + o.b_fc1, stream, b.a, M));
+    RUN(gemm(b.h2, D, sh + o.w_fc1, D, T, M, D, LAFS_EPI_BF16_GELU, b.u, M, d->master + o.b_fc1, stream, b.a, M, nullptr, 0, nullptr,
+             nullptr, nullptr, 0, dp, ds + 1));
     RUN(gemm(b.a, M, sh + o.w_fc2, M, T, D, M, LAFS_EPI_RESID_F32, nxt, D, d->master + o.b_fc2, stream, nullptr, 0, b.x1, D, sm,
-             d->row2seq));
+             d->row2seq, nullptr, 0, dp, ds + 2));
     cur = nxt;
   }
   return LAFS_OK;
@@ -167,7 +173,10 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   };
   std::vector<hipEvent_t> done(d->depth, nullptr);
   auto scale = [&](int l, int br) { return d->drop_scales ? d->drop_scales + ((size_t)l * 2 + br) * d->n_seq : nullptr; };
-  RUN(lafs_scale_cast_bf16(g, D, s.gbm[(layer_hi - 1) & 1], D, scale(layer_hi - 1, 1), d->row2seq, T, D, stream));
+  const float dp = d->dropout_p;
+  auto dseed = [&](int l, int site) { return d->dropout_seed + 3u * (uint32_t)l + (uint32_t)site; };
+  RUN(lafs_scale_cast_bf16(g, D, s.gbm[(layer_hi - 1) & 1], D, scale(layer_hi - 1, 1), d->row2seq, T, D, dp, dseed(layer_hi - 1, 2),
+                           stream));
   for (int l = layer_hi - 1; l >= layer_lo; --l) {
     const lafs_block_offsets& o = d->blocks[l];
     const LayerBuf& b = c.layers[l];
@@ -178,12 +187,12 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     fork();
     RUN(lafs_gemm_tn_acc(s.gbm[p], D, b.a, M, gr + o.w_fc2, M, T, D, M, 0, gr + o.b_fc2, s2));
     RUN(gemm(s.gbm[p], D, sht + o.w_fc2_t, D, T, M, D, LAFS_EPI_DGELU_BF16, s.du[p], M, nullptr, stream, nullptr, 0, nullptr, 0, nullptr,
-             nullptr, b.u, M));
+             nullptr, b.u, M, dp, dseed(l, 1)));
     fork();
     RUN(lafs_gemm_tn_acc(s.du[p], M, b.h2, D, gr + o.w_fc1, D, T, M, D, 0, gr + o.b_fc1, s2));
     RUN(gemm(s.du[p], M, sht + o.w_fc1_t, M, T, D, M, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, b.x1, D, b.st2, d->master + o.ln2_g, g, D, 1, s.gba[p], D, scale(l, 0), d->row2seq,
-                           gr + o.ln2_g, gr + o.ln2_b, T, D, stream));
+                           gr + o.ln2_g, gr + o.ln2_b, T, D, dp, dseed(l, 0), stream));
     // ---- attention branch ----
     fork();
     RUN(lafs_gemm_tn_acc(s.gba[p], D, b.o, I, gr + o.w_proj, I, T, D, I, 0, gr + o.b_proj, s2));
@@ -196,7 +205,8 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     RUN(gemm(s.dqkv[p], 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     const bool more = l > 0;
     RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, x0, D, b.st1, d->master + o.ln1_g, g, D, 1, more ? s.gbm[(l - 1) & 1] : nullptr, D,
-                           more ? scale(l - 1, 1) : nullptr, d->row2seq, gr + o.ln1_g, gr + o.ln1_b, T, D, stream));
+                           more ? scale(l - 1, 1) : nullptr, d->row2seq, gr + o.ln1_g, gr + o.ln1_b, T, D, more ? dp : 0.f,
+                           more ? dseed(l - 1, 2) : 0u, stream));
   }
   if (two) (void)hipStreamWaitEvent(stream, done[layer_lo], 0);                        // join (s2 is in-order)
   LAFS_LAUNCH_CHECK();

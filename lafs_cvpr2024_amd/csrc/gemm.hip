@@ -38,6 +38,7 @@ struct NTArgs {
   const bf16_t* aux; int ldaux;
   const float* pos; int npatch;
   int dbg;                          // timing ablations (lafs_debug_set): 16 = no epilogue stores, 32 = no MFMA/ds_read
+  DropCfg drop;                     // element dropout on the linear's output (RESID_F32) / on GELU(u) (BF16_GELU, DGELU_BF16)
 };
 
 constexpr int BM = 128, BN = 128;
@@ -232,6 +233,10 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
 #pragma unroll
             for (int e = 0; e < VPL; ++e) if (n + e < p.N) w[e] *= gelu_grad_f(bf2f(ax[e]));
           }
+          if (p.drop.thresh) {                                     // d(dropout(gelu(u))): the forward's mask, regenerated
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) w[e] *= drop_mult(p.drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
+          }
         }
         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
         if (full) {
@@ -244,6 +249,10 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
           bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n;
           if (full && (p.dbg & 128)) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+          } else if (p.drop.thresh) {
+#pragma unroll
+            for (int e = 0; e < VPL; ++e)
+              if (n + e < p.N) c2[e] = f2bf(gelu_f(w[e]) * drop_mult(p.drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e)));
           } else if (full) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(gelu_f(w[0]), gelu_f(w[1])), pack_bf2(gelu_f(w[2]), gelu_f(w[3])),
                                                        pack_bf2(gelu_f(w[4]), gelu_f(w[5])), pack_bf2(gelu_f(w[6]), gelu_f(w[7])));
@@ -259,6 +268,10 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
       } else {                                                                        // VPL == 4: one float4
         if (EPI == EPI_RESID_F32) {
           const float* rs = p.resid + (size_t)m * p.ldr + n;
+          if (p.drop.thresh) {
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) w[e] *= drop_mult(p.drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
+          }
           if (full) {
             const float4 r4 = *reinterpret_cast<const float4*>(rs);
             w[0] = r4.x + sc * w[0]; w[1] = r4.y + sc * w[1]; w[2] = r4.z + sc * w[2]; w[3] = r4.w + sc * w[3];
@@ -287,6 +300,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
 struct TNArgs {
   const bf16_t* A; const bf16_t* B; float* C; float* colsum;
   int M, N1, N2, lda, ldb, ldc, mlen, mode, splits, tiles;
+  long part_stride;                                // mode 2: C is [n_xcd][...] partial sums, one image per XCD
 };
 
 constexpr int TN_BM = 32;                          // reduction rows per pipeline stage
@@ -395,6 +409,11 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(TNArgs p) {
       for (int a = 0; a < 4; ++a) accs[a] = mfma16(fa[a], ones, accs[a]);
     }
   }
+  // mode 2: every XCD accumulates into its OWN image of C, so all adds to one address come from CUs behind the same L2
+  // and can be executed there (workgroup-scope atomics: no write-through to the fabric); lafs_reduce_partials folds the
+  // images afterwards.  XCC_ID is read from the hardware register, so this does not depend on the dispatch order.
+  float* Cx = p.C;
+  if (p.mode == 2) Cx += (size_t)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15) * p.part_stride;
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -405,12 +424,30 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(TNArgs p) {
       for (int b = 0; b < 4; ++b) {
         const int n2 = n2_0 + wn * 64 + b * 16 + pl;
         if (n2 < p.N2) {
-          if (p.mode == 0) atomicAdd(p.C + (size_t)n1 * p.ldc + n2, acc[a][b][r]);
-          else p.C[(size_t)n1 * p.ldc + n2] = acc[a][b][r];          // timing experiment only (lafs_debug_set)
+          float* dst = Cx + (size_t)n1 * p.ldc + n2;
+          if (p.mode == 0) atomicAdd(dst, acc[a][b][r]);
+          else if (p.mode == 2) __hip_atomic_fetch_add(dst, acc[a][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else *dst = acc[a][b][r];                                   // timing experiment only (lafs_debug_set)
         }
       }
       if (do_colsum && pl == 0) atomicAdd(p.colsum + n1, accs[a][r]);
     }
+}
+
+// out[i] += sum_x part[x][i]; part[x][i] = 0   (the images are left zeroed for the next accumulation)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(float* __restrict__ part, long stride, int n_part, long n4,
+                                                             float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 acc = reinterpret_cast<const float4*>(out)[i];
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int x = 0; x < n_part; ++x) {
+    float4* src = reinterpret_cast<float4*>(part + x * stride) + i;
+    const float4 v = *src;
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    *src = z;
+  }
+  reinterpret_cast<float4*>(out)[i] = acc;
 }
 
 int g_debug_flags = 0;
@@ -454,6 +491,9 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   a.bias = g->bias; a.resid = g->resid; a.ldr = g->ldr;
   a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
   a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux; a.pos = g->pos; a.npatch = g->npatch; a.dbg = g_debug_flags;
+  a.drop = make_drop(g->drop_p, g->drop_seed);
+  LAFS_CHECK_ARG(g->drop_p >= 0.f && g->drop_p < 1.f, "drop_p must be in [0, 1)");
+  LAFS_CHECK_ARG(!(g->drop_p > 0.f) || (long)g->M * g->N < 4294967296L, "dropout needs M*N < 2^32");
   int splits = 1;
   a.klen = g->K;
   if (g->epilogue == LAFS_EPI_ATOMIC_F32) {
@@ -488,15 +528,16 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   }
 }
 
-extern "C" int lafs_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* C, int ldc,
-                                int M, int N1, int N2, int splits, float* colsum_a, hipStream_t stream) {
-  LAFS_CLEAR_ERROR();
+static int launch_tn(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2, int splits,
+                     float* colsum_a, long part_stride, hipStream_t stream) {
   LAFS_CHECK_ARG(A && B && C, "null operand");
   LAFS_CHECK_ARG(M > 0 && N1 > 0 && N2 > 0, "empty problem");
   LAFS_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && N1 % 8 == 0 && N2 % 8 == 0, "N1/N2/lda/ldb must be multiples of 8");
   TNArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.colsum = colsum_a;
   a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.mode = g_debug_flags & 1;
+  a.part_stride = part_stride;
+  if (part_stride > 0) a.mode = 2;
   const int msteps = ceil_div(M, TN_BM);
   const int tiles = ceil_div(N1, 128) * ceil_div(N2, 128);
   if (splits <= 0) {                       // ~2 workgroups per CU, slices in multiples of 8 (one run of slices per XCD)
@@ -508,6 +549,29 @@ extern "C" int lafs_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, 
   if (splits % 8 != 0) splits = ceil_div(M, a.mlen);       // (empty trailing slices are harmless for the x8 layout)
   a.splits = splits; a.tiles = tiles;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 0, stream, a);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_gemm_tn_acc(const void* A, int lda, const void* B, int ldb, float* C, int ldc,
+                                int M, int N1, int N2, int splits, float* colsum_a, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  return launch_tn(A, lda, B, ldb, C, ldc, M, N1, N2, splits, colsum_a, 0, stream);
+}
+
+extern "C" int lafs_gemm_tn_part(const void* A, int lda, const void* B, int ldb, float* part, int ldc, int64_t part_stride,
+                                 int M, int N1, int N2, int splits, float* colsum_a, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(part_stride > 0, "part_stride must be positive");
+  return launch_tn(A, lda, B, ldb, part, ldc, M, N1, N2, splits, colsum_a, part_stride, stream);
+}
+
+extern "C" int lafs_reduce_partials(float* part, int64_t part_stride, int n_part, int64_t n, float* out, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(part && out && n_part > 0 && n > 0 && n % 4 == 0 && part_stride % 4 == 0, "n and part_stride must be multiples of 4");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, part, (long)part_stride,
+                     n_part, n4, out);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

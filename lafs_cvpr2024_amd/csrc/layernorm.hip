@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                     float* __restrict__ g_io, int ldg, int accumulate,
                                                     bf16_t* __restrict__ gb, int ldgb, const float* __restrict__ seq_scale,
                                                     const int* __restrict__ row2seq, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, int rows, int D) {
+                                                    float* __restrict__ dbeta, int rows, int D, DropCfg drop) {
   __shared__ float red[2][4][NI * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 gam[NI], ag[NI], ab[NI];
@@ -112,9 +112,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
           o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
         }
         *reinterpret_cast<float4*>(gp) = o;
-        if (gb != nullptr)
-          *reinterpret_cast<uint2*>(gb + (size_t)row * ldgb + c) =
-              make_uint2(pack_bf2(sc * o.x, sc * o.y), pack_bf2(sc * o.z, sc * o.w));
+        if (gb != nullptr) {
+          float4 q = make_float4(sc * o.x, sc * o.y, sc * o.z, sc * o.w);
+          if (drop.thresh) {                              // gradient entering the dropped-out branch output
+            const unsigned idx = (unsigned)row * (unsigned)D + (unsigned)c;
+            q.x *= drop_mult(drop, idx); q.y *= drop_mult(drop, idx + 1); q.z *= drop_mult(drop, idx + 2); q.w *= drop_mult(drop, idx + 3);
+          }
+          *reinterpret_cast<uint2*>(gb + (size_t)row * ldgb + c) = make_uint2(pack_bf2(q.x, q.y), pack_bf2(q.z, q.w));
+        }
       }
     }
   }
@@ -134,14 +139,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 
 __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ g, int ldg, bf16_t* __restrict__ gb, int ldgb,
                                                         const float* __restrict__ seq_scale, const int* __restrict__ row2seq,
-                                                        int rows, int D) {
+                                                        int rows, int D, DropCfg drop) {
   const int per_row = D >> 2;
   const size_t total = (size_t)rows * per_row;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int row = (int)(i / per_row), c = (int)(i % per_row) * 4;
     const float sc = (seq_scale != nullptr) ? seq_scale[row2seq[row]] : 1.0f;
-    const float4 v = *reinterpret_cast<const float4*>(g + (size_t)row * ldg + c);
-    *reinterpret_cast<uint2*>(gb + (size_t)row * ldgb + c) = make_uint2(pack_bf2(sc * v.x, sc * v.y), pack_bf2(sc * v.z, sc * v.w));
+    float4 v = *reinterpret_cast<const float4*>(g + (size_t)row * ldg + c);
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    if (drop.thresh) {
+      const unsigned idx = (unsigned)row * (unsigned)D + (unsigned)c;
+      v.x *= drop_mult(drop, idx); v.y *= drop_mult(drop, idx + 1); v.z *= drop_mult(drop, idx + 2); v.w *= drop_mult(drop, idx + 3);
+    }
+    *reinterpret_cast<uint2*>(gb + (size_t)row * ldgb + c) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
+  }
+}
+
+// x(f32)[r, c] *= mask(r, c)/(1-p) in place (embedding dropout and its backward); out_mask (optional) receives the factors
+__global__ __launch_bounds__(256) void dropout_f32_kernel(float* __restrict__ x, int ldx, int rows, int D, DropCfg drop,
+                                                         float* __restrict__ out_mask) {
+  const size_t total = (size_t)rows * D;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / D), c = (int)(i % D);
+    const float f = drop.thresh ? drop_mult(drop, (unsigned)i) : 1.0f;
+    if (x != nullptr) x[(size_t)row * ldx + c] *= f;
+    if (out_mask != nullptr) out_mask[i] = f;
   }
 }
 
@@ -190,7 +212,8 @@ extern "C" int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, c
 extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf, const float* x, int ldx,
                                   const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
                                   void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
-                                  float* dgamma, float* dbeta, int rows, int D, hipStream_t stream) {
+                                  float* dgamma, float* dbeta, int rows, int D, float drop_p, uint32_t drop_seed,
+                                  hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG((dy_bf16 || dy_f32) && x && stats && gamma && g_io && dgamma && dbeta, "null operand");
   LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
@@ -200,20 +223,45 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
   const dim3 grid(blocks);
   const int ni = ceil_div(D, 256);
   LN_DISPATCH(ni, ln_bwd_kernel, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
-              (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D);
+              (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D, make_drop(drop_p, drop_seed));
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
 
 extern "C" int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb, const float* seq_scale,
-                                    const int32_t* row2seq, int rows, int D, hipStream_t stream) {
+                                    const int32_t* row2seq, int rows, int D, float drop_p, uint32_t drop_seed,
+                                    hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g && gb && rows > 0 && D > 0 && D % 4 == 0, "bad operand");
   LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
   const size_t total = (size_t)rows * (D / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(scale_cast_kernel, dim3(blocks), dim3(256), 0, stream, g, ldg, (bf16_t*)gb, ldgb, seq_scale, row2seq, rows, D);
+  hipLaunchKernelGGL(scale_cast_kernel, dim3(blocks), dim3(256), 0, stream, g, ldg, (bf16_t*)gb, ldgb, seq_scale, row2seq, rows, D,
+                     make_drop(drop_p, drop_seed));
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_dropout_f32(float* x, int ldx, int rows, int D, float drop_p, uint32_t drop_seed, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(x && rows > 0 && D > 0 && drop_p >= 0.f && drop_p < 1.f && (long)rows * D < 4294967296L, "bad operand");
+  if (!(drop_p > 0.f)) return LAFS_OK;
+  const size_t total = (size_t)rows * D;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, rows, D, make_drop(drop_p, drop_seed), nullptr);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_debug_dropout_mask(int rows, int cols, float drop_p, uint32_t drop_seed, float* out, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(out && rows > 0 && cols > 0 && drop_p >= 0.f && drop_p < 1.f && (long)rows * cols < 4294967296L, "bad operand");
+  const size_t total = (size_t)rows * cols;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(blocks), dim3(256), 0, stream, nullptr, 0, rows, cols, make_drop(drop_p, drop_seed), out);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -11,6 +11,8 @@ kernel launches from Python.  Collectives stay outside the graphs and run throug
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -98,7 +100,8 @@ class LafsPretrainEngine:
         self.mid = self.depth // 2 if grad_slices > 1 else 0
         self.mid_start = self.sa.offsets[f"{self.spec_s.prefix}blocks.{self.mid}.norm1.weight"] if self.mid > 0 else 0
         self.reducer = FlatReducer()
-        self.side_stream = torch.cuda.Stream(device=self.device)      # teacher forward / weight-gradient GEMMs
+        # teacher forward / weight-gradient GEMMs run on a second stream; LAFS_SINGLE_STREAM=1 serialises everything (profiling)
+        self.side_stream = None if os.environ.get("LAFS_SINGLE_STREAM") == "1" else torch.cuda.Stream(device=self.device)
         self.use_graph = use_graph
         self._graphs = None
         self._st = {}
@@ -117,8 +120,9 @@ class LafsPretrainEngine:
         sa.grad.zero_()
         # teacher (two global views, no activations kept) runs on the side stream, concurrently with the student
         cur = torch.cuda.current_stream()
-        self.side_stream.wait_stream(cur)
-        with torch.cuda.stream(self.side_stream):
+        side = self.side_stream if self.side_stream is not None else cur
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
             pos_t = self._pos_tokens(ta, self.spec_t)[:1]
             feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, None, save=False)
             Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self.logits_t)
@@ -128,7 +132,7 @@ class LafsPretrainEngine:
         imgs = [self.in_global_all] + ([self.in_local_all] if self.n_local else [])
         feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s), drop, save=True)
         _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self.logits_s)
-        cur.wait_stream(self.side_stream)
+        cur.wait_stream(side)
         # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
         ops.dino_loss_fwd_bwd(self.logits_s, self.logits_t, self.dino_loss.center.view(-1), self.ncrops,
                               float(self.dino_loss.student_temp), 0.04, K=self.K, grad=self.dlogits, ws=self.loss_ws,

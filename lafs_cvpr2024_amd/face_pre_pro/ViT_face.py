@@ -140,7 +140,7 @@ class _PartFViTFunction(torch.autograd.Function):
         geom = Fn.geometry([(n_img, side)], x.device)
         drop = model._sample_drop_scales(geom) if model.training else None
         feat, st, _ = Fn.vit_forward(model._arena, model._spec, geom, [x.contiguous().float()], [pos.detach().contiguous()],
-                                     drop, save=save)
+                                     drop, save=save, dropout=model._next_dropout())
         ctx.model, ctx.st = model, (st if save else None)
         ctx.x_dim = x.dim()
         return feat
@@ -162,7 +162,9 @@ class ViT_face_landmark_patch8(nn.Module):
     ``heads * 64`` inner width, DropPath 0.1 on every residual branch, LayerNorm head; 4-D images or 3-D [B, n, 192]
     patch vectors.  ``with_land=True`` adds the trainable MobileNetV3 landmark regressor (``stn`` + ``output_layer``, stock
     PyTorch-ROCm / MIOpen) whose landmarks drive the single-launch HIP patch gather; gradients flow back through the patch
-    embedding and the gather into theta (reference :679-711).  Non-zero element dropout is not in this build."""
+    embedding and the gather into theta (reference :679-711).  Element dropout (``dropout`` after to_out / GELU / fc2,
+    ``emb_dropout`` on the embedded tokens) is fused into the GEMM epilogues with counter-based masks (same distribution as
+    nn.Dropout, different random stream)."""
 
     def __init__(self, *, loss_type, GPU_ID, num_class, image_size, patch_size, dim, depth, heads, mlp_dim, pool='cls',
                  num_patches=None, channels=3, dim_head=64, dropout=0., emb_dropout=0., fp16=True, with_land=False,
@@ -172,8 +174,8 @@ class ViT_face_landmark_patch8(nn.Module):
             raise NotImplementedError("HIP kernels are specialised for 3x8x8 patches and head_dim 64")
         if use_standcoord:
             raise NotImplementedError("use_standcoord (fixed grid + jitter) is never enabled by the reference's entry points")
-        if dropout or emb_dropout:
-            raise NotImplementedError("element dropout is not implemented in the fused epilogues (parity mode uses rate 0)")
+        if not (0.0 <= dropout < 1.0 and 0.0 <= emb_dropout < 1.0):
+            raise ValueError("dropout rates must be in [0, 1)")
         if pool != 'cls':
             raise NotImplementedError("only cls pooling is on the hot path")
         if num_patches is None:
@@ -188,6 +190,9 @@ class ViT_face_landmark_patch8(nn.Module):
         self.patch_shape = torch.tensor([patch_size, patch_size])
         self.dim, self.depth, self.heads, self.mlp_dim = dim, depth, heads, mlp_dim
         self.drop_path_rate = drop_path_rate
+        # element dropout (after to_out, after GELU, after fc2, and on the embedded tokens): fused into the GEMM epilogues
+        # with counter-based masks; `_drop_step` advances the seed every training forward
+        self.dropout_rate, self.emb_dropout_rate, self._drop_seed0, self._drop_step = float(dropout), float(emb_dropout), 0x5EED, 0
         inner = heads * dim_head
         self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 1, dim))
         self.patch_to_embedding = nn.Linear(channels * patch_size ** 2, dim)
@@ -236,6 +241,13 @@ class ViT_face_landmark_patch8(nn.Module):
         keep = 1.0 - self.drop_path_rate
         u = torch.rand(self.depth, 2, geom.n_seq, device=self._arena.device)
         return (torch.floor(keep + u) / keep).contiguous()
+
+    def _next_dropout(self):
+        """(p_trunk, p_embedding, seed) for this forward, or None in eval mode / at rate 0."""
+        if not self.training or (self.dropout_rate == 0.0 and self.emb_dropout_rate == 0.0):
+            return None
+        self._drop_step += 1
+        return (self.dropout_rate, self.emb_dropout_rate, (self._drop_seed0 + 7919 * self._drop_step) & 0x3FFFFFFF)
 
     def forward_embedding(self, x):
         if self._arena is None:

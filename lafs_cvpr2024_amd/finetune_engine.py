@@ -71,7 +71,7 @@ class FinetuneEngine:
             th = theta.detach().contiguous()
             img_in = torch.empty_like(self.x)
             call("lafs_patch_gather_fwd", _p(self.x), _p(th), B, self.x.shape[-1], th.shape[1], _p(img_in))
-        emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [pos], drop, save=True)
+        emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [pos], drop, save=True, dropout=m._next_dropout())
         # cosine logits
         xn = torch.empty(B, D, device=dev, dtype=bf16); inv_x = torch.empty(B, device=dev, dtype=f32)
         call("lafs_l2norm_fwd", _p(emb), D, _p(xn), D, _p(inv_x), B, D)

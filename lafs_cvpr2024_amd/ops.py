@@ -33,7 +33,7 @@ def _ld(t):
 
 
 def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=None, seq_scale=None, row2seq=None,
-            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None):
+            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0):
     """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*)."""
     _chk(A, bf16, "A"); _chk(B, bf16, "B")
     M, K = A.shape
@@ -49,6 +49,7 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     a = _lib.GemmNTArgs()
     a.A, a.lda, a.B, a.ldb = A.data_ptr(), _ld(A), B.data_ptr(), _ld(B)
     a.M, a.N, a.K, a.epilogue = M, N, K, epilogue
+    a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
     a.C, a.ldc = out.data_ptr(), _ld(out)
     if out2 is not None:
         _chk(out2, bf16, "out2"); a.C2, a.ldc2 = out2.data_ptr(), _ld(out2)
@@ -77,6 +78,21 @@ def gemm_tn_acc(A, B, Cacc, splits=0, colsum=None):
     return Cacc
 
 
+def gemm_tn_part(A, B, part, splits=0, colsum=None):
+    """part[x] += (A^T @ B restricted to the rows handled by XCD x); part f32 [N_XCD, N1, N2] (zero-initialised)."""
+    _chk(A, bf16, "A"); _chk(B, bf16, "B"); _chk(part, torch.float32, "part")
+    M, N1 = A.shape
+    N2 = B.shape[1]
+    call("lafs_gemm_tn_part", _p(A), _ld(A), _p(B), _ld(B), _p(part), part.stride(1), part.stride(0), M, N1, N2, splits, _p(colsum))
+    return part
+
+
+def reduce_partials(part, out):
+    """out += part.sum(0); part = 0."""
+    call("lafs_reduce_partials", _p(part), part.stride(0), part.shape[0], out.numel(), _p(out))
+    return out
+
+
 def colsum_bf16_acc(X, out):
     _chk(X, bf16, "X"); _chk(out, torch.float32, "out")
     call("lafs_colsum_bf16_acc", _p(X), _ld(X), X.shape[0], X.shape[1], _p(out))
@@ -93,22 +109,32 @@ def layernorm_fwd(x, gamma, beta, eps, want_bf16=True, want_f32=False):
     return y, yf, stats
 
 
-def layernorm_bwd(dy, x, stats, gamma, g_io, dgamma, dbeta, accumulate=True, gb_out=None, seq_scale=None, row2seq=None):
+def layernorm_bwd(dy, x, stats, gamma, g_io, dgamma, dbeta, accumulate=True, gb_out=None, seq_scale=None, row2seq=None,
+                  drop_p=0.0, drop_seed=0):
     """dy: bf16 or f32 [rows, D].  g_io (f32) receives (accumulates) dx; returns g_io."""
     rows, D = x.shape
     dy_b = dy if dy.dtype == bf16 else None
     dy_f = dy if dy.dtype == torch.float32 else None
     call("lafs_layernorm_bwd", _p(dy_b), D if dy_b is None else _ld(dy_b), _p(dy_f), D if dy_f is None else _ld(dy_f),
          _p(x), _ld(x), _p(stats), _p(gamma), _p(g_io), _ld(g_io), 1 if accumulate else 0,
-         _p(gb_out), D if gb_out is None else _ld(gb_out), _p(seq_scale), _p(row2seq), _p(dgamma), _p(dbeta), rows, D)
+         _p(gb_out), D if gb_out is None else _ld(gb_out), _p(seq_scale), _p(row2seq), _p(dgamma), _p(dbeta), rows, D,
+         float(drop_p), int(drop_seed) & 0xFFFFFFFF)
     return g_io
 
 
-def scale_cast_bf16(g, seq_scale=None, row2seq=None, out=None):
+def scale_cast_bf16(g, seq_scale=None, row2seq=None, out=None, drop_p=0.0, drop_seed=0):
     rows, D = g.shape
     if out is None:
         out = torch.empty(rows, D, device=g.device, dtype=bf16)
-    call("lafs_scale_cast_bf16", _p(g), _ld(g), _p(out), _ld(out), _p(seq_scale), _p(row2seq), rows, D)
+    call("lafs_scale_cast_bf16", _p(g), _ld(g), _p(out), _ld(out), _p(seq_scale), _p(row2seq), rows, D,
+         float(drop_p), int(drop_seed) & 0xFFFFFFFF)
+    return out
+
+
+def dropout_mask(rows, cols, p, seed, device="cuda"):
+    """The factor matrix (0 or 1/(1-p)) the kernels apply for (seed, rows x cols) -- test/debug helper."""
+    out = torch.empty(rows, cols, device=device, dtype=torch.float32)
+    call("lafs_debug_dropout_mask", rows, cols, float(p), int(seed) & 0xFFFFFFFF, _p(out))
     return out
 
 

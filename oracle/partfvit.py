@@ -73,33 +73,40 @@ def attention(P, pre, x, cfg):
     return F.linear(o, P[pre + "to_out.0.weight"], P[pre + "to_out.0.bias"])
 
 
-def transformer(P, x, cfg, drop_scales=None):
+def transformer(P, x, cfg, drop_scales=None, masks=None):
     """Transformer of Residual_droppath(PreNorm(.)) pairs (ViT_face.py:106-120, 184-213).
-    Dropout rates are taken as 0 (parity mode); drop_scales [depth, 2, B] as in oracle.vit."""
+    drop_scales [depth, 2, B] as in oracle.vit.  Element dropout (nn.Dropout after to_out :150-153, after GELU and
+    after the second Linear :126-133) is applied through explicit factor tensors: masks[(layer, site)] with site
+    0 = to_out [B, N, D], 1 = GELU [B, N, mlp], 2 = fc2 [B, N, D], entries 0 or 1/(1-p); None = rate 0."""
     D = cfg.dim
+    mk = lambda i, s, t: t if masks is None or (i, s) not in masks else t * masks[(i, s)].view(t.shape)
     for i in range(cfg.depth):
         a, f = f"transformer.layers.{i}.0.fn.", f"transformer.layers.{i}.1.fn."
         y = attention(P, a + "fn.", F.layer_norm(x, (D,), P[a + "norm.weight"], P[a + "norm.bias"], cfg.ln_eps), cfg)
+        y = mk(i, 0, y)
         if drop_scales is not None:
             y = y * drop_scales[i, 0].view(-1, 1, 1)
         x = y + x
         h = F.layer_norm(x, (D,), P[f + "norm.weight"], P[f + "norm.bias"], cfg.ln_eps)
-        h = F.gelu(F.linear(h, P[f + "fn.net.0.weight"], P[f + "fn.net.0.bias"]))
-        h = F.linear(h, P[f + "fn.net.3.weight"], P[f + "fn.net.3.bias"])
+        h = mk(i, 1, F.gelu(F.linear(h, P[f + "fn.net.0.weight"], P[f + "fn.net.0.bias"])))
+        h = mk(i, 2, F.linear(h, P[f + "fn.net.3.weight"], P[f + "fn.net.3.bias"]))
         if drop_scales is not None:
             h = h * drop_scales[i, 1].view(-1, 1, 1)
         x = h + x
     return x
 
 
-def forward_embedding(P, x, cfg, drop_scales=None):
+def forward_embedding(P, x, cfg, drop_scales=None, masks=None):
     """ViT_face_landmark_patch8.forward without the landmark branch: 4-D image or 3-D [B,n,192]
-    patches -> emb [B, dim] (ViT_face.py:759-776)."""
+    patches -> emb [B, dim] (ViT_face.py:759-776).  masks: see transformer(); masks["emb"] [B, n+1, D] is the
+    embedding dropout (:614, 768)."""
     if x.dim() == 4:
         x = patches_from_image(x, cfg.patch_size)
     t = F.linear(x, P["patch_to_embedding.weight"], P["patch_to_embedding.bias"])
     B, n, _ = t.shape
     t = torch.cat((P["cls_token"].expand(B, -1, -1), t), dim=1)
     t = t + P["pos_embedding"][:, :n + 1]
-    t = transformer(P, t, cfg, drop_scales)
+    if masks is not None and "emb" in masks:
+        t = t * masks["emb"].view(t.shape)
+    t = transformer(P, t, cfg, drop_scales, masks)
     return F.layer_norm(t[:, 0], (cfg.dim,), P["mlp_head.0.weight"], P["mlp_head.0.bias"], cfg.ln_eps)

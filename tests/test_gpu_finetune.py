@@ -280,3 +280,49 @@ def test_landmark_frontend_matches_module_calls():
     clean = lc.landmarks(views[0]).detach()
     d = fe.theta_g[:B] - clean
     assert 3.5 < float(d.std()) < 6.5 and abs(float(d.mean())) < 1.0
+
+
+def test_partfvit_element_dropout_matches_oracle_with_same_masks():
+    """dropout=0.1 / emb_dropout=0.1 as train_largescale.py:552-555 configures the model: the masks are regenerated from
+    (seed, row, col) in every forward/backward kernel.  The factor matrices are exported (lafs_debug_dropout_mask) and fed
+    to the oracle (whose dropout sites are pinned to the reference by F14): embedding and gradients must agree."""
+    from lafs_cvpr2024_amd import functional as Fn, ops
+    from oracle import partfvit
+    fx = load_golden("f14_partfvit_dropout")
+    p = 0.1
+    m = ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=128, depth=2,
+                                 heads=3, mlp_dim=256, dropout=p, emb_dropout=p, with_land=False, drop_path_rate=0.0)
+    m.load_state_dict(sub(fx, "p."))
+    attach_arena(m, DEV)
+    m.train()
+    x = fx["x"].to(DEV)
+    e = m(x)
+    seed = (m._drop_seed0 + 7919 * m._drop_step) & 0x3FFFFFFF
+    (e * fx["w"].to(DEV)).sum().backward()
+    B, N, D, H = 2, 197, 128, 256
+    fac = lambda rows, cols, s: ops.dropout_mask(rows, cols, p, s, DEV).cpu()
+    masks = {"emb": fac(B * N, D, seed + Fn.EMB_DROP_SITE).view(B, N, D)}
+    for l in range(2):
+        masks[(l, 0)] = fac(B * N, D, seed + 3 * l + 0).view(B, N, D)
+        masks[(l, 1)] = fac(B * N, H, seed + 3 * l + 1).view(B, N, H)
+        masks[(l, 2)] = fac(B * N, D, seed + 3 * l + 2).view(B, N, D)
+    # the masks are Bernoulli(1-p) scaled by 1/(1-p), independent across sites
+    for k, v in masks.items():
+        kept = float((v > 0).float().mean())
+        assert abs(kept - (1 - p)) < 0.01, (k, kept)
+        assert torch.all((v == 0) | ((v - 1 / (1 - p)).abs() < 1e-6))
+    assert float(((masks[(0, 0)] > 0) == (masks[(0, 2)] > 0)).float().mean()) < 0.85
+    cfg = partfvit.PartFViTConfig(patch_size=8, dim=128, depth=2, heads=3, mlp_dim=256, num_patches=196)
+    P = {k: v.clone().requires_grad_(True) for k, v in sub(fx, "p.").items()}
+    ref = partfvit.forward_embedding(P, fx["x"], cfg, masks=masks)
+    (ref * fx["w"]).sum().backward()
+    assert rel_l2(e, ref) < 2e-2, rel_l2(e, ref)
+    named = dict(m.named_parameters())
+    bad = {k: rel_l2(named[k].grad, v.grad) for k, v in P.items() if v.grad is not None}
+    bad = {k: v for k, v in bad.items() if v > 6e-2}
+    assert not bad, bad
+    # a second forward draws a different mask; eval mode draws none and is deterministic
+    e2 = m(x)
+    assert rel_l2(e2, e) > 1e-3
+    m.eval()
+    assert rel_l2(m(x), m(x)) == 0.0

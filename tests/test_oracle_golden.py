@@ -196,3 +196,22 @@ def test_f13_oracle_gather_plus_partfvit_matches_reference_landmark_branch():
     mosaic = gather.extract_patches(fx["x"], fx["theta"])
     e = partfvit.forward_embedding(sub(fx, "p."), mosaic, cfg)
     torch.testing.assert_close(e, fx["e"], rtol=1e-4, atol=1e-5)
+
+
+def test_f14_oracle_dropout_sites_match_reference():
+    """Element-dropout sites of Part-fViT in train mode (embedding, to_out, after GELU, after fc2): the oracle fed with the
+    masks the reference drew reproduces its embedding and gradients."""
+    from oracle import partfvit
+    fx = load_golden("f14_partfvit_dropout")
+    cfg = partfvit.PartFViTConfig(patch_size=8, dim=128, depth=2, heads=3, mlp_dim=256, num_patches=196)
+    P = {k: v.clone().requires_grad_(True) for k, v in sub(fx, "p.").items()}
+    sc = 1.0 / (1.0 - float(fx["p"]))
+    keeps = [fx[f"keep{i}"].float() * sc for i in range(7)]
+    masks = {"emb": keeps[0]}
+    for l in range(2):
+        masks[(l, 0)], masks[(l, 1)], masks[(l, 2)] = keeps[1 + 3 * l], keeps[2 + 3 * l], keeps[3 + 3 * l]
+    e = partfvit.forward_embedding(P, fx["x"], cfg, masks=masks)
+    torch.testing.assert_close(e, fx["e"], rtol=1e-4, atol=1e-5)
+    (e * fx["w"]).sum().backward()
+    for k, g in sub(fx, "g.").items():
+        close(P[k].grad, g, 2e-4)

@@ -59,6 +59,22 @@ if "nt" in which:
 if "tn" in which:
     tn(T, 384, 1536, "fc2 wgrad"); tn(T, 1536, 384, "fc1 wgrad"); tn(T, 384, 384, "proj wgrad"); tn(T, 1152, 384, "qkv wgrad")
     tn(640, 100096, 256, "last wgrad")
+if "tnpart" in which:
+    print("--- TN wgrad: device atomics vs per-XCD partial images (+ fold) vs plain stores (wrong results, upper bound)")
+    for (M, N1, N2, name) in ((T, 384, 1536, "fc2 wgrad"), (T, 1536, 384, "fc1 wgrad"), (T, 384, 384, "proj wgrad"), (T, 1152, 384, "qkv wgrad")):
+        A = torch.randn(M, N1, device=dev).to(bf); B = torch.randn(M, N2, device=dev).to(bf)
+        Cd = torch.zeros(N1, N2, device=dev); part = torch.zeros(8, N1, N2, device=dev)
+        ops.gemm_tn_acc(A, B, Cd)
+        ops.gemm_tn_part(A, B, part); Cp = ops.reduce_partials(part, torch.zeros(N1, N2, device=dev))
+        ref = A.float().t() @ B.float()
+        print(f"   {name}: max|atomics-ref| {float((Cd-ref).abs().max()):.3e}  max|partials-ref| {float((Cp-ref).abs().max()):.3e}  (|ref| {float(ref.abs().max()):.1f})"
+              f"  images left zero: {float(part.abs().max()) == 0.0}")
+        t0 = timeit(lambda: ops.gemm_tn_acc(A, B, Cd))
+        t1 = timeit(lambda: ops.gemm_tn_part(A, B, part))
+        out = torch.zeros(N1, N2, device=dev)
+        t2 = timeit(lambda: ops.reduce_partials(part, out))
+        _lib.lib().lafs_debug_set(1); t3 = timeit(lambda: ops.gemm_tn_acc(A, B, Cd)); _lib.lib().lafs_debug_set(0)
+        print(f"   {name}: atomics {t0*1e6:7.1f} us | partial {t1*1e6:7.1f} us + fold {t2*1e6:6.1f} us | stores {t3*1e6:7.1f} us")
 if "tiles" in which:
     print("--- NT tile variants: flag 2 = 128x128 bk32, 4 = 256x128 bk32, 10 = 128x128 bk64, 12 = 256x128 bk64")
     for flag in (2, 4, 10, 12):

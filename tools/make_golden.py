@@ -311,6 +311,39 @@ def main():
          gnorm_keys=np.array(sorted(g13.keys())), gnorms=np.array([float(g13[k].norm()) for k in sorted(g13.keys())]),
          **{"g." + k: g13[k] for k in keep},
          **{"p." + k: v for k, v in pl.state_dict().items() if not k.startswith(("stn.", "output_layer."))})
+    # ---------------------------------------------------------------- F14 Part-fViT element dropout (train mode)
+    # nn.Dropout sites of the reference (emb :614,768; to_out :150-153; after GELU and after fc2 :126-133) with the masks
+    # captured: F.dropout is replaced by a recording implementation for this one forward, DropPath forced to 0.
+    print("F14 part-fvit dropout sites")
+    torch.manual_seed(14)
+    pd_ = ref_face.ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8,
+                                            dim=128, depth=2, heads=3, mlp_dim=256, dropout=0.1, emb_dropout=0.1,
+                                            with_land=False)
+    for m in pd_.modules():
+        if isinstance(m, ref_vit.DropPath):
+            m.drop_prob = 0.0
+    pd_.train()
+    rec = []
+    orig_dropout = torch.nn.functional.dropout
+
+    def recording_dropout(inp, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return inp
+        keep = torch.rand_like(inp) >= p
+        rec.append(keep)
+        return inp * keep / (1.0 - p)
+
+    torch.nn.functional.dropout = recording_dropout
+    try:
+        x14 = torch.randn(2, 3, 112, 112).clamp(-1, 1)
+        w14 = torch.randn(2, 128)
+        e14 = pd_(x14)
+        (e14 * w14).sum().backward()
+    finally:
+        torch.nn.functional.dropout = orig_dropout
+    assert len(rec) == 1 + 3 * 2, len(rec)
+    save("f14_partfvit_dropout", x=x14, w=w14, e=e14, p=np.float32(0.1),
+         **{f"keep{i}": k.to(torch.uint8) for i, k in enumerate(rec)}, **sd(pd_), **grads(pd_))
     print("done")
 
 
