@@ -20,9 +20,11 @@ f32, bf16 = torch.float32, torch.bfloat16
 
 class FinetuneEngine:
     def __init__(self, backbone: ViT_face_landmark_patch8, batch_size, acc_step=3, mixup_alpha=0.2, mixup_prob=0.1,
-                 s=64.0, m=0.4, margin_type=0, image_size=112, device=None):
-        if not isinstance(backbone, ViT_face_landmark_patch8) or not hasattr(backbone, "loss"):
-            raise _lib.LafsHipError("FinetuneEngine drives ViT_face_landmark_patch8(loss_type='CosFace')")
+                 s=64.0, m=0.4, margin_type=0, image_size=112, device=None, sharded_head=None):
+        """margin_type 0 = CosFace (the reference), 1 = ArcFace (parity unpinned), on the dense `backbone.loss.weight` head;
+        `sharded_head` (a partial_fc.PartialFC) replaces it by the class-sharded head (hard labels: mixup is off)."""
+        if not isinstance(backbone, ViT_face_landmark_patch8) or (sharded_head is None and not hasattr(backbone, "loss")):
+            raise _lib.LafsHipError("FinetuneEngine drives ViT_face_landmark_patch8(loss_type='CosFace') or a sharded head")
         if batch_size % 8:
             raise _lib.LafsHipError("FinetuneEngine needs a batch size that is a multiple of 8 (16-byte rows in the class-gradient GEMM)")
         self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
@@ -31,7 +33,8 @@ class FinetuneEngine:
         self.s, self.m, self.margin_type = float(s), float(m), margin_type
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena = attach_arena(backbone, self.device)
-        self.C = backbone.loss.out_features
+        self.head = sharded_head
+        self.C = backbone.loss.out_features if sharded_head is None else 8
         self.Cpad = (self.C + 127) // 128 * 128
         self.D = backbone.dim
         self.geom = Fn.geometry([(batch_size, image_size)], self.device)
@@ -58,6 +61,8 @@ class FinetuneEngine:
         a, m, B, D, dev = self.arena, self.model, self.B, self.D, self.device
         a.ensure_fresh()
         lam = self.draw_lambda() if lam is None else float(lam)
+        if self.head is not None:
+            lam = 1.0                                    # the sharded head takes hard labels
         call("lafs_mixup_normalize", _p(inputs_u8.contiguous()), _p(self.x), B, self.x.shape[-1], lam)
         y1 = labels.to(dev, torch.int32).contiguous()
         y2 = y1.flip(0).contiguous()
@@ -72,6 +77,14 @@ class FinetuneEngine:
             img_in = torch.empty_like(self.x)
             call("lafs_patch_gather_fwd", _p(self.x), _p(th), B, self.x.shape[-1], th.shape[1], _p(img_in))
         emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [pos], drop, save=True, dropout=m._next_dropout())
+        if self.head is not None:
+            # class-sharded head: all-gather embeddings, local logits, exchanged softmax statistics, reduce-scatter of dE.
+            # demb is the gradient of the GLOBAL-batch mean loss, so the later all-reduce of the backbone gradients is a SUM.
+            loss, demb = self.head.forward_backward(emb, labels, grad_scale=1.0 / self.acc_step)
+            self.loss = loss.detach().view(1)
+            self._backward_trunk(st, demb, th if m.with_land else None, theta)
+            self.micro += 1
+            return self.loss
         # cosine logits
         xn = torch.empty(B, D, device=dev, dtype=bf16); inv_x = torch.empty(B, device=dev, dtype=f32)
         call("lafs_l2norm_fwd", _p(emb), D, _p(xn), D, _p(inv_x), B, D)
@@ -92,6 +105,12 @@ class FinetuneEngine:
              _p(a.view(a.grad, wname)), None, 1)
         demb = torch.empty(B, D, device=dev, dtype=f32)
         call("lafs_l2norm_bwd", _p(emb), D, _p(dxn), D, _p(inv_x), _p(demb), D, B, D)
+        self._backward_trunk(st, demb, th if m.with_land else None, theta)
+        self.micro += 1
+        return self.loss
+
+    def _backward_trunk(self, st, demb, th, theta):
+        a, m, B, D = self.arena, self.model, self.B, self.D
         if m.with_land:
             dpos, dx = Fn.vit_backward(a, m._spec, st, demb, want_dx=True)
             dmosaic = Fn.unpatchify_grad(dx[0], m._spec.patch_order).contiguous()
@@ -101,8 +120,6 @@ class FinetuneEngine:
         else:
             dpos = Fn.vit_backward(a, m._spec, st, demb)
         a.view(a.grad, m._spec.prefix + "pos_embedding").view(-1, D)[: dpos[0].shape[0]] += dpos[0]
-        self.micro += 1
-        return self.loss
 
     def optimizer_step(self, lr, weight_decay=0.1, beta1=0.9, beta2=0.999, eps=1e-8):
         """AdamW over every tensor (decay only on >= 2-D tensors, train_largescale.py:122-173); all-reduces the flat gradient
@@ -112,8 +129,12 @@ class FinetuneEngine:
             dist.all_reduce(a.grad)
         h = torch.zeros(_lib.HP_COUNT, dtype=f32)
         h[_lib.HP_LR], h[_lib.HP_WD], h[_lib.HP_BETA1], h[_lib.HP_BETA2], h[_lib.HP_EPS] = lr, weight_decay, beta1, beta2, eps
-        h[_lib.HP_CLIP], h[_lib.HP_EMA_M], h[_lib.HP_FREEZE_LAST], h[_lib.HP_GRAD_SCALE] = 0.0, 0.0, 0.0, 1.0 / self.world
+        # dense head: every rank's loss is its local mean -> average; sharded head: gradients of the global mean -> sum
+        gscale = 1.0 if self.head is not None else 1.0 / self.world
+        h[_lib.HP_CLIP], h[_lib.HP_EMA_M], h[_lib.HP_FREEZE_LAST], h[_lib.HP_GRAD_SCALE] = 0.0, 0.0, 0.0, gscale
         self.hyper.copy_(h)
+        if self.head is not None:
+            self.head.optimizer_step(lr, weight_decay, beta1, beta2, eps)
         call("lafs_clip_adamw_ema", _p(a.master), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq), None, _p(a.shadow), None,
              _p(a.chunk_seg), a.n_chunks, _p(a.seg_flags), _p(a.seg_step), a.n_seg, _p(a.seg_sumsq), _p(self.hyper))
         a.refresh_transposed()

@@ -59,7 +59,10 @@ def get_args_parser():
     p.add_argument('--optimizer', default='adamw', type=str, choices=['adamw'])
     p.add_argument('--drop_path_rate', type=float, default=0.1)
     p.add_argument('--local_crops_number', type=int, default=8)
-    p.add_argument('--data', default='synthetic', type=str, help="'synthetic' (landmark-crop shaped random tensors)")
+    p.add_argument('--data', default='synthetic', type=str,
+                   help="'synthetic': random landmark-crop shaped tensors; 'synthetic_views': the 20 augmented 112x112 views of "
+                        "DataAugmentation_LAFS (clean/augmented pairs) pushed through the landmark front-end")
+    p.add_argument('--landmark_ckpt', default='', type=str, help="state_dict of the frozen landmark CNN (reference :262-268)")
     p.add_argument('--steps_per_epoch', default=100, type=int, help="iterations per epoch for --data synthetic")
     p.add_argument('--output_dir', default=".", type=str)
     p.add_argument('--saveckp_freq', default=10, type=int)
@@ -87,6 +90,36 @@ class SyntheticCrops:
             yield g + l, None
 
 
+class SyntheticViews:
+    """The loader contract of the reference (lafs_train.py:790-886): per batch a list of 2*(2+n_local) tensors [B,3,112,112],
+    (clean, augmented) pairs: g0, g0', g1, g1', l0, l0', ...  Random tensors here; the landmark front-end turns them into the
+    2 global + n local mosaics."""
+
+    def __init__(self, steps, batch, n_local, device, seed):
+        self.steps, self.batch, self.n_local, self.device = steps, batch, n_local, device
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            yield torch.randn(2 * (2 + self.n_local), self.batch, 3, 112, 112, device=self.device, generator=self.gen).clamp_(-1, 1), None
+
+
+def build_landmark_frontend(args, device):
+    """Frozen landmark CNN (reference lafs_train.py:241-269: face_landmark_4simmin_glo_loc, eval mode) + the fused front-end."""
+    from .face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
+    from .landmark_frontend import LandmarkFrontEnd
+    cnn = face_landmark_4simmin_glo_loc(loss_type='None', GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=768,
+                                        depth=12, heads=11, mlp_dim=2048)
+    if args.landmark_ckpt:
+        sd = torch.load(args.landmark_ckpt, map_location="cpu", weights_only=False)
+        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+        print("=> landmark CNN:", cnn.load_state_dict(sd, strict=False))
+    return LandmarkFrontEnd(cnn, args.batch_size_per_gpu, n_local=args.local_crops_number, device=device)
+
+
 def train_lafs(args, dataset=None):
     utils.init_distributed_mode(args)
     utils.fix_random_seeds(args.seed)
@@ -111,9 +144,16 @@ def train_lafs(args, dataset=None):
                                 device=device)
     print(f"Student and Teacher are built: they are both {args.arch} networks.")
 
-    data_loader = dataset if dataset is not None else SyntheticCrops(args.steps_per_epoch, args.batch_size_per_gpu,
-                                                                      args.local_crops_number, device,
-                                                                      args.seed + utils.get_rank())
+    frontend = None
+    if dataset is not None:
+        data_loader = dataset
+    elif args.data == 'synthetic_views':
+        data_loader = SyntheticViews(args.steps_per_epoch, args.batch_size_per_gpu, args.local_crops_number, device,
+                                     args.seed + utils.get_rank())
+        frontend = build_landmark_frontend(args, device)
+    else:
+        data_loader = SyntheticCrops(args.steps_per_epoch, args.batch_size_per_gpu, args.local_crops_number, device,
+                                     args.seed + utils.get_rank())
     n_it = len(data_loader)
     # ---- schedules (reference :411-424) ----
     lr_schedule = utils.cosine_scheduler(args.lr * (args.batch_size_per_gpu * world) / 256., args.min_lr, args.epochs, n_it,
@@ -131,7 +171,8 @@ def train_lafs(args, dataset=None):
     start = time.time()
     print("Starting LAFS training !")
     for epoch in range(start_epoch, args.epochs):
-        stats = train_one_epoch(engine, dino_loss, data_loader, lr_schedule, wd_schedule, momentum_schedule, epoch, args)
+        stats = train_one_epoch(engine, dino_loss, data_loader, lr_schedule, wd_schedule, momentum_schedule, epoch, args,
+                                frontend=frontend)
         save_dict = {
             'student': {"module." + k: v for k, v in student.state_dict().items()},     # DDP-style prefix, as the reference saves
             'teacher': teacher.state_dict(),
@@ -165,15 +206,49 @@ def _load_checkpoint(path, student, teacher, dino_loss, engine, run_variables):
     run_variables["epoch"] = ck.get("epoch", 0)
 
 
-def train_one_epoch(engine, dino_loss, data_loader, lr_schedule, wd_schedule, momentum_schedule, epoch, args):
+class _Pipelined:
+    """Software pipeline over the view loader: batch i+1 is fetched (and its `produced` event recorded) BEFORE step i is
+    launched and handed to the landmark front-end right AFTER, so the frozen CNN + gathers of the next batch run on the
+    front-end stream underneath the training step."""
+
+    def __init__(self, data_loader, frontend, engine):
+        self.loader, self.fe, self.engine = data_loader, frontend, engine
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        cur = torch.cuda.current_stream()
+        try:
+            views, _ = next(it)
+        except StopIteration:
+            return
+        self.fe.prefetch(views)
+        while True:
+            try:
+                nxt, _ = next(it)
+                ev = cur.record_event()
+            except StopIteration:
+                nxt = None
+            self.fe.commit(self.engine)                    # staged mosaics -> the engine's (graph-captured) input buffers
+            yield None, nxt is not None and (lambda n=nxt, e=ev: self.fe.prefetch(n, produced=e))
+            if nxt is None:
+                return
+
+
+def train_one_epoch(engine, dino_loss, data_loader, lr_schedule, wd_schedule, momentum_schedule, epoch, args, frontend=None):
     metric_logger = utils.MetricLogger(delimiter="  ")
     header = 'Epoch: [{}/{}]'.format(epoch, args.epochs)
     tt = float(dino_loss.teacher_temp_schedule[epoch])
     n = len(data_loader)
-    for it, (images, _) in enumerate(metric_logger.log_every(data_loader, 100, header)):
+    source = _Pipelined(data_loader, frontend, engine) if frontend is not None else data_loader
+    for it, (images, after) in enumerate(metric_logger.log_every(source, 100, header)):
         it = n * epoch + it
         loss = engine.step(images, lr=float(lr_schedule[it]), wd=float(wd_schedule[it]), momentum=float(momentum_schedule[it]),
                            teacher_temp=tt, epoch=epoch)
+        if callable(after):
+            after()                                         # front-end of the next batch, overlapping this step
         if it % 20 == 0:                                   # the only host sync: loss sanity check (reference :585-587 does it every step)
             lv = float(loss.item())
             if not math.isfinite(lv):

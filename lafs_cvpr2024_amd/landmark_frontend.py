@@ -48,15 +48,23 @@ class LandmarkFrontEnd:
         return self.cnn.output_layer(self.cnn.stn(x).mean(dim=(-2, -1))).float().contiguous()
 
     @torch.no_grad()
-    def prefetch(self, views, noise=None, sel=None):
+    def prefetch(self, views, noise=None, sel=None, produced=None):
         """views: list of 2*(2+n_local) tensors [B,3,S,S] in the reference's order (clean, augmented pairs: g0, g0', g1, g1',
         l0, l0', ...) or one stacked tensor [2*(2+n_local), B, 3, S, S].  noise [(2+n_local)*B, n_full, 2] ~ N(0,1) and
-        sel int32 [n_local*B, 36] may be supplied (tests); otherwise they are drawn on the device."""
+        sel int32 [n_local*B, 36] may be supplied (tests); otherwise they are drawn on the device.  `produced`: event recorded
+        when the views became valid; without it the front-end stream waits for everything enqueued on the current stream so
+        far (which would serialise it behind a training step launched in between)."""
         B, nl, dev = self.B, self.n_local, self.device
         cur = torch.cuda.current_stream(dev)
-        self.stream.wait_stream(cur)                           # the views were produced on the caller's stream
+        if produced is not None:
+            self.stream.wait_event(produced)
+        else:
+            self.stream.wait_stream(cur)                       # the views were produced on the caller's stream
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(self.consumed)              # staging buffers free again
+            for t_ in ([views] if torch.is_tensor(views) else views):
+                if t_.is_cuda:
+                    t_.record_stream(self.stream)             # allocated on the caller's stream, consumed here
             if torch.is_tensor(views):
                 v = views.to(dev, f32)
                 clean, aug = v[0::2].reshape(-1, 3, self.S, self.S), v[1::2].reshape(-1, 3, self.S, self.S)

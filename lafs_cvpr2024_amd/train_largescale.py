@@ -1,4 +1,7 @@
-"""Supervised Part-fViT + CosFace fine-tuning loop (reference train_largescale.py:317-963) on the HIP fine-tune engine.
+"""Supervised Part-fViT + CosFace / ArcFace / PartialFC fine-tuning loop (reference train_largescale.py:317-963) on the HIP
+fine-tune engine.  Model configuration as the reference builds it (:432, 542-557): with_land=True (trainable MobileNetV3
+landmark branch), dropout = emb_dropout = 0.1, DropPath 0.1, CosFace(s=64, m=0.4) over all classes on every rank.
+`--head PartialFC` / `--head ArcFace` select the class-sharded head of config C5 (parity unpinned, see partial_fc.py).
 
 Kept from the reference: flags that define the step (batch size, epochs, lr rescale `lr * bs * world / 512`, weight decay
 0.1, mixup alpha/prob, acc_step=3 from supervised_config.py:37, warm-up(5 epochs)+cosine(eta_min 1e-6) LR, loading
@@ -31,7 +34,14 @@ def get_args_parser():
     p.add_argument("--epochs", "-e", default=34, type=int)
     p.add_argument("--lr", default=3e-4, type=float)
     p.add_argument("--weight_decay", default=0.1, type=float)
-    p.add_argument("--head", default="CosFace", type=str, choices=["CosFace"])
+    p.add_argument("--head", default="CosFace", type=str, choices=["CosFace", "PartialFC", "ArcFace"],
+                   help="CosFace: the reference's dense head; ArcFace: dense head with the additive angular margin (m=0.5); "
+                        "PartialFC: class centres sharded over the ranks (config C5)")
+    p.add_argument("--partial_margin", default="CosFace", type=str, choices=["CosFace", "ArcFace"])
+    p.add_argument("--sample_rate", default=1.0, type=float, help="PartialFC negative-class sampling rate")
+    p.add_argument("--with_land", default=True, type=utils.bool_flag, help="trainable landmark branch (reference :432)")
+    p.add_argument("--dropout", default=0.1, type=float, help="dropout = emb_dropout of the reference (:552-555)")
+    p.add_argument("--landmark_ckpt", default="", type=str, help="stn./output_layer. weights (reference :659-661)")
     p.add_argument("--num_class", default=205990, type=int)
     p.add_argument("--mixup", default=0.2, type=float)
     p.add_argument("--mixup-prob", dest="mixup_prob", default=0.1, type=float)
@@ -67,19 +77,44 @@ def load_ssl_teacher(backbone, path):
     print("=> loaded SSL teacher:", backbone.load_state_dict(clean, strict=False))
 
 
+def load_landmark_branch(backbone, path):
+    """load_part_checkpoint_landmark(pretrain_name=['stn', 'output']) (train_largescale.py:659-661): copy the tensors whose
+    key starts with stn. / output_layer. from a stage-1 checkpoint."""
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    sd = sd.get("model", sd)
+    part = {}
+    for k, v in sd.items():
+        k = k[len("module."):] if k.startswith("module.") else k
+        if k.startswith(("stn.", "output_layer.")):
+            part[k] = v
+    print("=> landmark branch:", len(part), "tensors;", backbone.load_state_dict(part, strict=False))
+
+
 def main(args):
     utils.init_distributed_mode(args)
     cfg = get_config(args)
     utils.fix_random_seeds(cfg["SEED"])
     device = torch.device("cuda", args.gpu)
     world = utils.get_world_size()
-    backbone = ViT_face_landmark_patch8(loss_type=args.head, GPU_ID=None, num_class=args.num_class, image_size=112, patch_size=8,
-                                        dim=768, depth=12, heads=11, mlp_dim=2048, dropout=0.0, emb_dropout=0.0,
-                                        with_land=False, drop_path_rate=args.drop_path)
+    sharded = args.head == "PartialFC"
+    arc = (args.partial_margin if sharded else args.head) == "ArcFace"
+    # the dense ArcFace head lives in the same `loss.weight` tensor as CosFace (the reference names an ArcFace class it never
+    # defines, ViT_face.py:654-655); the margin is applied by the fused kernel
+    backbone = ViT_face_landmark_patch8(loss_type="None" if sharded else "CosFace", GPU_ID=None, num_class=args.num_class,
+                                        image_size=112, patch_size=8, dim=768, depth=12, heads=11, mlp_dim=2048,
+                                        dropout=args.dropout, emb_dropout=args.dropout, with_land=args.with_land,
+                                        drop_path_rate=args.drop_path)
     if args.model_dir:
         load_ssl_teacher(backbone, args.model_dir)
+    if args.landmark_ckpt:
+        load_landmark_branch(backbone, args.landmark_ckpt)
+    head = None
+    if sharded:
+        from .partial_fc import PartialFC
+        head = PartialFC(768, args.num_class, args.batch_size, sample_rate=args.sample_rate, s=64.0, m=0.5 if arc else 0.4,
+                         margin_type=1 if arc else 0, device=device, seed=cfg["SEED"])
     engine = FinetuneEngine(backbone, args.batch_size, acc_step=cfg["acc_step"], mixup_alpha=args.mixup, mixup_prob=args.mixup_prob,
-                            device=device)
+                            s=64.0, m=0.5 if arc else 0.4, margin_type=1 if arc else 0, device=device, sharded_head=head)
     base_lr = args.lr * args.batch_size * world / 512.0                     # train_largescale.py:472
     n_it = args.steps_per_epoch
     gen = torch.Generator(device=device).manual_seed(cfg["SEED"] + utils.get_rank())

@@ -326,3 +326,33 @@ def test_partfvit_element_dropout_matches_oracle_with_same_masks():
     assert rel_l2(e2, e) > 1e-3
     m.eval()
     assert rel_l2(m(x), m(x)) == 0.0
+
+
+def test_finetune_engine_with_sharded_head_single_rank():
+    """FinetuneEngine(sharded_head=PartialFC) at world 1 == the dense CosFace engine path on the same weights (hard labels)."""
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    from lafs_cvpr2024_amd.partial_fc import PartialFC
+    B, C = 8, 512
+    mk = lambda lt: ViT_face_landmark_patch8(loss_type=lt, GPU_ID=None, num_class=C, image_size=112, patch_size=8, dim=128, depth=2,
+                                             heads=3, mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=False, drop_path_rate=0.0)
+    torch.manual_seed(8)
+    dense = mk("CosFace")
+    bare = mk("None")
+    bare.load_state_dict({k: v for k, v in dense.state_dict().items() if not k.startswith("loss.")})
+    u8 = torch.randint(0, 256, (B, 3, 112, 112), dtype=torch.uint8, device=DEV)
+    labels = torch.randint(0, C, (B,), device=DEV)
+    e1 = FinetuneEngine(dense, B, acc_step=1, device=DEV)
+    l1 = float(e1.micro_step(u8, labels, lam=1.0).item())
+    head = PartialFC(128, C, B, sample_rate=1.0, device=DEV)
+    with torch.no_grad():
+        head.weight.copy_(dense.loss.weight.detach())
+    head.arena.refresh_shadows()
+    e2 = FinetuneEngine(bare, B, acc_step=1, device=DEV, sharded_head=head)
+    l2 = float(e2.micro_step(u8, labels).item())
+    assert abs(l1 - l2) < 5e-3 * abs(l1), (l1, l2)
+    g1, g2 = dict(dense.named_parameters()), dict(bare.named_parameters())
+    for k in ("patch_to_embedding.weight", "transformer.layers.0.0.fn.fn.to_qkv.weight", "transformer.layers.1.1.fn.fn.net.3.weight"):
+        assert rel_l2(g2[k].grad, g1[k].grad) < 3e-2, k
+    assert rel_l2(head.arena.view(head.arena.grad, "weight", (C, 128)), g1["loss.weight"].grad) < 3e-2
+    e2.optimizer_step(lr=1e-3)
+    assert float(head.arena.grad.abs().max()) == 0.0 and float(e2.arena.grad.abs().max()) == 0.0
