@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--frontend", action="store_true",
+                    help="include the landmark front-end (frozen MobileNetV3 on 10*B views + theta + gathers) in every step, "
+                         "software-pipelined on its own stream; default off = landmark crops resident in HBM (the headline metric)")
     return ap.parse_args()
 
 
@@ -149,6 +152,17 @@ def main():
     eng.in_global_all.copy_(torch.randn(eng.in_global_all.shape, device=device, generator=g).clamp_(-1, 1))
     eng.in_local_all.copy_(torch.randn(eng.in_local_all.shape, device=device, generator=g).clamp_(-1, 1))
 
+    fe, views = None, None
+    if args.frontend:
+        from lafs_cvpr2024_amd.face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
+        from lafs_cvpr2024_amd.landmark_frontend import LandmarkFrontEnd
+        cnn = face_landmark_4simmin_glo_loc(loss_type='None', GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=768,
+                                            depth=12, heads=11, mlp_dim=2048)
+        fe = LandmarkFrontEnd(cnn, B, n_local=nl, device=device,
+                              cnn_dtype=torch.bfloat16 if os.environ.get("LAFS_FRONTEND_BF16", "1") == "1" else torch.float32)
+        views = torch.randn(2 * (2 + nl), B, 3, 112, 112, device=device, generator=g).clamp_(-1, 1)
+        fe.prefetch(views)
+
     niter = 1000
     lr_s = cosine_scheduler(5e-4 * B * world / 256., 1e-6, 41, niter, warmup_epochs=10)
     wd_s = cosine_scheduler(0.04, 0.4, 41, niter)
@@ -157,7 +171,13 @@ def main():
     tt = float(crit.teacher_temp_schedule[epoch])
 
     def one(it):
-        return eng.step(lr=float(lr_s[it]), wd=float(wd_s[it]), momentum=float(mom_s[it]), teacher_temp=tt, epoch=epoch)
+        if fe is None:
+            return eng.step(lr=float(lr_s[it]), wd=float(wd_s[it]), momentum=float(mom_s[it]), teacher_temp=tt, epoch=epoch)
+        ev = torch.cuda.current_stream().record_event()          # "next batch's views are ready"
+        fe.commit(eng)
+        loss = eng.step(lr=float(lr_s[it]), wd=float(wd_s[it]), momentum=float(mom_s[it]), teacher_temp=tt, epoch=epoch)
+        fe.prefetch(views, produced=ev)                          # front-end of the next batch overlaps this step
+        return loss
 
     it0 = epoch * niter
     for i in range(args.warmup):
@@ -189,7 +209,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.arch}/8 LAFS pretrain step, 2 global 112x112 + {nl} local 48x48 crops, "
                                    f"batch {B}/GPU, out_dim {K}, drop_path 0.1, dp{world}",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "landmark_frontend_in_step": bool(args.frontend)},
             "images_per_s": round(world * B / (ms * 1e-3), 1),
             "step_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
             "step_mfma_frac": round(fl / (ms * 1e-3) / 2.5e15, 4),

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Fine-tune step benchmark (BASELINE.json configs C4/C5 on ONE GPU): Part-fViT ViT-B (dim 768, depth 12, heads 11, mlp 2048)
++ margin head, batch 128, uint8 112x112 synthetic faces resident in HBM.  GPU box only.
+usage: python tools/bench_finetune.py [--head CosFace|ArcFace|PartialFC] [--with-land 0|1] [--dropout 0.1] [--classes N] [--batch B]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8
+from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--head", default="CosFace")
+ap.add_argument("--with-land", type=int, default=1)
+ap.add_argument("--dropout", type=float, default=0.1)
+ap.add_argument("--classes", type=int, default=205990)
+ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--sample-rate", type=float, default=0.1)
+ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--warmup", type=int, default=3)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+sharded = a.head == "PartialFC"
+m = ViT_face_landmark_patch8(loss_type="None" if sharded else "CosFace", GPU_ID=None, num_class=a.classes, image_size=112, patch_size=8,
+                             dim=768, depth=12, heads=11, mlp_dim=2048, dropout=a.dropout, emb_dropout=a.dropout,
+                             with_land=bool(a.with_land), drop_path_rate=0.1)
+head = None
+if sharded:
+    from lafs_cvpr2024_amd.partial_fc import PartialFC
+    head = PartialFC(768, a.classes, a.batch, sample_rate=a.sample_rate, device=dev)
+eng = FinetuneEngine(m, a.batch, acc_step=1, margin_type=1 if a.head == "ArcFace" else 0, m=0.5 if a.head == "ArcFace" else 0.4,
+                     device=dev, sharded_head=head)
+m.train()
+x = torch.randint(0, 256, (a.batch, 3, 112, 112), dtype=torch.uint8, device=dev)
+y = torch.randint(0, a.classes, (a.batch,), device=dev)
+for _ in range(a.warmup):
+    eng.step(x, y, lr=1e-4)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(a.steps):
+    loss = eng.step(x, y, lr=1e-4)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+print(json.dumps({"workload": f"Part-fViT ViT-B + {a.head} fine-tune step, batch {a.batch}, {a.classes} classes, with_land={a.with_land}, "
+                              f"dropout={a.dropout}" + (f", sample_rate={a.sample_rate}" if sharded else ""),
+                  "ms_per_step": round(dt * 1e3, 2), "images_per_s": round(a.batch / dt, 1), "loss": round(float(loss.item()), 4)}))
