@@ -41,6 +41,21 @@ struct NTArgs {
   DropCfg drop;                     // element dropout on the linear's output (RESID_F32) / on GELU(u) (BF16_GELU, DGELU_BF16)
 };
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+// 16-byte epilogue stores; `nt` selects the non-temporal (streaming) form -- activations written here are consumed by a
+// later kernel, never by this one
+__device__ __forceinline__ void st16(void* p, unsigned a, unsigned b, unsigned c, unsigned d, bool nt) {
+  const u32x4_t v = {a, b, c, d};
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p));
+  else *reinterpret_cast<u32x4_t*>(p) = v;
+}
+__device__ __forceinline__ void st16f(void* p, float a, float b, float c, float d, bool nt) {
+  const f32x4v_t v = {a, b, c, d};
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4v_t*>(p));
+  else *reinterpret_cast<f32x4v_t*>(p) = v;
+}
+
 constexpr int BM = 128, BN = 128;
 constexpr int NT_BK = 32;                          // k-depth of one pipeline stage
 constexpr int NT_NS = 3;                           // LDS ring depth (stages in flight: NS-1)
@@ -208,6 +223,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[j][i][r] + bias[j * 4 + r];
     float sc = 1.0f;
+    const bool ntst = (p.dbg & 256) != 0;              // streaming stores: A/B experiment only (no gain in a real layer chain)
     size_t orow = (size_t)m;
     int tpos = 0;
     if (EPI == EPI_RESID_F32 && p.seq_scale != nullptr) sc = p.seq_scale[p.row2seq[m]];
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
         }
         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
         if (full) {
-          *reinterpret_cast<uint4*>(c) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+          st16(c, pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]), ntst);
         } else {
 #pragma unroll
           for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(w[e]);
@@ -254,8 +270,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
             for (int e = 0; e < VPL; ++e)
               if (n + e < p.N) c2[e] = f2bf(gelu_f(w[e]) * drop_mult(p.drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e)));
           } else if (full) {
-            *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(gelu_f(w[0]), gelu_f(w[1])), pack_bf2(gelu_f(w[2]), gelu_f(w[3])),
-                                                       pack_bf2(gelu_f(w[4]), gelu_f(w[5])), pack_bf2(gelu_f(w[6]), gelu_f(w[7])));
+            st16(c2, pack_bf2(gelu_f(w[0]), gelu_f(w[1])), pack_bf2(gelu_f(w[2]), gelu_f(w[3])),
+                 pack_bf2(gelu_f(w[4]), gelu_f(w[5])), pack_bf2(gelu_f(w[6]), gelu_f(w[7])), ntst);
           } else {
 #pragma unroll
             for (int e = 0; e < VPL; ++e) if (n + e < p.N) c2[e] = f2bf(gelu_f(w[e]));
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
         }
         float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
         if (full) {
-          *reinterpret_cast<float4*>(c) = make_float4(w[0], w[1], w[2], w[3]);
+          st16f(c, w[0], w[1], w[2], w[3], ntst);
         } else {
 #pragma unroll
           for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = w[e];

@@ -75,6 +75,30 @@ if "tnpart" in which:
         t2 = timeit(lambda: ops.reduce_partials(part, out))
         _lib.lib().lafs_debug_set(1); t3 = timeit(lambda: ops.gemm_tn_acc(A, B, Cd)); _lib.lib().lafs_debug_set(0)
         print(f"   {name}: atomics {t0*1e6:7.1f} us | partial {t1*1e6:7.1f} us + fold {t2*1e6:6.1f} us | stores {t3*1e6:7.1f} us")
+if "ntstore" in which:
+    print("--- NT epilogue stores: normal (default) vs non-temporal (flag 256)")
+    for flag in (0, 256):
+        _lib.lib().lafs_debug_set(flag)
+        for M, N, K, e, n in SHAPES[:8]:
+            nt(M, N, K, e, f"{n} f{flag}")
+    _lib.lib().lafs_debug_set(0)
+if "mlp" in which:
+    print("--- fc1 (+GELU) -> fc2 (+residual) back to back, student shape; flags: 0 normal stores, 256 non-temporal stores")
+    A = torch.randn(T, 384, device=dev).to(bf); W1 = (torch.randn(1536, 384, device=dev) * .02).to(bf); W2 = (torch.randn(384, 1536, device=dev) * .02).to(bf)
+    b1 = torch.zeros(1536, device=dev); b2 = torch.zeros(384, device=dev)
+    # distinct buffers per "layer" so that the working set does not sit in the Infinity Cache between iterations
+    L = 6
+    us = [torch.empty(T, 1536, device=dev, dtype=bf) for _ in range(L)]; as_ = [torch.empty(T, 1536, device=dev, dtype=bf) for _ in range(L)]
+    xs = [torch.randn(T, 384, device=dev) for _ in range(L + 1)]
+    def chain():
+        for l in range(L):
+            ops.gemm_nt(A, W1, _lib.EPI_BF16_GELU, bias=b1, out=us[l], out2=as_[l])
+            ops.gemm_nt(as_[l], W2, _lib.EPI_RESID_F32, bias=b2, resid=xs[l], out=xs[l + 1])
+    for flag in (0, 256):
+        _lib.lib().lafs_debug_set(flag)
+        t = timeit(chain, iters=10)
+        print(f"   flag {flag:4d}: {t / L * 1e6:8.1f} us per fc1+fc2 pair")
+    _lib.lib().lafs_debug_set(0)
 if "tiles" in which:
     print("--- NT tile variants: flag 2 = 128x128 bk32, 4 = 256x128 bk32, 10 = 128x128 bk64, 12 = 256x128 bk64")
     for flag in (2, 4, 10, 12):
@@ -84,10 +108,14 @@ if "tiles" in which:
     _lib.lib().lafs_debug_set(0)
 if "ablate" in which:
     print("--- NT ablations: 0 full, 16 no stores, 32 no mfma, 48 loads only, 64 no second (GELU) store")
-    for flag in (0, 16, 32, 48, 64):
+    for flag in (0, 16, 32, 48, 64, 128, 192):
         _lib.lib().lafs_debug_set(flag)
         nt(T, 1152, 384, _lib.EPI_BF16, f"qkv fwd abl{flag}")
         nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd abl{flag}")
+    for flag in (2, 4):
+        _lib.lib().lafs_debug_set(flag)
+        nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd tile f{flag}")
+        nt(T, 1536, 384, _lib.EPI_DGELU_BF16, f"fc2 dgrad tile f{flag}")
     _lib.lib().lafs_debug_set(1)
     print("--- TN with plain stores instead of atomics (flag 1)")
     tn(T, 384, 1536, "fc2 wgrad")
