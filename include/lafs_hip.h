@@ -47,8 +47,11 @@ enum {
   LAFS_EPI_F32 = 3,        /* C(f32) = acc + bias                                                    */
   LAFS_EPI_DGELU_BF16 = 4, /* C(bf16) = acc * GELU'(aux[m][n])                                       */
   LAFS_EPI_ATOMIC_F32 = 5, /* C(f32) += acc, K split into `splits` slices (C must be pre-zeroed)     */
-  LAFS_EPI_EMBED_F32 = 6   /* C(f32)[m + m/npatch + 1] = acc + bias + pos[1 + m%npatch]  (tokens)    */
+  LAFS_EPI_EMBED_F32 = 6,  /* C(f32)[m + m/npatch + 1] = acc + bias + pos[1 + m%npatch]  (tokens)    */
+  LAFS_EPI_BF16_ACT = 7    /* C(bf16) = act(acc + bias + aux[m][n])   (aux bf16 residual or NULL)    */
 };
+
+enum { LAFS_ACT_NONE = 0, LAFS_ACT_RELU = 1, LAFS_ACT_HSWISH = 2, LAFS_ACT_HSIGMOID = 3 };
 
 typedef struct lafs_gemm_nt_args {
   const void* A; int lda;          /* bf16 [M, K]                                  */
@@ -67,6 +70,7 @@ typedef struct lafs_gemm_nt_args {
   float drop_p; uint32_t drop_seed; /* element dropout (0 = off): on the linear's output before the residual add
                                       (RESID_F32), on GELU(u) (BF16_GELU: C2 only), and its backward (DGELU_BF16).
                                       Counter-based mask of (drop_seed, row, col): see lafs_debug_dropout_mask.       */
+  int act;                         /* BF16_ACT: LAFS_ACT_*                         */
 } lafs_gemm_nt_args;
 
 /* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue. */
@@ -286,6 +290,24 @@ int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_lo
                            const float* gmax, const float* Z, float grad_scale, hipStream_t stream);
 /* x(f32) [B,3,S,S]: x = lam*x + (1-lam)*flip_batch(x) in place, from u8 or f32 source with (x/255*2-1) folded in. */
 int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, hipStream_t stream);
+/* ------------------------------------------------------------------------------------------------
+ * Frozen landmark CNN, inference only (MobileNetV3-large trunk, face_pre_pro/mobilenet.py:224-313, called by
+ * face_landmark_4simmin_glo_loc.forward, face_pre_pro/ViT_face.py:1338-1344).  NHWC bf16 activations, channel counts padded
+ * to multiples of 32, BatchNorm folded into (w, b) by the host; the 1x1 convolutions are lafs_gemm_nt(LAFS_EPI_BF16_ACT).
+ * act: LAFS_ACT_* (negative = none).
+ * ------------------------------------------------------------------------------------------------ */
+/* stem: x f32 NCHW [N,3,S,S], w f32 [27][16] (index (c*9+ky*3+kx)*16+o), b f32 [16] -> y bf16 NHWC [N,S/2,S/2,ldy]
+ * = act(conv3x3 stride 2 pad 1 + b) in channels 0..15, zeros in 16..ldy-1. */
+int lafs_cnn_stem(const float* x, const float* w, const float* b, int N, int S, int act, void* y, int ldy, hipStream_t stream);
+/* depthwise k x k (k in {3,5}), stride in {1,2}, pad (k-1)/2: x bf16 [N,H,W,C], w f32 [k*k][C], b f32 [C] -> y bf16
+ * [N,ceil(H/stride),ceil(W/stride),C] = act(conv + b).  C % 8 == 0. */
+int lafs_cnn_dwconv(const void* x, const float* w, const float* b, int N, int H, int W, int C, int k, int stride, int act,
+                    void* y, hipStream_t stream);
+/* out(bf16)[n, c] = mean over the HW positions of x bf16 [N,HW,C]  (squeeze; final average pool). */
+int lafs_cnn_pool(const void* x, int N, int HW, int C, void* out, int ldo, hipStream_t stream);
+/* x(bf16)[n,p,c] = act(x[n,p,c] * s(bf16)[n,c]) in place  (excite + the block's non-linearity). */
+int lafs_cnn_scale_act(void* x, const void* s, int lds, int N, int HW, int C, int act, hipStream_t stream);
+
 /* Landmark post-processing (face_pre_pro/ViT_face.py:1347-1378, 698-706): t f32 [B, 2*n_full] raw regressor output ->
  * theta f32 [B, n_out, 2] pixels:  theta = (t - min_b)/(max_b - min_b)*111  (+ noise_scale * noise[B, n_full, 2], the
  * N(0,1)*5 px jitter), landmark k of the output = landmark sel[b,k] of the input (random choice with replacement) or k

@@ -21,7 +21,7 @@ class GemmNTArgs(C.Structure):
                 ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int),
                 ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
                 ("aux", C.c_void_p), ("ldaux", C.c_int), ("pos", C.c_void_p), ("npatch", C.c_int),
-                ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32)]
+                ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("act", C.c_int)]
 
 
 class BlockOffsets(C.Structure):
@@ -40,7 +40,8 @@ class TrunkDesc(C.Structure):
                 ("blocks", C.POINTER(BlockOffsets))]
 
 
-EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32 = range(7)
+EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32, EPI_BF16_ACT = range(8)
+ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = range(4)
 PATCH_ORDER_CHW, PATCH_ORDER_HWC = 0, 1
 CHUNK = 1024
 SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE = 1, 2, 4
@@ -87,6 +88,10 @@ _PROTOS = {
     "lafs_shard_margin_rowmax": [vp, i32, i32, i32, vp, f32, f32, i32, vp],
     "lafs_shard_margin_rowsum": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, vp],
     "lafs_shard_margin_grad": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, f32],
+    "lafs_cnn_stem": [vp, vp, vp, i32, i32, i32, vp, i32],
+    "lafs_cnn_dwconv": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "lafs_cnn_pool": [vp, i32, i32, i32, vp, i32],
+    "lafs_cnn_scale_act": [vp, vp, i32, i32, i32, i32, i32],
     "lafs_landmark_theta": [vp, i32, i32, vp, f32, vp, i32, vp],
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],

@@ -88,6 +88,14 @@ inline DropCfg make_drop(float p, unsigned seed) {
   return d;
 }
 
+// ---- activations of the landmark CNN (MobileNetV3: relu, x*relu6(x+3)/6, relu6(x+3)/6) ----
+__device__ __forceinline__ float act_f(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  if (act == 3) return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  return v;
+}
+
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -27,6 +27,7 @@ enum {
   EPI_DGELU_BF16 = LAFS_EPI_DGELU_BF16,
   EPI_ATOMIC_F32 = LAFS_EPI_ATOMIC_F32,
   EPI_EMBED_F32 = LAFS_EPI_EMBED_F32,
+  EPI_BF16_ACT = LAFS_EPI_BF16_ACT,
 };
 
 struct NTArgs {
@@ -39,6 +40,7 @@ struct NTArgs {
   const float* pos; int npatch;
   int dbg;                          // timing ablations (lafs_debug_set): 16 = no epilogue stores, 32 = no MFMA/ds_read
   DropCfg drop;                     // element dropout on the linear's output (RESID_F32) / on GELU(u) (BF16_GELU, DGELU_BF16)
+  int act;                          // BF16_ACT: LAFS_ACT_*
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -238,7 +240,16 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
       if (n >= p.N) continue;
       const bool full = (n + VPL <= p.N);
       float* w = v + q * VPL;
-      if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_DGELU_BF16) {        // VPL == 8: one 16-byte store
+      if (EPI == EPI_BF16_ACT) {                          // 1x1 convolution of the landmark CNN: + residual (bf16), activation
+        if (p.aux != nullptr) {
+          const bf16_t* ax = p.aux + (size_t)m * p.ldaux + n;
+#pragma unroll
+          for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) w[e] += bf2f(ax[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < VPL; ++e) w[e] = act_f(w[e], p.act);
+      }
+      if (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_DGELU_BF16 || EPI == EPI_BF16_ACT) {   // VPL == 8: one 16-byte store
         if (EPI == EPI_DGELU_BF16) {
           const bf16_t* ax = p.aux + (size_t)m * p.ldaux + n;
           if (full) {
@@ -508,6 +519,7 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
   a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux; a.pos = g->pos; a.npatch = g->npatch; a.dbg = g_debug_flags;
   a.drop = make_drop(g->drop_p, g->drop_seed);
+  a.act = g->act;
   LAFS_CHECK_ARG(g->drop_p >= 0.f && g->drop_p < 1.f, "drop_p must be in [0, 1)");
   LAFS_CHECK_ARG(!(g->drop_p > 0.f) || (long)g->M * g->N < 4294967296L, "dropout needs M*N < 2^32");
   int splits = 1;
@@ -535,6 +547,9 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
       LAFS_CHECK_ARG(g->aux != nullptr, "dGELU epilogue needs aux (pre-activation)");
       return launch_nt<EPI_DGELU_BF16>(a, 1, stream);
     case LAFS_EPI_ATOMIC_F32: return launch_nt<EPI_ATOMIC_F32>(a, splits, stream);
+    case LAFS_EPI_BF16_ACT:
+      LAFS_CHECK_ARG(g->act >= 0 && g->act <= LAFS_ACT_HSIGMOID, "unknown activation");
+      return launch_nt<EPI_BF16_ACT>(a, 1, stream);
     case LAFS_EPI_EMBED_F32:
       LAFS_CHECK_ARG(g->pos != nullptr && g->npatch > 0 && g->M % g->npatch == 0, "embed epilogue needs pos/npatch");
       return launch_nt<EPI_EMBED_F32>(a, 1, stream);

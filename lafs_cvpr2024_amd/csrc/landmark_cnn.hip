@@ -1,0 +1,176 @@
+// Inference kernels of the frozen landmark CNN (MobileNetV3-large trunk, reference face_pre_pro/mobilenet.py:224-313, driven
+// by face_landmark_4simmin_glo_loc.forward, face_pre_pro/ViT_face.py:1338-1344).  Activations are NHWC bf16 with the channel
+// count padded to a multiple of 32 so that every 1x1 convolution is a plain lafs_gemm_nt call (epilogue BF16_ACT: folded
+// BatchNorm bias + residual + activation); what is left -- the 3x3 stem, the depthwise convolutions, the squeeze-excite
+// pooling and rescale -- are the bandwidth-bound kernels below.  BatchNorm is folded into weights/biases on the host
+// (eval mode: the CNN is frozen on the LAFS path, lafs_train.py:262-269).
+#include "common.hpp"
+#include "lafs_hip.h"
+
+namespace {
+
+// x f32 NCHW [N,3,S,S] -> y bf16 NHWC [N,S/2,S/2,ldy]: 16 channels of act(conv3x3 stride 2 pad 1 + b), channels 16.. zero
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                   int N, int S, int act, bf16_t* __restrict__ y, int ldy) {
+  __shared__ float sw[27 * 16 + 16];
+  for (int i = threadIdx.x; i < 27 * 16 + 16; i += 256) sw[i] = i < 27 * 16 ? w[i] : b[i - 27 * 16];
+  __syncthreads();
+  const int So = S >> 1;
+  const long total = (long)N * So * So;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ox = (int)(idx % So), oy = (int)((idx / So) % So), n = (int)(idx / ((long)So * So));
+  float acc[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) acc[o] = sw[27 * 16 + o];
+  const float* xn = x + (size_t)n * 3 * S * S;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if (iy < 0 || iy >= S) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if (ix < 0 || ix >= S) continue;
+        const float v = xn[((size_t)c * S + iy) * S + ix];
+        const float* wk = sw + (c * 9 + ky * 3 + kx) * 16;
+#pragma unroll
+        for (int o = 0; o < 16; ++o) acc[o] = fmaf(v, wk[o], acc[o]);
+      }
+    }
+  bf16_t* yo = y + (size_t)idx * ldy;
+  uint4 lo = make_uint4(pack_bf2(act_f(acc[0], act), act_f(acc[1], act)), pack_bf2(act_f(acc[2], act), act_f(acc[3], act)),
+                        pack_bf2(act_f(acc[4], act), act_f(acc[5], act)), pack_bf2(act_f(acc[6], act), act_f(acc[7], act)));
+  uint4 hi = make_uint4(pack_bf2(act_f(acc[8], act), act_f(acc[9], act)), pack_bf2(act_f(acc[10], act), act_f(acc[11], act)),
+                        pack_bf2(act_f(acc[12], act), act_f(acc[13], act)), pack_bf2(act_f(acc[14], act), act_f(acc[15], act)));
+  *reinterpret_cast<uint4*>(yo) = lo;
+  *reinterpret_cast<uint4*>(yo + 8) = hi;
+  for (int c = 16; c < ldy; c += 8) *reinterpret_cast<uint4*>(yo + c) = make_uint4(0, 0, 0, 0);
+}
+
+// depthwise k x k convolution, NHWC bf16, 8 channels per thread: y = act(conv(x) + b)   (act < 0: none)
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                     int N, int H, int W, int C, int stride, int act, bf16_t* __restrict__ y) {
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride, C8 = C >> 3;
+  const long total = (long)N * Ho * Wo * C8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C8) * 8;
+  const long pix = idx / C8;
+  const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), n = (int)(pix / ((long)Wo * Ho));
+  constexpr int P = (K - 1) / 2;
+  float acc[8];
+  {
+    const float4 b0 = *reinterpret_cast<const float4*>(b + c), b1 = *reinterpret_cast<const float4*>(b + c + 4);
+    acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+  }
+  const bf16_t* xn = x + (size_t)n * H * W * C + c;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = oy * stride - P + ky;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int ix = ox * stride - P + kx;
+      if (ix < 0 || ix >= W) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(xn + ((size_t)iy * W + ix) * C);
+      const float* wk = w + (size_t)(ky * K + kx) * C + c;
+      const float4 w0 = *reinterpret_cast<const float4*>(wk), w1 = *reinterpret_cast<const float4*>(wk + 4);
+      acc[0] = fmaf(bf_lo(v.x), w0.x, acc[0]); acc[1] = fmaf(bf_hi(v.x), w0.y, acc[1]);
+      acc[2] = fmaf(bf_lo(v.y), w0.z, acc[2]); acc[3] = fmaf(bf_hi(v.y), w0.w, acc[3]);
+      acc[4] = fmaf(bf_lo(v.z), w1.x, acc[4]); acc[5] = fmaf(bf_hi(v.z), w1.y, acc[5]);
+      acc[6] = fmaf(bf_lo(v.w), w1.z, acc[6]); acc[7] = fmaf(bf_hi(v.w), w1.w, acc[7]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = act_f(acc[e], act);
+  *reinterpret_cast<uint4*>(y + (size_t)pix * C + c) =
+      make_uint4(pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3]), pack_bf2(acc[4], acc[5]), pack_bf2(acc[6], acc[7]));
+}
+
+// out(bf16)[n, c] = mean_p x[n, p, c]     (squeeze of squeeze-excite; final 4x4 average pool)
+__global__ __launch_bounds__(256) void pool_kernel(const bf16_t* __restrict__ x, int N, int HW, int C, bf16_t* __restrict__ out, int ldo) {
+  const int C8 = C >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * C8) return;
+  const int c = (int)(idx % C8) * 8, n = (int)(idx / C8);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bf16_t* xn = x + (size_t)n * HW * C + c;
+  for (int p = 0; p < HW; ++p) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xn + (size_t)p * C);
+    acc[0] += bf_lo(v.x); acc[1] += bf_hi(v.x); acc[2] += bf_lo(v.y); acc[3] += bf_hi(v.y);
+    acc[4] += bf_lo(v.z); acc[5] += bf_hi(v.z); acc[6] += bf_lo(v.w); acc[7] += bf_hi(v.w);
+  }
+  const float inv = 1.0f / (float)HW;
+  *reinterpret_cast<uint4*>(out + (size_t)n * ldo + c) =
+      make_uint4(pack_bf2(acc[0] * inv, acc[1] * inv), pack_bf2(acc[2] * inv, acc[3] * inv),
+                 pack_bf2(acc[4] * inv, acc[5] * inv), pack_bf2(acc[6] * inv, acc[7] * inv));
+}
+
+// x[n, p, c] = act(x[n, p, c] * s[n, c])   in place (excite + the block's non-linearity)
+__global__ __launch_bounds__(256) void scale_act_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ s, int lds_, int N, int HW, int C,
+                                                        int act) {
+  const int C8 = C >> 3;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)N * HW * C8) return;
+  const int c = (int)(idx % C8) * 8;
+  const long pix = idx / C8;
+  const int n = (int)(pix / HW);
+  bf16_t* xp = x + (size_t)pix * C + c;
+  const uint4 v = *reinterpret_cast<const uint4*>(xp), g = *reinterpret_cast<const uint4*>(s + (size_t)n * lds_ + c);
+  *reinterpret_cast<uint4*>(xp) =
+      make_uint4(pack_bf2(act_f(bf_lo(v.x) * bf_lo(g.x), act), act_f(bf_hi(v.x) * bf_hi(g.x), act)),
+                 pack_bf2(act_f(bf_lo(v.y) * bf_lo(g.y), act), act_f(bf_hi(v.y) * bf_hi(g.y), act)),
+                 pack_bf2(act_f(bf_lo(v.z) * bf_lo(g.z), act), act_f(bf_hi(v.z) * bf_hi(g.z), act)),
+                 pack_bf2(act_f(bf_lo(v.w) * bf_lo(g.w), act), act_f(bf_hi(v.w) * bf_hi(g.w), act)));
+}
+
+inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int lafs_cnn_stem(const float* x, const float* w, const float* b, int N, int S, int act, void* y, int ldy, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(x && w && b && y && N > 0 && S > 0 && S % 2 == 0 && ldy >= 16 && ldy % 8 == 0, "bad operand");
+  const long total = (long)N * (S / 2) * (S / 2);
+  hipLaunchKernelGGL(stem_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, x, w, b, N, S, act, (bf16_t*)y, ldy);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_dwconv(const void* x, const float* w, const float* b, int N, int H, int W, int C, int k, int stride, int act,
+                               void* y, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(x && w && b && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "C must be a multiple of 8");
+  LAFS_CHECK_ARG((k == 3 || k == 5) && (stride == 1 || stride == 2), "k in {3,5}, stride in {1,2}");
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const long total = (long)N * Ho * Wo * (C / 8);
+  if (k == 3)
+    hipLaunchKernelGGL(dwconv_kernel<3>, dim3(blocks_for(total)), dim3(256), 0, stream, (const bf16_t*)x, w, b, N, H, W, C, stride, act,
+                       (bf16_t*)y);
+  else
+    hipLaunchKernelGGL(dwconv_kernel<5>, dim3(blocks_for(total)), dim3(256), 0, stream, (const bf16_t*)x, w, b, N, H, W, C, stride, act,
+                       (bf16_t*)y);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_pool(const void* x, int N, int HW, int C, void* out, int ldo, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(x && out && N > 0 && HW > 0 && C > 0 && C % 8 == 0 && ldo >= C && ldo % 8 == 0, "bad operand");
+  hipLaunchKernelGGL(pool_kernel, dim3(blocks_for((long)N * (C / 8))), dim3(256), 0, stream, (const bf16_t*)x, N, HW, C, (bf16_t*)out, ldo);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_scale_act(void* x, const void* s, int lds_, int N, int HW, int C, int act, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(x && s && N > 0 && HW > 0 && C > 0 && C % 8 == 0 && lds_ >= C && lds_ % 8 == 0, "bad operand");
+  hipLaunchKernelGGL(scale_act_kernel, dim3(blocks_for((long)N * HW * (C / 8))), dim3(256), 0, stream, (bf16_t*)x, (const bf16_t*)s, lds_,
+                     N, HW, C, act);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}

@@ -20,17 +20,24 @@ f32 = torch.float32
 
 class LandmarkFrontEnd:
     def __init__(self, landmarkcnn, batch_size, n_local=8, image_size=112, n_local_landmarks=36, jitter_px=5.0, device=None,
-                 cnn_dtype=torch.float32):
-        """cnn_dtype: torch.float32 (parity with the reference's fp32 CNN) or torch.bfloat16 (2.3x faster on MI355X: the
-        frozen CNN is activation-bandwidth bound; theta moves by a fraction of a pixel, far below the 5 px jitter)."""
+                 cnn_impl="hip", cnn_dtype=torch.float32):
+        """cnn_impl: "hip" = the frozen CNN compiled to the HIP launch plan of landmark_cnn.HipLandmarkCNN (NHWC bf16
+        activations, folded BatchNorm, 1x1 convolutions on the MFMA GEMM); "torch" = the nn.Module on PyTorch-ROCm/MIOpen in
+        `cnn_dtype` (float32 reproduces the reference's CNN bit-for-bit-ish and is what the parity tests use)."""
         self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
         self.cnn = landmarkcnn.to(self.device).eval()
         for p in self.cnn.parameters():                       # frozen (lafs_train.py:269: landmarkcnn.eval())
             p.requires_grad_(False)
-        self.cnn_dtype = cnn_dtype
-        self.cnn.stn.to(memory_format=torch.channels_last)
-        if cnn_dtype != torch.float32:
-            self.cnn.stn.to(cnn_dtype)
+        self.cnn_dtype, self.cnn_impl = cnn_dtype, cnn_impl
+        if cnn_impl == "hip":
+            from .landmark_cnn import HipLandmarkCNN
+            self.hipcnn = HipLandmarkCNN(self.cnn, self.device)
+        elif cnn_impl == "torch":
+            self.cnn.stn.to(memory_format=torch.channels_last)
+            if cnn_dtype != torch.float32:
+                self.cnn.stn.to(cnn_dtype)
+        else:
+            raise ValueError("cnn_impl must be 'hip' or 'torch'")
         self.B, self.n_local, self.S = batch_size, n_local, image_size
         self.n_full = landmarkcnn.row_num * landmarkcnn.row_num
         self.n_loc_lm, self.jitter = n_local_landmarks, float(jitter_px)
@@ -50,6 +57,8 @@ class LandmarkFrontEnd:
     @torch.no_grad()
     def _raw_landmarks(self, clean):
         """[N,3,S,S] -> raw regressor output [N, 2*n_full] (ViT_face.py:1338-1344: trunk, mean pool, Dropout(eval)+Linear)."""
+        if self.cnn_impl == "hip":
+            return self.hipcnn(clean.float())
         x = clean.to(self.cnn_dtype).contiguous(memory_format=torch.channels_last)
         return self.cnn.output_layer(self.cnn.stn(x).float().mean(dim=(-2, -1))).float().contiguous()
 

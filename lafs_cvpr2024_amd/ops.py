@@ -33,7 +33,7 @@ def _ld(t):
 
 
 def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=None, seq_scale=None, row2seq=None,
-            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0):
+            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0, act=0):
     """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*)."""
     _chk(A, bf16, "A"); _chk(B, bf16, "B")
     M, K = A.shape
@@ -50,6 +50,7 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     a.A, a.lda, a.B, a.ldb = A.data_ptr(), _ld(A), B.data_ptr(), _ld(B)
     a.M, a.N, a.K, a.epilogue = M, N, K, epilogue
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
+    a.act = int(act)
     a.C, a.ldc = out.data_ptr(), _ld(out)
     if out2 is not None:
         _chk(out2, bf16, "out2"); a.C2, a.ldc2 = out2.data_ptr(), _ld(out2)

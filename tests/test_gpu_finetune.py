@@ -257,7 +257,7 @@ def test_landmark_frontend_matches_module_calls():
     sel = torch.randint(0, 196, (nl * B, 36), device=DEV, generator=g, dtype=torch.int32)
     eng = types.SimpleNamespace(in_global_all=torch.zeros(2 * B, 3, 112, 112, device=DEV),
                                 in_local_all=torch.zeros(nl * B, 3, 48, 48, device=DEV))
-    fe = LandmarkFrontEnd(lc, B, n_local=nl, device=DEV)
+    fe = LandmarkFrontEnd(lc, B, n_local=nl, device=DEV, cnn_impl="torch")
     fe(views, eng, noise=noise, sel=sel)
     fe(torch.stack(views), eng, noise=noise, sel=sel)            # stacked input, second round trip through the staging buffers
     torch.cuda.synchronize()
@@ -356,3 +356,34 @@ def test_finetune_engine_with_sharded_head_single_rank():
     assert rel_l2(head.arena.view(head.arena.grad, "weight", (C, 128)), g1["loss.weight"].grad) < 3e-2
     e2.optimizer_step(lr=1e-3)
     assert float(head.arena.grad.abs().max()) == 0.0 and float(e2.arena.grad.abs().max()) == 0.0
+
+
+def test_hip_landmark_cnn_matches_torch_module():
+    """HipLandmarkCNN (folded BN, NHWC bf16 activations, 1x1 convolutions on the MFMA GEMM, HIP stem / depthwise /
+    squeeze-excite kernels) vs the fp32 nn.Module it was compiled from (which F9 pins to the reference): raw regressor output
+    and the resulting landmarks."""
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
+    from lafs_cvpr2024_amd.landmark_cnn import HipLandmarkCNN
+    torch.manual_seed(21)
+    lc = face_landmark_4simmin_glo_loc(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=64, depth=1,
+                                       heads=1, mlp_dim=64)
+    with torch.no_grad():                                   # non-trivial BatchNorm statistics / affine, a wider theta head
+        for m in lc.stn.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.6, 1.4); m.weight.uniform_(0.8, 1.2); m.bias.normal_(0, 0.1)
+        lc.output_layer[1].weight.normal_(0, 0.05); lc.output_layer[1].bias.normal_(0, 0.1)
+    lc = lc.to(DEV).eval()
+    x = torch.randn(6, 3, 112, 112, device=DEV).clamp(-1, 1)
+    hip = HipLandmarkCNN(lc, DEV)
+    with torch.no_grad():
+        t_ref = lc.output_layer(lc.stn(x).mean(dim=(-2, -1)))
+        th_ref = lc.landmarks(x)
+    t = hip(x)
+    assert t.shape == t_ref.shape
+    assert rel_l2(t, t_ref) < 3e-2, rel_l2(t, t_ref)
+    tmin, tmax = t.min(1, keepdim=True)[0], t.max(1, keepdim=True)[0]
+    th = ((t - tmin) / (tmax - tmin) * 111).view(-1, 196, 2)
+    d = (th - th_ref).abs()
+    assert float(d.mean()) < 0.6 and float(d.max()) < 4.0, (float(d.mean()), float(d.max()))       # pixels (jitter is 5 px)
+    # batch-size independent plan cache + a second resolution-free call gives identical results
+    assert torch.equal(hip(x), t)

@@ -29,6 +29,12 @@ with torch.no_grad():
     nb2 = MobileNetV3_backbone(mode="large").to(dev).eval().to(torch.bfloat16)
     xb2 = x.to(torch.bfloat16)
     print(f"infer N=640 pure bf16 NCHW     : {timeit(lambda: nb2(xb2)):8.2f} ms")
+from lafs_cvpr2024_amd.face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
+from lafs_cvpr2024_amd.landmark_cnn import HipLandmarkCNN
+lc = face_landmark_4simmin_glo_loc(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=64, depth=1, heads=1,
+                                   mlp_dim=64).to(dev).eval()
+hip = HipLandmarkCNN(lc, dev)
+print(f"infer N=640 HIP plan (bf16 NHWC): {timeit(lambda: hip(x)):8.2f} ms   (includes the theta head)")
 net.train()
 x2 = torch.randn(128, 3, 112, 112, device=dev)
 def fb(model, inp, ac=False):
