@@ -13,7 +13,17 @@ def timeit(fn, n=5):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
+HIP_ONLY = "--hip-only" in sys.argv
 torch.manual_seed(0)
+if HIP_ONLY:
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
+    from lafs_cvpr2024_amd.landmark_cnn import HipLandmarkCNN
+    lc = face_landmark_4simmin_glo_loc(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=64, depth=1,
+                                       heads=1, mlp_dim=64).to(dev).eval()
+    hip = HipLandmarkCNN(lc, dev)
+    x = torch.randn(640, 3, 112, 112, device=dev)
+    print(f"infer N=640 HIP plan (bf16 NHWC): {timeit(lambda: hip(x), n=20):8.2f} ms")
+    sys.exit(0)
 net = MobileNetV3_backbone(mode="large").to(dev).eval()
 x = torch.randn(640, 3, 112, 112, device=dev)
 with torch.no_grad():
