@@ -111,3 +111,32 @@ def test_engine_matches_cpu_oracle():
         assert abs(float(loss.item()) - float(ref["loss"])) / float(ref["loss"]) < 5e-3     # small-K config, see above
     errs = torch.cat([(teacher.state_dict()[k].cpu() - v).abs().flatten() for k, v in st.teacher.items()])
     assert float(errs.median()) < 0.05 * 1e-3 * 0.2 and float(errs.max()) < 3e-3
+
+
+@pytest.mark.parametrize("nl", [2, 0])
+def test_c1_config_vit_tiny_step_matches_oracle(nl):
+    """BASELINE.json configs[0] (the reference's CPU-runnable case): ViT-Tiny/8, 2 global + 2 local crops, batch 8, DINO head
+    with the default 65536 prototypes -- one graph-captured step vs the CPU oracle: loss to 1e-3, center and teacher EMA.
+    nl = 0 is the degenerate multi-crop (global views only, two loss terms)."""
+    from oracle import step as ostep, vit as ovit
+    torch.manual_seed(11)
+    B, K = 8, 65536
+    student = MultiCropWrapper(vits.vit_tiny(patch_size=8, drop_path_rate=0.0), vits.DINOHead(192, K, use_bn=False, norm_last_layer=True))
+    teacher = MultiCropWrapper(vits.vit_tiny(patch_size=8), vits.DINOHead(192, K, use_bn=False))
+    teacher.load_state_dict(student.state_dict())
+    init = {k: v.clone() for k, v in student.state_dict().items()}
+    crops = [torch.randn(B, 3, 112, 112).clamp(-1, 1) for _ in range(2)] + [torch.randn(B, 3, 48, 48).clamp(-1, 1) for _ in range(nl)]
+    crit = DINOLoss(K, 2 + nl, 0.07, 0.04, 3, 10)
+    eng = LafsPretrainEngine(student, teacher, crit, B, n_local=nl, clip_grad=3.0, freeze_last_layer=1, use_graph=True, device=DEV)
+    cfg = ovit.ViTConfig(patch_size=8, embed_dim=192, depth=12, num_heads=3, img_size=224)
+    st = ostep.LafsState(cfg, out_dim=K, seed=0)
+    st.student = {k: v.clone() for k, v in init.items()}; st.teacher = {k: v.clone() for k, v in init.items()}
+    st.exp_avg = {k: torch.zeros_like(v) for k, v in init.items()}; st.exp_avg_sq = {k: torch.zeros_like(v) for k, v in init.items()}
+    tt = float(crit.teacher_temp_schedule[1])
+    loss = eng.step(crops, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=tt, epoch=1)
+    ref = ostep.lafs_step(st, crops, epoch=1, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=tt, clip_grad=3.0, freeze_last_layer=1)
+    assert abs(float(loss.item()) - float(ref["loss"])) < 1e-3 * float(ref["loss"]), (float(loss.item()), float(ref["loss"]))
+    c = crit.center.detach().cpu().view(-1)
+    assert float((c - st.center.view(-1)).abs().max()) < 2e-3 * float(ref["teacher_out"].abs().max())
+    errs = torch.cat([(teacher.state_dict()[k].cpu() - v).abs().flatten() for k, v in st.teacher.items()])
+    assert float(errs.median()) < 1e-5 and float(errs.max()) < 5e-4 * 0.004 * 50      # EMA moves by (1-m)*|delta| <= 0.004*lr-ish

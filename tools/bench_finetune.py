@@ -23,7 +23,10 @@ ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--sample-rate", type=float, default=0.1)
 ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--miopen-find", type=int, default=0, help="torch.backends.cudnn.benchmark (MIOpen exhaustive find) for the CNN branch")
+ap.add_argument("--channels-last", type=int, default=0)
 a = ap.parse_args()
+torch.backends.cudnn.benchmark = bool(a.miopen_find)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 sharded = a.head == "PartialFC"
@@ -37,6 +40,8 @@ if sharded:
 eng = FinetuneEngine(m, a.batch, acc_step=1, margin_type=1 if a.head == "ArcFace" else 0, m=0.5 if a.head == "ArcFace" else 0.4,
                      device=dev, sharded_head=head)
 m.train()
+if a.channels_last and a.with_land:
+    m.stn.to(memory_format=torch.channels_last)
 x = torch.randint(0, 256, (a.batch, 3, 112, 112), dtype=torch.uint8, device=dev)
 y = torch.randint(0, a.classes, (a.batch,), device=dev)
 for _ in range(a.warmup):
