@@ -42,7 +42,7 @@ const char* lafs_last_error(void);
  * ------------------------------------------------------------------------------------------------ */
 enum {
   LAFS_EPI_BF16 = 0,       /* C(bf16) = acc + bias                                                   */
-  LAFS_EPI_BF16_GELU = 1,  /* C(bf16) = u = acc + bias ; C2(bf16) = GELU_erf(u)                      */
+  LAFS_EPI_BF16_GELU = 1,  /* C(bf16) = u = acc + bias (skipped when C is NULL) ; C2(bf16) = GELU_erf(u) */
   LAFS_EPI_RESID_F32 = 2,  /* C(f32) = resid + seq_scale[row2seq[m]] * (acc + bias)   (DropPath)     */
   LAFS_EPI_F32 = 3,        /* C(f32) = acc + bias                                                    */
   LAFS_EPI_DGELU_BF16 = 4, /* C(bf16) = acc * GELU'(aux[m][n])                                       */

@@ -127,8 +127,9 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
     RUN(gemm(b.o, I, sh + o.w_proj, I, T, D, I, LAFS_EPI_RESID_F32, b.x1, D, d->master + o.b_proj, stream, nullptr, 0, cur, D, sa,
              d->row2seq, nullptr, 0, dp, ds + 0));
     RUN(lafs_layernorm_fwd(b.x1, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2, D, nullptr, 0, b.st2, T, D, stream));
-    RUN(gemm(b.h2, D, sh + o.w_fc1, D, T, M, D, LAFS_EPI_BF16_GELU, b.u, M, d->master + o.b_fc1, stream, b.a, M, nullptr, 0, nullptr,
-             nullptr, nullptr, 0, dp, ds + 1));
+    // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2)
+    RUN(gemm(b.h2, D, sh + o.w_fc1, D, T, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u : nullptr, M, d->master + o.b_fc1, stream,
+             b.a, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1));
     RUN(gemm(b.a, M, sh + o.w_fc2, M, T, D, M, LAFS_EPI_RESID_F32, nxt, D, d->master + o.b_fc2, stream, nullptr, 0, b.x1, D, sm,
              d->row2seq, nullptr, 0, dp, ds + 2));
     cur = nxt;

@@ -266,7 +266,9 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
           }
         }
         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
-        if (full) {
+        if (EPI == EPI_BF16_GELU && p.C == nullptr) {
+          // forward-only pass (teacher): the pre-activation is not needed, only GELU(u) is written
+        } else if (full) {
           st16(c, pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]), ntst);
         } else {
 #pragma unroll
@@ -507,7 +509,7 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
 
 extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
-  LAFS_CHECK_ARG(g != nullptr && g->A && g->B && g->C, "null operand");
+  LAFS_CHECK_ARG(g != nullptr && g->A && g->B && (g->C || (g->epilogue == LAFS_EPI_BF16_GELU && g->C2)), "null operand");
   LAFS_CHECK_ARG(g->M > 0 && g->N > 0 && g->K > 0, "empty problem");
   LAFS_CHECK_ARG(g->K % 32 == 0, "K must be a multiple of 32");
   LAFS_CHECK_ARG(g->lda % 8 == 0 && g->ldb % 8 == 0, "lda/ldb must be multiples of 8 elements (16-byte rows)");
@@ -531,7 +533,7 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
     a.klen = ceil_div(ksteps, splits) * 32;
     splits = ceil_div(g->K, a.klen);
   }
-  const bool vec_ok = (g->ldc % 8 == 0);
+  const bool vec_ok = (g->ldc % 8 == 0) || g->C == nullptr;
   LAFS_CHECK_ARG(vec_ok, "ldc must be a multiple of 8 elements");
   switch (g->epilogue) {
     case LAFS_EPI_BF16: return launch_nt<EPI_BF16>(a, 1, stream);
