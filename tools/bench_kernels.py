@@ -59,6 +59,11 @@ if "nt" in which:
 if "tn" in which:
     tn(T, 384, 1536, "fc2 wgrad"); tn(T, 1536, 384, "fc1 wgrad"); tn(T, 384, 384, "proj wgrad"); tn(T, 1152, 384, "qkv wgrad")
     tn(640, 100096, 256, "last wgrad")
+if "tnsplits" in which:
+    print("--- TN wgrad vs number of M-slices (0 = library default)")
+    for sp in (0, 8, 16, 24, 32):
+        tn(T, 384, 1536, f"fc2 wgrad s{sp}", splits=sp); tn(T, 1536, 384, f"fc1 wgrad s{sp}", splits=sp)
+        tn(T, 384, 384, f"proj wgrad s{sp}", splits=sp); tn(T, 1152, 384, f"qkv wgrad s{sp}", splits=sp)
 if "tnpart" in which:
     print("--- TN wgrad: device atomics vs per-XCD partial images (+ fold) vs plain stores (wrong results, upper bound)")
     for (M, N1, N2, name) in ((T, 384, 1536, "fc2 wgrad"), (T, 1536, 384, "fc1 wgrad"), (T, 384, 384, "proj wgrad"), (T, 1152, 384, "qkv wgrad")):
