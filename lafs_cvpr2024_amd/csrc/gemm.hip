@@ -333,16 +333,26 @@ struct TNArgs {
 };
 
 constexpr int TN_BM = 32;                          // reduction rows per pipeline stage
-constexpr int TN_STAGE = 2 * TN_BM * 256;          // 16 KiB: A rows then B rows (128 bf16 = 256 B each)
+constexpr int TN_PANEL = TN_BM * 256;              // one 128-column operand panel of a stage: 32 rows x 256 B = 8 KiB
 
 // XOR applied to the 8-byte unit index (0..31) of a 256-byte row so that ds_read_b64_tr_b16 of 4 consecutive rows x
 // 4 units is conflict-free for both 16-lane groups sharing an LDS cycle (rows r..r+3 and r+8..r+11).
 __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) & 1) << 2)) << 2; }
 
-__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(TNArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NT_NS * TN_STAGE];
+// Output tile (64*WM) x (64*WN), one 64x64 block of 4x4 MFMA tiles per wave.  Operands are staged as 128-column panels
+// (WM/2 panels of A, WN/2 of B per stage).  The product path uses 2x2 (see launch_tn for the measured comparison).
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(TNArgs p) {
+  constexpr int NTH = 64 * WM * WN;
+  constexpr int PA = WM / 2, PB = WN / 2;
+  constexpr int STAGE = (PA + PB) * TN_PANEL;
+  constexpr int NCH = (PA + PB) * TN_BM * 16;        // 16-byte chunks per stage
+  constexpr int NI = NCH / NTH;                      // LDS-DMA loads per thread and stage
+  static_assert(WM % 2 == 0 && WN % 2 == 0 && NCH % NTH == 0, "tile shape");
+  constexpr int TN1 = 64 * WM, TN2 = 64 * WN;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NT_NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   // 1-D grid.  All output tiles of one M-slice run on the SAME XCD (blocks b, b+8, ... share an L2), back to back, so
   // the slice's rows are fetched from HBM once and re-read by the other tiles out of that L2.
   int zslice, tile;
@@ -354,32 +364,36 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(TNArgs p) {
     zslice = blockIdx.x / p.tiles;
     tile = blockIdx.x % p.tiles;
   }
-  const int tiles_n2 = (p.N2 + 127) >> 7;
-  const int n1_0 = (tile / tiles_n2) * 128, n2_0 = (tile % tiles_n2) * 128;
+  const int tiles_n2 = (p.N2 + TN2 - 1) / TN2;
+  const int n1_0 = (tile / tiles_n2) * TN1, n2_0 = (tile % tiles_n2) * TN2;
   const int mbeg = zslice * p.mlen;
   const int mend = min(p.M, mbeg + p.mlen);
   const int nk = (mend - mbeg + TN_BM - 1) / TN_BM;
   const bool do_colsum = (p.colsum != nullptr) && n2_0 == 0 && wn == 0;
 
-  // LDS-DMA staging: the image is lane-linear, so the unit swizzle goes on the source column.  Rows past the end of
-  // the slice are clamped to a valid row here and zeroed in LDS before use (last stage only).
-  const bf16_t* ga[2]; const bf16_t* gb[2]; int ldsoff[2], srow[2];
+  // LDS-DMA staging: the image is lane-linear (chunk q of the stage lands at byte 16*q), so the unit swizzle goes on the
+  // source column.  Rows past the end of the slice are clamped to a valid row here and zeroed in LDS before use.
+  const bf16_t* gsrc[NI]; int gld[NI], ldsoff[NI], srow[NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int q = i * 256 + tid, row = q >> 4, ch = (q & 15) ^ (tn_f(row) >> 1);
+  for (int i = 0; i < NI; ++i) {
+    const int q = i * NTH + tid, panel = q / (TN_BM * 16), within = q % (TN_BM * 16);
+    const int row = within >> 4, ch = (within & 15) ^ (tn_f(row) >> 1);
     srow[i] = row;
-    const int ca = n1_0 + ch * 8, cb = n2_0 + ch * 8;
-    ga[i] = p.A + (ca < p.N1 ? ca : 0);
-    gb[i] = p.B + (cb < p.N2 ? cb : 0);
-    ldsoff[i] = (i * 256 + wave * 64) * 16;
+    if (panel < PA) {
+      const int c = n1_0 + panel * 128 + ch * 8;
+      gsrc[i] = p.A + (c < p.N1 ? c : 0); gld[i] = p.lda;
+    } else {
+      const int c = n2_0 + (panel - PA) * 128 + ch * 8;
+      gsrc[i] = p.B + (c < p.N2 ? c : 0); gld[i] = p.ldb;
+    }
+    ldsoff[i] = (i * NTH + wave * 64) * 16;
   }
   auto issue = [&](int t) {
-    unsigned char* st = smem + (t % NT_NS) * TN_STAGE;
+    unsigned char* st = smem + (t % NT_NS) * STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int m = min(mbeg + t * TN_BM + srow[i], mend - 1);
-      glds16(ga[i] + (size_t)m * p.lda, st + ldsoff[i]);
-      glds16(gb[i] + (size_t)m * p.ldb, st + TN_BM * 256 + ldsoff[i]);
+      glds16(gsrc[i] + (size_t)m * gld[i], st + ldsoff[i]);
     }
   };
 
@@ -399,23 +413,24 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(TNArgs p) {
   int offa0[4], offa1[4], offb0[4], offb1[4];
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
-    const int ua = wm * 16 + x * 4 + (pl & 3), ub = wn * 16 + x * 4 + (pl & 3);
-    offa0[x] = r0 * 256 + ((ua ^ tn_f(r0)) << 3);
-    offa1[x] = r1 * 256 + ((ua ^ tn_f(r1)) << 3);
-    offb0[x] = TN_BM * 256 + r0 * 256 + ((ub ^ tn_f(r0)) << 3);
-    offb1[x] = TN_BM * 256 + r1 * 256 + ((ub ^ tn_f(r1)) << 3);
+    const int ua = (wm & 1) * 16 + x * 4 + (pl & 3), ub = (wn & 1) * 16 + x * 4 + (pl & 3);
+    const int pa = (wm >> 1) * TN_PANEL, pb = (PA + (wn >> 1)) * TN_PANEL;
+    offa0[x] = pa + r0 * 256 + ((ua ^ tn_f(r0)) << 3);
+    offa1[x] = pa + r1 * 256 + ((ua ^ tn_f(r1)) << 3);
+    offb0[x] = pb + r0 * 256 + ((ub ^ tn_f(r0)) << 3);
+    offb1[x] = pb + r1 * 256 + ((ub ^ tn_f(r1)) << 3);
   }
   if (nk > 0) issue(0);
   if (nk > 1) issue(1);
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (t + 2 < nk) issue(t + 2);
-    unsigned char* st = smem + (t % NT_NS) * TN_STAGE;
+    unsigned char* st = smem + (t % NT_NS) * STAGE;
     const int valid = mend - (mbeg + t * TN_BM);
     if (valid < TN_BM) {                              // ragged tail: clear the rows that were clamped
-      for (int q = tid; q < 2 * TN_BM * 16; q += 256) {
+      for (int q = tid; q < NCH; q += NTH) {
         const int row = (q >> 4) % TN_BM;
         if (row >= valid) *reinterpret_cast<uint4*>(st + q * 16) = make_uint4(0, 0, 0, 0);
       }
@@ -572,16 +587,36 @@ static int launch_tn(const void* A, int lda, const void* B, int ldb, float* C, i
   a.part_stride = part_stride;
   if (part_stride > 0) a.mode = 2;
   const int msteps = ceil_div(M, TN_BM);
-  const int tiles = ceil_div(N1, 128) * ceil_div(N2, 128);
-  if (splits <= 0) {                       // ~2 workgroups per CU, slices in multiples of 8 (one run of slices per XCD)
-    splits = ceil_div(512, tiles);
-    if (splits > 4) splits = (splits + 7) & ~7;
+  // Tile shape.  128x128 (4 waves, 3 workgroups per CU) is the fastest on every LAFS shape: the wider variants re-read the
+  // operands from L2 fewer times but measured 1.2-1.9x SLOWER on MI355X (8-16 waves per barrier, fewer bytes in flight per
+  // CU; tools/bench_kernels.py tn) -- they stay selectable for experiments: debug flags 2048 = 256x256, 4096 = 256x128.
+  static const int cand[4][2] = {{2, 2}, {4, 2}, {2, 4}, {4, 4}};
+  int best = 0;
+  if (g_debug_flags & 2048) best = 3;
+  if (g_debug_flags & 4096) best = (N1 >= N2) ? 1 : 2;
+  const int wm = cand[best][0], wn = cand[best][1];
+  const int tiles = ceil_div(N1, 64 * wm) * ceil_div(N2, 64 * wn);
+  if (splits <= 0) {
+    if (best == 0) {                       // 3 workgroups of 4 waves per CU: ~2 per CU, slices in multiples of 8 (one run per XCD)
+      splits = ceil_div(512, tiles);
+      if (splits > 4) splits = (splits + 7) & ~7;
+    } else if (best == 3) {                // 1 workgroup of 16 waves per CU: a single wave of workgroups
+      splits = 256 / tiles;
+      if (splits < 1) splits = 1;
+    } else {                               // 2 workgroups of 8 waves per CU: a bit more than one per CU
+      splits = ceil_div(288, tiles);
+      if (splits > 4) splits = (splits + 7) & ~7;
+    }
   }
   if (splits > msteps) splits = msteps;
   a.mlen = ceil_div(msteps, splits) * TN_BM;
   if (splits % 8 != 0) splits = ceil_div(M, a.mlen);       // (empty trailing slices are harmless for the x8 layout)
   a.splits = splits; a.tiles = tiles;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles * splits), dim3(256), 0, stream, a);
+  const dim3 grid(tiles * splits);
+  if (best == 0) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, stream, a);
+  else if (best == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 2>), grid, dim3(512), 0, stream, a);
+  else if (best == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), grid, dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, dim3(1024), 0, stream, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -59,6 +59,12 @@ if "nt" in which:
 if "tn" in which:
     tn(T, 384, 1536, "fc2 wgrad"); tn(T, 1536, 384, "fc1 wgrad"); tn(T, 384, 384, "proj wgrad"); tn(T, 1152, 384, "qkv wgrad")
     tn(640, 100096, 256, "last wgrad")
+    TB = 25216                                                          # ViT-B fine-tune: 128 x 197 tokens
+    tn(TB, 768, 2048, "B fc2 wgrad"); tn(TB, 2048, 768, "B fc1 wgrad"); tn(TB, 2112, 768, "B qkv wgrad"); tn(TB, 768, 704, "B proj wgrad")
+    for flag, nm in ((4096, "256x128"), (2048, "256x256")):
+        _lib.lib().lafs_debug_set(flag)
+        tn(T, 1536, 384, f"fc1 wgrad {nm}"); tn(TB, 2048, 768, f"B fc1 wgrad {nm}"); tn(TB, 2112, 768, f"B qkv wgrad {nm}")
+    _lib.lib().lafs_debug_set(0)
 if "tnsplits" in which:
     print("--- TN wgrad vs number of M-slices (0 = library default)")
     for sp in (0, 8, 16, 24, 32):
