@@ -332,8 +332,8 @@ struct TNArgs {
   long part_stride;                                // mode 2: C is [n_xcd][...] partial sums, one image per XCD
 };
 
-constexpr int TN_BM = 32;                          // reduction rows per pipeline stage
-constexpr int TN_PANEL = TN_BM * 256;              // one 128-column operand panel of a stage: 32 rows x 256 B = 8 KiB
+// Reduction rows per pipeline stage: KB = 32 (3-stage ring) or 64 (2-stage ring, half as many barriers per row).
+// One 128-column operand panel of a stage is KB rows x 256 B.
 
 // XOR applied to the 8-byte unit index (0..31) of a 256-byte row so that ds_read_b64_tr_b16 of 4 consecutive rows x
 // 4 units is conflict-free for both 16-lane groups sharing an LDS cycle (rows r..r+3 and r+8..r+11).
@@ -341,16 +341,17 @@ __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) 
 
 // Output tile (64*WM) x (64*WN), one 64x64 block of 4x4 MFMA tiles per wave.  Operands are staged as 128-column panels
 // (WM/2 panels of A, WN/2 of B per stage).  The product path uses 2x2 (see launch_tn for the measured comparison).
-template <int WM, int WN>
+template <int WM, int WN, int KB>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(TNArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int PA = WM / 2, PB = WN / 2;
+  constexpr int TN_BM = KB, TN_PANEL = KB * 256, NS = (KB == 32) ? 3 : 2;
   constexpr int STAGE = (PA + PB) * TN_PANEL;
   constexpr int NCH = (PA + PB) * TN_BM * 16;        // 16-byte chunks per stage
   constexpr int NI = NCH / NTH;                      // LDS-DMA loads per thread and stage
   static_assert(WM % 2 == 0 && WN % 2 == 0 && NCH % NTH == 0, "tile shape");
   constexpr int TN1 = 64 * WM, TN2 = 64 * WN;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NT_NS * STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   // 1-D grid.  All output tiles of one M-slice run on the SAME XCD (blocks b, b+8, ... share an L2), back to back, so
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(TNArgs p) {
     ldsoff[i] = (i * NTH + wave * 64) * 16;
   }
   auto issue = [&](int t) {
-    unsigned char* st = smem + (t % NT_NS) * STAGE;
+    unsigned char* st = smem + (t % NS) * STAGE;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int m = min(mbeg + t * TN_BM + srow[i], mend - 1);
@@ -421,13 +422,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(TNArgs p) {
     offb1[x] = pb + r1 * 256 + ((ub ^ tn_f(r1)) << 3);
   }
   if (nk > 0) issue(0);
-  if (nk > 1) issue(1);
+  if (NS == 3 && nk > 1) issue(1);
   for (int t = 0; t < nk; ++t) {
-    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+    // NS == 3: stage t+1 may still be in flight; NS == 2: only stage t is outstanding here
+    if (NS == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 2 < nk) issue(t + 2);
-    unsigned char* st = smem + (t % NT_NS) * STAGE;
+    if (t + NS - 1 < nk) issue(t + NS - 1);
+    unsigned char* st = smem + (t % NS) * STAGE;
     const int valid = mend - (mbeg + t * TN_BM);
     if (valid < TN_BM) {                              // ragged tail: clear the rows that were clamped
       for (int q = tid; q < NCH; q += NTH) {
@@ -436,21 +438,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(TNArgs p) {
       }
       __syncthreads();
     }
-    bf16x8_t fa[4], fb[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-      s16x8_t va = __builtin_shufflevector(lds_read_tr16(st + offa0[x]), lds_read_tr16(st + offa1[x]), 0, 1, 2, 3, 4, 5, 6, 7);
-      s16x8_t vb = __builtin_shufflevector(lds_read_tr16(st + offb0[x]), lds_read_tr16(st + offb1[x]), 0, 1, 2, 3, 4, 5, 6, 7);
-      fa[x] = __builtin_bit_cast(bf16x8_t, va);
-      fb[x] = __builtin_bit_cast(bf16x8_t, vb);
-    }
+    for (int kk = 0; kk < KB / 32; ++kk) {            // one k = 32 MFMA step per 32 staged rows
+      const unsigned char* sk = st + kk * 32 * 256;
+      bf16x8_t fa[4], fb[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+      for (int x = 0; x < 4; ++x) {
+        s16x8_t va = __builtin_shufflevector(lds_read_tr16(sk + offa0[x]), lds_read_tr16(sk + offa1[x]), 0, 1, 2, 3, 4, 5, 6, 7);
+        s16x8_t vb = __builtin_shufflevector(lds_read_tr16(sk + offb0[x]), lds_read_tr16(sk + offb1[x]), 0, 1, 2, 3, 4, 5, 6, 7);
+        fa[x] = __builtin_bit_cast(bf16x8_t, va);
+        fb[x] = __builtin_bit_cast(bf16x8_t, vb);
+      }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
-    if (do_colsum) {                                  // column sums of A (bias gradient) ride along as A^T * ones
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int a = 0; a < 4; ++a) accs[a] = mfma16(fa[a], ones, accs[a]);
+        for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+      if (do_colsum) {                                // column sums of A (bias gradient) ride along as A^T * ones
+#pragma unroll
+        for (int a = 0; a < 4; ++a) accs[a] = mfma16(fa[a], ones, accs[a]);
+      }
     }
   }
   // mode 2: every XCD accumulates into its OWN image of C, so all adds to one address come from CUs behind the same L2
@@ -586,12 +592,25 @@ static int launch_tn(const void* A, int lda, const void* B, int ldb, float* C, i
   a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.mode = g_debug_flags & 1;
   a.part_stride = part_stride;
   if (part_stride > 0) a.mode = 2;
-  const int msteps = ceil_div(M, TN_BM);
+  // 32-row stages in a 3-stage ring.  (64-row stages in a 2-stage ring -- half the barriers -- measured 1.8x slower: the
+  // next stage's DMA cannot be issued before the barrier and only 2 workgroups fit a CU; debug flag 8192 selects them.)
+  const int kb = (g_debug_flags & 8192) ? 64 : 32;
+  const int msteps = ceil_div(M, kb);
   // Tile shape.  128x128 (4 waves, 3 workgroups per CU) is the fastest on every LAFS shape: the wider variants re-read the
   // operands from L2 fewer times but measured 1.2-1.9x SLOWER on MI355X (8-16 waves per barrier, fewer bytes in flight per
   // CU; tools/bench_kernels.py tn) -- they stay selectable for experiments: debug flags 2048 = 256x256, 4096 = 256x128.
   static const int cand[4][2] = {{2, 2}, {4, 2}, {2, 4}, {4, 4}};
   int best = 0;
+  {
+    // ... except when the 128x128 grid would spill into a second round of workgroups (3 fit a CU: 768 slots) and 256x256
+    // tiles cover the output without much padding: one workgroup per CU then wins (ViT-B qkv wgrad: 141 vs 191 us)
+    const int t22 = ceil_div(N1, 128) * ceil_div(N2, 128);
+    int s22 = ceil_div(512, t22);
+    if (s22 > 4) s22 = (s22 + 7) & ~7;
+    const double t44 = (double)ceil_div(N1, 256) * ceil_div(N2, 256);
+    if (splits <= 0 && t22 * s22 > 768 && t44 <= 256 && t44 * 65536.0 <= 1.15 * (double)N1 * N2 && M >= 8192) best = 3;
+  }
+  if (g_debug_flags & 1024) best = 0;
   if (g_debug_flags & 2048) best = 3;
   if (g_debug_flags & 4096) best = (N1 >= N2) ? 1 : 2;
   const int wm = cand[best][0], wn = cand[best][1];
@@ -609,14 +628,15 @@ static int launch_tn(const void* A, int lda, const void* B, int ldb, float* C, i
     }
   }
   if (splits > msteps) splits = msteps;
-  a.mlen = ceil_div(msteps, splits) * TN_BM;
+  a.mlen = ceil_div(msteps, splits) * kb;
   if (splits % 8 != 0) splits = ceil_div(M, a.mlen);       // (empty trailing slices are harmless for the x8 layout)
   a.splits = splits; a.tiles = tiles;
   const dim3 grid(tiles * splits);
-  if (best == 0) hipLaunchKernelGGL((gemm_tn_kernel<2, 2>), grid, dim3(256), 0, stream, a);
-  else if (best == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 2>), grid, dim3(512), 0, stream, a);
-  else if (best == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 4>), grid, dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_tn_kernel<4, 4>), grid, dim3(1024), 0, stream, a);
+  if (best == 0 && kb == 64) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 64>), grid, dim3(256), 0, stream, a);   // experiment
+  else if (best == 0) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 32>), grid, dim3(256), 0, stream, a);
+  else if (best == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 2, 32>), grid, dim3(512), 0, stream, a);
+  else if (best == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 4, 32>), grid, dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<4, 4, 32>), grid, dim3(1024), 0, stream, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

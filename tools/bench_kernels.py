@@ -61,7 +61,7 @@ if "tn" in which:
     tn(640, 100096, 256, "last wgrad")
     TB = 25216                                                          # ViT-B fine-tune: 128 x 197 tokens
     tn(TB, 768, 2048, "B fc2 wgrad"); tn(TB, 2048, 768, "B fc1 wgrad"); tn(TB, 2112, 768, "B qkv wgrad"); tn(TB, 768, 704, "B proj wgrad")
-    for flag, nm in ((4096, "256x128"), (2048, "256x256")):
+    for flag, nm in ((1024, "128x128 kb32"), (4096, "256x128"), (2048, "256x256")):
         _lib.lib().lafs_debug_set(flag)
         tn(T, 1536, 384, f"fc1 wgrad {nm}"); tn(TB, 2048, 768, f"B fc1 wgrad {nm}"); tn(TB, 2112, 768, f"B qkv wgrad {nm}")
     _lib.lib().lafs_debug_set(0)
