@@ -308,6 +308,15 @@ int lafs_cnn_pool(const void* x, int N, int HW, int C, void* out, int ldo, hipSt
 /* x(bf16)[n,p,c] = act(x[n,p,c] * s(bf16)[n,c]) in place  (excite + the block's non-linearity). */
 int lafs_cnn_scale_act(void* x, const void* s, int lds, int N, int HW, int C, int act, hipStream_t stream);
 
+/* Depthwise convolution of the TRAINABLE landmark branch (fine-tune step, nn.Conv2d(C, C, k, stride, (k-1)//2, groups=C,
+ * bias=False) of face_pre_pro/mobilenet.py:177-186 and its two gradients), fp32 NCHW.  x [N,C,H,W], w [C,1,k,k],
+ * y / dy [N,C,ceil(H/stride),ceil(W/stride)]; k in {3,5}, stride in {1,2}.  bwd_weight ACCUMULATES into dw (zero it first). */
+int lafs_dwconv_nchw_fwd(const float* x, const float* w, int N, int C, int H, int W, int k, int stride, float* y, hipStream_t stream);
+int lafs_dwconv_nchw_bwd_data(const float* dy, const float* w, int N, int C, int H, int W, int k, int stride, float* dx,
+                              hipStream_t stream);
+int lafs_dwconv_nchw_bwd_weight(const float* x, const float* dy, int N, int C, int H, int W, int k, int stride, float* dw,
+                                hipStream_t stream);
+
 /* Landmark post-processing (face_pre_pro/ViT_face.py:1347-1378, 698-706): t f32 [B, 2*n_full] raw regressor output ->
  * theta f32 [B, n_out, 2] pixels:  theta = (t - min_b)/(max_b - min_b)*111  (+ noise_scale * noise[B, n_full, 2], the
  * N(0,1)*5 px jitter), landmark k of the output = landmark sel[b,k] of the input (random choice with replacement) or k

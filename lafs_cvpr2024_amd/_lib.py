@@ -92,6 +92,9 @@ _PROTOS = {
     "lafs_cnn_dwconv": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "lafs_cnn_pool": [vp, i32, i32, i32, vp, i32],
     "lafs_cnn_scale_act": [vp, vp, i32, i32, i32, i32, i32],
+    "lafs_dwconv_nchw_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lafs_dwconv_nchw_bwd_data": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "lafs_dwconv_nchw_bwd_weight": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lafs_landmark_theta": [vp, i32, i32, vp, f32, vp, i32, vp],
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],

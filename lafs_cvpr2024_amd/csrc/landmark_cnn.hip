@@ -174,3 +174,158 @@ extern "C" int lafs_cnn_scale_act(void* x, const void* s, int lds_, int N, int H
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Trainable landmark branch of the fine-tune step (Part-fViT with_land=True, train_largescale.py:432): the MobileNetV3 trunk
+// stays on torch autograd there, but its depthwise convolutions are the kernels below -- on this ROCm image MIOpen has no
+// tuned depthwise solver for these shapes (naive / Winograd / im2col fall-backs: ~14 ms of a 50 ms step at batch 128).
+// fp32 NCHW, bias-free, pad (k-1)/2, exactly nn.Conv2d(C, C, k, stride, (k-1)//2, groups=C) and its two gradients.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int K>
+__global__ __launch_bounds__(256) void dw_nchw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int C, int H, int W,
+                                                          int stride, float* __restrict__ y) {
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= Ho * Wo) return;
+  const int oy = o / Wo, ox = o % Wo;
+  constexpr int P = (K - 1) / 2;
+  float wk[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) wk[t] = w[(size_t)c * K * K + t];
+  const float* xp = x + ((size_t)n * C + c) * H * W;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = oy * stride - P + ky;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int ix = ox * stride - P + kx;
+      if (ix < 0 || ix >= W) continue;
+      acc = fmaf(xp[iy * W + ix], wk[ky * K + kx], acc);
+    }
+  }
+  y[((size_t)n * C + c) * Ho * Wo + o] = acc;
+}
+
+// dx[iy,ix] = sum_{ky,kx} dy[(iy+P-ky)/s, (ix+P-kx)/s] * w[ky,kx]   over the taps where the division is exact and in range
+template <int K>
+__global__ __launch_bounds__(256) void dw_nchw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, int C, int H,
+                                                               int W, int stride, float* __restrict__ dx) {
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= H * W) return;
+  const int iy = i / W, ix = i % W;
+  constexpr int P = (K - 1) / 2;
+  float wk[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) wk[t] = w[(size_t)c * K * K + t];
+  const float* dp = dy + ((size_t)n * C + c) * Ho * Wo;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int ty = iy + P - ky;
+    if (ty < 0 || (ty % stride) != 0) continue;
+    const int oy = ty / stride;
+    if (oy >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int tx = ix + P - kx;
+      if (tx < 0 || (tx % stride) != 0) continue;
+      const int ox = tx / stride;
+      if (ox >= Wo) continue;
+      acc = fmaf(dp[oy * Wo + ox], wk[ky * K + kx], acc);
+    }
+  }
+  dx[((size_t)n * C + c) * H * W + i] = acc;
+}
+
+// dw[c, ky, kx] += sum_{n in chunk, oy, ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx];  grid (C, n_chunks)
+template <int K>
+__global__ __launch_bounds__(256) void dw_nchw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int C,
+                                                                 int H, int W, int stride, int n_per_block, float* __restrict__ dw) {
+  __shared__ float red[4][K * K];
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const int c = blockIdx.x, n0 = blockIdx.y * n_per_block, n1 = min(N, n0 + n_per_block);
+  constexpr int P = (K - 1) / 2;
+  float acc[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
+  const int per_img = Ho * Wo, total = (n1 - n0) * per_img;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int n = n0 + e / per_img, o = e % per_img;
+    const int oy = o / Wo, ox = o % Wo;
+    const float g = dy[((size_t)n * C + c) * per_img + o];
+    const float* xp = x + ((size_t)n * C + c) * H * W;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * stride - P + ky;
+      if (iy < 0 || iy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int ix = ox * stride - P + kx;
+        if (ix < 0 || ix >= W) continue;
+        acc[ky * K + kx] = fmaf(g, xp[iy * W + ix], acc[ky * K + kx]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) {
+    const float s = wave_sum(acc[t]);
+    if (lane == 0) red[wave][t] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < K * K) atomicAdd(dw + (size_t)c * K * K + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int dw_check(const void* a, const void* b, const void* c, int N, int C, int H, int W, int k, int stride) {
+  LAFS_CHECK_ARG(a && b && c && N > 0 && C > 0 && H > 0 && W > 0, "bad operand");
+  LAFS_CHECK_ARG((k == 3 || k == 5) && (stride == 1 || stride == 2), "k in {3,5}, stride in {1,2}");
+  LAFS_CHECK_ARG(C <= 65535 && N <= 65535, "N and C must fit a grid dimension");
+  return LAFS_OK;
+}
+
+}  // namespace
+
+extern "C" int lafs_dwconv_nchw_fwd(const float* x, const float* w, int N, int C, int H, int W, int k, int stride, float* y,
+                                    hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  if (int rc = dw_check(x, w, y, N, C, H, W, k, stride)) return rc;
+  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const dim3 grid((Ho * Wo + 255) / 256, C, N);
+  if (k == 3) hipLaunchKernelGGL(dw_nchw_fwd_kernel<3>, grid, dim3(256), 0, stream, x, w, C, H, W, stride, y);
+  else hipLaunchKernelGGL(dw_nchw_fwd_kernel<5>, grid, dim3(256), 0, stream, x, w, C, H, W, stride, y);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_dwconv_nchw_bwd_data(const float* dy, const float* w, int N, int C, int H, int W, int k, int stride, float* dx,
+                                         hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  if (int rc = dw_check(dy, w, dx, N, C, H, W, k, stride)) return rc;
+  const dim3 grid((H * W + 255) / 256, C, N);
+  if (k == 3) hipLaunchKernelGGL(dw_nchw_bwd_data_kernel<3>, grid, dim3(256), 0, stream, dy, w, C, H, W, stride, dx);
+  else hipLaunchKernelGGL(dw_nchw_bwd_data_kernel<5>, grid, dim3(256), 0, stream, dy, w, C, H, W, stride, dx);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_dwconv_nchw_bwd_weight(const float* x, const float* dy, int N, int C, int H, int W, int k, int stride, float* dw,
+                                           hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  if (int rc = dw_check(x, dy, dw, N, C, H, W, k, stride)) return rc;
+  const int Ho = (H + stride - 1) / stride;
+  int n_per_block = (8 * 56 * 56) / (Ho * Ho);                     // ~25k (image, pixel) pairs per workgroup
+  if (n_per_block < 1) n_per_block = 1;
+  if (n_per_block > N) n_per_block = N;
+  const dim3 grid(C, (N + n_per_block - 1) / n_per_block);
+  if (k == 3) hipLaunchKernelGGL(dw_nchw_bwd_weight_kernel<3>, grid, dim3(256), 0, stream, x, dy, N, C, H, W, stride, n_per_block, dw);
+  else hipLaunchKernelGGL(dw_nchw_bwd_weight_kernel<5>, grid, dim3(256), 0, stream, x, dy, N, C, H, W, stride, n_per_block, dw);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}

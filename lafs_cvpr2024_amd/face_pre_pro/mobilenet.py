@@ -2,13 +2,63 @@
 3x112x112 -> 160x4x4.  Table-driven re-implementation with the reference's ``state_dict`` key layout
 (``features.0.{0,1}``, ``features.{i}.conv.{0,1,3,4,5.fc.{0,2},7,8}``).  It runs on stock PyTorch-ROCm (MIOpen depthwise
 convolutions): north_star lists no HIP kernel for it and it is frozen / in eval mode on the LAFS path."""
+import torch
 import torch.nn as nn
+
+from .. import _lib
+from ..ops import _p, call
 
 # kernel, expansion, out channels, squeeze-excite, non-linearity, stride   (MobileNetV3-large, Howard et al. Table 1)
 _LARGE = ((3, 16, 16, 0, "RE", 1), (3, 64, 24, 0, "RE", 2), (3, 72, 24, 0, "RE", 1), (5, 72, 40, 1, "RE", 2),
           (5, 120, 40, 1, "RE", 1), (5, 120, 40, 1, "RE", 1), (3, 240, 80, 0, "HS", 2), (3, 200, 80, 0, "HS", 1),
           (3, 184, 80, 0, "HS", 1), (3, 184, 80, 0, "HS", 1), (3, 480, 112, 1, "HS", 1), (3, 672, 112, 1, "HS", 1),
           (5, 672, 160, 1, "HS", 2), (5, 960, 160, 1, "HS", 1), (5, 960, 160, 1, "HS", 1))
+
+
+class _DepthwiseFn(torch.autograd.Function):
+    """Depthwise k x k convolution (pad (k-1)//2, no bias) and both gradients on the HIP kernels (fp32 NCHW)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride):
+        x = x.contiguous(); w = w.contiguous()
+        N, C, H, W = x.shape
+        k = w.shape[-1]
+        Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+        y = torch.empty(N, C, Ho, Wo, device=x.device, dtype=torch.float32)
+        call("lafs_dwconv_nchw_fwd", _p(x), _p(w), N, C, H, W, k, stride, _p(y))
+        ctx.save_for_backward(x, w)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, C, H, W = x.shape
+        k, stride = w.shape[-1], ctx.stride
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("lafs_dwconv_nchw_bwd_data", _p(dy), _p(w), N, C, H, W, k, stride, _p(dx))
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            call("lafs_dwconv_nchw_bwd_weight", _p(x), _p(dy), N, C, H, W, k, stride, _p(dw))
+        return dx, dw, None
+
+
+class DepthwiseConv2d(nn.Conv2d):
+    """nn.Conv2d(C, C, k, stride, (k-1)//2, groups=C, bias=False) with the same parameters / state_dict key, whose forward and
+    backward on fp32 device tensors are the hand-written depthwise kernels (MIOpen has no tuned solver for these shapes on this
+    image: its fall-backs cost ~14 ms of a 50 ms fine-tune step).  Other inputs (CPU, bf16) take the stock path."""
+
+    def __init__(self, channels, k, stride):
+        super().__init__(channels, channels, k, stride, (k - 1) // 2, groups=channels, bias=False)
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and self.kernel_size[0] in (3, 5) \
+                and self.stride[0] in (1, 2):
+            return _DepthwiseFn.apply(x, self.weight, self.stride[0])
+        return super().forward(x)
 
 
 def _act(kind):
@@ -32,7 +82,7 @@ class _InvertedResidual(nn.Module):
         self.residual = stride == 1 and cin == cout
         self.conv = nn.Sequential(
             nn.Conv2d(cin, cexp, 1, bias=False), nn.BatchNorm2d(cexp), _act(nl),
-            nn.Conv2d(cexp, cexp, k, stride, (k - 1) // 2, groups=cexp, bias=False), nn.BatchNorm2d(cexp),
+            DepthwiseConv2d(cexp, k, stride), nn.BatchNorm2d(cexp),
             _SqueezeExcite(cexp) if se else nn.Identity(), _act(nl),
             nn.Conv2d(cexp, cout, 1, bias=False), nn.BatchNorm2d(cout))
 

@@ -145,3 +145,26 @@ def test_attention_fwd_bwd(lens, heads):
     for i, name in enumerate("qkv"):
         e = relerr(dqkv[:, i * inner:(i + 1) * inner].float(), xr.grad[:, i * inner:(i + 1) * inner])
         assert e < 3e-2, f"d{name}: {e}"
+
+
+@pytest.mark.parametrize("k,stride,H", [(3, 1, 14), (3, 2, 56), (5, 1, 7), (5, 2, 7), (5, 2, 28), (3, 2, 9)])
+def test_depthwise_conv_nchw_forward_and_gradients(k, stride, H):
+    """DepthwiseConv2d (trainable landmark branch): HIP forward / data gradient / weight gradient vs torch's grouped
+    convolution in fp32 (same arithmetic, different summation order)."""
+    import torch.nn.functional as F
+    from lafs_cvpr2024_amd.face_pre_pro.mobilenet import DepthwiseConv2d
+    torch.manual_seed(k * 10 + stride)
+    N, C = 3, 24
+    conv = DepthwiseConv2d(C, k, stride).to("cuda")
+    x = torch.randn(N, C, H, H, device="cuda", requires_grad=True)
+    y = conv(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().clone().requires_grad_(True)
+    wr = conv.weight.detach().clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, (k - 1) // 2, 1, C)
+    yr.backward(gy)
+    assert y.shape == yr.shape
+    torch.testing.assert_close(y, yr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x.grad, xr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(conv.weight.grad, wr.grad, rtol=1e-4, atol=1e-4)
