@@ -2,6 +2,8 @@
 3x112x112 -> 160x4x4.  Table-driven re-implementation with the reference's ``state_dict`` key layout
 (``features.0.{0,1}``, ``features.{i}.conv.{0,1,3,4,5.fc.{0,2},7,8}``).  It runs on stock PyTorch-ROCm (MIOpen depthwise
 convolutions): north_star lists no HIP kernel for it and it is frozen / in eval mode on the LAFS path."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -56,7 +58,7 @@ class DepthwiseConv2d(nn.Conv2d):
 
     def forward(self, x):
         if x.is_cuda and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and self.kernel_size[0] in (3, 5) \
-                and self.stride[0] in (1, 2):
+                and self.stride[0] in (1, 2) and os.environ.get("LAFS_DW_STOCK") != "1":      # env switch: A/B against MIOpen
             return _DepthwiseFn.apply(x, self.weight, self.stride[0])
         return super().forward(x)
 

@@ -44,12 +44,13 @@ if a.channels_last and a.with_land:
     m.stn.to(memory_format=torch.channels_last)
 x = torch.randint(0, 256, (a.batch, 3, 112, 112), dtype=torch.uint8, device=dev)
 y = torch.randint(0, a.classes, (a.batch,), device=dev)
+trace = []
 for _ in range(a.warmup):
-    eng.step(x, y, lr=1e-4)
+    trace.append(round(float(eng.step(x, y, lr=1e-4).item()), 3))
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     loss = eng.step(x, y, lr=1e-4)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"workload": f"Part-fViT ViT-B + {a.head} fine-tune step, batch {a.batch}, {a.classes} classes, with_land={a.with_land}, "
                               f"dropout={a.dropout}" + (f", sample_rate={a.sample_rate}" if sharded else ""),
-                  "ms_per_step": round(dt * 1e3, 2), "images_per_s": round(a.batch / dt, 1), "loss": round(float(loss.item()), 4)}))
+                  "ms_per_step": round(dt * 1e3, 2), "images_per_s": round(a.batch / dt, 1), "loss": round(float(loss.item()), 4), "warmup_losses": trace}))
