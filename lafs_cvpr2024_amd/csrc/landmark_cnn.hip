@@ -184,18 +184,18 @@ extern "C" int lafs_cnn_scale_act(void* x, const void* s, int lds_, int N, int H
 namespace {
 
 template <int K>
-__global__ __launch_bounds__(256) void dw_nchw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, int C, int H, int W,
-                                                          int stride, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void dw_nchw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, long total, int C,
+                                                          int H, int W, int stride, float* __restrict__ y) {
   const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
-  const int c = blockIdx.y, n = blockIdx.z;
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= Ho * Wo) return;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // flat (n, c, oy, ox): small planes still fill the workgroup
+  if (idx >= total) return;
+  const int o = (int)(idx % (Ho * Wo));
+  const long nc = idx / (Ho * Wo);
+  const int c = (int)(nc % C);
   const int oy = o / Wo, ox = o % Wo;
   constexpr int P = (K - 1) / 2;
-  float wk[K * K];
-#pragma unroll
-  for (int t = 0; t < K * K; ++t) wk[t] = w[(size_t)c * K * K + t];
-  const float* xp = x + ((size_t)n * C + c) * H * W;
+  const float* wk = w + (size_t)c * K * K;
+  const float* xp = x + (size_t)nc * H * W;
   float acc = 0.f;
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
@@ -208,23 +208,23 @@ __global__ __launch_bounds__(256) void dw_nchw_fwd_kernel(const float* __restric
       acc = fmaf(xp[iy * W + ix], wk[ky * K + kx], acc);
     }
   }
-  y[((size_t)n * C + c) * Ho * Wo + o] = acc;
+  y[idx] = acc;
 }
 
 // dx[iy,ix] = sum_{ky,kx} dy[(iy+P-ky)/s, (ix+P-kx)/s] * w[ky,kx]   over the taps where the division is exact and in range
 template <int K>
-__global__ __launch_bounds__(256) void dw_nchw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, int C, int H,
-                                                               int W, int stride, float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void dw_nchw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, long total,
+                                                               int C, int H, int W, int stride, float* __restrict__ dx) {
   const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
-  const int c = blockIdx.y, n = blockIdx.z;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= H * W) return;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // flat (n, c, iy, ix)
+  if (idx >= total) return;
+  const int i = (int)(idx % (H * W));
+  const long nc = idx / (H * W);
+  const int c = (int)(nc % C);
   const int iy = i / W, ix = i % W;
   constexpr int P = (K - 1) / 2;
-  float wk[K * K];
-#pragma unroll
-  for (int t = 0; t < K * K; ++t) wk[t] = w[(size_t)c * K * K + t];
-  const float* dp = dy + ((size_t)n * C + c) * Ho * Wo;
+  const float* wk = w + (size_t)c * K * K;
+  const float* dp = dy + (size_t)nc * Ho * Wo;
   float acc = 0.f;
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void dw_nchw_bwd_data_kernel(const float* __re
       acc = fmaf(dp[oy * Wo + ox], wk[ky * K + kx], acc);
     }
   }
-  dx[((size_t)n * C + c) * H * W + i] = acc;
+  dx[idx] = acc;
 }
 
 // dw[c, ky, kx] += sum_{n in chunk, oy, ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx];  grid (C, n_chunks)
@@ -297,9 +297,10 @@ extern "C" int lafs_dwconv_nchw_fwd(const float* x, const float* w, int N, int C
   LAFS_CLEAR_ERROR();
   if (int rc = dw_check(x, w, y, N, C, H, W, k, stride)) return rc;
   const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
-  const dim3 grid((Ho * Wo + 255) / 256, C, N);
-  if (k == 3) hipLaunchKernelGGL(dw_nchw_fwd_kernel<3>, grid, dim3(256), 0, stream, x, w, C, H, W, stride, y);
-  else hipLaunchKernelGGL(dw_nchw_fwd_kernel<5>, grid, dim3(256), 0, stream, x, w, C, H, W, stride, y);
+  const long total = (long)N * C * Ho * Wo;
+  const dim3 grid(blocks_for(total));
+  if (k == 3) hipLaunchKernelGGL(dw_nchw_fwd_kernel<3>, grid, dim3(256), 0, stream, x, w, total, C, H, W, stride, y);
+  else hipLaunchKernelGGL(dw_nchw_fwd_kernel<5>, grid, dim3(256), 0, stream, x, w, total, C, H, W, stride, y);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -308,9 +309,10 @@ extern "C" int lafs_dwconv_nchw_bwd_data(const float* dy, const float* w, int N,
                                          hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   if (int rc = dw_check(dy, w, dx, N, C, H, W, k, stride)) return rc;
-  const dim3 grid((H * W + 255) / 256, C, N);
-  if (k == 3) hipLaunchKernelGGL(dw_nchw_bwd_data_kernel<3>, grid, dim3(256), 0, stream, dy, w, C, H, W, stride, dx);
-  else hipLaunchKernelGGL(dw_nchw_bwd_data_kernel<5>, grid, dim3(256), 0, stream, dy, w, C, H, W, stride, dx);
+  const long total = (long)N * C * H * W;
+  const dim3 grid(blocks_for(total));
+  if (k == 3) hipLaunchKernelGGL(dw_nchw_bwd_data_kernel<3>, grid, dim3(256), 0, stream, dy, w, total, C, H, W, stride, dx);
+  else hipLaunchKernelGGL(dw_nchw_bwd_data_kernel<5>, grid, dim3(256), 0, stream, dy, w, total, C, H, W, stride, dx);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
