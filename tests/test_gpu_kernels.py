@@ -168,3 +168,27 @@ def test_depthwise_conv_nchw_forward_and_gradients(k, stride, H):
     torch.testing.assert_close(y, yr, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(x.grad, xr.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(conv.weight.grad, wr.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_invalid_arguments_fail_loudly():
+    """Unsupported shapes are rejected by the C entry points (negative return code -> LafsHipError with the reason), never
+    silently mis-computed or routed to another implementation."""
+    from lafs_cvpr2024_amd import _lib
+    from lafs_cvpr2024_amd.ops import _p, call
+    A = torch.zeros(64, 40, device=DEV, dtype=torch.bfloat16)            # K = 40 is not a multiple of 32
+    B = torch.zeros(128, 40, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(_lib.LafsHipError, match="multiple of 32"):
+        ops.gemm_nt(A, B)
+    qkv = torch.zeros(300, 192, device=DEV, dtype=torch.bfloat16)
+    cu = torch.tensor([0, 300], dtype=torch.int32, device=DEV)
+    with pytest.raises(_lib.LafsHipError, match="1..256"):
+        ops.attention_fwd(qkv, cu, 300, 1, 0.125)                         # sequences longer than 256 tokens
+    img = torch.zeros(1, 3, 112, 112, device=DEV); th = torch.zeros(1, 30, 2, device=DEV); out = torch.zeros(1, 3, 48, 48, device=DEV)
+    with pytest.raises(_lib.LafsHipError, match="perfect square"):
+        call("lafs_patch_gather_fwd", _p(img), _p(th), 1, 112, 30, _p(out))
+    x = torch.zeros(4, 100, device=DEV)
+    with pytest.raises(_lib.LafsHipError):
+        ops.gemm_nt(x, B)                                                 # fp32 operand where bf16 is required
+    with pytest.raises(_lib.LafsHipError, match="drop_p"):
+        ops.gemm_nt(torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(128, 64, device=DEV, dtype=torch.bfloat16),
+                    _lib.EPI_RESID_F32, resid=torch.zeros(64, 128, device=DEV), drop_p=1.5)
