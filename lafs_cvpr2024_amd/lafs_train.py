@@ -62,7 +62,13 @@ def get_args_parser():
     p.add_argument('--data', default='synthetic', type=str,
                    help="'synthetic': random landmark-crop shaped tensors; 'synthetic_views': the 20 augmented 112x112 views of "
                         "DataAugmentation_LAFS (clean/augmented pairs) pushed through the landmark front-end")
-    p.add_argument('--landmark_ckpt', default='', type=str, help="state_dict of the frozen landmark CNN (reference :262-268)")
+    p.add_argument('--landmark_ckpt', '--landmark_path', dest='landmark_ckpt', default='', type=str,
+                   help="state_dict of the frozen landmark CNN (reference --landmark_path, :112, :262-268)")
+    # flags of the reference's PIL / recordio input pipeline: parsed for command-line compatibility, unused with synthetic data
+    p.add_argument('--data_path', default='', type=str)
+    p.add_argument('--num_workers', default=6, type=int)
+    p.add_argument('--global_crops_scale', type=float, nargs='+', default=(0.4, 1.))
+    p.add_argument('--local_crops_scale', type=float, nargs='+', default=(0.05, 0.4))
     p.add_argument('--steps_per_epoch', default=100, type=int, help="iterations per epoch for --data synthetic")
     p.add_argument('--output_dir', default=".", type=str)
     p.add_argument('--saveckp_freq', default=10, type=int)

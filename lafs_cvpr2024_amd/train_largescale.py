@@ -3,8 +3,9 @@ fine-tune engine.  Model configuration as the reference builds it (:432, 542-557
 landmark branch), dropout = emb_dropout = 0.1, DropPath 0.1, CosFace(s=64, m=0.4) over all classes on every rank.
 `--head PartialFC` / `--head ArcFace` select the class-sharded head of config C5 (parity unpinned, see partial_fc.py).
 
-Kept from the reference: flags that define the step (batch size, epochs, lr rescale `lr * bs * world / 512`, weight decay
-0.1, mixup alpha/prob, acc_step=3 from supervised_config.py:37, warm-up(5 epochs)+cosine(eta_min 1e-6) LR, loading
+Kept from the reference: flags that define the step (batch size, epochs, the lr rescale of :472
+`acc_step/480 * lr * sqrt(world*bs/336) * 336`, weight decay 0.1 on >= 2-D tensors (:618-627; `--weight-decay` is parsed by the
+reference but never reaches its optimizer), mixup alpha/prob, acc_step=3 from supervised_config.py:37, warm-up(5 epochs)+cosine(eta_min 1e-6) LR, loading
 `ckpt['teacher']` of an SSL checkpoint with the 'encoder.|backbone.|module.' prefixes stripped and strict=False).
 Out of scope here: MXNet recordio datasets, RandAugment, LFW/CFP/AgeDB evaluation,
 tensorboard; `--data synthetic` feeds uint8 batches of the right shape.
@@ -32,7 +33,7 @@ def get_args_parser():
     p = argparse.ArgumentParser("Part-fViT fine-tuning", add_help=False)
     p.add_argument("--batch_size", "-b", default=128, type=int)
     p.add_argument("--epochs", "-e", default=34, type=int)
-    p.add_argument("--lr", default=3e-4, type=float)
+    p.add_argument("--lr", default=1e-3, type=float, help="base rate before the reference's rescale (train_largescale.py:355,472)")
     p.add_argument("--weight_decay", default=0.1, type=float)
     p.add_argument("--head", default="CosFace", type=str, choices=["CosFace", "PartialFC", "ArcFace"],
                    help="CosFace: the reference's dense head; ArcFace: dense head with the additive angular margin (m=0.5); "
@@ -47,6 +48,7 @@ def get_args_parser():
     p.add_argument("--mixup-prob", dest="mixup_prob", default=0.1, type=float)
     p.add_argument("--drop_path", default=0.1, type=float)
     p.add_argument("--model_dir", default="", type=str, help="LAFS checkpoint whose ['teacher'] weights initialise the backbone")
+    p.add_argument("--pretrain_path", default="", type=str, help="stage-1 checkpoint with the landmark CNN (alias of --landmark_ckpt)")
     p.add_argument("--data", default="synthetic", type=str)
     p.add_argument("--steps_per_epoch", default=100, type=int)
     p.add_argument("--outdir", "-o", default=".", type=str)
@@ -106,8 +108,8 @@ def main(args):
                                         drop_path_rate=args.drop_path)
     if args.model_dir:
         load_ssl_teacher(backbone, args.model_dir)
-    if args.landmark_ckpt:
-        load_landmark_branch(backbone, args.landmark_ckpt)
+    if args.landmark_ckpt or args.pretrain_path:
+        load_landmark_branch(backbone, args.landmark_ckpt or args.pretrain_path)
     head = None
     if sharded:
         from .partial_fc import PartialFC
@@ -115,7 +117,8 @@ def main(args):
                          margin_type=1 if arc else 0, device=device, seed=cfg["SEED"])
     engine = FinetuneEngine(backbone, args.batch_size, acc_step=cfg["acc_step"], mixup_alpha=args.mixup, mixup_prob=args.mixup_prob,
                             s=64.0, m=0.5 if arc else 0.4, margin_type=1 if arc else 0, device=device, sharded_head=head)
-    base_lr = args.lr * args.batch_size * world / 512.0                     # train_largescale.py:472
+    # train_largescale.py:472:  lr = acc_step / 480 * lr * sqrt(world * BATCH_SIZE / 336) * 336
+    base_lr = cfg["acc_step"] / 480.0 * args.lr * math.sqrt(world * args.batch_size / 336.0) * 336
     n_it = args.steps_per_epoch
     gen = torch.Generator(device=device).manual_seed(cfg["SEED"] + utils.get_rank())
     t0 = time.time()
