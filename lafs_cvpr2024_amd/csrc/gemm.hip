@@ -506,10 +506,10 @@ template <int EPI>
 int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   // Shape heuristics from tools/bench_kernels.py on MI355X (ViT-S/B shapes):
   //  * wide outputs (N >= 1024) on many rows: 256x128 tiles (less L2->LDS traffic per flop, 16 resident waves/CU);
-  //  * long reductions (K >= 1024): 64-deep stages (full 128-byte lines per row piece) in a 2-stage ring.
+  //  * long reductions (K >= 640): 64-deep stages (full 128-byte lines per row piece) in a 2-stage ring, 128x128 tiles.
   const int tn = ceil_div(a.N, BN);
   const long t2 = (long)ceil_div(a.M, 128) * tn * splits, t4 = (long)ceil_div(a.M, 256) * tn * splits;
-  bool bk64 = (a.klen % 64 == 0) && a.klen >= 1024 && splits == 1;
+  bool bk64 = (a.klen % 64 == 0) && a.klen >= 640 && splits == 1;    // K = 704 / 768 (ViT-B) included: 5-15 % over 32-deep stages
   int wm = (!bk64 && a.N >= 1024 && a.M >= 4096) ? 4 : 2;
   if (g_debug_flags & 2) wm = 2;
   if (g_debug_flags & 4) wm = 4;

@@ -110,6 +110,20 @@ if "mlp" in which:
         t = timeit(chain, iters=10)
         print(f"   flag {flag:4d}: {t / L * 1e6:8.1f} us per fc1+fc2 pair")
     _lib.lib().lafs_debug_set(0)
+TB = 25216
+SHAPES_B = [(TB, 2112, 768, _lib.EPI_BF16, "B qkv fwd"), (TB, 768, 704, _lib.EPI_RESID_F32, "B proj fwd"),
+            (TB, 2048, 768, _lib.EPI_BF16_GELU, "B fc1 fwd"), (TB, 768, 2048, _lib.EPI_RESID_F32, "B fc2 fwd"),
+            (TB, 2048, 768, _lib.EPI_DGELU_BF16, "B fc2 dgrad"), (TB, 768, 2048, _lib.EPI_BF16, "B fc1 dgrad"),
+            (TB, 704, 768, _lib.EPI_BF16, "B proj dgrad"), (TB, 768, 2112, _lib.EPI_BF16, "B qkv dgrad")]
+if "tilesb" in which:
+    print("--- ViT-B (fine-tune) NT tile variants: 0 = heuristic, 2 = 128x128 bk32, 4 = 256x128 bk32, 10 = 128x128 bk64, 12 = 256x128 bk64")
+    for flag in (0, 2, 4, 10, 12):
+        _lib.lib().lafs_debug_set(flag)
+        for M, N, K, e, n in SHAPES_B:
+            if (flag & 8) and K % 64:
+                continue
+            nt(M, N, K, e, f"{n} f{flag}")
+    _lib.lib().lafs_debug_set(0)
 if "tiles" in which:
     print("--- NT tile variants: flag 2 = 128x128 bk32, 4 = 256x128 bk32, 10 = 128x128 bk64, 12 = 256x128 bk64")
     for flag in (2, 4, 10, 12):
