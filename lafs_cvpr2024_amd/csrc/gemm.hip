@@ -234,12 +234,21 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
       tpos = m - b * p.npatch + 1;
       orow = (size_t)m + b + 1;                         // one cls row in front of every sequence
     }
+    // BF16_GELU writes two tensors: all pieces of u first, then all pieces of GELU(u), so that the 64-byte halves of a
+    // 128-byte line leave the CU back to back and merge into full-line writes (fc1 at C2: 150 -> ~125 us; debug flag 32768
+    // restores the piece-by-piece order for A/B runs)
+    constexpr int NPASS = (EPI == EPI_BF16_GELU) ? 2 : 1;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       const int n = ncol0 + q * 4 * VPL;
       if (n >= p.N) continue;
       const bool full = (n + VPL <= p.N);
       float* w = v + q * VPL;
+      const bool legacy = (p.dbg & 32768) != 0;
+      const bool do_first = legacy ? (pass == 0) : (pass == 0), do_second = legacy ? (pass == 0) : (pass == NPASS - 1);
+      if (legacy && pass > 0) continue;
       if (EPI == EPI_BF16_ACT) {                          // 1x1 convolution of the landmark CNN: + residual (bf16), activation
         if (p.aux != nullptr) {
           const bf16_t* ax = p.aux + (size_t)m * p.ldaux + n;
@@ -266,16 +275,20 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
           }
         }
         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
-        if (EPI == EPI_BF16_GELU && p.C == nullptr) {
-          // forward-only pass (teacher): the pre-activation is not needed, only GELU(u) is written
+        // experiment (debug flag 16384): u and GELU(u) interleaved in 64-byte pieces of ONE [M, 2N] buffer, so the two stores
+        // of a lane group complete a 128-byte line
+        if (EPI == EPI_BF16_GELU && (p.dbg & 16384)) c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc * 2 + (n >> 5) * 64 + (n & 31);
+        if (EPI == EPI_BF16_GELU && (p.C == nullptr || !do_first)) {
+          // forward-only pass (teacher): the pre-activation is not needed, only GELU(u) is written; second pass: already stored
         } else if (full) {
           st16(c, pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]), ntst);
         } else {
 #pragma unroll
           for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(w[e]);
         }
-        if (EPI == EPI_BF16_GELU && !(p.dbg & 64)) {
+        if (EPI == EPI_BF16_GELU && !(p.dbg & 64) && do_second) {
           bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n;
+          if (p.dbg & 16384) c2 = c + 32;
           if (full && (p.dbg & 128)) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
           } else if (p.drop.thresh) {

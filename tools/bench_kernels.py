@@ -124,6 +124,27 @@ if "tilesb" in which:
                 continue
             nt(M, N, K, e, f"{n} f{flag}")
     _lib.lib().lafs_debug_set(0)
+if "interleave" in which:
+    print("--- fc1: separate u / GELU(u) buffers vs 64-byte interleaved in one [M, 2N] buffer (flag 16384)")
+    A = torch.randn(T, 384, device=dev).to(bf); W1 = (torch.randn(1536, 384, device=dev) * .02).to(bf); b1 = torch.zeros(1536, device=dev)
+    L = 6
+    bufs = [torch.empty(T, 3072, device=dev, dtype=bf) for _ in range(L)]
+    def chain():
+        for l in range(L):
+            ops.gemm_nt(A, W1, _lib.EPI_BF16_GELU, bias=b1, out=bufs[l][:, :1536], out2=bufs[l][:, 1536:])
+    def chain_i():
+        for l in range(L):
+            ops.gemm_nt(A, W1, _lib.EPI_BF16_GELU, bias=b1, out=bufs[l].view(-1)[:T * 1536].view(T, 1536), out2=bufs[l].view(-1)[T * 1536:].view(T, 1536))
+    _lib.lib().lafs_debug_set(32768)
+    tl = timeit(chain_i, iters=10) / L
+    _lib.lib().lafs_debug_set(0)
+    print(f"   piece-by-piece order (flag 32768), two buffers: {tl*1e6:7.1f} us")
+    t0 = timeit(chain, iters=10) / L
+    t0b = timeit(chain_i, iters=10) / L
+    _lib.lib().lafs_debug_set(16384)
+    t1 = timeit(chain_i, iters=10) / L
+    _lib.lib().lafs_debug_set(0)
+    print(f"   halves of one [M,3072] row: {t0*1e6:7.1f} us | two [M,1536] buffers: {t0b*1e6:7.1f} us | 64-B interleaved: {t1*1e6:7.1f} us")
 if "tiles" in which:
     print("--- NT tile variants: flag 2 = 128x128 bk32, 4 = 256x128 bk32, 10 = 128x128 bk64, 12 = 256x128 bk64")
     for flag in (2, 4, 10, 12):
