@@ -215,9 +215,32 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
       if (n < p.N) bias[e] = p.bias[n];
     }
   }
+  // Operands the epilogue reads per output piece (the fp32 residual of RESID_F32, the pre-activation of DGELU_BF16) are
+  // fetched one ROW AHEAD of their use: resid may alias C, so the compiler cannot hoist these loads above the previous row's
+  // stores by itself, and a load -> use -> store chain per piece exposes a full memory round trip 8-16 times per tile.
+  constexpr bool PRE = (EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16);
+  uint4 pre[PRE ? NG : 1], cur[PRE ? NG : 1];
+  auto prefetch = [&](int i) {
+    if (!PRE || i >= 4) return;
+    const int mi = m0 + wr * 64 + i * 16 + frow;
+    if (mi >= p.M) return;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const int n = ncol0 + q * 4 * VPL;
+      if (n + VPL > p.N) continue;
+      if (EPI == EPI_RESID_F32) pre[q] = *reinterpret_cast<const uint4*>(p.resid + (size_t)mi * p.ldr + n);
+      else pre[q] = *reinterpret_cast<const uint4*>(p.aux + (size_t)mi * p.ldaux + n);
+    }
+  };
+  prefetch(0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wr * 64 + i * 16 + frow;
+    if (PRE) {
+#pragma unroll
+      for (int q = 0; q < NG; ++q) cur[q] = pre[q];
+      prefetch(i + 1);
+    }
     if (m >= p.M) continue;
     float v[16];
 #pragma unroll
@@ -262,7 +285,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
         if (EPI == EPI_DGELU_BF16) {
           const bf16_t* ax = p.aux + (size_t)m * p.ldaux + n;
           if (full) {
-            const uint4 a4 = *reinterpret_cast<const uint4*>(ax);
+            const uint4 a4 = cur[q];
             w[0] *= gelu_grad_f(bf_lo(a4.x)); w[1] *= gelu_grad_f(bf_hi(a4.x)); w[2] *= gelu_grad_f(bf_lo(a4.y)); w[3] *= gelu_grad_f(bf_hi(a4.y));
             w[4] *= gelu_grad_f(bf_lo(a4.z)); w[5] *= gelu_grad_f(bf_hi(a4.z)); w[6] *= gelu_grad_f(bf_lo(a4.w)); w[7] *= gelu_grad_f(bf_hi(a4.w));
           } else {
@@ -315,7 +338,8 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
             for (int e = 0; e < VPL; ++e) w[e] *= drop_mult(p.drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
           }
           if (full) {
-            const float4 r4 = *reinterpret_cast<const float4*>(rs);
+            const float4 r4 = make_float4(__uint_as_float(cur[q].x), __uint_as_float(cur[q].y), __uint_as_float(cur[q].z),
+                                          __uint_as_float(cur[q].w));
             w[0] = r4.x + sc * w[0]; w[1] = r4.y + sc * w[1]; w[2] = r4.z + sc * w[2]; w[3] = r4.w + sc * w[3];
           } else {
 #pragma unroll
