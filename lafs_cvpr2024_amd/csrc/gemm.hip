@@ -233,6 +233,14 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
     }
   };
   prefetch(0);
+  float scv[4] = {1.0f, 1.0f, 1.0f, 1.0f};              // DropPath scales of the 4 rows: two dependent loads each, issued together
+  if (EPI == EPI_RESID_F32 && p.seq_scale != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mi = m0 + wr * 64 + i * 16 + frow;
+      if (mi < p.M) scv[i] = p.seq_scale[p.row2seq[mi]];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wr * 64 + i * 16 + frow;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
     const bool ntst = (p.dbg & 256) != 0;              // streaming stores: A/B experiment only (no gain in a real layer chain)
     size_t orow = (size_t)m;
     int tpos = 0;
-    if (EPI == EPI_RESID_F32 && p.seq_scale != nullptr) sc = p.seq_scale[p.row2seq[m]];
+    if (EPI == EPI_RESID_F32) sc = scv[i];
     if (EPI == EPI_EMBED_F32) {
       const int b = m / p.npatch;
       tpos = m - b * p.npatch + 1;
