@@ -387,7 +387,7 @@ __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) 
 // Output tile (64*WM) x (64*WN), one 64x64 block of 4x4 MFMA tiles per wave.  Operands are staged as 128-column panels
 // (WM/2 panels of A, WN/2 of B per stage).  The product path uses 2x2 (see launch_tn for the measured comparison).
 template <int WM, int WN, int KB>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(TNArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_kernel(TNArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int PA = WM / 2, PB = WN / 2;
   constexpr int TN_BM = KB, TN_PANEL = KB * 256, NS = (KB == 32) ? 3 : 2;
@@ -456,16 +456,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(TNArgs p) {
 
   const int g = lane >> 4, pl = lane & 15;
   const int r0 = g * 8 + (pl >> 2), r1 = r0 + 4;
-  int offa0[4], offa1[4], offb0[4], offb1[4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    const int ua = (wm & 1) * 16 + x * 4 + (pl & 3), ub = (wn & 1) * 16 + x * 4 + (pl & 3);
-    const int pa = (wm >> 1) * TN_PANEL, pb = (PA + (wn >> 1)) * TN_PANEL;
-    offa0[x] = pa + r0 * 256 + ((ua ^ tn_f(r0)) << 3);
-    offa1[x] = pa + r1 * 256 + ((ua ^ tn_f(r1)) << 3);
-    offb0[x] = pb + r0 * 256 + ((ub ^ tn_f(r0)) << 3);
-    offb1[x] = pb + r1 * 256 + ((ub ^ tn_f(r1)) << 3);
-  }
+  // Fragment x (0..3) of a wave reads unit (base | x*4) ^ tn_f(row): the x field occupies its own two bits, so the offset of
+  // fragment x is the offset of fragment 0 XOR (x << 5) -- four base offsets instead of sixteen live registers.
+  const int ua = (wm & 1) * 16 + (pl & 3), ub = (wn & 1) * 16 + (pl & 3);
+  const int pa = (wm >> 1) * TN_PANEL, pb = (PA + (wn >> 1)) * TN_PANEL;
+  const int oa0 = r0 * 256 + ((ua ^ tn_f(r0)) << 3), oa1 = r1 * 256 + ((ua ^ tn_f(r1)) << 3);
+  const int ob0 = r0 * 256 + ((ub ^ tn_f(r0)) << 3), ob1 = r1 * 256 + ((ub ^ tn_f(r1)) << 3);
   if (nk > 0) issue(0);
   if (NS == 3 && nk > 1) issue(1);
   for (int t = 0; t < nk; ++t) {
@@ -489,8 +485,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_tn_kernel(TNArgs p) {
       bf16x8_t fa[4], fb[4];
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        s16x8_t va = __builtin_shufflevector(lds_read_tr16(sk + offa0[x]), lds_read_tr16(sk + offa1[x]), 0, 1, 2, 3, 4, 5, 6, 7);
-        s16x8_t vb = __builtin_shufflevector(lds_read_tr16(sk + offb0[x]), lds_read_tr16(sk + offb1[x]), 0, 1, 2, 3, 4, 5, 6, 7);
+        s16x8_t va = __builtin_shufflevector(lds_read_tr16(sk + pa + (oa0 ^ (x << 5))), lds_read_tr16(sk + pa + (oa1 ^ (x << 5))),
+                                             0, 1, 2, 3, 4, 5, 6, 7);
+        s16x8_t vb = __builtin_shufflevector(lds_read_tr16(sk + pb + (ob0 ^ (x << 5))), lds_read_tr16(sk + pb + (ob1 ^ (x << 5))),
+                                             0, 1, 2, 3, 4, 5, 6, 7);
         fa[x] = __builtin_bit_cast(bf16x8_t, va);
         fb[x] = __builtin_bit_cast(bf16x8_t, vb);
       }
