@@ -183,27 +183,31 @@ extern "C" int lafs_cnn_scale_act(void* x, const void* s, int lds_, int N, int H
 // ------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-template <int K>
+// Index arithmetic: planes are at most 56x56 and the divisors are run-time values, so quotients are taken with a float
+// reciprocal (exact for operands < 2^22 with the +0.5 bias) instead of the ~40-instruction integer division sequence.
+__device__ __forceinline__ int fdiv(int a, float inv_b) { return (int)(((float)a + 0.5f) * inv_b); }
+
+template <int K, int S>
 __global__ __launch_bounds__(256) void dw_nchw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, long total, int C,
-                                                          int H, int W, int stride, float* __restrict__ y) {
-  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+                                                          int H, int W, float* __restrict__ y) {
+  const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S, plane = Ho * Wo;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // flat (n, c, oy, ox): small planes still fill the workgroup
   if (idx >= total) return;
-  const int o = (int)(idx % (Ho * Wo));
-  const long nc = idx / (Ho * Wo);
-  const int c = (int)(nc % C);
-  const int oy = o / Wo, ox = o % Wo;
+  const int nc = (int)(idx / plane);                                 // (the flat index exceeds fdiv's exact range)
+  const int o = (int)(idx - (long)nc * plane);
+  const int c = nc - fdiv(nc, 1.0f / (float)C) * C;
+  const int oy = fdiv(o, 1.0f / (float)Wo), ox = o - oy * Wo;
   constexpr int P = (K - 1) / 2;
   const float* wk = w + (size_t)c * K * K;
   const float* xp = x + (size_t)nc * H * W;
   float acc = 0.f;
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
-    const int iy = oy * stride - P + ky;
+    const int iy = oy * S - P + ky;
     if (iy < 0 || iy >= H) continue;
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
-      const int ix = ox * stride - P + kx;
+      const int ix = ox * S - P + kx;
       if (ix < 0 || ix >= W) continue;
       acc = fmaf(xp[iy * W + ix], wk[ky * K + kx], acc);
     }
@@ -212,16 +216,16 @@ __global__ __launch_bounds__(256) void dw_nchw_fwd_kernel(const float* __restric
 }
 
 // dx[iy,ix] = sum_{ky,kx} dy[(iy+P-ky)/s, (ix+P-kx)/s] * w[ky,kx]   over the taps where the division is exact and in range
-template <int K>
+template <int K, int S>
 __global__ __launch_bounds__(256) void dw_nchw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w, long total,
-                                                               int C, int H, int W, int stride, float* __restrict__ dx) {
-  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+                                                               int C, int H, int W, float* __restrict__ dx) {
+  const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S, plane = H * W;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;            // flat (n, c, iy, ix)
   if (idx >= total) return;
-  const int i = (int)(idx % (H * W));
-  const long nc = idx / (H * W);
-  const int c = (int)(nc % C);
-  const int iy = i / W, ix = i % W;
+  const int nc = (int)(idx / plane);
+  const int i = (int)(idx - (long)nc * plane);
+  const int c = nc - fdiv(nc, 1.0f / (float)C) * C;
+  const int iy = fdiv(i, 1.0f / (float)W), ix = i - iy * W;
   constexpr int P = (K - 1) / 2;
   const float* wk = w + (size_t)c * K * K;
   const float* dp = dy + (size_t)nc * Ho * Wo;
@@ -229,14 +233,14 @@ __global__ __launch_bounds__(256) void dw_nchw_bwd_data_kernel(const float* __re
 #pragma unroll
   for (int ky = 0; ky < K; ++ky) {
     const int ty = iy + P - ky;
-    if (ty < 0 || (ty % stride) != 0) continue;
-    const int oy = ty / stride;
+    if (ty < 0 || (S == 2 && (ty & 1))) continue;
+    const int oy = ty / S;
     if (oy >= Ho) continue;
 #pragma unroll
     for (int kx = 0; kx < K; ++kx) {
       const int tx = ix + P - kx;
-      if (tx < 0 || (tx % stride) != 0) continue;
-      const int ox = tx / stride;
+      if (tx < 0 || (S == 2 && (tx & 1))) continue;
+      const int ox = tx / S;
       if (ox >= Wo) continue;
       acc = fmaf(dp[oy * Wo + ox], wk[ky * K + kx], acc);
     }
@@ -245,29 +249,30 @@ __global__ __launch_bounds__(256) void dw_nchw_bwd_data_kernel(const float* __re
 }
 
 // dw[c, ky, kx] += sum_{n in chunk, oy, ox} dy[n,c,oy,ox] * x[n,c,oy*s-P+ky, ox*s-P+kx];  grid (C, n_chunks)
-template <int K>
+template <int K, int S>
 __global__ __launch_bounds__(256) void dw_nchw_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int C,
-                                                                 int H, int W, int stride, int n_per_block, float* __restrict__ dw) {
+                                                                 int H, int W, int n_per_block, float* __restrict__ dw) {
   __shared__ float red[4][K * K];
-  const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const int Ho = (H + S - 1) / S, Wo = (W + S - 1) / S;
   const int c = blockIdx.x, n0 = blockIdx.y * n_per_block, n1 = min(N, n0 + n_per_block);
   constexpr int P = (K - 1) / 2;
   float acc[K * K];
 #pragma unroll
   for (int t = 0; t < K * K; ++t) acc[t] = 0.f;
   const int per_img = Ho * Wo, total = (n1 - n0) * per_img;
+  const float inv_img = 1.0f / (float)per_img, inv_wo = 1.0f / (float)Wo;
   for (int e = threadIdx.x; e < total; e += 256) {
-    const int n = n0 + e / per_img, o = e % per_img;
-    const int oy = o / Wo, ox = o % Wo;
+    const int dn = fdiv(e, inv_img), o = e - dn * per_img, n = n0 + dn;
+    const int oy = fdiv(o, inv_wo), ox = o - oy * Wo;
     const float g = dy[((size_t)n * C + c) * per_img + o];
     const float* xp = x + ((size_t)n * C + c) * H * W;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
-      const int iy = oy * stride - P + ky;
+      const int iy = oy * S - P + ky;
       if (iy < 0 || iy >= H) continue;
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
-        const int ix = ox * stride - P + kx;
+        const int ix = ox * S - P + kx;
         if (ix < 0 || ix >= W) continue;
         acc[ky * K + kx] = fmaf(g, xp[iy * W + ix], acc[ky * K + kx]);
       }
@@ -283,10 +288,19 @@ __global__ __launch_bounds__(256) void dw_nchw_bwd_weight_kernel(const float* __
   if (threadIdx.x < K * K) atomicAdd(dw + (size_t)c * K * K + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+#define DW_DISPATCH(KERNEL, ...)                                                              \
+  do {                                                                                        \
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((KERNEL<3, 1>), __VA_ARGS__);               \
+    else if (k == 3) hipLaunchKernelGGL((KERNEL<3, 2>), __VA_ARGS__);                         \
+    else if (stride == 1) hipLaunchKernelGGL((KERNEL<5, 1>), __VA_ARGS__);                    \
+    else hipLaunchKernelGGL((KERNEL<5, 2>), __VA_ARGS__);                                     \
+  } while (0)
+
 int dw_check(const void* a, const void* b, const void* c, int N, int C, int H, int W, int k, int stride) {
   LAFS_CHECK_ARG(a && b && c && N > 0 && C > 0 && H > 0 && W > 0, "bad operand");
   LAFS_CHECK_ARG((k == 3 || k == 5) && (stride == 1 || stride == 2), "k in {3,5}, stride in {1,2}");
   LAFS_CHECK_ARG(C <= 65535 && N <= 65535, "N and C must fit a grid dimension");
+  LAFS_CHECK_ARG((long)N * C * H * W < (1L << 31) && (long)N * C < (1L << 22) && H * W < (1 << 22), "tensor too large for the index arithmetic");
   return LAFS_OK;
 }
 
@@ -299,8 +313,7 @@ extern "C" int lafs_dwconv_nchw_fwd(const float* x, const float* w, int N, int C
   const int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
   const long total = (long)N * C * Ho * Wo;
   const dim3 grid(blocks_for(total));
-  if (k == 3) hipLaunchKernelGGL(dw_nchw_fwd_kernel<3>, grid, dim3(256), 0, stream, x, w, total, C, H, W, stride, y);
-  else hipLaunchKernelGGL(dw_nchw_fwd_kernel<5>, grid, dim3(256), 0, stream, x, w, total, C, H, W, stride, y);
+  DW_DISPATCH(dw_nchw_fwd_kernel, grid, dim3(256), 0, stream, x, w, total, C, H, W, y);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -311,8 +324,7 @@ extern "C" int lafs_dwconv_nchw_bwd_data(const float* dy, const float* w, int N,
   if (int rc = dw_check(dy, w, dx, N, C, H, W, k, stride)) return rc;
   const long total = (long)N * C * H * W;
   const dim3 grid(blocks_for(total));
-  if (k == 3) hipLaunchKernelGGL(dw_nchw_bwd_data_kernel<3>, grid, dim3(256), 0, stream, dy, w, total, C, H, W, stride, dx);
-  else hipLaunchKernelGGL(dw_nchw_bwd_data_kernel<5>, grid, dim3(256), 0, stream, dy, w, total, C, H, W, stride, dx);
+  DW_DISPATCH(dw_nchw_bwd_data_kernel, grid, dim3(256), 0, stream, dy, w, total, C, H, W, dx);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -322,12 +334,11 @@ extern "C" int lafs_dwconv_nchw_bwd_weight(const float* x, const float* dy, int 
   LAFS_CLEAR_ERROR();
   if (int rc = dw_check(x, dy, dw, N, C, H, W, k, stride)) return rc;
   const int Ho = (H + stride - 1) / stride;
-  int n_per_block = (8 * 56 * 56) / (Ho * Ho);                     // ~25k (image, pixel) pairs per workgroup
+  int n_per_block = 4096 / (Ho * Ho);                              // ~4k (image, pixel) pairs per workgroup: thousands of workgroups
   if (n_per_block < 1) n_per_block = 1;
   if (n_per_block > N) n_per_block = N;
   const dim3 grid(C, (N + n_per_block - 1) / n_per_block);
-  if (k == 3) hipLaunchKernelGGL(dw_nchw_bwd_weight_kernel<3>, grid, dim3(256), 0, stream, x, dy, N, C, H, W, stride, n_per_block, dw);
-  else hipLaunchKernelGGL(dw_nchw_bwd_weight_kernel<5>, grid, dim3(256), 0, stream, x, dy, N, C, H, W, stride, n_per_block, dw);
+  DW_DISPATCH(dw_nchw_bwd_weight_kernel, grid, dim3(256), 0, stream, x, dy, N, C, H, W, n_per_block, dw);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
