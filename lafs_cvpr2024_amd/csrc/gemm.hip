@@ -58,11 +58,9 @@ __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float 
   else *reinterpret_cast<f32x4v_t*>(p) = v;
 }
 
-constexpr int BM = 128, BN = 128;
+constexpr int BM = 128;
 constexpr int NT_BK = 32;                          // k-depth of one pipeline stage
 constexpr int NT_NS = 3;                           // LDS ring depth (stages in flight: NS-1)
-constexpr int NT_STAGE = (BM + BN) * NT_BK * 2;    // 16 KiB: A tile then B tile
-constexpr int TILE_BYTES = 128 * 64 * 2;           // TN kernel operand tile
 
 // LDS row -> weight row inside the 128-row tile.  MFMA row slot s = (rho & 15) of column-group j = (rho >> 4) & 3 ends
 // up in lane group g = s >> 2, register r = s & 3.  VPL = how many CONSECUTIVE output columns one lane should own so
@@ -73,7 +71,7 @@ template <int VPL>
 __device__ __forceinline__ int nt_perm(int rho) {
   const int j = (rho >> 4) & 3, g = (rho >> 2) & 3, r = rho & 3;
   if (VPL == 4) return rho;
-  return (rho & 64) + (j >> 1) * 32 + g * 8 + (j & 1) * 4 + r;
+  return (rho & ~63) + (j >> 1) * 32 + g * 8 + (j & 1) * 4 + r;       // bits >= 6: which 64-column wave slice (WN up to 4)
 }
 template <int EPI> struct EpiTraits {
   static constexpr bool f32_out = (EPI == LAFS_EPI_RESID_F32 || EPI == LAFS_EPI_F32 || EPI == LAFS_EPI_ATOMIC_F32 || EPI == LAFS_EPI_EMBED_F32);
@@ -100,9 +98,11 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
 // cache lines per row piece).
 template <int BK> __device__ __forceinline__ int nt_swzk(int row) { return BK == 32 ? nt_swz(row) : (row & 7); }
 
-template <int EPI, int WM, int BK>
-__global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2)) void gemm_nt_kernel(NTArgs p) {
-  constexpr int THREADS = WM * 128, BMT = WM * 64;
+// WN = wave columns: 2 -> 128-wide tiles (default), 4 -> 256-wide (256x256 with WM = 4: 16 waves, one workgroup per CU, half the
+// L2->LDS traffic of 128x128 per flop).
+template <int EPI, int WM, int BK, int WN = 2>
+__global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2))) void gemm_nt_kernel(NTArgs p) {
+  constexpr int THREADS = WM * WN * 64, BMT = WM * 64, BN = WN * 64;
   constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
   constexpr int ROWB = BK * 2;                        // bytes per LDS row
   constexpr int STAGE = (BMT + BN) * ROWB;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
   constexpr int NMAX = NA > NB ? NA : NB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
@@ -175,8 +175,7 @@ __global__ __launch_bounds__(WM * 128, (WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 3
     for (int t = 0; t < nk; ++t) {
       // stage t has landed once at most the NA+NB loads of stage t+1 are still in flight (loads retire in order)
       if (t + 1 < nk) {
-        if (NA + NB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -550,8 +549,19 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   // Shape heuristics from tools/bench_kernels.py on MI355X (ViT-S/B shapes):
   //  * wide outputs (N >= 1024) on many rows: 256x128 tiles (less L2->LDS traffic per flop, 16 resident waves/CU);
   //  * long reductions (K >= 640): 64-deep stages (full 128-byte lines per row piece) in a 2-stage ring, 128x128 tiles.
-  const int tn = ceil_div(a.N, BN);
+  const int tn = ceil_div(a.N, 128);
   const long t2 = (long)ceil_div(a.M, 128) * tn * splits, t4 = (long)ceil_div(a.M, 256) * tn * splits;
+  //  * 256x256 tiles (16 waves, one workgroup per CU, half the operand re-reads of 128x128) win 6-9 % on the isolated ViT-S
+  //    fc1 forward / GELU' dgrad (141 -> 128 us, 138 -> 129 us) but LOSE in the real step (21.3 -> 21.5 ms: a 16-wave
+  //    workgroup owns the CU while the weight-gradient stream wants to share it); kept behind debug flag 65536.
+  const bool wide256 = (g_debug_flags & 65536) != 0;
+  if (wide256 && splits == 1 &&
+      (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_DGELU_BF16)) {
+    const unsigned t44 = (unsigned)(ceil_div(a.M, 256) * ceil_div(a.N, 256));
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32, 4>), dim3(t44, 1, 1), dim3(1024), 0, s, a);
+    LAFS_LAUNCH_CHECK();
+    return LAFS_OK;
+  }
   bool bk64 = (a.klen % 64 == 0) && a.klen >= 640 && splits == 1;    // K = 704 / 768 (ViT-B) included: 5-15 % over 32-deep stages
   int wm = (!bk64 && a.N >= 1024 && a.M >= 4096) ? 4 : 2;
   if (g_debug_flags & 2) wm = 2;

@@ -145,6 +145,14 @@ if "interleave" in which:
     t1 = timeit(chain_i, iters=10) / L
     _lib.lib().lafs_debug_set(0)
     print(f"   halves of one [M,3072] row: {t0*1e6:7.1f} us | two [M,1536] buffers: {t0b*1e6:7.1f} us | 64-B interleaved: {t1*1e6:7.1f} us")
+if "nt256" in which:
+    print("--- NT 256x256 tiles (flag 65536) vs the heuristic choice, wide-output shapes")
+    wide = [x for x in SHAPES[:8] + SHAPES_B if x[1] >= 1024 and x[3] in (_lib.EPI_BF16, _lib.EPI_BF16_GELU, _lib.EPI_DGELU_BF16)]
+    for flag in (0, 65536):
+        _lib.lib().lafs_debug_set(flag)
+        for M, N, K, e, n in wide:
+            nt(M, N, K, e, f"{n} f{flag}")
+    _lib.lib().lafs_debug_set(0)
 if "tiles" in which:
     print("--- NT tile variants: flag 2 = 128x128 bk32, 4 = 256x128 bk32, 10 = 128x128 bk64, 12 = 256x128 bk64")
     for flag in (2, 4, 10, 12):
