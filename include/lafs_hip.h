@@ -317,6 +317,17 @@ int lafs_dwconv_nchw_bwd_data(const float* dy, const float* w, int N, int C, int
 int lafs_dwconv_nchw_bwd_weight(const float* x, const float* dy, int N, int C, int H, int W, int k, int stride, float* dw,
                                 hipStream_t stream);
 
+/* BatchNorm2d (+ activation LAFS_ACT_NONE / RELU / HSWISH) of the trainable landmark branch, fp32 NCHW
+ * (face_pre_pro/mobilenet.py:104-111,177-190).  x, y, dy, dx [N,C,HW]; stat f32 [2C] receives {mean, rstd} (saved for the
+ * backward); sums_ws / dsum f32 [2C] are scratch (dsum returns {dbeta, dgamma} = {sum dz, sum dz*xhat}).
+ * training = 1: batch statistics (biased variance) + running-statistics update with `momentum` (unbiased variance), exactly
+ * nn.BatchNorm2d.train(); training = 0: running statistics, the backward treats them as constants. */
+int lafs_bn_act_fwd_nchw(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float eps,
+                         float momentum, int training, int N, int C, int HW, int act, float* sums_ws, float* stat, float* y,
+                         hipStream_t stream);
+int lafs_bn_act_bwd_nchw(const float* x, const float* dy, const float* stat, const float* gamma, const float* beta, int training,
+                         int N, int C, int HW, int act, float* dsum, float* dx, hipStream_t stream);
+
 /* Landmark post-processing (face_pre_pro/ViT_face.py:1347-1378, 698-706): t f32 [B, 2*n_full] raw regressor output ->
  * theta f32 [B, n_out, 2] pixels:  theta = (t - min_b)/(max_b - min_b)*111  (+ noise_scale * noise[B, n_full, 2], the
  * N(0,1)*5 px jitter), landmark k of the output = landmark sel[b,k] of the input (random choice with replacement) or k

@@ -342,3 +342,163 @@ extern "C" int lafs_dwconv_nchw_bwd_weight(const float* x, const float* dy, int 
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// BatchNorm2d (+ ReLU / h-swish) of the trainable landmark branch, fp32 NCHW, training and eval mode, forward and backward
+// (face_pre_pro/mobilenet.py:104-111,177-190: Conv -> BatchNorm2d -> activation).  Replaces MIOpen BatchNorm + separate
+// activation kernels (2 + 2 passes per pair and direction) by one statistics pass + one apply pass.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float act_grad_f(float z, int act) {       // d act(z) / dz
+  if (act == 1) return z > 0.f ? 1.f : 0.f;
+  if (act == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) * (1.f / 6.f));
+  return 1.f;
+}
+
+// sums[c] += sum x, sums[C + c] += sum x^2 over the (n-chunk, HW) slab of channel c.   grid (C, n_chunks)
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int N, int C, int HW, int n_per_block,
+                                                       float* __restrict__ sums) {
+  __shared__ float red[2][4];
+  const int c = blockIdx.x, n0 = blockIdx.y * n_per_block, n1 = min(N, n0 + n_per_block);
+  float s = 0.f, q = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const float* xp = x + ((size_t)n * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) { const float v = xp[i]; s += v; q = fmaf(v, v, q); }
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(sums + c, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(sums + C + c, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// stat[c] = mean, stat[C + c] = rstd from the sums (training: also the running-statistics update) or from running stats (eval)
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, float eps, float momentum, int C, int training,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ stat) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  if (training) {
+    const float mean = sums[c] / count;
+    const float var = fmaxf(sums[C + c] / count - mean * mean, 0.f);
+    stat[c] = mean; stat[C + c] = rsqrtf(var + eps);
+    if (running_mean != nullptr) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+    }
+  } else {
+    stat[c] = running_mean[c]; stat[C + c] = rsqrtf(running_var[c] + eps);
+  }
+}
+
+// y = act((x - mean) * rstd * gamma + beta)
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, long total4, int C,
+                                                         int HW4, int act, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;                 // float4 index; HW % 4 == 0 planes only (else HW4 = HW, scalar)
+  if (i >= total4) return;
+  const int c = (int)((i / HW4) % C);
+  const float sc = stat[C + c] * gamma[c], sh = beta[c] - stat[c] * sc;
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  reinterpret_cast<float4*>(y)[i] = make_float4(act_f(fmaf(v.x, sc, sh), act), act_f(fmaf(v.y, sc, sh), act), act_f(fmaf(v.z, sc, sh), act),
+                                                act_f(fmaf(v.w, sc, sh), act));
+}
+__global__ __launch_bounds__(256) void bn_act_fwd_scalar_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, long total,
+                                                                int C, int HW, int act, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)((i / HW) % C);
+  const float sc = stat[C + c] * gamma[c], sh = beta[c] - stat[c] * sc;
+  y[i] = act_f(fmaf(x[i], sc, sh), act);
+}
+
+// dsum[c] += sum dz, dsum[C + c] += sum dz * xhat   with z = xhat*gamma + beta, dz = dy * act'(z)
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int N, int C, int HW, int n_per_block, int act,
+                                                                float* __restrict__ dsum) {
+  __shared__ float red[2][4];
+  const int c = blockIdx.x, n0 = blockIdx.y * n_per_block, n1 = min(N, n0 + n_per_block);
+  const float mean = stat[c], rstd = stat[C + c], g = gamma[c], b = beta[c];
+  float s = 0.f, q = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const size_t base = ((size_t)n * C + c) * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      const float xh = (x[base + i] - mean) * rstd;
+      const float dz = dy[base + i] * act_grad_f(fmaf(xh, g, b), act);
+      s += dz; q = fmaf(dz, xh, q);
+    }
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(dsum + c, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(dsum + C + c, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// training: dx = gamma*rstd*(dz - dsum/cnt - xhat*dsumx/cnt);  eval: dx = gamma*rstd*dz
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ dsum, float inv_count,
+                                                               long total, int C, int HW, int act, int training, float* __restrict__ dx) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)((i / HW) % C);
+  const float mean = stat[c], rstd = stat[C + c], g = gamma[c];
+  const float xh = (x[i] - mean) * rstd;
+  const float dz = dy[i] * act_grad_f(fmaf(xh, g, beta[c]), act);
+  float v = dz;
+  if (training) v -= (dsum[c] + xh * dsum[C + c]) * inv_count;
+  dx[i] = g * rstd * v;
+}
+
+inline int bn_chunk(int N, int HW) {                                   // ~8k elements per workgroup of the reduction kernels
+  int n = 8192 / (HW > 0 ? HW : 1);
+  if (n < 1) n = 1;
+  return n > N ? N : n;
+}
+
+}  // namespace
+
+extern "C" int lafs_bn_act_fwd_nchw(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    float eps, float momentum, int training, int N, int C, int HW, int act, float* sums_ws, float* stat,
+                                    float* y, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(x && gamma && beta && stat && y && N > 0 && C > 0 && HW > 0, "bad operand");
+  LAFS_CHECK_ARG(training ? (sums_ws != nullptr) : (running_mean && running_var), "training needs sums_ws, eval needs running statistics");
+  LAFS_CHECK_ARG(C <= 65535, "C must fit a grid dimension");
+  if (training) {
+    (void)hipMemsetAsync(sums_ws, 0, 2 * (size_t)C * sizeof(float), stream);
+    const int npb = bn_chunk(N, HW);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, (N + npb - 1) / npb), dim3(256), 0, stream, x, N, C, HW, npb, sums_ws);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, sums_ws, (float)N * (float)HW, eps, momentum, C, training,
+                     running_mean, running_var, stat);
+  const long total = (long)N * C * HW;
+  if (HW % 4 == 0)
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(blocks_for(total / 4)), dim3(256), 0, stream, x, stat, gamma, beta, total / 4, C, HW / 4, act, y);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_scalar_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, x, stat, gamma, beta, total, C, HW, act, y);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_bn_act_bwd_nchw(const float* x, const float* dy, const float* stat, const float* gamma, const float* beta, int training,
+                                    int N, int C, int HW, int act, float* dsum, float* dx, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(x && dy && stat && gamma && beta && dsum && dx && N > 0 && C > 0 && HW > 0 && C <= 65535, "bad operand");
+  (void)hipMemsetAsync(dsum, 0, 2 * (size_t)C * sizeof(float), stream);
+  const int npb = bn_chunk(N, HW);
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(C, (N + npb - 1) / npb), dim3(256), 0, stream, x, dy, stat, gamma, beta, N, C, HW, npb, act,
+                     dsum);
+  const long total = (long)N * C * HW;
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(blocks_for(total)), dim3(256), 0, stream, x, dy, stat, gamma, beta, dsum,
+                     1.0f / ((float)N * (float)HW), total, C, HW, act, training, dx);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}

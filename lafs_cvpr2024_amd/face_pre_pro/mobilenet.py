@@ -63,6 +63,53 @@ class DepthwiseConv2d(nn.Conv2d):
         return super().forward(x)
 
 
+class _BNActFn(torch.autograd.Function):
+    """BatchNorm2d (training or eval) + optional ReLU / h-swish, forward and backward, on the fused HIP kernels (fp32 NCHW).
+    Running statistics are updated in place by the forward kernel exactly as nn.BatchNorm2d does (num_batches_tracked by the
+    caller)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, training, act):
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        dev = x.device
+        stat = torch.empty(2 * C, device=dev, dtype=torch.float32)
+        ws = torch.empty(2 * C, device=dev, dtype=torch.float32) if training else None
+        y = torch.empty_like(x)
+        call("lafs_bn_act_fwd_nchw", _p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), float(momentum),
+             1 if training else 0, N, C, H * W, act, _p(ws), _p(stat), _p(y))
+        ctx.save_for_backward(x, gamma, beta, stat)
+        ctx.training, ctx.act = training, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stat = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dsum = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        call("lafs_bn_act_bwd_nchw", _p(x), _p(dy.contiguous()), _p(stat), _p(gamma), _p(beta), 1 if ctx.training else 0, N, C, H * W,
+             ctx.act, _p(dsum), _p(dx))
+        return dx, dsum[C:], dsum[:C], None, None, None, None, None, None
+
+
+_ACT_CODE = {nn.ReLU: _lib.ACT_RELU, nn.Hardswish: _lib.ACT_HSWISH, nn.Identity: _lib.ACT_NONE, type(None): _lib.ACT_NONE}
+
+
+def bn_act(x, bn, act=None):
+    """act(bn(x)) for a BatchNorm2d module and a ReLU / Hardswish / None: ONE statistics pass + ONE apply pass on fp32 device
+    tensors (MIOpen BatchNorm + a separate activation kernel otherwise); stock modules for anything else."""
+    fused = (x.is_cuda and x.dtype == torch.float32 and bn.weight.dtype == torch.float32 and type(act) in _ACT_CODE
+             and bn.track_running_stats and bn.affine and os.environ.get("LAFS_BN_STOCK") != "1")
+    if not fused:
+        y = bn(x)
+        return act(y) if act is not None else y
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BNActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, bn.training, _ACT_CODE[type(act)])
+
+
 def _act(kind):
     return nn.ReLU(inplace=True) if kind == "RE" else nn.Hardswish(inplace=True)      # hswish = x*relu6(x+3)/6
 
@@ -89,8 +136,23 @@ class _InvertedResidual(nn.Module):
             nn.Conv2d(cexp, cout, 1, bias=False), nn.BatchNorm2d(cout))
 
     def forward(self, x):
-        y = self.conv(x)
+        c = self.conv                                      # same modules / state_dict keys as the reference's nn.Sequential
+        y = bn_act(c[0](x), c[1], c[2])
+        y = c[3](y)
+        if isinstance(c[5], nn.Identity):
+            y = bn_act(y, c[4], c[6])
+        else:                                              # squeeze-excite sits between the BatchNorm and the activation
+            y = c[6](c[5](bn_act(y, c[4])))
+        y = bn_act(c[7](y), c[8])
         return x + y if self.residual else y
+
+
+class _Stem(nn.Sequential):
+    def __init__(self):
+        super().__init__(nn.Conv2d(3, 16, 3, 2, 1, bias=False), nn.BatchNorm2d(16), nn.Hardswish(inplace=True))
+
+    def forward(self, x):
+        return bn_act(self[0](x), self[1], self[2])
 
 
 class MobileNetV3_backbone(nn.Module):
@@ -98,7 +160,7 @@ class MobileNetV3_backbone(nn.Module):
         super().__init__()
         if mode != 'large' or width_mult != 1.0:
             raise NotImplementedError("the landmark CNN is MobileNetV3-large at width 1.0")
-        layers = [nn.Sequential(nn.Conv2d(3, 16, 3, 2, 1, bias=False), nn.BatchNorm2d(16), nn.Hardswish(inplace=True))]
+        layers = [_Stem()]
         cin = 16
         for k, cexp, cout, se, nl, s in _LARGE:
             layers.append(_InvertedResidual(cin, cout, k, s, cexp, bool(se), nl))

@@ -192,3 +192,35 @@ def test_invalid_arguments_fail_loudly():
     with pytest.raises(_lib.LafsHipError, match="drop_p"):
         ops.gemm_nt(torch.zeros(64, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(128, 64, device=DEV, dtype=torch.bfloat16),
                     _lib.EPI_RESID_F32, resid=torch.zeros(64, 128, device=DEV), drop_p=1.5)
+
+
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("act_name,H", [("relu", 14), ("hswish", 7), ("none", 4), ("hswish", 56)])
+def test_fused_batchnorm_activation_matches_torch(training, act_name, H):
+    """bn_act (fused BatchNorm2d + activation, fp32 NCHW) vs nn.BatchNorm2d followed by the activation module: output,
+    running statistics, and the three gradients, in training and eval mode (7x7 planes exercise the non-float4 path)."""
+    import copy
+    from lafs_cvpr2024_amd.face_pre_pro.mobilenet import bn_act
+    torch.manual_seed(H)
+    N, C = 6, 24
+    bn = torch.nn.BatchNorm2d(C).to("cuda")
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    ref_bn = copy.deepcopy(bn)
+    act = {"relu": torch.nn.ReLU(), "hswish": torch.nn.Hardswish(), "none": None}[act_name]
+    bn.train(training); ref_bn.train(training)
+    x = (torch.randn(N, C, H, H, device="cuda") * 2 + 0.5).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = bn_act(x, bn, act)
+    yr = ref_bn(xr)
+    yr = act(yr) if act is not None else yr
+    torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bn.running_mean, ref_bn.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn.running_var, ref_bn.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+    gy = torch.randn_like(y)
+    y.backward(gy); yr.backward(gy)
+    scale = float(xr.grad.abs().max())
+    assert float((x.grad - xr.grad).abs().max()) < 2e-4 * max(scale, 1.0)
+    torch.testing.assert_close(bn.weight.grad, ref_bn.weight.grad, rtol=1e-3, atol=2e-3)
+    torch.testing.assert_close(bn.bias.grad, ref_bn.bias.grad, rtol=1e-3, atol=2e-3)
