@@ -362,9 +362,12 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   __shared__ float red[2][4];
   const int c = blockIdx.x, n0 = blockIdx.y * n_per_block, n1 = min(N, n0 + n_per_block);
   float s = 0.f, q = 0.f;
-  for (int n = n0; n < n1; ++n) {
-    const float* xp = x + ((size_t)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += 256) { const float v = xp[i]; s += v; q = fmaf(v, v, q); }
+  const float inv_hw = 1.0f / (float)HW;
+  const int total = (n1 - n0) * HW;                                  // flat (image, pixel): small planes keep all lanes busy
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int dn = fdiv(e, inv_hw), i = e - dn * HW;
+    const float v = x[((size_t)(n0 + dn) * C + c) * HW + i];
+    s += v; q = fmaf(v, v, q);
   }
   s = wave_sum(s); q = wave_sum(q);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
@@ -397,9 +400,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, float count, 
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stat,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, long total4, int C,
                                                          int HW4, int act, float* __restrict__ y) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;                 // float4 index; HW % 4 == 0 planes only (else HW4 = HW, scalar)
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;                  // float4 index (< 2^32: checked by the launcher); 32-bit division
   if (i >= total4) return;
-  const int c = (int)((i / HW4) % C);
+  const int c = (int)((i / (unsigned)HW4) % (unsigned)C);
   const float sc = stat[C + c] * gamma[c], sh = beta[c] - stat[c] * sc;
   const float4 v = reinterpret_cast<const float4*>(x)[i];
   reinterpret_cast<float4*>(y)[i] = make_float4(act_f(fmaf(v.x, sc, sh), act), act_f(fmaf(v.y, sc, sh), act), act_f(fmaf(v.z, sc, sh), act),
@@ -408,9 +411,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void bn_act_fwd_scalar_kernel(const float* __restrict__ x, const float* __restrict__ stat,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, long total,
                                                                 int C, int HW, int act, float* __restrict__ y) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)((i / HW) % C);
+  const int c = (int)((i / (unsigned)HW) % (unsigned)C);
   const float sc = stat[C + c] * gamma[c], sh = beta[c] - stat[c] * sc;
   y[i] = act_f(fmaf(x[i], sc, sh), act);
 }
@@ -424,13 +427,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(const float* __r
   const int c = blockIdx.x, n0 = blockIdx.y * n_per_block, n1 = min(N, n0 + n_per_block);
   const float mean = stat[c], rstd = stat[C + c], g = gamma[c], b = beta[c];
   float s = 0.f, q = 0.f;
-  for (int n = n0; n < n1; ++n) {
-    const size_t base = ((size_t)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-      const float xh = (x[base + i] - mean) * rstd;
-      const float dz = dy[base + i] * act_grad_f(fmaf(xh, g, b), act);
-      s += dz; q = fmaf(dz, xh, q);
-    }
+  const float inv_hw = 1.0f / (float)HW;
+  const int total = (n1 - n0) * HW;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int dn = fdiv(e, inv_hw), i = e - dn * HW;
+    const size_t at = ((size_t)(n0 + dn) * C + c) * HW + i;
+    const float xh = (x[at] - mean) * rstd;
+    const float dz = dy[at] * act_grad_f(fmaf(xh, g, b), act);
+    s += dz; q = fmaf(dz, xh, q);
   }
   s = wave_sum(s); q = wave_sum(q);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
@@ -446,9 +450,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
                                                                const float* __restrict__ stat, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const float* __restrict__ dsum, float inv_count,
                                                                long total, int C, int HW, int act, int training, float* __restrict__ dx) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
-  const int c = (int)((i / HW) % C);
+  const int c = (int)((i / (unsigned)HW) % (unsigned)C);
   const float mean = stat[c], rstd = stat[C + c], g = gamma[c];
   const float xh = (x[i] - mean) * rstd;
   const float dz = dy[i] * act_grad_f(fmaf(xh, g, beta[c]), act);
@@ -471,7 +475,7 @@ extern "C" int lafs_bn_act_fwd_nchw(const float* x, const float* gamma, const fl
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && gamma && beta && stat && y && N > 0 && C > 0 && HW > 0, "bad operand");
   LAFS_CHECK_ARG(training ? (sums_ws != nullptr) : (running_mean && running_var), "training needs sums_ws, eval needs running statistics");
-  LAFS_CHECK_ARG(C <= 65535, "C must fit a grid dimension");
+  LAFS_CHECK_ARG(C <= 65535 && (long)N * C * HW < (1L << 32), "tensor too large for the 32-bit index arithmetic");
   if (training) {
     (void)hipMemsetAsync(sums_ws, 0, 2 * (size_t)C * sizeof(float), stream);
     const int npb = bn_chunk(N, HW);
@@ -492,6 +496,7 @@ extern "C" int lafs_bn_act_bwd_nchw(const float* x, const float* dy, const float
                                     int N, int C, int HW, int act, float* dsum, float* dx, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && dy && stat && gamma && beta && dsum && dx && N > 0 && C > 0 && HW > 0 && C <= 65535, "bad operand");
+  LAFS_CHECK_ARG((long)N * C * HW < (1L << 32), "tensor too large for the 32-bit index arithmetic");
   (void)hipMemsetAsync(dsum, 0, 2 * (size_t)C * sizeof(float), stream);
   const int npb = bn_chunk(N, HW);
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(C, (N + npb - 1) / npb), dim3(256), 0, stream, x, dy, stat, gamma, beta, N, C, HW, npb, act,

@@ -97,10 +97,12 @@ _ACT_CODE = {nn.ReLU: _lib.ACT_RELU, nn.Hardswish: _lib.ACT_HSWISH, nn.Identity:
 
 
 def bn_act(x, bn, act=None):
-    """act(bn(x)) for a BatchNorm2d module and a ReLU / Hardswish / None: ONE statistics pass + ONE apply pass on fp32 device
-    tensors (MIOpen BatchNorm + a separate activation kernel otherwise); stock modules for anything else."""
-    fused = (x.is_cuda and x.dtype == torch.float32 and bn.weight.dtype == torch.float32 and type(act) in _ACT_CODE
-             and bn.track_running_stats and bn.affine and os.environ.get("LAFS_BN_STOCK") != "1")
+    """act(bn(x)) for a BatchNorm2d module and a ReLU / Hardswish / None.  Default: the stock modules (MIOpen's BatchNorm is
+    already bandwidth-efficient: the fused HIP path -- one statistics pass + one apply pass, `lafs_bn_act_*_nchw` -- measured
+    0.9 ms SLOWER per fine-tune step, 37.6 vs 36.7 ms).  LAFS_BN_FUSED=1 selects the fused kernels (kept correct by
+    tests/test_gpu_kernels.py) for fp32 device tensors."""
+    fused = (os.environ.get("LAFS_BN_FUSED") == "1" and x.is_cuda and x.dtype == torch.float32 and bn.weight.dtype == torch.float32
+             and type(act) in _ACT_CODE and bn.track_running_stats and bn.affine)
     if not fused:
         y = bn(x)
         return act(y) if act is not None else y

@@ -196,11 +196,12 @@ def test_invalid_arguments_fail_loudly():
 
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("act_name,H", [("relu", 14), ("hswish", 7), ("none", 4), ("hswish", 56)])
-def test_fused_batchnorm_activation_matches_torch(training, act_name, H):
+def test_fused_batchnorm_activation_matches_torch(training, act_name, H, monkeypatch):
     """bn_act (fused BatchNorm2d + activation, fp32 NCHW) vs nn.BatchNorm2d followed by the activation module: output,
     running statistics, and the three gradients, in training and eval mode (7x7 planes exercise the non-float4 path)."""
     import copy
     from lafs_cvpr2024_amd.face_pre_pro.mobilenet import bn_act
+    monkeypatch.setenv("LAFS_BN_FUSED", "1")               # opt-in path (the default keeps MIOpen's BatchNorm: it is faster)
     torch.manual_seed(H)
     N, C = 6, 24
     bn = torch.nn.BatchNorm2d(C).to("cuda")
