@@ -78,3 +78,36 @@ def test_partial_fc_shard_range_and_sampling():
     # sample_rate 1: identity
     index3, y3 = sample_classes(labels, start, n_local, n_local, g)
     assert torch.equal(index3, torch.arange(n_local)) and torch.equal(y3[own].long(), labels[own] - start)
+
+
+def test_f15_checkpoint_layout_matches_reference_at_full_scale():
+    """state_dict names AND shapes of the real configurations (ViT-S/8 + DINOHead(100000) student/teacher, DINOLoss, the
+    with_land=True ViT-B fine-tune backbone with CosFace, the landmark CNN) equal the reference's: a checkpoint written by one
+    side loads strictly on the other (lafs_train.py:451-460, train_largescale.py:639-661)."""
+    import json
+    import numpy as np
+    import os
+    from lafs_cvpr2024_amd import vision_transformer as vits
+    from lafs_cvpr2024_amd.dino_loss import DINOLoss
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8, face_landmark_4simmin_glo_loc
+    from lafs_cvpr2024_amd.utils import MultiCropWrapper
+    path = os.path.join(os.path.dirname(__file__), "golden", "f15_checkpoint_manifests.npz")
+    ref = json.loads(str(np.load(path, allow_pickle=False)["manifest"]))
+    man = lambda m: {k: list(v.shape) for k, v in m.state_dict().items()}
+    mine = {
+        "student": man(MultiCropWrapper(vits.vit_small(patch_size=8, drop_path_rate=0.1),
+                                        vits.DINOHead(384, 100000, use_bn=False, norm_last_layer=True))),
+        "teacher": man(MultiCropWrapper(vits.vit_small(patch_size=8), vits.DINOHead(384, 100000, False))),
+        "dino_loss": man(DINOLoss(100000, 10, 0.07, 0.04, 30, 41)),
+        "finetune_backbone": man(ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=1000, image_size=112,
+                                                          patch_size=8, dim=768, depth=12, heads=11, mlp_dim=2048, dropout=0.1,
+                                                          emb_dropout=0.1, with_land=True)),
+        "landmark_cnn": man(face_landmark_4simmin_glo_loc(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8,
+                                                          dim=768, depth=12, heads=11, mlp_dim=2048)),
+    }
+    for name in ref:
+        missing = sorted(set(ref[name]) - set(mine[name]))
+        extra = sorted(set(mine[name]) - set(ref[name]))
+        assert not missing and not extra, (name, missing[:5], extra[:5])
+        bad = {k: (mine[name][k], v) for k, v in ref[name].items() if mine[name][k] != v}
+        assert not bad, (name, dict(list(bad.items())[:5]))

@@ -344,6 +344,23 @@ def main():
     assert len(rec) == 1 + 3 * 2, len(rec)
     save("f14_partfvit_dropout", x=x14, w=w14, e=e14, p=np.float32(0.1),
          **{f"keep{i}": k.to(torch.uint8) for i, k in enumerate(rec)}, **sd(pd_), **grads(pd_))
+    # ---------------------------------------------------------------- F15 checkpoint layout at full scale (keys + shapes only)
+    # What lafs_train.py saves (:451-460) and train_largescale.py loads (:639-661): the state_dict manifests of the real
+    # configurations, so that the drop-in's checkpoint compatibility is pinned on names AND shapes.
+    print("F15 checkpoint manifests")
+    torch.manual_seed(15)
+    man = lambda m: {k: list(v.shape) for k, v in m.state_dict().items()}
+    vs = ref_vit.__dict__["vit_small"](patch_size=8, drop_path_rate=0.1)
+    stu = ref_utils.MultiCropWrapper(vs, ref_vit.DINOHead(384, 100000, use_bn=False, norm_last_layer=True))
+    tea = ref_utils.MultiCropWrapper(ref_vit.__dict__["vit_small"](patch_size=8), ref_vit.DINOHead(384, 100000, False))
+    dl = ref_lafs.DINOLoss(100000, 10, 0.07, 0.04, 30, 41)
+    ft = ref_face.ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=1000, image_size=112, patch_size=8, dim=768,
+                                           depth=12, heads=11, mlp_dim=2048, dropout=0.1, emb_dropout=0.1, with_land=True)
+    lm = ref_face.face_landmark_4simmin_glo_loc(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=768,
+                                                depth=12, heads=11, mlp_dim=2048)
+    import json as _json
+    save("f15_checkpoint_manifests", manifest=np.array(_json.dumps({
+        "student": man(stu), "teacher": man(tea), "dino_loss": man(dl), "finetune_backbone": man(ft), "landmark_cnn": man(lm)})))
     print("done")
 
 
