@@ -328,6 +328,14 @@ int lafs_bn_act_fwd_nchw(const float* x, const float* gamma, const float* beta, 
 int lafs_bn_act_bwd_nchw(const float* x, const float* dy, const float* stat, const float* gamma, const float* beta, int training,
                          int N, int C, int HW, int act, float* dsum, float* dx, hipStream_t stream);
 
+/* View augmentation of the loader (DataAugmentation_LAFS, lafs_train.py:790-886; Pillow arithmetic, bit-exact):
+ * images u8 NCHW [B,3,112,112]; params i32 [B,K,20] records (lafs_cvpr2024_amd/augment.py pack_params: crop box, flags
+ * {flip, jitter, gray, solarize}, ColorJitter order + factors, hue shift, box-blur radius/weights); table i32 [113,112,8] =
+ * Pillow's bicubic resampling coefficients for every source extent (augment.py coeff_table).
+ * views f32 [2K,B,3,112,112]: view 2k = normalised resized crop (+flip) of crop k, view 2k+1 = its colour-augmented twin. */
+int lafs_augment_views(const uint8_t* images, const int32_t* params, const int32_t* table, int B, int K, float* views,
+                       hipStream_t stream);
+
 /* Landmark post-processing (face_pre_pro/ViT_face.py:1347-1378, 698-706): t f32 [B, 2*n_full] raw regressor output ->
  * theta f32 [B, n_out, 2] pixels:  theta = (t - min_b)/(max_b - min_b)*111  (+ noise_scale * noise[B, n_full, 2], the
  * N(0,1)*5 px jitter), landmark k of the output = landmark sel[b,k] of the input (random choice with replacement) or k

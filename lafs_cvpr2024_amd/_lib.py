@@ -97,6 +97,7 @@ _PROTOS = {
     "lafs_dwconv_nchw_bwd_weight": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lafs_bn_act_fwd_nchw": [vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, i32, i32, vp, vp, vp],
     "lafs_bn_act_bwd_nchw": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+    "lafs_augment_views": [vp, vp, vp, i32, i32, vp],
     "lafs_landmark_theta": [vp, i32, i32, vp, f32, vp, i32, vp],
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],
