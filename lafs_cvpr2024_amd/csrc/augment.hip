@@ -7,6 +7,10 @@
 #include "common.hpp"
 #include "lafs_hip.h"
 
+// Pillow's results depend on every float operation being rounded on its own: no fused multiply-add anywhere in this file
+// (hipcc contracts a*b+c by default, and HIP's __fmul_rn / __fadd_rn are plain operators that contract as well).
+#pragma STDC FP_CONTRACT OFF
+
 namespace {
 
 constexpr int S = 112, NPIX = S * S, NBYTE = NPIX * 3;
@@ -19,7 +23,9 @@ __device__ __forceinline__ int luma(int r, int g, int b) { return (r * 19595 + g
 
 // Image.blend(degenerate d, image v, alpha) (Blend.c): float arithmetic WITHOUT contraction, truncation, clip when extrapolating
 __device__ __forceinline__ int blend(int d, int v, float a, bool interp) {
-  const float t = __fadd_rn((float)d, __fmul_rn(a, (float)(v - d)));
+#pragma clang fp contract(off)
+  const float prod = a * (float)(v - d);              // two separately rounded operations (plain operators under contract(off);
+  const float t = (float)d + prod;                    // HIP's __fmul_rn/__fadd_rn are inlined WITH contraction allowed)
   if (interp) return (int)t;
   if (t <= 0.0f) return 0;
   if (t >= 255.0f) return 255;
@@ -27,14 +33,15 @@ __device__ __forceinline__ int blend(int d, int v, float a, bool interp) {
 }
 
 __device__ void rgb2hsv(int r, int g, int b, int& uh, int& us, int& uv) {          // Convert.c rgb2hsv_row
+#pragma clang fp contract(off)
   const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
   uv = maxc;
   if (minc == maxc) { uh = 0; us = 0; return; }
   const float cr = (float)(maxc - minc);
-  const float s = __fdiv_rn(cr, (float)maxc);
-  const float rc = __fdiv_rn((float)(maxc - r), cr), gc = __fdiv_rn((float)(maxc - g), cr), bc = __fdiv_rn((float)(maxc - b), cr);
+  const float s = cr / (float)maxc;
+  const float rc = (float)(maxc - r) / cr, gc = (float)(maxc - g) / cr, bc = (float)(maxc - b) / cr;
   float h;
-  if (r == maxc) h = __fsub_rn(bc, gc);
+  if (r == maxc) h = bc - gc;
   else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
   else h = (float)(4.0 + (double)gc - (double)rc);
   h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
@@ -43,14 +50,19 @@ __device__ void rgb2hsv(int r, int g, int b, int& uh, int& us, int& uv) {       
 }
 
 __device__ void hsv2rgb(int h, int s, int v, int& r, int& g, int& b) {               // Convert.c hsv2rgb
+#pragma clang fp contract(off)
   if (s == 0) { r = g = b = v; return; }
   const double fh = (double)h * 6.0 / 255.0;
   const int i = (int)floor(fh);
   const float f = (float)(fh - (double)i);
-  const float fs = __fdiv_rn((float)s, 255.0f), vf = (float)v;
-  const int p = clip8((int)rint((double)__fmul_rn(vf, __fsub_rn(1.0f, fs))));
-  const int q = clip8((int)rint((double)__fmul_rn(vf, __fsub_rn(1.0f, __fmul_rn(fs, f)))));
-  const int t = clip8((int)rint((double)__fmul_rn(vf, __fsub_rn(1.0f, __fmul_rn(fs, __fsub_rn(1.0f, f))))));
+  const float fs = (float)s / 255.0f, vf = (float)v;
+  const float one_fs = 1.0f - fs;
+  const float fsf = fs * f, one_fsf = 1.0f - fsf;
+  const float omf = 1.0f - f, fsomf = fs * omf, one_fsomf = 1.0f - fsomf;
+  const float pf = vf * one_fs, qf = vf * one_fsf, tf = vf * one_fsomf;
+  const int p = clip8((int)rint((double)pf));
+  const int q = clip8((int)rint((double)qf));
+  const int t = clip8((int)rint((double)tf));
   switch (i % 6) {
     case 0: r = v; g = t; b = p; break;
     case 1: r = q; g = v; b = p; break;
@@ -62,7 +74,10 @@ __device__ void hsv2rgb(int h, int s, int v, int& r, int& g, int& b) {          
 }
 
 __device__ __forceinline__ float norm_px(int v) {                                    // ToTensor + Normalize(0.5, 0.5)
-  return __fdiv_rn(__fsub_rn(__fdiv_rn((float)v, 255.0f), 0.5f), 0.5f);
+#pragma clang fp contract(off)
+  const float x = (float)v / 255.0f;
+  const float y = x - 0.5f;
+  return y / 0.5f;
 }
 
 __device__ void write_view(const unsigned char* img, float* __restrict__ out) {      // HWC uint8 in LDS -> CHW float in HBM

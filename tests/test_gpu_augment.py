@@ -45,6 +45,24 @@ def test_device_augmenter_matches_oracle_bit_for_bit():
     assert worst == 0.0
 
 
+def test_device_augmenter_sampled_parameters_bit_exact():
+    """A full loader batch with SAMPLED parameters (8 images x 10 crops = 160 views): still zero differing bytes."""
+    from lafs_cvpr2024_amd import augment as aug
+    from oracle import augment as A
+    B, nl = 8, 8
+    rng = np.random.RandomState(3)
+    imgs = _images(B - 2, 1) + [rng.randint(0, 256, (112, 112, 3)).astype(np.uint8), np.full((112, 112, 3), 255, np.uint8)]
+    da = aug.DeviceAugmenter(B, n_local=nl, device="cuda", seed=11)
+    params = da.sample()
+    x = torch.from_numpy(np.stack(imgs).transpose(0, 3, 1, 2).copy()).cuda()
+    views = da(x, params).cpu().numpy()
+    bad = 0
+    for b in range(B):
+        for v, r in enumerate(A.make_views(imgs[b], params[b])):
+            bad += int((views[v, b] != r).sum())
+    assert bad == 0
+
+
 def test_resampling_table_matches_oracle():
     from lafs_cvpr2024_amd import augment as aug
     from oracle import augment as A
