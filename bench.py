@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
     ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--augment", action="store_true",
+                    help="with --frontend: also run the device-side DataAugmentation_LAFS (uint8 batch -> 20 views) every step")
     ap.add_argument("--frontend", action="store_true",
                     help="include the landmark front-end (frozen MobileNetV3 on 10*B views + theta + gathers) in every step, "
                          "software-pipelined on its own stream; default off = landmark crops resident in HBM (the headline metric)")
@@ -162,6 +164,12 @@ def main():
         fe = LandmarkFrontEnd(cnn, B, n_local=nl, device=device, cnn_impl="hip" if impl == "hip" else "torch",
                               cnn_dtype=torch.bfloat16 if impl == "torch_bf16" else torch.float32)
         views = torch.randn(2 * (2 + nl), B, 3, 112, 112, device=device, generator=g).clamp_(-1, 1)
+        augm, u8 = None, None
+        if args.augment:
+            from lafs_cvpr2024_amd.augment import DeviceAugmenter
+            augm = DeviceAugmenter(B, n_local=nl, device=device, seed=rank)
+            u8 = torch.randint(0, 256, (B, 3, 112, 112), device=device, dtype=torch.uint8, generator=g)
+            views = augm(u8)
         fe.prefetch(views)
 
     niter = 1000
@@ -174,10 +182,11 @@ def main():
     def one(it):
         if fe is None:
             return eng.step(lr=float(lr_s[it]), wd=float(wd_s[it]), momentum=float(mom_s[it]), teacher_temp=tt, epoch=epoch)
+        nxt = augm(u8) if augm is not None else views            # next batch: uint8 images -> 20 views (one launch)
         ev = torch.cuda.current_stream().record_event()          # "next batch's views are ready"
         fe.commit(eng)
         loss = eng.step(lr=float(lr_s[it]), wd=float(wd_s[it]), momentum=float(mom_s[it]), teacher_temp=tt, epoch=epoch)
-        fe.prefetch(views, produced=ev)                          # front-end of the next batch overlaps this step
+        fe.prefetch(nxt, produced=ev)                            # front-end of the next batch overlaps this step
         return loss
 
     it0 = epoch * niter
@@ -211,7 +220,7 @@ def main():
             "config": {"workload": f"{args.arch}/8 LAFS pretrain step, 2 global 112x112 + {nl} local 48x48 crops, "
                                    f"batch {B}/GPU, out_dim {K}, drop_path 0.1, dp{world}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
-                       "landmark_frontend_in_step": bool(args.frontend)},
+                       "landmark_frontend_in_step": bool(args.frontend), "device_augmentation_in_step": bool(args.augment)},
             "images_per_s": round(world * B / (ms * 1e-3), 1),
             "step_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
             "step_mfma_frac": round(fl / (ms * 1e-3) / 2.5e15, 4),

@@ -61,7 +61,9 @@ def get_args_parser():
     p.add_argument('--local_crops_number', type=int, default=8)
     p.add_argument('--data', default='synthetic', type=str,
                    help="'synthetic': random landmark-crop shaped tensors; 'synthetic_views': the 20 augmented 112x112 views of "
-                        "DataAugmentation_LAFS (clean/augmented pairs) pushed through the landmark front-end")
+                        "DataAugmentation_LAFS (clean/augmented pairs) pushed through the landmark front-end; "
+                        "'synthetic_u8': uint8 112x112 images, augmented ON THE DEVICE (augment.DeviceAugmenter, Pillow-exact) into "
+                        "the 20 views, then the landmark front-end -- the whole input pipeline of the reference on the GPU")
     p.add_argument('--landmark_ckpt', '--landmark_path', dest='landmark_ckpt', default='', type=str,
                    help="state_dict of the frozen landmark CNN (reference --landmark_path, :112, :262-268)")
     # flags of the reference's PIL / recordio input pipeline: parsed for command-line compatibility, unused with synthetic data
@@ -113,6 +115,25 @@ class SyntheticViews:
             yield torch.randn(2 * (2 + self.n_local), self.batch, 3, 112, 112, device=self.device, generator=self.gen).clamp_(-1, 1), None
 
 
+class SyntheticU8Views:
+    """uint8 images [B,3,112,112] (what the recordio reader yields after decoding, lafs_train.py:176) -> 20 views through the
+    device-side DataAugmentation_LAFS."""
+
+    def __init__(self, steps, batch, n_local, device, seed):
+        from .augment import DeviceAugmenter
+        self.steps, self.batch, self.device = steps, batch, device
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.aug = DeviceAugmenter(batch, n_local=n_local, device=device, seed=seed)
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            u8 = torch.randint(0, 256, (self.batch, 3, 112, 112), device=self.device, dtype=torch.uint8, generator=self.gen)
+            yield self.aug(u8), None
+
+
 def build_landmark_frontend(args, device):
     """Frozen landmark CNN (reference lafs_train.py:241-269: face_landmark_4simmin_glo_loc, eval mode) + the fused front-end."""
     from .face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
@@ -153,9 +174,9 @@ def train_lafs(args, dataset=None):
     frontend = None
     if dataset is not None:
         data_loader = dataset
-    elif args.data == 'synthetic_views':
-        data_loader = SyntheticViews(args.steps_per_epoch, args.batch_size_per_gpu, args.local_crops_number, device,
-                                     args.seed + utils.get_rank())
+    elif args.data in ('synthetic_views', 'synthetic_u8'):
+        cls = SyntheticViews if args.data == 'synthetic_views' else SyntheticU8Views
+        data_loader = cls(args.steps_per_epoch, args.batch_size_per_gpu, args.local_crops_number, device, args.seed + utils.get_rank())
         frontend = build_landmark_frontend(args, device)
     else:
         data_loader = SyntheticCrops(args.steps_per_epoch, args.batch_size_per_gpu, args.local_crops_number, device,
