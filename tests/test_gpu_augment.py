@@ -63,6 +63,33 @@ def test_device_augmenter_sampled_parameters_bit_exact():
     assert bad == 0
 
 
+def test_vectorised_sampler_records_bit_exact_and_distributed():
+    """sample_packed (the per-step host path): its records drive the kernel to the same bytes as the oracle fed with the decoded
+    parameters, and the draws follow the loader's distributions."""
+    from lafs_cvpr2024_amd import augment as aug
+    from lafs_cvpr2024_amd.ops import _p, call
+    from oracle import augment as A
+    B, nl = 4, 8
+    rng = np.random.RandomState(21)
+    rec, dicts = aug.sample_packed(rng, B, nl, return_dicts=True)
+    imgs = _images(B, 2)
+    da = aug.DeviceAugmenter(B, n_local=nl, device="cuda", seed=0)
+    x = torch.from_numpy(np.stack(imgs).transpose(0, 3, 1, 2).copy()).cuda()
+    da.params_dev.copy_(torch.from_numpy(rec))
+    call("lafs_augment_views", _p(x), _p(da.params_dev), _p(da.table), B, 2 + nl, _p(da.views))
+    views = da.views.cpu().numpy()
+    bad = sum(int((views[v, b] != r).sum()) for b in range(B) for v, r in enumerate(A.make_views(imgs[b], dicts[b])))
+    assert bad == 0
+    r = np.concatenate([aug.sample_packed(rng, 64, 8).reshape(-1, aug.P_WORDS) for _ in range(10)])
+    assert ((r[:, 0] + r[:, 2]) <= 112).all() and ((r[:, 1] + r[:, 3]) <= 112).all() and (r[:, 2:4] > 0).all()
+    area = r[:, 2] * r[:, 3] / 112.0 ** 2
+    assert 0.38 < area.min() and 0.6 < area.mean() < 0.8
+    assert abs((r[:, 4] & 1).mean() - 0.5) < 0.03 and abs(((r[:, 4] >> 1) & 1).mean() - 0.8) < 0.03 and abs(((r[:, 4] >> 2) & 1).mean() - 0.2) < 0.03
+    k = np.tile(np.arange(10), len(r) // 10)
+    assert r[k == 0, 13].mean() > 0.99 and abs(r[k == 1, 13].mean() - 0.1) < 0.05 and abs(r[k >= 2, 13].mean() - 0.5) < 0.03
+    assert abs(((r[k == 1, 4] >> 3) & 1).mean() - 0.2) < 0.06 and ((r[k != 1, 4] >> 3) & 1).sum() == 0
+
+
 def test_resampling_table_matches_oracle():
     from lafs_cvpr2024_amd import augment as aug
     from oracle import augment as A
