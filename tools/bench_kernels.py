@@ -157,10 +157,11 @@ if "augment" in which:
     from lafs_cvpr2024_amd.augment import DeviceAugmenter
     da = DeviceAugmenter(64, n_local=8, device=dev, seed=0)
     u8 = torch.randint(0, 256, (64, 3, 112, 112), device=dev, dtype=torch.uint8)
-    params = da.sample()
-    t = timeit(lambda: da(u8, params), iters=10)
-    print(f"--- device augmentation: 64 images -> 1280 views: {t*1e6:8.1f} us per batch (incl. {64*10*20*4} B parameter upload), "
-          f"{1280/t/1e6:.2f} M views/s")
+    t = timeit(lambda: da(u8), iters=20)                     # vectorised host sampling + parameter upload + one launch
+    from lafs_cvpr2024_amd.ops import _p, call
+    tk = timeit(lambda: call("lafs_augment_views", _p(u8), _p(da.params_dev), _p(da.table), 64, 10, _p(da.views)), iters=20)
+    print(f"--- device augmentation: 64 images -> 1280 views: {t*1e6:8.1f} us per batch end to end, kernel alone {tk*1e6:8.1f} us "
+          f"({1280/tk/1e6:.2f} M views/s)")
 if "tiles" in which:
     print("--- NT tile variants: flag 2 = 128x128 bk32, 4 = 256x128 bk32, 10 = 128x128 bk64, 12 = 256x128 bk64")
     for flag in (2, 4, 10, 12):
