@@ -102,13 +102,13 @@ __device__ void box_pass(const unsigned char* src, unsigned char* dst, int radiu
   }
 }
 
-__global__ __launch_bounds__(256) void augment_kernel(const unsigned char* __restrict__ images, const int* __restrict__ params,
+__global__ __launch_bounds__(1024) void augment_kernel(const unsigned char* __restrict__ images, const int* __restrict__ params,
                                                       const int* __restrict__ table, int B, int K, float* __restrict__ views) {
   extern __shared__ unsigned char lds[];
   unsigned char* bufA = lds;
   unsigned char* bufB = lds + NBYTE;
   unsigned char* tmp = lds + 2 * NBYTE;
-  __shared__ int red[4];
+  __shared__ int red[16];
   __shared__ int pr[PW];
   const int b = blockIdx.x / K, k = blockIdx.x % K;
   if (threadIdx.x < PW) pr[threadIdx.x] = params[((size_t)b * K + k) * PW + threadIdx.x];
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void augment_kernel(const unsigned char* __res
   }
   __syncthreads();
   write_view(bufA, views + ((size_t)(2 * k) * B + b) * NBYTE);
+  __syncthreads();                                           // the colour operations below rewrite bufA in place
 
   // ---- ColorJitter in its sampled order ----
   if (flags & 2) {
@@ -174,7 +175,9 @@ __global__ __launch_bounds__(256) void augment_kernel(const unsigned char* __res
           part = (int)wave_sum((float)part);                 // exact: partial sums < 2^24
           if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
           __syncthreads();
-          mean = (int)((double)(red[0] + red[1] + red[2] + red[3]) / (double)NPIX + 0.5);
+          int tot = 0;
+          for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) tot += red[wv];
+          mean = (int)((double)tot / (double)NPIX + 0.5);
           __syncthreads();
         }
         for (int p = threadIdx.x; p < NPIX; p += blockDim.x) {
@@ -228,7 +231,8 @@ extern "C" int lafs_augment_views(const uint8_t* images, const int32_t* params, 
     if (e != hipSuccess) { lafs_set_error("lafs_augment_views: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
     configured = true;
   }
-  hipLaunchKernelGGL(augment_kernel, dim3(B * K), dim3(256), lds, stream, images, params, table, B, K, views);
+  // one workgroup per CU (3 x 37 KB of LDS): 16 waves each to keep the CU busy
+  hipLaunchKernelGGL(augment_kernel, dim3(B * K), dim3(1024), lds, stream, images, params, table, B, K, views);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
