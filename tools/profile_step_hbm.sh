@@ -4,9 +4,22 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/stephbm; mkdir -p $O; cd /tmp; export TMPDIR=/tmp; export LAFS_SINGLE_STREAM=1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o f --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $O/f.json 2> $O/f.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o w --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $O/w.json 2> $O/w.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/m -o m --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $O/m.json 2> $O/m.err
 python3 - <<PY
 import csv, glob, json
 out = {}
+# MFMA pipe occupancy of one step: SQ_VALU_MFMA_BUSY_CYCLES counts 16 cycles per v_mfma_f32_16x16x32_bf16 on its SIMD
+f = glob.glob("$O/m/**/*counter_collection.csv", recursive=True)[0]
+rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"]
+rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+marks = [i for i, r in enumerate(rows) if "clip_adamw_ema" in r["Kernel_Name"]]
+step = rows[marks[-2] + 1:marks[-1] + 1]
+busy = sum(float(r["Counter_Value"]) for r in step)
+dur_ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)
+out["mfma_busy_cycles_per_step"] = busy
+out["kernel_time_ms_per_step_serialised"] = dur_ns / 1e6
+out["mfma_pipe_busy_frac"] = busy / (dur_ns * 1e-9 * 2.4e9 * 1024)      # 256 CUs x 4 SIMDs at 2.4 GHz
+out["mfma_flops_per_step_from_counter"] = busy / 16.0 * 16384
 for tag, ctr in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
     f = glob.glob("$O/%s/**/*counter_collection.csv" % tag, recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
