@@ -63,7 +63,9 @@ def get_args_parser():
                    help="'synthetic': random landmark-crop shaped tensors; 'synthetic_views': the 20 augmented 112x112 views of "
                         "DataAugmentation_LAFS (clean/augmented pairs) pushed through the landmark front-end; "
                         "'synthetic_u8': uint8 112x112 images, augmented ON THE DEVICE (augment.DeviceAugmenter, Pillow-exact) into "
-                        "the 20 views, then the landmark front-end -- the whole input pipeline of the reference on the GPU")
+                        "the 20 views, then the landmark front-end -- the whole input pipeline of the reference on the GPU; "
+                        "'recordio': the same from --data_path/train.rec (MXNet RecordIO, InsightFace layout; JPEG decode on "
+                        "--num_workers CPU workers, everything after it on the device)")
     p.add_argument('--landmark_ckpt', '--landmark_path', dest='landmark_ckpt', default='', type=str,
                    help="state_dict of the frozen landmark CNN (reference --landmark_path, :112, :262-268)")
     # flags of the reference's PIL / recordio input pipeline: parsed for command-line compatibility, unused with synthetic data
@@ -134,6 +136,32 @@ class SyntheticU8Views:
             yield self.aug(u8), None
 
 
+class RecordIOViews:
+    """--data_path/train.rec (reference lafs_train.py:157-191: FaceDataset over MXNet recordio + DataLoader) -> decoded uint8
+    batches -> device-side DataAugmentation_LAFS.  One pass over the dataset per epoch, sharded over the ranks."""
+
+    def __init__(self, path, batch, n_local, device, seed, num_workers, rank=0, world=1):
+        from .augment import DeviceAugmenter
+        from .recordio import FaceRecordDataset
+        self.ds = FaceRecordDataset(os.path.join(path, 'train.rec'))
+        if world > 1:                                        # DistributedSampler-style strided shard
+            self.ds.seq = self.ds.seq[rank::world]
+        self.batch, self.device, self.seed, self.workers = batch, device, seed, num_workers
+        self.aug = DeviceAugmenter(batch, n_local=n_local, device=device, seed=seed)
+        self.epoch = 0
+        print(f"Data loaded: there are {len(self.ds)} images.")
+
+    def __len__(self):
+        return len(self.ds) // self.batch
+
+    def __iter__(self):
+        from .recordio import device_batches
+        self.epoch += 1
+        for u8, _ in device_batches(self.ds, self.batch, self.device, num_workers=self.workers, shuffle=True,
+                                    seed=self.seed + self.epoch):
+            yield self.aug(u8), None
+
+
 def build_landmark_frontend(args, device):
     """Frozen landmark CNN (reference lafs_train.py:241-269: face_landmark_4simmin_glo_loc, eval mode) + the fused front-end."""
     from .face_pre_pro.ViT_face import face_landmark_4simmin_glo_loc
@@ -174,6 +202,10 @@ def train_lafs(args, dataset=None):
     frontend = None
     if dataset is not None:
         data_loader = dataset
+    elif args.data == 'recordio':
+        data_loader = RecordIOViews(args.data_path, args.batch_size_per_gpu, args.local_crops_number, device,
+                                    args.seed + utils.get_rank(), args.num_workers, utils.get_rank(), world)
+        frontend = build_landmark_frontend(args, device)
     elif args.data in ('synthetic_views', 'synthetic_u8'):
         cls = SyntheticViews if args.data == 'synthetic_views' else SyntheticU8Views
         data_loader = cls(args.steps_per_epoch, args.batch_size_per_gpu, args.local_crops_number, device, args.seed + utils.get_rank())
