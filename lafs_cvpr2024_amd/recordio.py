@@ -17,6 +17,7 @@ of which holds the [first, last) range of its images) and yields (uint8 HWC RGB 
 augment.DeviceAugmenter -- the rest of the reference's loader (PIL transforms in 6 workers) runs on the GPU here.
 """
 import io
+import os
 import struct
 from collections import namedtuple
 
@@ -89,15 +90,17 @@ class IndexedRecordIO:
                 k, off = line.strip().split("\t")
                 self.idx[int(k)] = int(off)
                 self.keys.append(int(k))
-        self._f = None
+        self._f, self._pid = None, None
 
-    def _file(self):                                           # opened lazily: one handle per DataLoader worker process
-        if self._f is None:
-            self._f = open(self.rec_path, "rb")
+    def _file(self):
+        # One handle per PROCESS: DataLoader workers are forked after the parent has already read the headers, and a file
+        # description shared across processes would interleave their seek/read pairs.
+        if self._f is None or self._pid != os.getpid():
+            self._f, self._pid = open(self.rec_path, "rb"), os.getpid()
         return self._f
 
     def __getstate__(self):
-        d = dict(self.__dict__); d["_f"] = None
+        d = dict(self.__dict__); d["_f"], d["_pid"] = None, None
         return d
 
     def read_idx(self, key):

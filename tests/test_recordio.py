@@ -70,6 +70,20 @@ def test_payload_containing_the_magic_word_is_split_and_rejoined(tmp_path):
         assert struct.unpack("<I", f.read(4))[0] == R.MAGIC
 
 
+def test_forked_loader_workers_do_not_share_the_file_offset(tmp_path):
+    """The parent reads the identity headers before the DataLoader forks its workers: each process must get its own handle."""
+    torch = pytest.importorskip("torch")
+    rec, imgs, labels = _build(tmp_path, n_ids=4, per_id=(6, 6, 6, 6))
+    ds = R.FaceRecordDataset(rec)
+    seen = 0
+    for _ in range(3):
+        for x, y in R.device_batches(ds, 4, "cpu", num_workers=3, shuffle=False):
+            for b in range(x.shape[0]):
+                assert np.array_equal(x[b].permute(1, 2, 0).numpy(), imgs[seen % len(imgs)]) and int(y[b]) == labels[seen % len(imgs)]
+                seen += 1
+    assert seen == 3 * len(imgs)
+
+
 def test_device_batches_on_cpu(tmp_path):
     torch = pytest.importorskip("torch")
     rec, imgs, labels = _build(tmp_path)
