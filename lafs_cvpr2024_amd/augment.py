@@ -206,7 +206,8 @@ class DeviceAugmenter:
         self.table = torch.from_numpy(coeff_table()).to(self.device)
         self.views = torch.empty(2 * self.K, batch_size, 3, OUT, OUT, device=self.device, dtype=torch.float32)
         self.params_dev = torch.empty(batch_size, self.K, P_WORDS, device=self.device, dtype=torch.int32)
-        self.params_host = torch.empty(batch_size, self.K, P_WORDS, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else None
+        from .utils import PinnedRing
+        self.params_ring = PinnedRing((batch_size, self.K, P_WORDS), torch.int32)      # see PinnedRing: the host runs ahead
 
     def sample(self):
         return [sample_view_params(self.rng, self.K - 2) for _ in range(self.B)]
@@ -216,7 +217,6 @@ class DeviceAugmenter:
         if images_u8.dtype != torch.uint8 or not images_u8.is_cuda or tuple(images_u8.shape) != (self.B, 3, OUT, OUT):
             raise _lib.LafsHipError("DeviceAugmenter expects a uint8 device tensor [B,3,112,112]")
         rec = pack_params(params) if params is not None else sample_packed(self.rng, self.B, self.K - 2)
-        self.params_host.copy_(torch.from_numpy(rec))
-        self.params_dev.copy_(self.params_host, non_blocking=True)
+        self.params_ring.upload(self.params_dev, lambda buf: buf.copy_(torch.from_numpy(rec)))
         call("lafs_augment_views", _p(images_u8.contiguous()), _p(self.params_dev), _p(self.table), self.B, self.K, _p(self.views))
         return self.views

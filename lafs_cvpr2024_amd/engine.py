@@ -20,6 +20,7 @@ from . import _lib, functional as Fn, ops
 from .arena import ParamArena
 from .distributed import FlatReducer
 from .ops import _p, call
+from .utils import PinnedRing
 from .vision_transformer import VisionTransformer, attach_arena, _is_matrix_for_dgrad
 
 f32, bf16 = torch.float32, torch.bfloat16
@@ -79,9 +80,9 @@ class LafsPretrainEngine:
         # static buffers
         dev = self.device
         self.hyper = torch.zeros(_lib.HP_COUNT, device=dev, dtype=f32)
-        self.hyper_host = torch.zeros(_lib.HP_COUNT, dtype=f32).pin_memory()
-        self.temps = torch.zeros(2, device=dev, dtype=f32)
-        self.temps_host = torch.zeros(2, dtype=f32).pin_memory()
+        self.hyper_ring = PinnedRing((_lib.HP_COUNT,), f32)   # the host runs steps ahead of the GPU: never reuse a pinned
+        self.temps = torch.zeros(2, device=dev, dtype=f32)    # staging buffer whose copy may still be pending
+        self.temps_ring = PinnedRing((2,), f32)
         self.logits_s = torch.zeros(self.ncrops * B, self.Kpad, device=dev, dtype=f32)
         self.logits_t = torch.zeros(2 * B, self.Kpad, device=dev, dtype=f32)
         self.dlogits = torch.zeros(self.ncrops * B, self.Kpad, device=dev, dtype=bf16)
@@ -200,19 +201,22 @@ class LafsPretrainEngine:
         """One optimisation step.  Returns the device scalar loss (no host sync)."""
         if crops is not None:
             self.set_inputs(crops)
-        h = self.hyper_host
-        h[_lib.HP_LR], h[_lib.HP_WD], h[_lib.HP_BETA1], h[_lib.HP_BETA2], h[_lib.HP_EPS] = lr, wd, beta1, beta2, eps
-        h[_lib.HP_CLIP], h[_lib.HP_EMA_M] = self.clip_grad, momentum
-        h[_lib.HP_FREEZE_LAST] = 1.0 if epoch < self.freeze_last_layer else 0.0
-        h[_lib.HP_GRAD_SCALE] = 1.0 / self.world            # DDP mean of the summed gradients
-        self.hyper.copy_(h, non_blocking=True)
-        self.temps_host[0], self.temps_host[1] = float(self.dino_loss.student_temp), teacher_temp
-        self.temps.copy_(self.temps_host, non_blocking=True)
+        def fill_hyper(h):
+            h[_lib.HP_LR], h[_lib.HP_WD], h[_lib.HP_BETA1], h[_lib.HP_BETA2], h[_lib.HP_EPS] = lr, wd, beta1, beta2, eps
+            h[_lib.HP_CLIP], h[_lib.HP_EMA_M] = self.clip_grad, momentum
+            h[_lib.HP_FREEZE_LAST] = 1.0 if epoch < self.freeze_last_layer else 0.0
+            h[_lib.HP_GRAD_SCALE] = 1.0 / self.world        # DDP mean of the summed gradients
+
+        def fill_temps(t):
+            t[0], t[1] = float(self.dino_loss.student_temp), teacher_temp
+
+        self.hyper_ring.upload(self.hyper, fill_hyper)
+        self.temps_ring.upload(self.temps, fill_temps)
         if self.use_graph and self._graphs is None:
             saved = self._snapshot()
             self._capture()
             self._restore(saved)
-            self.hyper.copy_(h, non_blocking=True)
+            self.hyper_ring.upload(self.hyper, fill_hyper)
         run = (lambda i, f: self._graphs[i].replay()) if self.use_graph else (lambda i, f: f())
         run(0, self._seg_forward)
         # head gradients + center sums go out over RCCL while the trunk backward runs; each half of the trunk follows as

@@ -276,3 +276,31 @@ class MetricLogger:
             end = time.time()
         total = time.time() - start
         print("{} Total time: {} ({:.6f} s / it)".format(header, str(datetime.timedelta(seconds=int(total))), total / max(n, 1)))
+
+
+# --------------------------------------------------------------------------------------------- host -> device staging
+class PinnedRing:
+    """Pinned staging buffers for small per-step host -> device uploads (hyper-parameters, augmentation records).
+
+    An asynchronous copy from ONE reused pinned buffer races with the host: the training loop runs many steps ahead of the GPU,
+    so the host would overwrite the buffer before an earlier step's copy has executed (that step would then see a later step's
+    learning rate / freeze flag / crop boxes).  Each upload takes the next of `depth` buffers and blocks only if the copy issued
+    `depth` uploads ago has still not run -- which also bounds how far the host can run ahead."""
+
+    def __init__(self, shape, dtype, depth=8):
+        self.bufs = [torch.zeros(shape, dtype=dtype).pin_memory() for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def upload(self, dst, fill):
+        """fill(host_buffer) writes the values; they are then copied to the device tensor `dst` on the current stream."""
+        k = self.i
+        self.i = (k + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        fill(self.bufs[k])
+        dst.copy_(self.bufs[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return self.bufs[k]

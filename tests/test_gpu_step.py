@@ -140,3 +140,21 @@ def test_c1_config_vit_tiny_step_matches_oracle(nl):
     assert float((c - st.center.view(-1)).abs().max()) < 2e-3 * float(ref["teacher_out"].abs().max())
     errs = torch.cat([(teacher.state_dict()[k].cpu() - v).abs().flatten() for k, v in st.teacher.items()])
     assert float(errs.median()) < 1e-5 and float(errs.max()) < 5e-4 * 0.004 * 50      # EMA moves by (1-m)*|delta| <= 0.004*lr-ish
+
+
+def test_pinned_ring_uploads_survive_a_host_that_runs_ahead():
+    """Per-step host->device uploads (hyper-parameters, augmentation records) while the GPU is far behind the host: every
+    upload must deliver ITS values (a single reused pinned buffer would hand later steps' values to earlier steps)."""
+    from lafs_cvpr2024_amd.utils import PinnedRing
+    a = torch.randn(8192, 8192, device=DEV)
+    ring = PinnedRing((4,), torch.float32, depth=4)
+    dst = torch.zeros(4, device=DEV)
+    out = torch.zeros(24, 4, device=DEV)
+    for _ in range(6):                                   # ~tens of ms of queued GPU work ahead of the uploads
+        a = a @ a * 1e-4
+    for i in range(24):
+        ring.upload(dst, lambda b, i=i: b.fill_(float(i)))
+        out[i].copy_(dst)
+        a = a @ a * 1e-4                                 # keep the queue deep between uploads
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), torch.arange(24.0).view(-1, 1).expand(24, 4))
