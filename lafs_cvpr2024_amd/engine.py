@@ -40,7 +40,7 @@ def _interp_matrix(grid_src, grid_dst, device):
 
 class LafsPretrainEngine:
     def __init__(self, student, teacher, dino_loss, batch_size, n_local=8, global_size=112, local_size=48,
-                 clip_grad=3.0, freeze_last_layer=1, use_graph=True, device=None, grad_slices=2):
+                 clip_grad=3.0, freeze_last_layer=1, use_graph=True, device=None, grad_slices=4):
         self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
         self.student, self.teacher, self.dino_loss = student, teacher, dino_loss
         self.B, self.n_local, self.ncrops = batch_size, n_local, 2 + n_local
@@ -98,8 +98,12 @@ class LafsPretrainEngine:
         self.depth = vit_s.depth
         # the trunk backward is cut in two graph segments so that the upper blocks' gradients are already on the wire
         # (RCCL) while the lower blocks are still being computed
-        self.mid = self.depth // 2 if grad_slices > 1 else 0
-        self.mid_start = self.sa.offsets[f"{self.spec_s.prefix}blocks.{self.mid}.norm1.weight"] if self.mid > 0 else 0
+        # the trunk backward is cut into `grad_slices` graph segments (blocks depth-1 .. 0 in equal runs) so that each run's
+        # gradients are already on the wire (RCCL) while the next run is computed; only the last run's all-reduce is exposed
+        ns = max(1, min(int(grad_slices), self.depth))
+        self.cuts = [self.depth - (self.depth * k) // ns for k in range(ns + 1)]            # e.g. depth 12, 4 slices: 12 9 6 3 0
+        off = lambda blk: self.sa.offsets[f"{self.spec_s.prefix}blocks.{blk}.norm1.weight"] if blk > 0 else 0
+        self.cut_offsets = [off(c) for c in self.cuts[1:]]                                   # arena offset where each run starts
         self.reducer = FlatReducer()
         # teacher forward / weight-gradient GEMMs run on a second stream; LAFS_SINGLE_STREAM=1 serialises everything (profiling)
         self.side_stream = None if os.environ.get("LAFS_SINGLE_STREAM") == "1" else torch.cuda.Stream(device=self.device)
@@ -143,24 +147,22 @@ class LafsPretrainEngine:
         dfeat = Fn.head_backward(sa, self.head_prefix_s, st_h, self.dlogits, train_g=train_g)
         self._st = dict(vit=st_v, dfeat=dfeat)
 
-    def _seg_trunk_backward_hi(self):
-        """Upper half of the trunk (final norm + blocks depth-1 .. mid)."""
-        self._st["g"] = Fn.vit_backward_begin(self.sa, self.spec_s, self._st["vit"], self._st["dfeat"])
-        Fn.vit_backward_layers(self._st["vit"], self._st["g"], self.depth, self.mid, wgrad_stream=self.side_stream)
-
-    def _seg_trunk_backward_lo(self):
-        """Lower half (blocks mid-1 .. 0), patch embedding, position table."""
+    def _seg_trunk_backward(self, k):
+        """Run k of the trunk backward: blocks cuts[k]-1 .. cuts[k+1]; run 0 starts with the final norm, the last run ends with
+        the patch embedding and the position table."""
         sa = self.sa
-        if self.mid > 0:
-            Fn.vit_backward_layers(self._st["vit"], self._st["g"], self.mid, 0, wgrad_stream=self.side_stream)
-        dpos = Fn.vit_backward_end(sa, self.spec_s, self._st["vit"], self._st["g"])
-        gpe = sa.view(sa.grad, self.spec_s.prefix + "pos_embed").view(-1, self.spec_s.trunk.dim)
-        for M, dp in zip(self.interp, dpos):
-            if M is None:
-                gpe += dp
-            else:
-                gpe[:1] += dp[:1]
-                gpe[1:] += M.t() @ dp[1:]
+        if k == 0:
+            self._st["g"] = Fn.vit_backward_begin(sa, self.spec_s, self._st["vit"], self._st["dfeat"])
+        Fn.vit_backward_layers(self._st["vit"], self._st["g"], self.cuts[k], self.cuts[k + 1], wgrad_stream=self.side_stream)
+        if k == len(self.cuts) - 2:
+            dpos = Fn.vit_backward_end(sa, self.spec_s, self._st["vit"], self._st["g"])
+            gpe = sa.view(sa.grad, self.spec_s.prefix + "pos_embed").view(-1, self.spec_s.trunk.dim)
+            for M, dp in zip(self.interp, dpos):
+                if M is None:
+                    gpe += dp
+                else:
+                    gpe[:1] += dp[:1]
+                    gpe[1:] += M.t() @ dp[1:]
 
     def _seg_update(self):
         sa, ta = self.sa, self.ta
@@ -174,8 +176,12 @@ class LafsPretrainEngine:
         sa.refresh_transposed()
 
     # ------------------------------------------------------------------ step
+    def _segments(self):
+        runs = [(lambda k=k: self._seg_trunk_backward(k)) for k in range(len(self.cuts) - 1)]
+        return [self._seg_forward] + runs + [self._seg_update]
+
     def _capture(self):
-        segs = [self._seg_forward, self._seg_trunk_backward_hi, self._seg_trunk_backward_lo, self._seg_update]
+        segs = self._segments()
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                       # warm-up outside capture (lazy inits, caches)
@@ -217,19 +223,21 @@ class LafsPretrainEngine:
             self._capture()
             self._restore(saved)
             self.hyper_ring.upload(self.hyper, fill_hyper)
-        run = (lambda i, f: self._graphs[i].replay()) if self.use_graph else (lambda i, f: f())
-        run(0, self._seg_forward)
-        # head gradients + center sums go out over RCCL while the trunk backward runs; each half of the trunk follows as
-        # soon as its graph segment has been enqueued (arena order: [embed | blocks 0..depth-1 | norm | head])
+        segs = self._segments()
+        run = (lambda i: self._graphs[i].replay()) if self.use_graph else (lambda i: segs[i]())
+        run(0)
+        # head gradients + center sums go out over RCCL while the trunk backward runs; each run of blocks follows as soon as
+        # its graph segment has been enqueued (arena order: [embed | blocks 0..depth-1 | norm | head])
         self.reducer.launch(self.sa.grad[self.head_start:])
         self.reducer.launch(self.colsum)
-        run(1, self._seg_trunk_backward_hi)
-        self.reducer.launch(self.sa.grad[self.mid_start:self.head_start])
-        run(2, self._seg_trunk_backward_lo)
-        if self.mid_start > 0:
-            self.reducer.launch(self.sa.grad[:self.mid_start])
+        hi = self.head_start
+        for k, lo in enumerate(self.cut_offsets):
+            run(1 + k)
+            if hi > lo:
+                self.reducer.launch(self.sa.grad[lo:hi])
+            hi = lo
         self.reducer.wait_all()
-        run(3, self._seg_update)
+        run(len(segs) - 1)
         self.step_count += 1
         return self.loss
 
