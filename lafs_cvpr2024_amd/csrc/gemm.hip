@@ -385,7 +385,8 @@ __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) 
 
 // Output tile (64*WM) x (64*WN), one 64x64 block of 4x4 MFMA tiles per wave.  Operands are staged as 128-column panels
 // (WM/2 panels of A, WN/2 of B per stage).  The product path uses 2x2 (see launch_tn for the measured comparison).
-template <int WM, int WN, int KB>
+// CS = false compiles the bias-gradient (column-sum) accumulators out: 16 registers the 16-wave 256x256 variant needs back.
+template <int WM, int WN, int KB, bool CS = true>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_kernel(TNArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int PA = WM / 2, PB = WN / 2;
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_
   const int mbeg = zslice * p.mlen;
   const int mend = min(p.M, mbeg + p.mlen);
   const int nk = (mend - mbeg + TN_BM - 1) / TN_BM;
-  const bool do_colsum = (p.colsum != nullptr) && n2_0 == 0 && wn == 0;
+  const bool do_colsum = CS && (p.colsum != nullptr) && n2_0 == 0 && wn == 0;
 
   // LDS-DMA staging: the image is lane-linear (chunk q of the stage lands at byte 16*q), so the unit swizzle goes on the
   // source column.  Rows past the end of the slice are clamped to a valid row here and zeroed in LDS before use.
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
-      if (do_colsum) {                                // column sums of A (bias gradient) ride along as A^T * ones
+      if (CS && do_colsum) {                          // column sums of A (bias gradient) ride along as A^T * ones
 #pragma unroll
         for (int a = 0; a < 4; ++a) accs[a] = mfma16(fa[a], ones, accs[a]);
       }
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_
           else *dst = acc[a][b][r];                                   // timing experiment only (lafs_debug_set)
         }
       }
-      if (do_colsum && pl == 0) atomicAdd(p.colsum + n1, accs[a][r]);
+      if (CS && do_colsum && pl == 0) atomicAdd(p.colsum + n1, accs[a][r]);
     }
 }
 
@@ -689,7 +690,8 @@ static int launch_tn(const void* A, int lda, const void* B, int ldb, float* C, i
   else if (best == 0) hipLaunchKernelGGL((gemm_tn_kernel<2, 2, 32>), grid, dim3(256), 0, stream, a);
   else if (best == 1) hipLaunchKernelGGL((gemm_tn_kernel<4, 2, 32>), grid, dim3(512), 0, stream, a);
   else if (best == 2) hipLaunchKernelGGL((gemm_tn_kernel<2, 4, 32>), grid, dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((gemm_tn_kernel<4, 4, 32>), grid, dim3(1024), 0, stream, a);
+  else if (colsum_a != nullptr) hipLaunchKernelGGL((gemm_tn_kernel<4, 4, 32, true>), grid, dim3(1024), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<4, 4, 32, false>), grid, dim3(1024), 0, stream, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
