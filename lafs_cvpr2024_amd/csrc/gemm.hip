@@ -387,7 +387,7 @@ __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) 
 // (WM/2 panels of A, WN/2 of B per stage).  The product path uses 2x2 (see launch_tn for the measured comparison).
 // CS = false compiles the bias-gradient (column-sum) accumulators out: 16 registers the 16-wave 256x256 variant needs back.
 template <int WM, int WN, int KB, bool CS = true>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_kernel(TNArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : (WM * WN == 8 ? 4 : 1)) void gemm_tn_kernel(TNArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int PA = WM / 2, PB = WN / 2;
   constexpr int TN_BM = KB, TN_PANEL = KB * 256, NS = (KB == 32) ? 3 : 2;
@@ -419,40 +419,35 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_
 
   // LDS-DMA staging: the image is lane-linear (chunk q of the stage lands at byte 16*q), so the unit swizzle goes on the
   // source column.  Rows past the end of the slice are clamped to a valid row here and zeroed in LDS before use.
-  const bf16_t* gsrc[NI]; int gld[NI], ldsoff[NI], srow[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int q = i * NTH + tid, panel = q / (TN_BM * 16), within = q % (TN_BM * 16);
-    const int row = within >> 4, ch = (within & 15) ^ (tn_f(row) >> 1);
-    srow[i] = row;
-    if (panel < PA) {
-      const int c = n1_0 + panel * 128 + ch * 8;
-      gsrc[i] = p.A + (c < p.N1 ? c : 0); gld[i] = p.lda;
-    } else {
-      const int c = n2_0 + (panel - PA) * 128 + ch * 8;
-      gsrc[i] = p.B + (c < p.N2 ? c : 0); gld[i] = p.ldb;
-    }
-    ldsoff[i] = (i * NTH + wave * 64) * 16;
-  }
+  // Nothing about a chunk is kept in registers: its panel / row / source column are recomputed from the thread index at issue
+  // time (a dozen integer operations per 1 KiB DMA), which frees ~20 VGPRs for occupancy.
+  constexpr int CHP = TN_BM * 16;                    // chunks per panel
   auto issue = [&](int t) {
     unsigned char* st = smem + (t % NS) * STAGE;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      const int m = min(mbeg + t * TN_BM + srow[i], mend - 1);
-      glds16(gsrc[i] + (size_t)m * gld[i], st + ldsoff[i]);
+      const int q = i * NTH + tid, panel = q / CHP, within = q % CHP;
+      const int row = within >> 4, ch = (within & 15) ^ (tn_f(row) >> 1);
+      const int m = min(mbeg + t * TN_BM + row, mend - 1);
+      const bf16_t* src;
+      if (panel < PA) {
+        const int c = n1_0 + panel * 128 + ch * 8;
+        src = p.A + (size_t)m * p.lda + (c < p.N1 ? c : 0);
+      } else {
+        const int c = n2_0 + (panel - PA) * 128 + ch * 8;
+        src = p.B + (size_t)m * p.ldb + (c < p.N2 ? c : 0);
+      }
+      glds16(src, st + (i * NTH + wave * 64) * 16);
     }
   };
 
-  f32x4_t acc[4][4], accs[4];
+  f32x4_t acc[4][4];
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};                // bias gradient: this lane's share of the column sums of A (fragment a)
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    accs[a] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-  const s16x8_t ones_s = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
-  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
   const int g = lane >> 4, pl = lane & 15;
   const int r0 = g * 8 + (pl >> 2), r1 = r0 + 4;
@@ -496,9 +491,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
-      if (CS && do_colsum) {                          // column sums of A (bias gradient) ride along as A^T * ones
+      if (CS && do_colsum) {                          // column sums of A (bias gradient): a lane holds 8 k-values of one column
 #pragma unroll
-        for (int a = 0; a < 4; ++a) accs[a] = mfma16(fa[a], ones, accs[a]);
+        for (int a = 0; a < 4; ++a) {
+          const uint4 w = __builtin_bit_cast(uint4, fa[a]);
+          cs[a] += (bf_lo(w.x) + bf_hi(w.x)) + (bf_lo(w.y) + bf_hi(w.y)) + (bf_lo(w.z) + bf_hi(w.z)) + (bf_lo(w.w) + bf_hi(w.w));
+        }
       }
     }
   }
@@ -523,8 +521,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : 1) void gemm_tn_
           else *dst = acc[a][b][r];                                   // timing experiment only (lafs_debug_set)
         }
       }
-      if (CS && do_colsum && pl == 0) atomicAdd(p.colsum + n1, accs[a][r]);
     }
+  if (CS && do_colsum) {                              // lanes l, l^16, l^32, l^48 hold the four k-slices of column (l & 15)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      float v = cs[a];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n1 = n1_0 + wm * 64 + a * 16 + pl;
+      if (g == 0 && n1 < p.N1) atomicAdd(p.colsum + n1, v);
+    }
+  }
 }
 
 // out[i] += sum_x part[x][i]; part[x][i] = 0   (the images are left zeroed for the next accumulation)
@@ -650,19 +657,18 @@ static int launch_tn(const void* A, int lda, const void* B, int ldb, float* C, i
   // next stage's DMA cannot be issued before the barrier and only 2 workgroups fit a CU; debug flag 8192 selects them.)
   const int kb = (g_debug_flags & 8192) ? 64 : 32;
   const int msteps = ceil_div(M, kb);
-  // Tile shape.  128x128 (4 waves, 3 workgroups per CU) is the fastest on every LAFS shape: the wider variants re-read the
-  // operands from L2 fewer times but measured 1.2-1.9x SLOWER on MI355X (8-16 waves per barrier, fewer bytes in flight per
-  // CU; tools/bench_kernels.py tn) -- they stay selectable for experiments: debug flags 2048 = 256x256, 4096 = 256x128.
+  // Tile shape.  128x128 (4 waves, 3 workgroups per CU) is the fastest on nearly every LAFS shape: the wider variants re-read the
+  // operands from L2 fewer times but 256x128 is on par at best (105 vs 97 us on the ViT-S fc1 wgrad, once it fits 128 VGPRs and
+  // two workgroups share a CU) and 256x256 slower (tools/bench_kernels.py tn); debug flags 2048 = 256x256, 4096 = 256x128.
   static const int cand[4][2] = {{2, 2}, {4, 2}, {2, 4}, {4, 4}};
   int best = 0;
   {
-    // ... except when the 128x128 grid would spill into a second round of workgroups (3 fit a CU: 768 slots) and 256x256
-    // tiles cover the output without much padding: one workgroup per CU then wins (ViT-B qkv wgrad: 141 vs 191 us)
+    // ... except when the 128x128 grid would spill into a second round of workgroups (3 fit a CU: 768 slots): then 256x128
+    // tiles (8 waves, 128 VGPRs, 2 workgroups per CU) win (ViT-B qkv wgrad: 123 us against 191 us; 256x256 gives 139 us)
     const int t22 = ceil_div(N1, 128) * ceil_div(N2, 128);
     int s22 = ceil_div(512, t22);
     if (s22 > 4) s22 = (s22 + 7) & ~7;
-    const double t44 = (double)ceil_div(N1, 256) * ceil_div(N2, 256);
-    if (splits <= 0 && t22 * s22 > 768 && t44 <= 256 && t44 * 65536.0 <= 1.15 * (double)N1 * N2 && M >= 8192) best = 3;
+    if (splits <= 0 && t22 * s22 > 768 && M >= 8192) best = (N1 >= N2) ? 1 : 2;
   }
   if (g_debug_flags & 1024) best = 0;
   if (g_debug_flags & 2048) best = 3;
