@@ -135,6 +135,9 @@ def lib():
             fn.argtypes = list(args)
             fn.restype = res
         _lib = h
+        flags = os.environ.get("LAFS_DEBUG_FLAGS")               # A/B experiments on whole steps (see lafs_debug_set in lafs_hip.h)
+        if flags:
+            h.lafs_debug_set(int(flags, 0))
     return _lib
 
 
