@@ -158,3 +158,56 @@ def test_pinned_ring_uploads_survive_a_host_that_runs_ahead():
         a = a @ a * 1e-4                                 # keep the queue deep between uploads
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), torch.arange(24.0).view(-1, 1).expand(24, 4))
+
+
+def test_full_size_c2_step_properties():
+    """BASELINE.json configs[1] at FULL size (ViT-S/8, batch 64, 2 global + 8 local crops, K = 100 000), checked through
+    size-independent properties instead of the CPU oracle (which would take minutes):
+      * the softmax-gradient rows of the fused loss kernel sum to zero;
+      * lr = 0 and wd = 0 leave the student bit-identical, momentum = 1 leaves the teacher bit-identical, while the center moves;
+      * the loss is invariant under a permutation of the images of the batch (all crops permuted alike);
+      * a real step changes the weights, and the graph-captured step reproduces the eager step."""
+    torch.manual_seed(0)
+    B, K, nl = 64, 100000, 8
+
+    def build(use_graph):
+        torch.manual_seed(0)
+        student = MultiCropWrapper(vits.vit_small(patch_size=8, drop_path_rate=0.0), vits.DINOHead(384, K, use_bn=False, norm_last_layer=True))
+        teacher = MultiCropWrapper(vits.vit_small(patch_size=8), vits.DINOHead(384, K, use_bn=False))
+        teacher.load_state_dict(student.state_dict())
+        crit = DINOLoss(K, 2 + nl, 0.07, 0.04, 30, 41)
+        return LafsPretrainEngine(student, teacher, crit, B, n_local=nl, clip_grad=3.0, freeze_last_layer=1, use_graph=use_graph, device=DEV)
+
+    g = torch.Generator(device=DEV).manual_seed(1)
+    crops = [torch.randn(B, 3, 112, 112, device=DEV, generator=g).clamp(-1, 1) for _ in range(2)] + \
+            [torch.randn(B, 3, 48, 48, device=DEV, generator=g).clamp(-1, 1) for _ in range(nl)]
+    eng = build(False)
+    # (1) forward segment: gradient rows of the loss sum to zero
+    eng.set_inputs(crops)
+    eng.temps.copy_(torch.tensor([0.1, 0.04]))
+    eng._seg_forward()
+    loss0 = float(eng.loss.item())
+    rows = eng.dlogits[:, :K].float().sum(1)
+    scale = float(eng.dlogits[:, :K].float().abs().sum(1).mean())
+    assert float(rows.abs().max()) < 2e-2 * scale                       # bf16 gradient entries: zero up to their rounding
+    assert 0.0 < loss0 < 2 * math.log(K)
+    # (2) permutation invariance of the loss
+    perm = torch.randperm(B, device=DEV, generator=g)
+    eng.set_inputs([c[perm] for c in crops])
+    eng._seg_forward()
+    assert abs(float(eng.loss.item()) - loss0) < 2e-4 * loss0
+    # (3) a step with lr = wd = 0 and momentum = 1 is the identity on student and teacher; the center still moves
+    s0, t0, c0 = eng.sa.master.clone(), eng.ta.master.clone(), eng.dino_loss.center.clone()
+    eng.step(crops, lr=0.0, wd=0.0, momentum=1.0, teacher_temp=0.04, epoch=1)
+    assert torch.equal(eng.sa.master, s0) and torch.equal(eng.ta.master, t0)
+    assert float((eng.dino_loss.center - c0).abs().max()) > 0
+    # (4) a real step: weights move by about lr; the graph engine reproduces the eager one
+    eng.dino_loss.center.copy_(c0)
+    l_eager = float(eng.step(crops, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04, epoch=1).item())
+    d = (eng.sa.master - s0).abs()
+    assert 1e-4 < float(d.max()) < 2e-3 and float((eng.ta.master - t0).abs().max()) > 0
+    eng_g = build(True)
+    l_graph = float(eng_g.step(crops, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04, epoch=1).item())
+    assert abs(l_graph - l_eager) < 1e-4 * l_eager
+    diff = (eng_g.sa.master - eng.sa.master).abs()
+    assert float(diff.median()) < 1e-7 and float((diff > 1e-4).float().mean()) < 0.02     # Adam sign flips where g is round-off
