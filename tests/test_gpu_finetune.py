@@ -387,3 +387,35 @@ def test_hip_landmark_cnn_matches_torch_module():
     assert float(d.mean()) < 0.6 and float(d.max()) < 4.0, (float(d.mean()), float(d.max()))       # pixels (jitter is 5 px)
     # batch-size independent plan cache + a second resolution-free call gives identical results
     assert torch.equal(hip(x), t)
+
+
+def test_full_size_c4_finetune_step_properties():
+    """BASELINE.json configs[3] at FULL size (Part-fViT ViT-B, batch 128, 205 990 classes, CosFace s=64 m=0.4) through
+    size-independent properties: the initial loss matches its closed-form expectation for random embeddings
+    (ln C + s^2 sigma^2 / 2 + s m with sigma^2 = 1/dim), the softmax-gradient rows sum to zero, an optimizer step with lr = 0 and
+    wd = 0 is the identity, a real one moves the weights by about lr."""
+    import math
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    torch.manual_seed(0)
+    B, C, D = 128, 205990, 768
+    model = ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=C, image_size=112, patch_size=8, dim=D, depth=12,
+                                     heads=11, mlp_dim=2048, dropout=0.0, emb_dropout=0.0, with_land=False, drop_path_rate=0.0)
+    eng = FinetuneEngine(model, B, acc_step=1, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    u8 = torch.randint(0, 256, (B, 3, 112, 112), device=DEV, dtype=torch.uint8, generator=g)
+    y = torch.randint(0, C, (B,), device=DEV, generator=g)
+    loss = float(eng.micro_step(u8, y, lam=1.0).item())
+    # dL/dcos is left in eng.cos (in place): rows sum to s * sum_k (p_k - y_k) / B = 0
+    rows = eng.cos[:, :C].sum(1)
+    assert float(rows.abs().max()) < 1e-3 * float(eng.cos[:, :C].abs().sum(1).mean())
+    # closed-form expectation.  The embeddings of one random-init network on random images are strongly correlated, so their
+    # cosines to the random class centres share less variance than independent vectors: allow the variance term to be partial
+    lo, hi = math.log(C) + 64 * 0.4, math.log(C) + 64 * 0.4 + 64 ** 2 / D / 2 + 0.5
+    assert lo - 0.5 < loss < hi, (loss, lo, hi)
+    w0 = eng.arena.master.clone()
+    eng.optimizer_step(lr=0.0, weight_decay=0.0)
+    assert torch.equal(eng.arena.master, w0)
+    eng.micro_step(u8, y, lam=1.0)
+    eng.optimizer_step(lr=1e-4, weight_decay=0.1)
+    d = (eng.arena.master - w0).abs()
+    assert 0.5e-4 < float(d.max()) < 3e-4

@@ -2,6 +2,8 @@
 and against the CPU oracle."""
 from functools import partial
 
+import math
+
 import numpy as np
 import pytest
 import torch
