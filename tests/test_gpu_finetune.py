@@ -419,3 +419,28 @@ def test_full_size_c4_finetune_step_properties():
     eng.optimizer_step(lr=1e-4, weight_decay=0.1)
     d = (eng.arena.master - w0).abs()
     assert 0.5e-4 < float(d.max()) < 3e-4
+
+
+def test_finetune_engine_dense_arcface_matches_oracle():
+    """--head ArcFace (config C4's margin; parity unpinned, Deng et al. formula in oracle.margin.arcface_logits): the fused
+    margin + softmax + CE kernel with margin_type = 1 against the autograd oracle, hard labels."""
+    import torch.nn.functional as F
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    from oracle import margin, partfvit
+    torch.manual_seed(9)
+    B, C = 8, 1000
+    model = ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=C, image_size=112, patch_size=8, dim=128, depth=2,
+                                     heads=3, mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=False, drop_path_rate=0.0)
+    P = {k: v.clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    u8 = torch.randint(0, 256, (B, 3, 112, 112), dtype=torch.uint8)
+    labels = torch.tensor([3, 999, 17, 3, 500, 0, 42, 999])
+    eng = FinetuneEngine(model, B, acc_step=1, s=64.0, m=0.5, margin_type=1, device=DEV)
+    loss = eng.micro_step(u8.to(DEV), labels.to(DEV), lam=1.0)
+    cfg = partfvit.PartFViTConfig(patch_size=8, dim=128, depth=2, heads=3, mlp_dim=256, num_patches=196)
+    emb = partfvit.forward_embedding(P, u8.float() / 255 * 2 - 1, cfg)
+    ref = F.cross_entropy(margin.arcface_logits(emb, P["loss.weight"], labels, 64.0, 0.5), labels)
+    ref.backward()
+    assert abs(float(loss.item()) - float(ref)) / float(ref) < 5e-3, (float(loss.item()), float(ref))
+    named = dict(model.named_parameters())
+    for k in ("loss.weight", "patch_to_embedding.weight", "transformer.layers.1.1.fn.fn.net.3.weight"):
+        assert rel_l2(named[k].grad, P[k].grad) < 8e-2, k
