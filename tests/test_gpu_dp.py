@@ -1,0 +1,75 @@
+"""GPU: the data-parallel path of the engine itself (parameter broadcast, asynchronous flat-gradient and center all-reduces between
+the graph segments, 1/world folded into the optimizer) with TWO processes sharing the one GPU over the gloo backend (RCCL needs
+one device per rank; gloo accepts device tensors), against a single process on the concatenated batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(__file__))
+pytestmark = pytest.mark.gpu
+
+
+def _build(B, use_graph):
+    import torch.nn as nn
+    from lafs_cvpr2024_amd import vision_transformer as vits
+    from lafs_cvpr2024_amd.dino_loss import DINOLoss
+    from lafs_cvpr2024_amd.engine import LafsPretrainEngine
+    from lafs_cvpr2024_amd.utils import MultiCropWrapper
+    torch.manual_seed(0)
+    LN6 = lambda d: nn.LayerNorm(d, eps=1e-6)
+    mk = lambda: vits.VisionTransformer(img_size=[224], patch_size=8, embed_dim=128, depth=4, num_heads=2, qkv_bias=True, norm_layer=LN6)
+    student = MultiCropWrapper(mk(), vits.DINOHead(128, 1024, hidden_dim=256, bottleneck_dim=64))
+    teacher = MultiCropWrapper(mk(), vits.DINOHead(128, 1024, hidden_dim=256, bottleneck_dim=64))
+    teacher.load_state_dict(student.state_dict())
+    crit = DINOLoss(1024, 4, 0.07, 0.04, 3, 10)
+    return LafsPretrainEngine(student, teacher, crit, B, n_local=2, use_graph=use_graph, device="cuda")
+
+
+def _crops(B):
+    g = torch.Generator().manual_seed(7)
+    return [torch.randn(B, 3, 112, 112, generator=g).clamp(-1, 1) for _ in range(2)] + [torch.randn(B, 3, 48, 48, generator=g).clamp(-1, 1) for _ in range(2)]
+
+
+def _worker(rank, world, port, out, use_graph):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 1:
+        torch.manual_seed(123)                       # a different initialisation on rank 1: the broadcast must override it
+    eng = _build(2, use_graph)
+    if rank == 1:
+        assert eng.world == 2
+    full = _crops(4)
+    mine = [c[rank * 2:(rank + 1) * 2].cuda() for c in full]
+    losses = []
+    for it in range(3):
+        losses.append(float(eng.step(mine, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item()))
+    torch.cuda.synchronize()
+    torch.save({"student": eng.sa.master.cpu(), "teacher": eng.ta.master.cpu(), "center": eng.dino_loss.center.cpu(), "losses": losses},
+               out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_ranks_on_one_gpu_equal_single_process_on_the_full_batch(tmp_path, use_graph):
+    out = str(tmp_path / "dp")
+    port = 29700 + os.getpid() % 200 + (50 if use_graph else 0)
+    mp.spawn(_worker, args=(2, port, out, use_graph), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    # the replicas stay identical (same broadcast start, same reduced gradients)
+    assert torch.equal(r0["student"], r1["student"]) and torch.equal(r0["teacher"], r1["teacher"]) and torch.equal(r0["center"], r1["center"])
+    eng = _build(4, use_graph)
+    full = [c.cuda() for c in _crops(4)]
+    losses = [float(eng.step(full, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item()) for _ in range(3)]
+    # first-step loss of the full batch = mean of the two half-batch losses (both depend only on the shared initial weights)
+    assert abs(0.5 * (r0["losses"][0] + r1["losses"][0]) - losses[0]) < 2e-4 * losses[0]
+    torch.testing.assert_close(r0["center"], eng.dino_loss.center.cpu(), rtol=1e-4, atol=1e-6)
+    d = (r0["student"] - eng.sa.master.cpu()).abs()
+    assert float(d.median()) < 1e-6 and float((d > 1e-4).float().mean()) < 0.03 and float(d.max()) < 6.5e-3   # Adam sign flips at round-off gradients
+    dt = (r0["teacher"] - eng.ta.master.cpu()).abs()
+    assert float(dt.max()) < 1e-3
