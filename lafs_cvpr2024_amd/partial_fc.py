@@ -23,6 +23,28 @@ from .ops import _p, call
 f32, bf16 = torch.float32, torch.bfloat16
 
 
+def _gather_rows(t, world):
+    """[n, ...] on every rank -> [world*n, ...] (rank-major).  One collective on RCCL; list form on backends without it."""
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    if dist.get_backend() == "nccl":
+        dist.all_gather_into_tensor(out, t)
+    else:
+        dist.all_gather(list(out.chunk(world)), t)
+    return out
+
+
+def _reduce_scatter_rows(t, world, rank):
+    """[world*n, ...] per rank -> sum over ranks of this rank's [n, ...] slice.  reduce-scatter on RCCL; all-reduce + slice on
+    backends without it (gloo: the CPU / single-GPU tests)."""
+    n = t.shape[0] // world
+    if dist.get_backend() == "nccl":
+        out = torch.empty((n,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        dist.reduce_scatter_tensor(out, t)
+        return out
+    dist.all_reduce(t)
+    return t[rank * n:(rank + 1) * n].contiguous()
+
+
 def shard_range(num_classes, rank, world):
     """[start, start+n) of the class ids rank owns (partial_fc_v2: ceil split, the last rank takes the remainder)."""
     n = num_classes // world + int(rank < num_classes % world)
@@ -103,10 +125,7 @@ class PartialFC:
         emb = emb.contiguous()
         labels = labels.to(dev, torch.int64).contiguous()
         if W > 1:
-            E = torch.empty(N, D, device=dev, dtype=f32)
-            L = torch.empty(N, device=dev, dtype=torch.int64)
-            dist.all_gather_into_tensor(E, emb)
-            dist.all_gather_into_tensor(L, labels)
+            E, L = _gather_rows(emb, W), _gather_rows(labels, W)
         else:
             E, L = emb, labels
         index, y = sample_classes(L, self.class_start, self.num_local, self.num_sample, self.gen)
@@ -143,11 +162,7 @@ class PartialFC:
             gw.index_add_(0, index, dv)                                 # row scatter back to the shard (indices are unique)
         dE = torch.empty(N, D, device=dev, dtype=f32)
         call("lafs_l2norm_bwd", _p(E), D, _p(den), D, _p(inv_e), _p(dE), D, N, D)
-        if W > 1:
-            demb = torch.empty(B, D, device=dev, dtype=f32)
-            dist.reduce_scatter_tensor(demb, dE)
-        else:
-            demb = dE
+        demb = _reduce_scatter_rows(dE, W, self.rank) if W > 1 else dE
         return loss, demb
 
     def optimizer_step(self, lr, weight_decay=0.1, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -74,3 +74,49 @@ def test_two_ranks_on_one_gpu_equal_single_process_on_the_full_batch(tmp_path, u
     assert float(d.median()) < 1e-6 and float((d > 1e-4).float().mean()) < 0.03 and float(d.max()) < 6.5e-3   # Adam sign flips at round-off gradients
     dt = (r0["teacher"] - eng.ta.master.cpu()).abs()
     assert float(dt.max()) < 1e-3
+
+
+def _pfc_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lafs_cvpr2024_amd.partial_fc import PartialFC, shard_range
+    g = torch.Generator().manual_seed(5)
+    C, D, B = 1000, 64, 8
+    Wfull = torch.randn(C, D, generator=g) * 0.05
+    emb = torch.randn(world * B, D, generator=g)
+    lab = torch.randint(0, C, (world * B,), generator=g)
+    pfc = PartialFC(D, C, B, sample_rate=1.0, device="cuda")
+    start, n = shard_range(C, rank, world)
+    assert (pfc.class_start, pfc.num_local) == (start, n)
+    with torch.no_grad():
+        pfc.weight.copy_(Wfull[start:start + n])
+    loss, demb = pfc.forward_backward(emb[rank * B:(rank + 1) * B].cuda(), lab[rank * B:(rank + 1) * B].cuda())
+    torch.cuda.synchronize()
+    torch.save({"loss": loss.cpu(), "demb": demb.cpu(), "dW": pfc.arena.view(pfc.arena.grad, "weight", (n, D)).cpu(), "start": start},
+               out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partial_fc_two_class_shards_on_one_gpu(tmp_path):
+    """PartialFC with the class centres sharded over two ranks (HIP kernels + the MAX / SUM statistics exchange + gather /
+    reduce-scatter of the embeddings) == the unsharded CosFace + cross-entropy of the oracle on the global batch."""
+    from oracle import margin
+    out = str(tmp_path / "pfc")
+    port = 29950 + os.getpid() % 40
+    mp.spawn(_pfc_worker, args=(2, port, out), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(5)
+    C, D, B = 1000, 64, 8
+    Wfull = (torch.randn(C, D, generator=g) * 0.05).requires_grad_(True)
+    emb = torch.randn(2 * B, D, generator=g).requires_grad_(True)
+    lab = torch.randint(0, C, (2 * B,), generator=g)
+    ref = margin.partial_fc_reference(emb, Wfull, lab)
+    ref.backward()
+    for r in range(2):
+        got = torch.load(out + f".{r}", weights_only=False)
+        assert abs(float(got["loss"]) - float(ref)) < 2e-2 * abs(float(ref))
+        e = emb.grad[r * B:(r + 1) * B]
+        assert float((got["demb"] - e).abs().max()) < 3e-2 * float(e.abs().max())
+        w = Wfull.grad[got["start"]:got["start"] + got["dW"].shape[0]]
+        assert float((got["dW"] - w).abs().max()) < 3e-2 * float(Wfull.grad.abs().max())
