@@ -47,7 +47,9 @@ def _worker(rank, world, port, out):
 
 def test_two_rank_step_equals_single_process_full_batch(tmp_path):
     out = str(tmp_path / "r0.pt")
-    port = 29600 + os.getpid() % 200
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = torch.load(out, weights_only=False)
     cfg, st = _make()
@@ -95,7 +97,9 @@ def test_partial_fc_two_shards_equal_unsharded(tmp_path):
     """The class-sharded softmax exchange (MAX, SUM, SUM; reduce-scatter of dE) reproduces the unsharded CosFace + CE."""
     from oracle import margin
     out = str(tmp_path / "pfc")
-    port = 29850 + os.getpid() % 100
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
     mp.spawn(_pfc_worker, args=(2, port, out), nprocs=2, join=True)
     g = torch.Generator().manual_seed(3)
     C, D, B = 37, 16, 4
