@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "profiles"), os.path.join(ROOT, "profiles")
 R = sys.argv[1] if len(sys.argv) > 1 else "round1"
-DOM = "gemm_nt_kernel<1, 4, 32>"          # BF16_GELU epilogue, 256x128 tile, 32-deep stages
+DOM = "gemm_nt_kernel<1, 4, 32"           # BF16_GELU epilogue, 256x128 tile, 32-deep stages (prefix: further template arguments follow)
 
 
 def per_launch(path, counters):
