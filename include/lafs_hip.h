@@ -95,6 +95,30 @@ int lafs_gemm_tn_part(const void* A, int lda, const void* B, int ldb, float* par
 /* out(f32)[i] += sum_x part[x*part_stride + i], then part[...] = 0;  n, part_stride multiples of 4. */
 int lafs_reduce_partials(float* part, int64_t part_stride, int n_part, int64_t n, float* out, hipStream_t stream);
 
+/* Second-generation weight gradient (csrc/wgrad.hip): C[N1,N2] = (accumulate ? C : 0) + A[M,N1]^T * B[M,N2].
+ * One 4-wave workgroup per CU (one wave per SIMD, 512 registers) owns a (64 FA) x (64 FB) tile of v_mfma_f32_32x32x16_bf16
+ * blocks (192x192 .. 256x256) over one slice of the token axis and STORES its fp32 tile into `workspace`
+ * ([slices][N1][N2] f32 per GEMM); a fold kernel then writes C: no atomics, and with accumulate = 0 the gradient buffer needs
+ * no memset.  colsum_a as in lafs_gemm_tn_acc (f32 atomics into a pre-zeroed vector).
+ * lafs_wgrad_group runs up to 8 such GEMMs that share the token count M (the four weight gradients of one transformer block)
+ * as ONE launch + ONE fold: the tiles of all GEMMs fill the chip together, so the token axis is cut into 4x fewer slices --
+ * 4x less partial-sum traffic, 4x longer main loops per workgroup.
+ * Calls that share a workspace must be ordered on one stream.  N1, N2, lda, ldb % 8 == 0, ldc % 4 == 0. */
+typedef struct lafs_wgrad_item {
+  const void* A; int lda;          /* bf16 [M, N1]  (dY)                            */
+  const void* B; int ldb;          /* bf16 [M, N2]  (X)                             */
+  float* C; int ldc;               /* f32 [N1, N2]  (dW)                            */
+  int N1, N2;
+  int accumulate;                  /* 0: C = A^T B ; 1: C += A^T B                  */
+  float* colsum_a;                 /* f32 [N1] += column sums of A (bias gradient), or NULL */
+} lafs_wgrad_item;
+int64_t lafs_wgrad_group_workspace_bytes(const lafs_wgrad_item* items, int n_items, int M);
+int lafs_wgrad_group(const lafs_wgrad_item* items, int n_items, int M, void* workspace, int64_t workspace_bytes,
+                     hipStream_t stream);
+int64_t lafs_wgrad_workspace_bytes(int M, int N1, int N2);
+int lafs_wgrad(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+               int accumulate, float* colsum_a, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
 /* out(f32)[n] += sum_m X(bf16)[m, n]   (bias gradients). */
 int lafs_colsum_bf16_acc(const void* X, int ldx, int M, int N, float* out, hipStream_t stream);
 

@@ -24,6 +24,11 @@ class GemmNTArgs(C.Structure):
                 ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("act", C.c_int)]
 
 
+class WgradItem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
+                ("N1", C.c_int), ("N2", C.c_int), ("accumulate", C.c_int), ("colsum_a", C.c_void_p)]
+
+
 class BlockOffsets(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_proj", "b_proj", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2",
@@ -57,6 +62,8 @@ _PROTOS = {
     "lafs_gemm_tn_acc": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "lafs_gemm_tn_part": [vp, i32, vp, i32, vp, i32, i64, i32, i32, i32, i32, vp],
     "lafs_reduce_partials": [vp, i64, i32, i64, vp],
+    "lafs_wgrad": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i64],
+    "lafs_wgrad_group": [C.POINTER(WgradItem), i32, i32, vp, i64],
     "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
     "lafs_layernorm_fwd": [vp, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32],
     "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, u32],
@@ -109,6 +116,8 @@ _NO_STREAM = {
     "lafs_last_error": ([], C.c_char_p),
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),
+    "lafs_wgrad_workspace_bytes": ([i32, i32, i32], i64),
+    "lafs_wgrad_group_workspace_bytes": ([C.POINTER(WgradItem), i32, i32], i64),
 }
 EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
 

@@ -118,4 +118,25 @@ __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- LDS-DMA (global_load_lds_dwordx4) issued from inline asm.  Each lane supplies its own 16-byte source; the destination
+// is lds_base (wave-uniform byte address inside the workgroup's LDS, carried in M0) + 16 * lane.  Why asm and not
+// __builtin_amdgcn_global_load_lds: hipcc's wait-count pass knows the builtin writes LDS and drains the whole DMA queue
+// (s_waitcnt vmcnt(0)) in front of every LDS read it cannot disambiguate -- ds_read_b64_tr_b16 has no memory operand, so the
+// round-1 weight-gradient kernel emptied its 3-stage ring at every stage.  An asm statement is invisible to that pass: the
+// kernels count these loads themselves (s_waitcnt vmcnt(N) + s_barrier before the first read of a stage).
+// M0 is compiler-reserved and not preserved around asm, so it is saved and restored inside the statement.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_base) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+// Same, without saving M0: for kernels whose compiled code never uses M0 itself (no LDS-DMA / GWS / movrel builtins) -- two
+// scalar instructions less per 1 KiB piece, which matters when a single wave per SIMD has to issue everything.
+__device__ __forceinline__ void lds_dma16_m0(const void* gsrc, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

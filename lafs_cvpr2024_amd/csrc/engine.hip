@@ -24,8 +24,19 @@ struct Carve {
   std::vector<LayerBuf> layers;   // depth entries when saving, 1 otherwise (reused)
   float* xalt;                    // ping-pong residual buffer for the no-save path
   Scratch s;
+  void* wg_ws; size_t wg_bytes;   // slice partials of the grouped weight-gradient launch (lafs_wgrad_group)
   size_t bytes;
 };
+
+// the four weight gradients of one block as lafs_wgrad_group items (pointers filled in by the caller)
+void block_wgrad_shapes(const lafs_trunk_desc* d, lafs_wgrad_item (&it)[4]) {
+  const int D = d->dim, I = d->inner, M = d->mlp;
+  for (auto& x : it) x = lafs_wgrad_item{};
+  it[0].N1 = D; it[0].N2 = M; it[0].lda = D; it[0].ldb = M; it[0].ldc = M;              // fc2:  dW = gbm^T a
+  it[1].N1 = M; it[1].N2 = D; it[1].lda = M; it[1].ldb = D; it[1].ldc = D;              // fc1:  dW = du^T h2
+  it[2].N1 = D; it[2].N2 = I; it[2].lda = D; it[2].ldb = I; it[2].ldc = I;              // proj: dW = gba^T o
+  it[3].N1 = 3 * I; it[3].N2 = D; it[3].lda = 3 * I; it[3].ldb = D; it[3].ldc = D;      // qkv:  dW = dqkv^T h1
+}
 
 Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
   Carve c;
@@ -60,8 +71,14 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
     c.s.dh = (bf16_t*)take(T * D * 2);
     c.s.d_o = (bf16_t*)take(T * I * 2);
     c.s.delta = (float*)take(T * H * 4);
+    lafs_wgrad_item it[4];
+    block_wgrad_shapes(d, it);
+    const int64_t wb = lafs_wgrad_group_workspace_bytes(it, 4, d->n_tok);
+    c.wg_bytes = wb > 0 ? (size_t)wb : 0;
+    c.wg_ws = take(c.wg_bytes > 0 ? c.wg_bytes : 256);
   } else {
     c.s = Scratch{};
+    c.wg_ws = nullptr; c.wg_bytes = 0;
   }
   c.bytes = off;
   return c;
@@ -163,8 +180,8 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   const bool two = (wgrad_stream != nullptr) && (wgrad_stream != stream);
   hipStream_t s2 = two ? wgrad_stream : stream;
   const int nl = layer_hi - layer_lo;
-  std::vector<hipEvent_t>& ev = event_pool(two ? (size_t)5 * nl + 1 : 0);
-  LAFS_CHECK_ARG(!two || ev.size() >= (size_t)5 * nl + 1, "could not create HIP events");
+  std::vector<hipEvent_t>& ev = event_pool(two ? (size_t)2 * nl + 1 : 0);
+  LAFS_CHECK_ARG(!two || ev.size() >= (size_t)2 * nl + 1, "could not create HIP events");
   int evi = 0;
   auto fork = [&]() {                      // work enqueued on s2 after this sees everything enqueued on `stream` so far
     if (!two) return;
@@ -185,26 +202,35 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const int p = l & 1;
     if (two && l + 2 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 2], 0);     // parity buffers free again
     // ---- MLP branch ----
-    fork();
-    RUN(lafs_gemm_tn_acc(s.gbm[p], D, b.a, M, gr + o.w_fc2, M, T, D, M, 0, gr + o.b_fc2, s2));
     RUN(gemm(s.gbm[p], D, sht + o.w_fc2_t, D, T, M, D, LAFS_EPI_DGELU_BF16, s.du[p], M, nullptr, stream, nullptr, 0, nullptr, 0, nullptr,
              nullptr, b.u, M, dp, dseed(l, 1)));
-    fork();
-    RUN(lafs_gemm_tn_acc(s.du[p], M, b.h2, D, gr + o.w_fc1, D, T, M, D, 0, gr + o.b_fc1, s2));
     RUN(gemm(s.du[p], M, sht + o.w_fc1_t, M, T, D, M, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, b.x1, D, b.st2, d->master + o.ln2_g, g, D, 1, s.gba[p], D, scale(l, 0), d->row2seq,
                            gr + o.ln2_g, gr + o.ln2_b, T, D, dp, dseed(l, 0), stream));
     // ---- attention branch ----
-    fork();
-    RUN(lafs_gemm_tn_acc(s.gba[p], D, b.o, I, gr + o.w_proj, I, T, D, I, 0, gr + o.b_proj, s2));
     RUN(gemm(s.gba[p], D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
     RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens, d->n_seq, T, d->max_len, d->heads,
                            d->attn_scale, s.dqkv[p], 3 * I, stream));
+    // ---- the block's four weight gradients: ONE grouped launch on the side stream, once all their operands exist.  Its
+    // 48 (ViT-S) output tiles x 5 token slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four
+    // separate launches (csrc/wgrad.hip)
     fork();
-    RUN(lafs_gemm_tn_acc(s.dqkv[p], 3 * I, b.h1, D, gr + o.w_qkv, D, T, 3 * I, D, 0, o.b_qkv >= 0 ? gr + o.b_qkv : nullptr, s2));
+    {
+      lafs_wgrad_item it[4];
+      block_wgrad_shapes(d, it);
+      it[0].A = s.gbm[p]; it[0].B = b.a; it[0].C = gr + o.w_fc2; it[0].colsum_a = gr + o.b_fc2;
+      it[1].A = s.du[p]; it[1].B = b.h2; it[1].C = gr + o.w_fc1; it[1].colsum_a = gr + o.b_fc1;
+      it[2].A = s.gba[p]; it[2].B = b.o; it[2].C = gr + o.w_proj; it[2].colsum_a = gr + o.b_proj;
+      it[3].A = s.dqkv[p]; it[3].B = b.h1; it[3].C = gr + o.w_qkv; it[3].colsum_a = o.b_qkv >= 0 ? gr + o.b_qkv : nullptr;
+      for (auto& x : it) x.accumulate = 1;
+      RUN(lafs_wgrad_group(it, 4, T, c.wg_ws, (int64_t)c.wg_bytes, s2));
+    }
     if (two) { done[l] = ev[evi++]; (void)hipEventRecord(done[l], s2); }
     RUN(gemm(s.dqkv[p], 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     const bool more = l > 0;
+    // the LayerNorm backward below writes gbm[(l-1)&1] == gbm[(l+1)&1], which layer l+1's fc2 weight-gradient GEMM reads on
+    // s2: gbm is produced one layer EARLY, so the two parity buffers only cover it if that GEMM has retired by now
+    if (two && more && l + 1 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 1], 0);
     RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, x0, D, b.st1, d->master + o.ln1_g, g, D, 1, more ? s.gbm[(l - 1) & 1] : nullptr, D,
                            more ? scale(l - 1, 1) : nullptr, d->row2seq, gr + o.ln1_g, gr + o.ln1_b, T, D, more ? dp : 0.f,
                            more ? dseed(l - 1, 2) : 0u, stream));

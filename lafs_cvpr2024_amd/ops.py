@@ -79,6 +79,48 @@ def gemm_tn_acc(A, B, Cacc, splits=0, colsum=None):
     return Cacc
 
 
+def wgrad_workspace(M, N1, N2, device):
+    n = int(_lib.lib().lafs_wgrad_workspace_bytes(M, N1, N2))
+    if n < 0:
+        raise _lib.LafsHipError("lafs_wgrad_workspace_bytes: bad shape")
+    return torch.empty(max(n, 16) // 4, device=device, dtype=torch.float32)
+
+
+def wgrad(A, B, C, accumulate=True, colsum=None, workspace=None):
+    """C[N1,N2] (f32) = (accumulate ? C : 0) + A[M,N1]^T @ B[M,N2] on the wide-tile kernel (csrc/wgrad.hip)."""
+    _chk(A, bf16, "A"); _chk(B, bf16, "B"); _chk(C, torch.float32, "C")
+    M, N1 = A.shape
+    N2 = B.shape[1]
+    if workspace is None:
+        workspace = wgrad_workspace(M, N1, N2, A.device)
+    call("lafs_wgrad", _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N1, N2, int(bool(accumulate)), _p(colsum),
+         _p(workspace), workspace.numel() * workspace.element_size())
+    return C
+
+
+def _wgrad_items(problems):
+    items = (_lib.WgradItem * len(problems))()
+    M = problems[0][0].shape[0]
+    for it, (A, B, Cacc, accumulate, colsum) in zip(items, problems):
+        _chk(A, bf16, "A"); _chk(B, bf16, "B"); _chk(Cacc, torch.float32, "C")
+        if A.shape[0] != M or B.shape[0] != M:
+            raise _lib.LafsHipError("wgrad_group: all GEMMs of a group share the token count M")
+        it.A, it.lda, it.B, it.ldb, it.C, it.ldc = A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), Cacc.data_ptr(), _ld(Cacc)
+        it.N1, it.N2, it.accumulate = A.shape[1], B.shape[1], int(bool(accumulate))
+        it.colsum_a = None if colsum is None else colsum.data_ptr()
+    return items, M
+
+
+def wgrad_group(problems, workspace=None):
+    """problems: list of (A[M,N1] bf16, B[M,N2] bf16, C[N1,N2] f32, accumulate, colsum or None); one launch + one fold."""
+    items, M = _wgrad_items(problems)
+    if workspace is None:
+        n = int(_lib.lib().lafs_wgrad_group_workspace_bytes(items, len(problems), M))
+        workspace = torch.empty(max(n, 16) // 4, device=problems[0][0].device, dtype=torch.float32)
+    call("lafs_wgrad_group", items, len(problems), M, _p(workspace), workspace.numel() * workspace.element_size())
+    return workspace
+
+
 def gemm_tn_part(A, B, part, splits=0, colsum=None):
     """part[x] += (A^T @ B restricted to the rows handled by XCD x); part f32 [N_XCD, N1, N2] (zero-initialised)."""
     _chk(A, bf16, "A"); _chk(B, bf16, "B"); _chk(part, torch.float32, "part")

@@ -88,6 +88,46 @@ def test_gemm_tn(M, N1, N2):
     assert relerr(cs, A.float().sum(0)) < 2e-5 * math.sqrt(M)
 
 
+@pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (1000, 384, 1152), (777, 200, 72), (5000, 1536, 384), (4099, 384, 1536),
+                                     (3000, 704, 768), (2500, 2112, 768), (130, 384, 384), (9000, 256, 256)])
+def test_wgrad_wide_tile(M, N1, N2):
+    """lafs_wgrad (slice-partial + fold, no atomics): overwrite, accumulate, bias gradient, ragged token tails and ragged
+    output edges, against fp32 math on the same bf16 operands."""
+    A, B = rnd_bf(M, N1, seed=1), rnd_bf(M, N2, seed=2)
+    ref = A.float().t() @ B.float()
+    Cd = torch.full((N1, N2), 7.0, device=DEV)                      # overwrite mode must not read the old contents
+    ops.wgrad(A.to(DEV), B.to(DEV), Cd, accumulate=False)
+    e0 = relerr(Cd, ref)
+    cs = torch.zeros(N1, device=DEV)
+    ops.wgrad(A.to(DEV), B.to(DEV), Cd, accumulate=True, colsum=cs)
+    e1, e2 = relerr(Cd, 2 * ref), relerr(cs, A.float().sum(0))
+    print(f"wgrad {M}x{N1}x{N2}: overwrite {e0:.2e} accumulate {e1:.2e} colsum {e2:.2e}")
+    assert e0 < 2e-5 * math.sqrt(M) and e1 < 2e-5 * math.sqrt(M) and e2 < 2e-5 * math.sqrt(M)
+    # strided operands (column slices of wider matrices, as the fused qkv gradient uses them)
+    Aw, Bw = rnd_bf(M, N1 + 64, seed=3).to(DEV), rnd_bf(M, N2 + 8, seed=4).to(DEV)
+    Cs = torch.zeros(N1, N2, device=DEV)
+    ops.wgrad(Aw[:, 64:], Bw[:, :N2], Cs, accumulate=False)
+    assert relerr(Cs, Aw[:, 64:].float().t() @ Bw[:, :N2].float()) < 2e-5 * math.sqrt(M)
+
+
+@pytest.mark.parametrize("M,dims", [(5000, [(384, 1536), (1536, 384), (384, 384), (1152, 384)]),
+                                    (1217, [(768, 2048), (2048, 768), (2112, 768), (768, 704)]), (300, [(64, 64), (200, 72)])])
+def test_wgrad_group(M, dims):
+    """The weight gradients of one transformer block as ONE grouped launch: every GEMM equals its own fp32 product; mixed
+    overwrite / accumulate flags; bias gradients ride along."""
+    probs, refs = [], []
+    for i, (n1, n2) in enumerate(dims):
+        A, B = rnd_bf(M, n1, seed=10 + i), rnd_bf(M, n2, seed=20 + i)
+        acc = bool(i & 1)
+        C0 = torch.randn(n1, n2, generator=torch.Generator().manual_seed(30 + i))
+        refs.append((A.float().t() @ B.float() + (C0 if acc else 0), A.float().sum(0)))
+        probs.append((A.to(DEV), B.to(DEV), C0.to(DEV), acc, torch.zeros(n1, device=DEV)))
+    ops.wgrad_group(probs)
+    for (A, B, Cd, acc, cs), (ref, csr) in zip(probs, refs):
+        assert relerr(Cd, ref) < 2e-5 * math.sqrt(M), (A.shape, B.shape)
+        assert relerr(cs, csr) < 2e-5 * math.sqrt(M)
+
+
 @pytest.mark.parametrize("rows,D", [(50, 64), (1000, 384), (333, 192), (64, 768), (7, 2048)])
 def test_layernorm_fwd_bwd(rows, D):
     g = torch.Generator().manual_seed(0)

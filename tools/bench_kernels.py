@@ -47,6 +47,15 @@ def tn(M, N1, N2, name, splits=0):
     print(f"TN {name:24s} M={M:6d} N1={N1:6d} N2={N2:5d}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TF/s  {(M*(N1+N2)*2)/t/1e9:7.0f} GB/s")
 
 
+def wg(M, N1, N2, name):
+    A = torch.randn(M, N1, device=dev).to(bf); B = torch.randn(M, N2, device=dev).to(bf)
+    C = torch.zeros(N1, N2, device=dev); ws = ops.wgrad_workspace(M, N1, N2, dev); cs = torch.zeros(N1, device=dev)
+    t = timeit(lambda: ops.wgrad(A, B, C, accumulate=False, colsum=cs, workspace=ws))
+    err = ((C - A.float().t() @ B.float()).abs().max() / C.abs().max()).item()
+    print(f"WG {name:24s} M={M:6d} N1={N1:6d} N2={N2:5d}: {t*1e6:8.1f} us  {2*M*N1*N2/t/1e12:7.1f} TF/s  {(M*(N1+N2)*2)/t/1e9:7.0f} GB/s  "
+          f"ws {ws.numel()*4/1e6:6.1f} MB  relerr {err:.1e}")
+
+
 SHAPES = [(T, 1152, 384, _lib.EPI_BF16, "qkv fwd"), (T, 384, 384, _lib.EPI_RESID_F32, "proj fwd"),
           (T, 1536, 384, _lib.EPI_BF16_GELU, "fc1 fwd"), (T, 384, 1536, _lib.EPI_RESID_F32, "fc2 fwd"),
           (T, 1536, 384, _lib.EPI_DGELU_BF16, "fc2 dgrad"), (T, 384, 1536, _lib.EPI_BF16, "fc1 dgrad"),
@@ -65,6 +74,29 @@ if "tn" in which:
         _lib.lib().lafs_debug_set(flag)
         tn(T, 1536, 384, f"fc1 wgrad {nm}"); tn(TB, 2048, 768, f"B fc1 wgrad {nm}"); tn(TB, 2112, 768, f"B qkv wgrad {nm}")
     _lib.lib().lafs_debug_set(0)
+if "wg" in which:
+    print("--- wide-tile weight gradient (lafs_wgrad) vs the round-1 kernel (lafs_gemm_tn_acc)")
+    TB = 25216
+    for (M, N1, N2, name) in ((T, 384, 1536, "fc2 wgrad"), (T, 1536, 384, "fc1 wgrad"), (T, 384, 384, "proj wgrad"), (T, 1152, 384, "qkv wgrad"),
+                              (TB, 768, 2048, "B fc2 wgrad"), (TB, 2048, 768, "B fc1 wgrad"), (TB, 2112, 768, "B qkv wgrad"),
+                              (TB, 768, 704, "B proj wgrad"), (8192, 4096, 4096, "square")):
+        wg(M, N1, N2, name); tn(M, N1, N2, name)
+if "wgg" in which:
+    print("--- the four weight gradients of one block: 4 x round-1 kernel | 4 x lafs_wgrad | ONE lafs_wgrad_group")
+    for (Mx, D, I, H, name) in ((T, 384, 384, 1536, "ViT-S student"), (25216, 384, 384, 1536, "ViT-S teacher-size"), (25216, 768, 704, 2048, "ViT-B fine-tune")):
+        mk = lambda r, c: torch.randn(r, c, device=dev).to(bf)
+        gbm, a, du, h2, gba, o, dqkv, h1 = mk(Mx, D), mk(Mx, H), mk(Mx, H), mk(Mx, D), mk(Mx, D), mk(Mx, I), mk(Mx, 3 * I), mk(Mx, D)
+        pairs = [(gbm, a), (du, h2), (gba, o), (dqkv, h1)]
+        Cs = [torch.zeros(x.shape[1], y.shape[1], device=dev) for x, y in pairs]
+        bs = [torch.zeros(x.shape[1], device=dev) for x, _ in pairs]
+        t0 = timeit(lambda: [ops.gemm_tn_acc(x, y, c, colsum=b) for (x, y), c, b in zip(pairs, Cs, bs)])
+        wss = [ops.wgrad_workspace(Mx, x.shape[1], y.shape[1], dev) for x, y in pairs]
+        t1 = timeit(lambda: [ops.wgrad(x, y, c, accumulate=True, colsum=b, workspace=w) for (x, y), c, b, w in zip(pairs, Cs, bs, wss)])
+        probs = [(x, y, c, True, b) for (x, y), c, b in zip(pairs, Cs, bs)]
+        ws = ops.wgrad_group(probs)
+        t2 = timeit(lambda: ops.wgrad_group(probs, workspace=ws))
+        fl = sum(2 * Mx * x.shape[1] * y.shape[1] for x, y in pairs)
+        print(f"   {name:20s} M={Mx}: round-1 {t0*1e6:7.1f} us | 4 x wgrad {t1*1e6:7.1f} us | group {t2*1e6:7.1f} us = {fl/t2/1e12:6.1f} TF/s  (ws {ws.numel()*4/1e6:.1f} MB)")
 if "tnsplits" in which:
     print("--- TN wgrad vs number of M-slices (0 = library default)")
     for sp in (0, 8, 16, 24, 32):
