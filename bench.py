@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """LAFS pre-training step benchmark on MI355X (BASELINE.json metric: face-crops/sec/node).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts its own N rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Workload (config C2/C3): ViT-S/8 student+teacher, DINO head K=100000, 2 global 112x112 + 8 local 48x48 synthetic
@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--local-crops", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--roofline-only", action="store_true", help="run only the dominant-kernel loop (for rocprofv3)")
+    ap.add_argument("--roofline-only", action="store_true", help="run only the roofline kernels' loops (for rocprofv3)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--augment", action="store_true",
                     help="with --frontend: also run the device-side DataAugmentation_LAFS (uint8 batch -> 20 views) every step")
@@ -59,10 +59,61 @@ def parse():
     return ap.parse_args()
 
 
-def dominant_kernel_roofline(device, iters=30):
-    """The dominant kernel of the step is the 128x128 MFMA GEMM; its heaviest instance is the student MLP fc1
-    (M = 64*(2*197+8*37) = 44160 tokens, N = 1536, K = 384, bias+GELU epilogue writing u and gelu(u)).  Timed with HIP
-    events on the stream it is launched on."""
+def _time_on_stream(fn, iters):
+    """Average duration of fn() with HIP events on the stream the kernels are launched on (torch's current stream)."""
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def _roof(kernel, dur, flops, alg_bytes, traffic=None):
+    """Both roofs of one launch: HBM (algorithmic bytes / time vs 8 TB/s) and MFMA (flops / time vs 2.5 PFLOP/s dense bf16).
+    `bound` is the roof the kernel's arithmetic intensity puts it under (machine balance 312 FLOP/B); `frac` is against it."""
+    gbs, tf = alg_bytes / dur / 1e9, flops / dur / 1e12
+    bound = "hbm" if flops / alg_bytes < 2.5e15 / 8e12 else "mfma"
+    return {"bound": bound, "kernel": kernel,
+            "achieved": round(gbs if bound == "hbm" else tf, 1), "peak": 8000.0 if bound == "hbm" else 2500.0,
+            "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(gbs / 8000.0 if bound == "hbm" else tf / 2500.0, 4),
+            "traffic": traffic, "avg_launch_us": round(dur * 1e6, 2), "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / 8000.0, 4),
+            "mfma_tflops": round(tf, 1), "mfma_frac": round(tf / 2500.0, 4), "intensity_flop_per_byte": round(flops / alg_bytes, 1)}
+
+
+def _pmc_traffic(name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/round2_kernel_pmc.json), or None."""
+    f = os.path.join(ROOT, "profiles", "round2_kernel_pmc.json")
+    try:
+        return round(json.load(open(f))[name]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def roofline_wgrad_group(device, iters=30):
+    """The four weight gradients of one ViT-S block (student: M = 64*(2*197+8*37) = 44160 tokens) as the engine launches
+    them: ONE lafs_wgrad_group call = wgrad_kernel<2,2,3,3,5> (240 workgroups: 48 tiles x 5 token slices) + the fold kernel.
+    Algorithmic bytes per launch: every operand read once (8 bf16 matrices) + the four fp32 gradients written once."""
+    from lafs_cvpr2024_amd import ops
+    M, D, I, H = 44160, 384, 384, 1536
+    mk = lambda r, c: torch.randn(r, c, device=device).to(torch.bfloat16)
+    pairs = [(mk(M, D), mk(M, H)), (mk(M, H), mk(M, D)), (mk(M, D), mk(M, I)), (mk(M, 3 * I), mk(M, D))]
+    probs = [(x, y, torch.zeros(x.shape[1], y.shape[1], device=device), True, torch.zeros(x.shape[1], device=device)) for x, y in pairs]
+    ws = ops.wgrad_group(probs)
+    dur = _time_on_stream(lambda: ops.wgrad_group(probs, workspace=ws), iters)
+    flops = sum(2.0 * M * x.shape[1] * y.shape[1] for x, y in pairs)
+    alg = sum(2.0 * M * (x.shape[1] + y.shape[1]) + 4.0 * x.shape[1] * y.shape[1] for x, y in pairs)
+    return _roof("wgrad_kernel<2,2,3,3,5> + wgrad_fold_kernel: the 4 weight gradients of one ViT-S block, M=44160 (lafs_wgrad_group)",
+                 dur, flops, alg, _pmc_traffic("wgrad_group"))
+
+
+def roofline_fc1(device, iters=30):
+    """Heaviest single launch of the NT GEMM family: student MLP fc1 (M = 44160, N = 1536, K = 384, bias+GELU epilogue writing
+    u and gelu(u)).  Algorithmic bytes: A and W (bf16) read once, u and GELU(u) (bf16) written once."""
     from lafs_cvpr2024_amd import _lib, ops
     M, N, K = 44160, 1536, 384
     A = torch.randn(M, K, device=device).to(torch.bfloat16)
@@ -70,33 +121,43 @@ def dominant_kernel_roofline(device, iters=30):
     b = torch.zeros(N, device=device)
     u = torch.empty(M, N, device=device, dtype=torch.bfloat16)
     a = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-    for _ in range(3):
-        ops.gemm_nt(A, W, _lib.EPI_BF16_GELU, bias=b, out=u, out2=a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        ops.gemm_nt(A, W, _lib.EPI_BF16_GELU, bias=b, out=u, out2=a)
-    e1.record()
-    torch.cuda.synchronize()
-    dur = e0.elapsed_time(e1) / iters * 1e-3
-    flops = 2.0 * M * N * K
-    # Algorithmic bytes per launch: A (bf16) + W (bf16) read once, u and GELU(u) (bf16) written once.  Arithmetic
-    # intensity 52.1 GFLOP / 306 MB = 170 FLOP/B is below the machine balance (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B):
-    # the roofline that bounds this kernel is HBM, not MFMA.
-    alg_bytes = (M * K + N * K + 2 * M * N) * 2.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "round1_dominant_kernel_pmc.json")
-    if os.path.isfile(pmc):                      # HBM bytes per launch from the committed rocprofv3 --pmc passes
-        try:
-            traffic = round(json.load(open(pmc))["hbm_bytes_per_launch"])
-        except Exception:
-            traffic = None
-    ach = alg_bytes / dur / 1e9
-    return {"bound": "hbm", "kernel": "gemm_nt_kernel<BF16_GELU> M=44160 N=1536 K=384 (student MLP fc1 + GELU)",
-            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
-            "avg_launch_us": round(dur * 1e6, 2), "mfma_tflops": round(flops / dur / 1e12, 1),
-            "mfma_frac": round(flops / dur / 2.5e15, 4)}
+    dur = _time_on_stream(lambda: ops.gemm_nt(A, W, _lib.EPI_BF16_GELU, bias=b, out=u, out2=a), iters)
+    return _roof("gemm_nt_kernel<BF16_GELU,4,32> M=44160 N=1536 K=384 (student MLP fc1 + GELU)", dur, 2.0 * M * N * K,
+                 (M * K + N * K + 2 * M * N) * 2.0, _pmc_traffic("fc1"))
+
+
+ROOFLINE_KERNELS = {"wgrad_kernel": roofline_wgrad_group, "gemm_nt_kernel": roofline_fc1}
+
+
+def dominant_kernel_name():
+    """The kernel with the largest per-step total in the committed serialised profile of the step
+    (profiles/round2_serial_kernel_stats.csv, rocprofv3 --kernel-trace --stats); falls back to the weight-gradient kernel."""
+    import csv
+    f = os.path.join(ROOT, "profiles", "round2_serial_kernel_stats.csv")
+    try:
+        rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
+        for r in rows:
+            for key in ROOFLINE_KERNELS:
+                if key in r["Name"]:
+                    return key
+    except Exception:
+        pass
+    return "wgrad_kernel"
+
+
+def dominant_kernel_roofline(device, iters=30):
+    dom = dominant_kernel_name()
+    out = ROOFLINE_KERNELS[dom](device, iters)
+    out["others"] = [fn(device, iters) for k, fn in ROOFLINE_KERNELS.items() if k != dom]
+    return out
+
+
+def step_hbm_bytes():
+    """HBM bytes of ONE whole step from profiles/round2_step_hbm_pmc.json (FETCH_SIZE x2 + WRITE_SIZE over all kernels)."""
+    try:
+        return int(json.load(open(os.path.join(ROOT, "profiles", "round2_step_hbm_pmc.json")))["hbm_bytes_per_step"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(arch_dims, n_local, K, batch):
@@ -116,20 +177,72 @@ def cpu_baseline(arch_dims, n_local, K, batch):
     t0 = time.time()
     r = ostep.lafs_step(st, crops, epoch=1, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04)
     dt = time.time() - t0
-    return {"value": round(batch * (2 + n_local) / dt, 3), "unit": "face-crops/s", "cores": cores, "kind": "port",
-            "sample": f"1 step of the same model/crops at batch {batch} (fp32, torch CPU, {dt:.1f} s), loss {float(r['loss']):.4f}"}
+    out = {"value": round(batch * (2 + n_local) / dt, 3), "unit": "face-crops/s", "cores": cores, "kind": "port",
+           "sample": f"1 step of the same model/crops at batch {batch} (fp32, torch CPU, {dt:.1f} s), loss {float(r['loss']):.4f}"}
+    # config C1 of BASELINE.json (ViT-Tiny, 2 global + 2 local crops, batch 8): the always-run CPU case, for round-to-round comparison
+    cfg1 = ovit.ViTConfig(patch_size=8, embed_dim=192, depth=12, num_heads=3, img_size=224)
+    st1 = ostep.LafsState(cfg1, out_dim=K, seed=0)
+    crops1 = [torch.randn(8, 3, 112, 112, generator=g).clamp(-1, 1) for _ in range(2)] + \
+             [torch.randn(8, 3, 48, 48, generator=g).clamp(-1, 1) for _ in range(2)]
+    t0 = time.time()
+    ostep.lafs_step(st1, crops1, epoch=1, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04)
+    dt1 = time.time() - t0
+    out["c1"] = {"value": round(8 * 4 / dt1, 3), "unit": "face-crops/s", "sample": f"C1: ViT-Tiny, 2g+2l, batch 8, out_dim {K}, 1 step ({dt1:.1f} s)"}
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one per GPU, RCCL over
+    127.0.0.1) BEFORE this process touches the GPU, relay rank 0's JSON line, exit with the worst return code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()                 # counting devices does not initialise the GPU
+    if have < n and os.environ.get("LAFS_BENCH_SHARE_GPU") != "1":
+        sys.exit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.exit(max(abs(rc) for rc in rcs))
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            spawn_ranks(args)                        # never returns
+        world, rank, local = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE={world} set by the launcher")
+    share = os.environ.get("LAFS_BENCH_SHARE_GPU") == "1"     # tests: every rank on GPU 0 over gloo (RCCL wants one device per rank)
+    if share:
+        local = 0
+    from lafs_cvpr2024_amd import _lib
+    dbg = int(_lib.lib().lafs_debug_get())
+    if dbg != 0 or _lib.lib().lafs_ablation_build():
+        sys.exit(f"bench.py: refusing to run with kernel debug flags set (lafs_debug_get() = {dbg}, ablation build = "
+                 f"{_lib.lib().lafs_ablation_build()}): unset LAFS_DEBUG_FLAGS / LAFS_USE_ABLATE_LIB")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from lafs_cvpr2024_amd import vision_transformer as vits
     from lafs_cvpr2024_amd.dino_loss import DINOLoss
@@ -224,8 +337,12 @@ def main():
             "images_per_s": round(world * B / (ms * 1e-3), 1),
             "step_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
             "step_mfma_frac": round(fl / (ms * 1e-3) / 2.5e15, 4),
-            "final_loss": round(loss_v, 4),
+            "final_loss": round(loss_v, 4), "debug_flags": dbg,
         }
+        hb = step_hbm_bytes()
+        if hb is not None:                           # measured HBM bytes of one step (committed PMC profile) over this run's time
+            out["step_hbm_bytes"] = hb
+            out["step_hbm_frac"] = round(hb / (ms * 1e-3) / 8e12, 4)
         out["roofline"] = dominant_kernel_roofline(device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, nl, K, args.cpu_batch)

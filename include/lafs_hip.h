@@ -30,14 +30,19 @@ int lafs_version(void);
 /* Diagnostic: lane l of one wave issues ds_read_b64_tr_b16 at LDS byte 8*l over in(i16)[512]; out(i16)[256] gets
  * the 4 values each lane received.  Pins the LDS-transpose-read model used by the attention / wgrad kernels. */
 int lafs_debug_tr16(const void* in, void* out, hipStream_t stream);
-/* Diagnostic flags for the timing experiments of tools/bench_kernels.py; never set on the product path.
- * Flags marked (W) make results WRONG, the others only select an alternative, equally correct code path.
+/* Kernel-selection flags for the timing experiments of tools/bench_kernels.py; never set on the product
+ * path, and bench.py refuses to run unless lafs_debug_get() == 0.  In liblafs_hip.so every flag only selects an alternative,
+ * equally correct code path.  The flags marked (W) make results WRONG (they skip work) and exist only in the -DLAFS_ABLATE
+ * build (`make -C lafs_cvpr2024_amd/csrc ablate` -> liblafs_hip_ablate.so, lafs_ablation_build() == 1); the product library
+ * compiles them out.
  *   1 (W) TN GEMM: plain stores instead of atomics      2 / 4  NT GEMM: force 128x128 / 256x128 tiles     8  NT: force 64-deep stages
  *  16 (W) NT: no epilogue stores   32 (W) NT: no MFMA   64 (W) NT GELU: no second store   128 (W) NT GELU: store u twice
  * 256     NT: non-temporal epilogue stores       1024  TN: force 128x128     2048 / 4096  TN: 256x256 / 256x128 tiles
  * 8192    TN: 64-row stages in a 2-stage ring   16384 (W) NT GELU: u / GELU(u) interleaved in one buffer
  * 32768   NT GELU: piece-by-piece store order (the pre-optimisation order)      65536  NT: 256x256 tiles for bf16 epilogues */
 int lafs_debug_set(int flags);
+int lafs_debug_get(void);
+int lafs_ablation_build(void);
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* lafs_last_error(void);
 

@@ -113,6 +113,8 @@ _PROTOS = {
 _NO_STREAM = {
     "lafs_version": ([], i32),
     "lafs_debug_set": ([i32], i32),
+    "lafs_debug_get": ([], i32),
+    "lafs_ablation_build": ([], i32),
     "lafs_last_error": ([], C.c_char_p),
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),
@@ -131,10 +133,13 @@ def lib():
         # torch bundles its own libamdhip64.so (same SONAME as /opt/rocm's): it must be mapped FIRST so that this
         # library binds to the very same HIP runtime instance (streams and device pointers are shared with torch).
         import torch  # noqa: F401
-        if not os.path.isfile(LIB_PATH):
-            raise LafsHipError(f"{LIB_PATH} not found: the HIP extension is not built (run __graft_entry__.build()); "
+        path = LIB_PATH
+        if os.environ.get("LAFS_USE_ABLATE_LIB") == "1":          # tools/bench_kernels.py ablate: result-changing timing flags
+            path = os.path.join(_HERE, "liblafs_hip_ablate.so")
+        if not os.path.isfile(path):
+            raise LafsHipError(f"{path} not found: the HIP extension is not built (run __graft_entry__.build()); "
                                "there is no CPU fallback")
-        h = C.CDLL(LIB_PATH)
+        h = C.CDLL(path)
         for name, args in _PROTOS.items():
             fn = getattr(h, name)
             fn.argtypes = list(args) + [vp]

@@ -17,6 +17,15 @@
 #include "common.hpp"
 #include "lafs_hip.h"
 
+// Timing ablations that change RESULTS (no stores / no MFMA / ...) exist only in the -DLAFS_ABLATE build (make ablate ->
+// liblafs_hip_ablate.so, used by tools/bench_kernels.py): in the product library the branches below are compiled out, so no
+// environment variable or lafs_debug_set call can make a kernel skip work.
+#ifdef LAFS_ABLATE
+#define DBG(p, bits) ((p).dbg & (bits))
+#else
+#define DBG(p, bits) (0)
+#endif
+
 namespace {
 
 enum {
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
   for (int i = 0; i < 4; ++i) { arow[i] = wr * 64 + i * 16 + frow; brow[i] = wc * 64 + i * 16 + frow; }
 
   auto compute = [&](int t) {
-    if (p.dbg & 32) return;
+    if DBG(p, 32) return;
     const unsigned char* st = smem + (t % NSTG) * STAGE;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
   // group q starts at n0 + wc*64 + q*4*VPL + fq*VPL; register e = j*4 + r of the row is element e % VPL of group e / VPL.
   constexpr int VPL = EpiTraits<EPI>::VPL, NG = 16 / VPL;
   const int ncol0 = n0 + wc * 64 + fq * VPL;
-  if (p.dbg & 16) {                                    // ablation: keep the accumulators live, store nothing
+  if DBG(p, 16) {                                    // ablation: keep the accumulators live, store nothing
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -255,7 +264,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[j][i][r] + bias[j * 4 + r];
     float sc = 1.0f;
-    const bool ntst = (p.dbg & 256) != 0;              // streaming stores: A/B experiment only (no gain in a real layer chain)
+    const bool ntst = DBG(p, 256) != 0;              // streaming stores: A/B experiment only (no gain in a real layer chain)
     size_t orow = (size_t)m;
     int tpos = 0;
     if (EPI == EPI_RESID_F32) sc = scv[i];
@@ -276,7 +285,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
       if (n >= p.N) continue;
       const bool full = (n + VPL <= p.N);
       float* w = v + q * VPL;
-      const bool legacy = (p.dbg & 32768) != 0;
+      const bool legacy = DBG(p, 32768) != 0;
       const bool do_first = legacy ? (pass == 0) : (pass == 0), do_second = legacy ? (pass == 0) : (pass == NPASS - 1);
       if (legacy && pass > 0) continue;
       if (EPI == EPI_BF16_ACT) {                          // 1x1 convolution of the landmark CNN: + residual (bf16), activation
@@ -307,7 +316,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
         // experiment (debug flag 16384): u and GELU(u) interleaved in 64-byte pieces of ONE [M, 2N] buffer, so the two stores
         // of a lane group complete a 128-byte line
-        if (EPI == EPI_BF16_GELU && (p.dbg & 16384)) c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc * 2 + (n >> 5) * 64 + (n & 31);
+        if (EPI == EPI_BF16_GELU && DBG(p, 16384)) c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc * 2 + (n >> 5) * 64 + (n & 31);
         if (EPI == EPI_BF16_GELU && (p.C == nullptr || !do_first)) {
           // forward-only pass (teacher): the pre-activation is not needed, only GELU(u) is written; second pass: already stored
         } else if (full) {
@@ -316,10 +325,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
 #pragma unroll
           for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(w[e]);
         }
-        if (EPI == EPI_BF16_GELU && !(p.dbg & 64) && do_second) {
+        if (EPI == EPI_BF16_GELU && !DBG(p, 64) && do_second) {
           bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n;
-          if (p.dbg & 16384) c2 = c + 32;
-          if (full && (p.dbg & 128)) {
+          if DBG(p, 16384) c2 = c + 32;
+          if (full && DBG(p, 128)) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
           } else if (p.drop.thresh) {
 #pragma unroll
@@ -650,7 +659,10 @@ static int launch_tn(const void* A, int lda, const void* B, int ldb, float* C, i
   LAFS_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && N1 % 8 == 0 && N2 % 8 == 0, "N1/N2/lda/ldb must be multiples of 8");
   TNArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.colsum = colsum_a;
-  a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.mode = g_debug_flags & 1;
+  a.M = M; a.N1 = N1; a.N2 = N2; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.mode = 0;
+#ifdef LAFS_ABLATE
+  a.mode = g_debug_flags & 1;
+#endif
   a.part_stride = part_stride;
   if (part_stride > 0) a.mode = 2;
   // 32-row stages in a 3-stage ring.  (64-row stages in a 2-stage ring -- half the barriers -- measured 1.8x slower: the
@@ -728,3 +740,11 @@ extern "C" int lafs_reduce_partials(float* part, int64_t part_stride, int n_part
 // Diagnostic knob for timing experiments (bit 0: TN GEMM stores instead of atomics -> WRONG results).  Never set by
 // the product path.
 extern "C" int lafs_debug_set(int flags) { g_debug_flags = flags; return LAFS_OK; }
+extern "C" int lafs_debug_get(void) { return g_debug_flags; }
+extern "C" int lafs_ablation_build(void) {
+#ifdef LAFS_ABLATE
+  return 1;
+#else
+  return 0;
+#endif
+}

@@ -213,3 +213,30 @@ def test_full_size_c2_step_properties():
     assert abs(l_graph - l_eager) < 1e-4 * l_eager
     diff = (eng_g.sa.master - eng.sa.master).abs()
     assert float(diff.median()) < 1e-7 and float((diff > 1e-4).float().mean()) < 0.02     # Adam sign flips where g is round-off
+
+
+def test_bench_owns_its_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher must start two rank processes by itself (before touching the GPU) and report
+    n_gpus = 2; here both ranks share the one GPU over gloo (LAFS_BENCH_SHARE_GPU=1).  A --gpus / WORLD_SIZE mismatch, more GPUs
+    than visible, or kernel debug flags must fail loudly instead of printing a 1-GPU number."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    small = ["--steps", "2", "--warmup", "1", "--batch", "2", "--arch", "vit_tiny", "--out-dim", "1024", "--local-crops", "2", "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LAFS_DEBUG_FLAGS")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, env=dict(env, LAFS_BENCH_SHARE_GPU="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 4
+    assert line["debug_flags"] == 0 and line["roofline"]["kernel"].startswith(("wgrad_kernel", "gemm_nt_kernel"))
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr                      # a 1-GPU box cannot run 2 RCCL ranks
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+    r = subprocess.run([sys.executable, bench] + small, env=dict(env, LAFS_DEBUG_FLAGS="16"), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "debug flags" in r.stderr
