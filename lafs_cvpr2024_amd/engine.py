@@ -23,6 +23,11 @@ from .ops import _p, call
 from .utils import PinnedRing
 from .vision_transformer import VisionTransformer, attach_arena, _is_matrix_for_dgrad
 
+
+def _is_partfvit(m):
+    from .face_pre_pro.ViT_face import ViT_face_landmark_patch8
+    return isinstance(m, ViT_face_landmark_patch8)
+
 f32, bf16 = torch.float32, torch.bfloat16
 
 
@@ -47,8 +52,15 @@ class LafsPretrainEngine:
         self.clip_grad, self.freeze_last_layer = float(clip_grad or 0.0), freeze_last_layer
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         vit_s, vit_t = student.backbone, teacher.backbone
-        if not isinstance(vit_s, VisionTransformer):
-            raise _lib.LafsHipError("LafsPretrainEngine drives the HIP VisionTransformer backbone")
+        # Two backbones: the DINO VisionTransformer (NCHW crops, bicubic-resampled position table) and Part-fViT,
+        # ViT_face_landmark_patch8 -- the pair the reference actually pre-trains (lafs_train.py:300-335, arch 'mynet'): landmark
+        # mosaics as [B, n, 192] patch tokens, position table sliced to n+1 rows, DropPath 0.1 + dropout 0.1 live in the student
+        # AND the teacher (the reference never calls teacher.eval()).
+        self.partfvit = _is_partfvit(vit_s)
+        if not (isinstance(vit_s, VisionTransformer) or self.partfvit) or type(vit_s) is not type(vit_t):
+            raise _lib.LafsHipError("LafsPretrainEngine drives a VisionTransformer or a ViT_face_landmark_patch8 pair")
+        if self.partfvit and (vit_s.with_land or vit_t.with_land):
+            raise _lib.LafsHipError("LAFS pre-training uses with_land=False backbones (the landmark CNN is the frozen front-end)")
         self.sa = attach_arena(student, self.device)
         self.ta = getattr(teacher, "_lafs_arena", None)
         if self.ta is None:
@@ -68,15 +80,27 @@ class LafsPretrainEngine:
             self.sa.refresh_shadows(); self.ta.refresh_shadows()
         self.K = student.head.out_dim
         self.Kpad = (self.K + 127) // 128 * 128
-        B, D = batch_size, vit_s.embed_dim
+        B, D = batch_size, (vit_s.dim if self.partfvit else vit_s.embed_dim)
         self.geom_s = Fn.geometry([(2 * B, global_size), (n_local * B, local_size)] if n_local else [(2 * B, global_size)], self.device)
         self.geom_t = Fn.geometry([(2 * B, global_size)], self.device)
         self.spec_s, self.spec_t = vit_s._spec, vit_t._spec
         self.head_prefix_s, self.head_prefix_t = student.head._prefix, teacher.head._prefix
-        # bicubic resampling matrices for the stored position table
-        g = int(math.isqrt(vit_s.pos_embed.shape[1] - 1))
+        # bicubic resampling matrices for the stored position table (Part-fViT: plain slices, no resampling)
         self.grids = [global_size // 8] + ([local_size // 8] if n_local else [])
-        self.interp = [None if r == g else _interp_matrix(g, r, self.device) for r in self.grids]
+        if self.partfvit:
+            if vit_s.num_patches < self.grids[0] ** 2:
+                raise _lib.LafsHipError("pos_embedding is shorter than the global crops' token count")
+            self.interp = [None for _ in self.grids]
+        else:
+            g = int(math.isqrt(vit_s.pos_embed.shape[1] - 1))
+            self.interp = [None if r == g else _interp_matrix(g, r, self.device) for r in self.grids]
+        # element dropout draws a new counter-based mask every step from a HOST-side seed (a kernel argument): a captured
+        # graph would replay one mask for ever, so such a model runs eagerly
+        self.has_dropout = self.partfvit and (vit_s.dropout_rate > 0 or vit_s.emb_dropout_rate > 0 or
+                                              vit_t.dropout_rate > 0 or vit_t.emb_dropout_rate > 0)
+        if self.has_dropout and use_graph:
+            print("LafsPretrainEngine: element dropout is active -> eager launches (hipGraph capture would freeze the masks)")
+            use_graph = False
         # static buffers
         dev = self.device
         self.hyper = torch.zeros(_lib.HP_COUNT, device=dev, dtype=f32)
@@ -96,13 +120,14 @@ class LafsPretrainEngine:
         # gradient ranges for the two all-reduces: [trunk | head]
         self.head_start = min(o for n, o in self.sa.offsets.items() if n.startswith(self.head_prefix_s))
         self.depth = vit_s.depth
+        self.pos_name = self.spec_s.pos
         # the trunk backward is cut in two graph segments so that the upper blocks' gradients are already on the wire
         # (RCCL) while the lower blocks are still being computed
         # the trunk backward is cut into `grad_slices` graph segments (blocks depth-1 .. 0 in equal runs) so that each run's
         # gradients are already on the wire (RCCL) while the next run is computed; only the last run's all-reduce is exposed
         ns = max(1, min(int(grad_slices), self.depth))
         self.cuts = [self.depth - (self.depth * k) // ns for k in range(ns + 1)]            # e.g. depth 12, 4 slices: 12 9 6 3 0
-        off = lambda blk: self.sa.offsets[f"{self.spec_s.prefix}blocks.{blk}.norm1.weight"] if blk > 0 else 0
+        off = lambda blk: self.sa.offsets[self.spec_s.trunk.block_names[blk]["ln1_g"]] if blk > 0 else 0
         self.cut_offsets = [off(c) for c in self.cuts[1:]]                                   # arena offset where each run starts
         self.reducer = FlatReducer()
         # teacher forward / weight-gradient GEMMs run on a second stream; LAFS_SINGLE_STREAM=1 serialises everything (profiling)
@@ -114,10 +139,13 @@ class LafsPretrainEngine:
 
     # ------------------------------------------------------------------ pieces (all capturable)
     def _pos_tokens(self, arena, spec):
-        pe = arena.view(arena.master, spec.prefix + "pos_embed").view(-1, spec.trunk.dim)
+        pe = arena.view(arena.master, spec.prefix + spec.pos).view(-1, spec.trunk.dim)
         out = []
-        for M in self.interp:
-            out.append(pe if M is None else torch.cat((pe[:1], M @ pe[1:])))
+        for M, r in zip(self.interp, self.grids):
+            if self.partfvit:
+                out.append(pe[:r * r + 1])                 # pos_embedding[:, :n+1] (reference ViT_face.py:766)
+            else:
+                out.append(pe if M is None else torch.cat((pe[:1], M @ pe[1:])))
         return out
 
     def _seg_forward(self):
@@ -129,13 +157,18 @@ class LafsPretrainEngine:
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             pos_t = self._pos_tokens(ta, self.spec_t)[:1]
-            feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, None, save=False)
+            vit_t = self.teacher.backbone
+            drop_t = vit_t._sample_drop_scales(self.geom_t) if vit_t.training else None      # rate 0 for the DINO ViT teacher
+            dd_t = vit_t._next_dropout() if self.partfvit else None
+            feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, drop_t, save=False, dropout=dd_t)
             Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self.logits_t)
         # student: all views in one packed pass
         vit = self.student.backbone
         drop = vit._sample_drop_scales(self.geom_s) if vit.training else None
         imgs = [self.in_global_all] + ([self.in_local_all] if self.n_local else [])
-        feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s), drop, save=True)
+        dd_s = vit._next_dropout() if self.partfvit else None
+        feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s), drop, save=True,
+                                         dropout=dd_s)
         _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self.logits_s)
         cur.wait_stream(side)
         # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
@@ -156,9 +189,11 @@ class LafsPretrainEngine:
         Fn.vit_backward_layers(self._st["vit"], self._st["g"], self.cuts[k], self.cuts[k + 1], wgrad_stream=self.side_stream)
         if k == len(self.cuts) - 2:
             dpos = Fn.vit_backward_end(sa, self.spec_s, self._st["vit"], self._st["g"])
-            gpe = sa.view(sa.grad, self.spec_s.prefix + "pos_embed").view(-1, self.spec_s.trunk.dim)
+            gpe = sa.view(sa.grad, self.spec_s.prefix + self.pos_name).view(-1, self.spec_s.trunk.dim)
             for M, dp in zip(self.interp, dpos):
-                if M is None:
+                if self.partfvit:
+                    gpe[:dp.shape[0]] += dp
+                elif M is None:
                     gpe += dp
                 else:
                     gpe[:1] += dp[:1]
@@ -199,8 +234,12 @@ class LafsPretrainEngine:
         self._graphs = graphs
 
     def set_inputs(self, crops):
-        """crops: list of 2 global + n_local local NCHW tensors (any device); copied into the static input buffers."""
+        """crops: list of 2 global + n_local local crops (any device), copied into the static NCHW input buffers.  Each is an
+        NCHW image or, as the reference feeds its Part-fViT pair (lafs_train.py:538-569), a [B, n, 192] tensor of '(p1 p2 c)'
+        patch vectors of the landmark mosaic -- the same pixels in another order, re-indexed here."""
         for dst, src in zip(self.in_global + self.in_local, crops):
+            if src.dim() == 3:
+                src = Fn.unpatchify_grad(src, _lib.PATCH_ORDER_HWC)
             dst.copy_(src, non_blocking=True)
 
     def step(self, crops=None, *, lr, wd, momentum, teacher_temp, epoch, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -231,7 +231,7 @@ class ViT_face_landmark_patch8(nn.Module):
         object.__setattr__(self, "_arena", arena)
         self._spec = Fn.ViTSpec(trunk=trunk, prefix=prefix, patch_order=_lib.PATCH_ORDER_HWC,
                                 w_patch="patch_to_embedding.weight", b_patch="patch_to_embedding.bias", cls="cls_token",
-                                final_g="mlp_head.0.weight", final_b="mlp_head.0.bias")
+                                final_g="mlp_head.0.weight", final_b="mlp_head.0.bias", pos="pos_embedding")
         self._hook = torch.zeros(1, device=arena.device, requires_grad=True)
 
     def _sample_drop_scales(self, geom):

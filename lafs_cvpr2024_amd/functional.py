@@ -121,6 +121,7 @@ class ViTSpec:
     cls: str = "cls_token"
     final_g: str = "norm.weight"
     final_b: str = "norm.bias"
+    pos: str = "pos_embed"             # position table: resampled per crop size (DINO ViT) or sliced [:n+1] (Part-fViT)
 
 
 class ViTState:

@@ -5,8 +5,10 @@ Launch (one process per GPU, RCCL):
     python -m torch.distributed.run --nproc-per-node=N --master-addr 127.0.0.1 lafs_train.py --arch vit_small ...
 
 Differences from the reference, all forced by its own breakage or by scope:
-  * --arch choices are the ViT family (the reference's default 'mynet' is not in its own `choices`, its xcit choices
-    need network access, and its vit_* path crashes on an undefined landmarkcnn);
+  * --arch defaults to 'mynet' exactly like the reference (lafs_train.py:34): the Part-fViT pair ViT_face_landmark_patch8(dim 768,
+    depth 12, heads 11, mlp 2048, dropout = emb_dropout = 0.1) of :300-335 -- the only configuration the reference can run, and
+    the one whose `teacher` checkpoint stage 3 (train_largescale.py:639-657) loads.  The DINO vit_* family is offered too (the
+    reference lists it but crashes on it: landmarkcnn undefined, :360); its xcit choices need network access and are dropped;
   * the data pipeline (MXNet recordio + PIL augmentations + landmark CNN) is out of scope: `--data synthetic` feeds the
     crop shapes the landmark gather emits (2 x 112^2 + n x 48^2), or pass any Dataset through `train_lafs(args, dataset=...)`
     yielding lists of 2 + n crops;
@@ -36,7 +38,7 @@ __all__ = ["DINOLoss", "get_args_parser", "train_lafs", "train_one_epoch", "Synt
 
 def get_args_parser():
     p = argparse.ArgumentParser('LAFS', add_help=False)
-    p.add_argument('--arch', default='vit_small', type=str, choices=['vit_tiny', 'vit_small', 'vit_base'])
+    p.add_argument('--arch', default='mynet', type=str, choices=['mynet', 'vit_tiny', 'vit_small', 'vit_base'])
     p.add_argument('--patch_size', default=8, type=int)
     p.add_argument('--out_dim', default=100000, type=int)
     p.add_argument('--norm_last_layer', default=True, type=utils.bool_flag)
@@ -58,6 +60,8 @@ def get_args_parser():
     p.add_argument('--min_lr', type=float, default=1e-6)
     p.add_argument('--optimizer', default='adamw', type=str, choices=['adamw'])
     p.add_argument('--drop_path_rate', type=float, default=0.1)
+    p.add_argument('--mynet_dims', default='768,12,11,2048', type=str, help="dim,depth,heads,mlp_dim of --arch mynet (reference :300-335)")
+    p.add_argument('--mynet_dropout', default=0.1, type=float, help="dropout = emb_dropout of --arch mynet (reference: 0.1)")
     p.add_argument('--local_crops_number', type=int, default=8)
     p.add_argument('--data', default='synthetic', type=str,
                    help="'synthetic': random landmark-crop shaped tensors; 'synthetic_views': the 20 augmented 112x112 views of "
@@ -175,6 +179,27 @@ def build_landmark_frontend(args, device):
     return LandmarkFrontEnd(cnn, args.batch_size_per_gpu, n_local=args.local_crops_number, device=device)
 
 
+def build_backbones(args):
+    """(student backbone, teacher backbone, embed_dim).  'mynet' = the reference's hard-coded Part-fViT pair
+    (lafs_train.py:300-335): both networks with dropout / emb_dropout 0.1 and Residual_droppath 0.1, and neither is ever put in
+    eval mode, so the teacher is stochastic too.  `--mynet_dims dim,depth,heads,mlp` shrinks it for smoke runs."""
+    if args.arch != 'mynet':
+        sb = vits.__dict__[args.arch](patch_size=args.patch_size, drop_path_rate=args.drop_path_rate)
+        tb = vits.__dict__[args.arch](patch_size=args.patch_size)
+        return sb, tb, sb.embed_dim
+    from .face_pre_pro.ViT_face import ViT_face_landmark_patch8
+    dim, depth, heads, mlp = (int(v) for v in args.mynet_dims.split(","))
+    mk = lambda: ViT_face_landmark_patch8(loss_type='CosFace', GPU_ID=None, num_class=30000, image_size=112, patch_size=8, dim=dim,
+                                          depth=depth, heads=heads, num_patches=196, mlp_dim=mlp, dropout=args.mynet_dropout,
+                                          emb_dropout=args.mynet_dropout, with_land=False, use_standcoord=False, Random_prob=False,
+                                          shuffle=False)
+    sb, tb = mk(), mk()
+    # `loss.weight` (CosFace, 30000 x dim) is part of the checkpoint layout but never used by the SSL step: the reference's
+    # AdamW skips it (its gradient is None); here it is simply not trainable, so the fused optimizer leaves it alone as well
+    sb.loss.weight.requires_grad_(False)
+    return sb, tb, dim
+
+
 def train_lafs(args, dataset=None):
     utils.init_distributed_mode(args)
     utils.fix_random_seeds(args.seed)
@@ -183,9 +208,7 @@ def train_lafs(args, dataset=None):
     world = utils.get_world_size()
 
     # ---- student / teacher: MultiCropWrapper(backbone, DINOHead), as reference lafs_train.py:200-356 ----
-    student_b = vits.__dict__[args.arch](patch_size=args.patch_size, drop_path_rate=args.drop_path_rate)
-    teacher_b = vits.__dict__[args.arch](patch_size=args.patch_size)
-    embed_dim = student_b.embed_dim
+    student_b, teacher_b, embed_dim = build_backbones(args)
     student = utils.MultiCropWrapper(student_b, DINOHead(embed_dim, args.out_dim, use_bn=args.use_bn_in_head,
                                                          norm_last_layer=args.norm_last_layer))
     teacher = utils.MultiCropWrapper(teacher_b, DINOHead(embed_dim, args.out_dim, args.use_bn_in_head))

@@ -66,17 +66,32 @@ def warmup_cosine(base_lr, epoch_float, warmup_epochs, total_epochs, eta_min=1e-
     return eta_min + 0.5 * (base_lr - eta_min) * (1 + math.cos(math.pi * t / T))
 
 
-def load_ssl_teacher(backbone, path):
-    """Initialise from ckpt['teacher'] with the prefixes stripped, strict=False (train_largescale.py:639-657)."""
+def load_ssl_teacher(backbone, path, min_matched=0.9):
+    """Initialise from ckpt['teacher'] with the 'encoder.' / 'backbone.' / 'module.' prefixes removed, strict=False
+    (train_largescale.py:639-657).  Unlike the reference this refuses to continue silently from random weights: a tensor whose
+    shape does not fit (e.g. a `loss.weight` of another class count) is dropped with a message, and fewer than `min_matched` of
+    the backbone's trunk tensors being initialised is an error -- that is what a checkpoint of the wrong architecture (a DINO
+    ViT teacher: keys blocks.N.attn.qkv..., pos_embed) looks like under strict=False."""
     ck = torch.load(path, map_location="cpu", weights_only=False)
     sd = ck.get("teacher", ck)
-    clean = {}
+    own = backbone.state_dict()
+    clean, dropped = {}, []
     for k, v in sd.items():
-        for pre in ("module.", "backbone.", "encoder."):
-            if k.startswith(pre):
-                k = k[len(pre):]
+        if 'dummy_orthogonal_classifier' not in k:
+            k = k.replace('encoder.', '').replace('backbone.', '').replace('module.', '')
+        if k in own and tuple(own[k].shape) != tuple(v.shape):
+            dropped.append((k, tuple(v.shape), tuple(own[k].shape)))
+            continue
         clean[k] = v
-    print("=> loaded SSL teacher:", backbone.load_state_dict(clean, strict=False))
+    trunk = [k for k in own if not k.startswith(("loss.", "stn.", "output_layer."))]
+    hit = [k for k in trunk if k in clean]
+    for k, a, b in dropped:
+        print(f"=> SSL teacher: skipping {k}: checkpoint {a} vs model {b}")
+    if len(hit) < min_matched * len(trunk):
+        raise RuntimeError(f"{path}: only {len(hit)} of the backbone's {len(trunk)} trunk tensors are in ckpt['teacher'] "
+                           f"(first missing: {[k for k in trunk if k not in clean][:3]}); is this a checkpoint of another architecture? "
+                           "LAFS pre-training must use --arch mynet for its teacher to initialise this model")
+    print(f"=> loaded SSL teacher: {len(hit)}/{len(trunk)} trunk tensors;", backbone.load_state_dict(clean, strict=False))
 
 
 def load_landmark_branch(backbone, path):

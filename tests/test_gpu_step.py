@@ -19,6 +19,9 @@ from lafs_cvpr2024_amd.utils import MultiCropWrapper  # noqa: E402
 
 DEV = "cuda"
 LN6 = partial(nn.LayerNorm, eps=1e-6)
+# per-tensor relative-L2 gate on bf16-MFMA gradients against the fp32 reference (depth-2 fixtures): 2x the worst error
+# observed on MI355X (DESIGN.md section 2 holds the observed table)
+GRAD_GATE = 8e-2
 
 
 def rel_l2(a, b):
@@ -240,3 +243,93 @@ def test_bench_owns_its_launch_two_ranks_on_one_gpu():
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
     r = subprocess.run([sys.executable, bench] + small, env=dict(env, LAFS_DEBUG_FLAGS="16"), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "debug flags" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------------ Part-fViT as the LAFS pair
+def _build_partfvit(fx, use_graph, dropout=0.0, drop_path=0.0):
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8
+    mk = lambda: ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=64, depth=2,
+                                          heads=2, num_patches=196, mlp_dim=128, dropout=dropout, emb_dropout=dropout, with_land=False,
+                                          drop_path_rate=drop_path)
+    student = MultiCropWrapper(mk(), vits.DINOHead(64, 256, hidden_dim=64, bottleneck_dim=32, norm_last_layer=True))
+    teacher = MultiCropWrapper(mk(), vits.DINOHead(64, 256, hidden_dim=64, bottleneck_dim=32))
+    init = sub(fx, "init.")
+    student.load_state_dict(init); teacher.load_state_dict(init)
+    crit = DINOLoss(256, 4, 0.07, 0.04, 3, 10)
+    eng = LafsPretrainEngine(student, teacher, crit, 2, n_local=2, clip_grad=3.0, freeze_last_layer=1, use_graph=use_graph, device=DEV)
+    return student, teacher, crit, eng
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_f16_partfvit_pair_two_steps_against_reference(use_graph, tmp_path):
+    """The reference's real LAFS configuration (arch 'mynet', lafs_train.py:300-335, 538-583): ViT_face_landmark_patch8 student and
+    teacher fed [B, n, 192] patch tokens, two full steps (clip, frozen last layer in step 0, AdamW, EMA, center) against the
+    fixture generated by the reference itself (rates 0).  Then the stage-2 -> stage-3 hand-off: the saved `teacher` initialises a
+    fine-tune backbone through load_ssl_teacher with every trunk tensor matched, and a DINO-ViT teacher is rejected."""
+    fx = load_golden("f16_lafs_step_partfvit")
+    student, teacher, crit, eng = _build_partfvit(fx, use_graph)
+    lrs, wds, moms = fx["hyper"].tolist()
+    tt = crit.teacher_temp_schedule
+    worst = 0.0
+    for s in range(2):
+        crops = [fx[f"s{s}.crop{i}"] for i in range(4)]                     # 3-D [B, n, 192] tokens, as the reference feeds them
+        loss = eng.step(crops, lr=lrs[s], wd=wds[s], momentum=moms[s], teacher_temp=float(tt[s]), epoch=s)
+        torch.cuda.synchronize()
+        ref_loss = float(fx[f"s{s}.loss"])
+        assert abs(float(loss.item()) - ref_loss) / ref_loss < 3e-3, (float(loss.item()), ref_loss)
+        assert rel_l2(eng.logits_s[:, :256], fx[f"s{s}.s_out"]) < 2e-2
+        assert rel_l2(eng.logits_t[:, :256], fx[f"s{s}.t_out"]) < 2e-2
+        torch.testing.assert_close(crit.center.cpu(), fx[f"s{s}.center"], rtol=0, atol=2e-3 * float(fx[f"s{s}.t_out"].abs().max()))
+        post = sub(fx, f"s{s}.grad_post.")
+        norms = dict(zip([str(n) for n in fx["norm_names"]], fx[f"s{s}.norms"].tolist()))
+        bad = {}
+        for k, g in post.items():
+            mine = dict(student.named_parameters())[k].grad
+            clip = min(1.0, 3.0 / (norms[k] + 1e-6))
+            if float(g.abs().max()) > 1e-6:
+                e = rel_l2(mine * clip, g)
+                worst = max(worst, e)
+                if e > GRAD_GATE:
+                    bad[k] = e
+        assert not bad, bad
+        for prefix, mod in (("student", student), ("teacher", teacher)):
+            e = torch.cat([(mod.state_dict()[k].cpu().double() - v.double()).abs().flatten() for k, v in sub(fx, f"s{s}.{prefix}.").items()]).numpy()
+            scale = lrs[s] if prefix == "student" else lrs[s] * (1 - moms[s]) * 2
+            assert np.median(e) < 0.05 * scale and np.quantile(e, 0.9) < 0.6 * scale, (prefix, np.median(e), np.quantile(e, 0.9), scale)
+    print(f"F16 worst per-tensor gradient rel-L2 error: {worst:.3e} (gate {GRAD_GATE})")
+    # ---- hand-off to stage 3 (train_largescale.py:639-657)
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8
+    from lafs_cvpr2024_amd.train_largescale import load_ssl_teacher
+    ck = tmp_path / "checkpoint.pth"
+    torch.save({"teacher": teacher.state_dict(), "student": {"module." + k: v for k, v in student.state_dict().items()}}, ck)
+    ft = ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=77, image_size=112, patch_size=8, dim=64, depth=2, heads=2,
+                                  mlp_dim=128, with_land=False)
+    before = {k: v.clone() for k, v in ft.state_dict().items()}
+    load_ssl_teacher(ft, str(ck))
+    want = [str(k) for k in fx["teacher_backbone_keys"]]                # what the reference's own teacher checkpoint holds
+    assert set(want) <= set(ft.state_dict()) | {"fc", "head"}
+    for k, v in teacher.state_dict().items():
+        if k.startswith("backbone."):
+            assert torch.equal(ft.state_dict()[k[len("backbone."):]].cpu(), v.cpu()), k
+    assert torch.equal(ft.state_dict()["loss.weight"], before["loss.weight"])          # the margin head is not in the SSL checkpoint
+    # a DINO-ViT teacher shares (almost) no key with Part-fViT: strict=False would silently keep the random init
+    vt = MultiCropWrapper(vits.VisionTransformer(img_size=[112], patch_size=8, embed_dim=64, depth=2, num_heads=1, qkv_bias=True, norm_layer=LN6),
+                          vits.DINOHead(64, 256, hidden_dim=64, bottleneck_dim=32))
+    torch.save({"teacher": vt.state_dict()}, ck)
+    with pytest.raises(RuntimeError, match="trunk tensors"):
+        load_ssl_teacher(ft, str(ck))
+
+
+def test_partfvit_pair_runs_with_live_dropout_and_droppath():
+    """The reference never puts its Part-fViT teacher in eval mode: dropout 0.1 and DropPath 0.1 are live in BOTH networks.
+    Such a pair must run (eagerly: the masks come from a host-side seed), give finite, step-dependent losses, and the teacher
+    output must differ between two passes over the same input (stochastic teacher)."""
+    fx = load_golden("f16_lafs_step_partfvit")
+    student, teacher, crit, eng = _build_partfvit(fx, True, dropout=0.1, drop_path=0.1)
+    assert eng.use_graph is False and eng.has_dropout
+    crops = [fx[f"s0.crop{i}"] for i in range(4)]
+    l0 = float(eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item())
+    t0 = eng.logits_t.clone()
+    l1 = float(eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item())
+    assert math.isfinite(l0) and math.isfinite(l1) and l0 != l1
+    assert not torch.equal(t0, eng.logits_t)

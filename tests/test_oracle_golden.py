@@ -125,6 +125,40 @@ def test_f5_full_lafs_step_two_iterations():
         close(st.center, fx[f"s{s}.center"], 1e-4, 1e-7)
 
 
+def test_f16_lafs_step_on_partfvit_backbones():
+    """The reference's real `mynet` pair: ViT_face_landmark_patch8 student / teacher on [B, n, 192] patch tokens."""
+    from oracle import partfvit
+    fx = load_golden("f16_lafs_step_partfvit")
+    cfg = partfvit.PartFViTConfig(dim=64, depth=2, heads=2, mlp_dim=128, num_patches=196)
+    st = step.LafsState(cfg, out_dim=256, seed=0, hidden_dim=64, bottleneck_dim=32)
+    init = sub(fx, "init.")
+    assert set(init) == set(st.student)
+    st.student = {k: v.clone() for k, v in init.items()}
+    st.teacher = {k: v.clone() for k, v in init.items()}
+    st.exp_avg = {k: torch.zeros_like(v) for k, v in init.items()}
+    st.exp_avg_sq = {k: torch.zeros_like(v) for k, v in init.items()}
+    st.steps = {k: 0 for k in init}
+    lrs, wds, moms = fx["hyper"].tolist()
+    tt = dino.teacher_temp_schedule(0.07, 0.04, 3, 10)
+    for s in range(2):
+        crops = [fx[f"s{s}.crop{i}"] for i in range(4)]
+        r = step.lafs_step(st, crops, epoch=s, lr=lrs[s], wd=wds[s], momentum=moms[s], teacher_temp=tt[s], clip_grad=3.0,
+                           freeze_last_layer=1)
+        close(r["loss"], fx[f"s{s}.loss"], 1e-5, 1e-6)
+        close(r["teacher_out"], fx[f"s{s}.t_out"], 1e-4, 1e-6)
+        close(r["student_out"], fx[f"s{s}.s_out"], 1e-4, 1e-6)
+        for k, g in sub(fx, f"s{s}.grad_post.").items():
+            if s == 0 and "last_layer" in k:
+                assert k not in r["grads"]
+                continue
+            close(r["grads"][k], g, 2e-3, 1e-7)
+        for k, v in sub(fx, f"s{s}.student.").items():
+            close_adam(st.student[k], v, lrs[s])
+        for k, v in sub(fx, f"s{s}.teacher.").items():
+            close_adam(st.teacher[k], v, lrs[s])
+        close(st.center, fx[f"s{s}.center"], 1e-4, 1e-7)
+
+
 def test_f6_schedules():
     fx = load_golden("f6_schedules")
     np.testing.assert_allclose(optim.cosine_scheduler(5e-4 * 64 / 256, 1e-6, 6, 11, warmup_epochs=2), fx["lr"].numpy(), rtol=1e-12)

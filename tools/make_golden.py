@@ -207,6 +207,58 @@ def main():
     fx["membership_reg"] = np.array(list(membership.values()))
     save("f5_lafs_step", **fx)
 
+    # ---------------------------------------------------------------- F16 LAFS step x2 on the reference's real pair:
+    # ViT_face_landmark_patch8 student / teacher (lafs_train.py:300-335) fed [B, n, 192] patch tokens (:538-569), rates 0
+    print("F16 lafs step, part-fvit backbones")
+    torch.manual_seed(16)
+    K, B, ncrops = 256, 2, 4
+    def mk_pf():
+        m = ref_face.ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=64,
+                                              depth=2, heads=2, num_patches=196, mlp_dim=128, dropout=0.0, emb_dropout=0.0,
+                                              with_land=False, use_standcoord=False, Random_prob=False, shuffle=False)
+        for q in m.modules():
+            if isinstance(q, ref_vit.DropPath):
+                q.drop_prob = 0.0
+        return m
+    student = ref_utils.MultiCropWrapper(mk_pf(), ref_vit.DINOHead(64, K, hidden_dim=64, bottleneck_dim=32, norm_last_layer=True))
+    teacher = ref_utils.MultiCropWrapper(mk_pf(), ref_vit.DINOHead(64, K, hidden_dim=64, bottleneck_dim=32))
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad = False
+    crit = ref_lafs.DINOLoss(K, ncrops, 0.07, 0.04, 3, 10)
+    opt = torch.optim.AdamW(ref_utils.get_params_groups(student))
+    fx = {"init." + k: v.clone() for k, v in student.state_dict().items()}
+    lrs, wds, moms = [5e-4, 4e-4], [0.04, 0.05], [0.9, 0.95]
+    for step in range(2):
+        epoch = step
+        toks = [torch.randn(B, 196, 192).clamp(-1, 1) for _ in range(2)] + [torch.randn(B, 36, 192).clamp(-1, 1) for _ in range(ncrops - 2)]
+        for i, g in enumerate(opt.param_groups):
+            g["lr"] = lrs[step]
+            if i == 0:
+                g["weight_decay"] = wds[step]
+        t_out = teacher(toks[:2]); s_out = student(toks)
+        loss = crit(s_out, t_out, epoch)
+        opt.zero_grad()
+        loss.backward()
+        norms = ref_utils.clip_gradients(student, 3.0)
+        post = {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
+        ref_utils.cancel_gradients_last_layer(epoch, student, 1)
+        opt.step()
+        with torch.no_grad():
+            for pq, pk in zip(student.parameters(), teacher.parameters()):
+                pk.data.mul_(moms[step]).add_((1 - moms[step]) * pq.detach().data)
+        fx.update({f"s{step}.crop{i}": im for i, im in enumerate(toks)})
+        fx.update({f"s{step}.loss": loss, f"s{step}.center": crit.center, f"s{step}.t_out": t_out, f"s{step}.s_out": s_out,
+                   f"s{step}.norms": np.array(norms)})
+        fx.update({f"s{step}.grad_post.{n}": g for n, g in post.items()})
+        fx.update({f"s{step}.student.{k}": v.clone() for k, v in student.state_dict().items()})
+        fx.update({f"s{step}.teacher.{k}": v.clone() for k, v in teacher.state_dict().items()})
+    fx["hyper"] = np.array([lrs, wds, moms])
+    fx["norm_names"] = np.array([n for n, p in student.named_parameters() if p.requires_grad])
+    # what the stage-3 script loads from this checkpoint: ckpt['teacher'] keys with 'backbone.' stripped (train_largescale.py:639-657)
+    fx["teacher_backbone_keys"] = np.array([k[len("backbone."):] for k in teacher.state_dict() if k.startswith("backbone.")])
+    save("f16_lafs_step_partfvit", **fx)
+
     # ---------------------------------------------------------------- F6 schedules
     print("F6 schedules")
     save("f6_schedules",
