@@ -62,3 +62,15 @@ def det_fill(module):
                 val = t * (1.5 / fan ** 0.5)
             v.copy_(val.view(v.shape).to(v.dtype))
 
+
+
+def gate_errors(name, errs, gate):
+    """Assert every per-tensor relative-L2 error in `errs` (dict key -> error) is below `gate`, and always PRINT the worst
+    observed value (pytest -s / the captured output of a failure): the gates are 2x the worst value seen on MI355X and the
+    observed table lives in DESIGN.md section 2, so a drift is visible before it becomes a failure."""
+    if not errs:
+        return
+    k = max(errs, key=errs.get)
+    print(f"[grad-gate] {name}: worst rel-L2 {errs[k]:.3e} at {k} (gate {gate:.1e}, {len(errs)} tensors)")
+    bad = {k: v for k, v in errs.items() if not v <= gate}
+    assert not bad, (name, bad)

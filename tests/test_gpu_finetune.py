@@ -4,8 +4,10 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+# per-tensor gradient gates = 2x the worst value observed on MI355X (conftest.gate_errors prints the observed value)
+GATE_F7, GATE_FT, GATE_F13, GATE_F14 = 1.1e-2, 1.5e-2, 3.5e-2, 1.1e-2     # observed 5.2e-3, 7.1e-3, 1.7e-2, 5.4e-3
 
-from conftest import load_golden, sub  # noqa: E402
+from conftest import gate_errors, load_golden, sub  # noqa: E402
 from lafs_cvpr2024_amd.face_pre_pro.ViT_face import CosFace, ViT_face_landmark_patch8, extract_patches_pytorch_gridsample  # noqa: E402
 from lafs_cvpr2024_amd.vision_transformer import attach_arena  # noqa: E402
 
@@ -27,12 +29,7 @@ def test_f7_partfvit_forward_backward():
     e1 = m(fx["ximg"].to(DEV)); e2 = m(fx["xpat"].to(DEV))
     assert rel_l2(e1, fx["e1"]) < 2e-2 and rel_l2(e2, fx["e2"]) < 2e-2
     ((e1 * fx["w1"].to(DEV)).sum() + (e2 * fx["w2"].to(DEV)).sum()).backward()
-    bad = {}
-    for k, g in sub(fx, "g.").items():
-        e = rel_l2(dict(m.named_parameters())[k].grad, g)
-        if e > 6e-2:
-            bad[k] = e
-    assert not bad, bad
+    gate_errors("F7 Part-fViT", {k: rel_l2(dict(m.named_parameters())[k].grad, g) for k, g in sub(fx, "g.").items()}, GATE_F7)
 
 
 @pytest.mark.parametrize("n", [196, 36])
@@ -97,13 +94,9 @@ def test_finetune_micro_step_against_oracle(lam):
     ref.backward()
     assert abs(float(loss.item()) - float(ref)) / float(ref) < 5e-3, (float(loss.item()), float(ref))
     named = dict(model.named_parameters())
-    bad = {}
-    for k in ("loss.weight", "patch_to_embedding.weight", "transformer.layers.0.0.fn.fn.to_qkv.weight", "transformer.layers.1.1.fn.fn.net.3.weight",
-              "pos_embedding", "cls_token", "mlp_head.0.weight", "transformer.layers.0.1.fn.fn.net.0.bias"):
-        e = rel_l2(named[k].grad, P[k].grad)
-        if e > 8e-2:
-            bad[k] = e
-    assert not bad, bad
+    keys = ("loss.weight", "patch_to_embedding.weight", "transformer.layers.0.0.fn.fn.to_qkv.weight", "transformer.layers.1.1.fn.fn.net.3.weight",
+            "pos_embedding", "cls_token", "mlp_head.0.weight", "transformer.layers.0.1.fn.fn.net.0.bias")
+    gate_errors("fine-tune micro step vs oracle", {k: rel_l2(named[k].grad, P[k].grad) for k in keys}, GATE_FT)
     # one AdamW step runs and moves the weights by about lr
     w0 = named["patch_to_embedding.weight"].detach().clone()
     eng.optimizer_step(lr=1e-3, weight_decay=0.1)
@@ -196,12 +189,7 @@ def test_f13_partfvit_with_trainable_landmark_branch():
     assert rel_l2(e, fx["e"]) < 2e-2
     (e * fx["w"].to(DEV)).sum().backward()
     params = dict(m.named_parameters())
-    bad = {}
-    for k, g in sub(fx, "g.").items():
-        err = rel_l2(params[k].grad, g)
-        if err > 8e-2:
-            bad[k] = err
-    assert not bad, bad
+    gate_errors("F13 Part-fViT with_land", {k: rel_l2(params[k].grad, g) for k, g in sub(fx, "g.").items()}, GATE_F13)
     # every tensor the reference gives a gradient gets one here, with a matching norm
     ref = dict(zip([str(k) for k in fx["gnorm_keys"]], fx["gnorms"].tolist()))
     got = {k: float(p.grad.norm()) for k, p in params.items() if p.grad is not None and float(p.grad.abs().max()) > 0}
@@ -318,9 +306,7 @@ def test_partfvit_element_dropout_matches_oracle_with_same_masks():
     (ref * fx["w"]).sum().backward()
     assert rel_l2(e, ref) < 2e-2, rel_l2(e, ref)
     named = dict(m.named_parameters())
-    bad = {k: rel_l2(named[k].grad, v.grad) for k, v in P.items() if v.grad is not None}
-    bad = {k: v for k, v in bad.items() if v > 6e-2}
-    assert not bad, bad
+    gate_errors("F14 dropout sites", {k: rel_l2(named[k].grad, v.grad) for k, v in P.items() if v.grad is not None}, GATE_F14)
     # a second forward draws a different mask; eval mode draws none and is deterministic
     e2 = m(x)
     assert rel_l2(e2, e) > 1e-3
@@ -442,5 +428,5 @@ def test_finetune_engine_dense_arcface_matches_oracle():
     ref.backward()
     assert abs(float(loss.item()) - float(ref)) / float(ref) < 5e-3, (float(loss.item()), float(ref))
     named = dict(model.named_parameters())
-    for k in ("loss.weight", "patch_to_embedding.weight", "transformer.layers.1.1.fn.fn.net.3.weight"):
-        assert rel_l2(named[k].grad, P[k].grad) < 8e-2, k
+    gate_errors("ArcFace micro step vs oracle", {k: rel_l2(named[k].grad, P[k].grad)
+                                                  for k in ("loss.weight", "patch_to_embedding.weight", "transformer.layers.1.1.fn.fn.net.3.weight")}, GATE_FT)

@@ -9,8 +9,9 @@ import torch
 import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
+GATE_F1 = 1e-2          # observed 5.0e-3 (patch_embed.proj.weight); gate = 2x (conftest.gate_errors prints the observed value)
 
-from conftest import load_golden, sub  # noqa: E402
+from conftest import gate_errors, load_golden, sub  # noqa: E402
 from lafs_cvpr2024_amd import vision_transformer as vits  # noqa: E402
 from lafs_cvpr2024_amd.dino_loss import DINOLoss  # noqa: E402
 from lafs_cvpr2024_amd.utils import MultiCropWrapper  # noqa: E402
@@ -39,15 +40,13 @@ def test_f1_vit_forward_backward():
         p = dict(m.named_parameters())[k]
         assert p.grad is not None, k
         worst[k] = rel_l2(p.grad, g)
-    bad = {k: v for k, v in worst.items() if v > 6e-2}
-    assert not bad, bad
+    gate_errors("F1 ViT two passes", worst, GATE_F1)
     # packed two-resolution pass == two separate passes
     m._arena.zero_grad()
     both = m.forward_groups([fx["xg"].to(DEV), fx["xl"].to(DEV)])
     assert rel_l2(both[:2], fx["og"]) < 2e-2 and rel_l2(both[2:], fx["ol"]) < 2e-2
     (both * torch.cat([fx["wg"], fx["wl"]]).to(DEV)).sum().backward()
-    for k, g in sub(fx, "g.").items():
-        assert rel_l2(dict(m.named_parameters())[k].grad, g) < 6e-2, k
+    gate_errors("F1 ViT packed pass", {k: rel_l2(dict(m.named_parameters())[k].grad, g) for k, g in sub(fx, "g.").items()}, GATE_F1)
 
 
 @pytest.mark.parametrize("name", ["f2_head", "f2_head_freeg"])

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
 
-from conftest import load_golden, sub  # noqa: E402
+from conftest import gate_errors, load_golden, sub  # noqa: E402
 from lafs_cvpr2024_amd import vision_transformer as vits  # noqa: E402
 from lafs_cvpr2024_amd.dino_loss import DINOLoss  # noqa: E402
 from lafs_cvpr2024_amd.engine import LafsPretrainEngine  # noqa: E402
@@ -21,7 +21,7 @@ DEV = "cuda"
 LN6 = partial(nn.LayerNorm, eps=1e-6)
 # per-tensor relative-L2 gate on bf16-MFMA gradients against the fp32 reference (depth-2 fixtures): 2x the worst error
 # observed on MI355X (DESIGN.md section 2 holds the observed table)
-GRAD_GATE = 8e-2
+GRAD_GATE = 6e-2          # observed: F5 3.0e-2 (step 1, qkv weight), F16 2.3e-2
 
 
 def rel_l2(a, b):
@@ -61,14 +61,13 @@ def test_f5_two_steps_against_reference(use_graph):
         # post-clip gradients (per-tensor), as left in the arena (scaled by 1/world = 1)
         post = sub(fx, f"s{s}.grad_post.")
         norms = dict(zip([str(n) for n in fx["norm_names"]], fx[f"s{s}.norms"].tolist()))
-        bad = {}
+        errs = {}
         for k, g in post.items():
             mine = dict(student.named_parameters())[k].grad
             clip = min(1.0, 3.0 / (norms[k] + 1e-6))        # the arena keeps UNclipped grads; the clip lives in the AdamW kernel
-            e = rel_l2(mine * clip, g)
-            if e > 8e-2 and float(g.abs().max()) > 1e-6:
-                bad[k] = e
-        assert not bad, bad
+            if float(g.abs().max()) > 1e-6:
+                errs[k] = rel_l2(mine * clip, g)
+        gate_errors(f"F5 step {s}", errs, GRAD_GATE)
         # weights after clip + AdamW, teacher after EMA.  Adam's m/sqrt(v) amplifies bf16 gradient noise where the
         # gradient is ~0, so the check is distributional in units of the learning rate.
         for prefix, mod in (("student", student), ("teacher", teacher)):
@@ -118,14 +117,15 @@ def test_engine_matches_cpu_oracle():
     assert float(errs.median()) < 0.05 * 1e-3 * 0.2 and float(errs.max()) < 3e-3
 
 
-@pytest.mark.parametrize("nl", [2, 0])
-def test_c1_config_vit_tiny_step_matches_oracle(nl):
+@pytest.mark.parametrize("nl,K", [(2, 100000), (2, 65536), (0, 65536)])
+def test_c1_config_vit_tiny_step_matches_oracle(nl, K):
     """BASELINE.json configs[0] (the reference's CPU-runnable case): ViT-Tiny/8, 2 global + 2 local crops, batch 8, DINO head
-    with the default 65536 prototypes -- one graph-captured step vs the CPU oracle: loss to 1e-3, center and teacher EMA.
-    nl = 0 is the degenerate multi-crop (global views only, two loss terms)."""
+    with the reference's default out_dim = 100000 (lafs_train.py:44; 65536, DINO's own default, is kept as a second size) --
+    one graph-captured step vs the CPU oracle: loss to 1e-3, center and teacher EMA.  nl = 0 is the degenerate multi-crop
+    (global views only, two loss terms)."""
     from oracle import step as ostep, vit as ovit
     torch.manual_seed(11)
-    B, K = 8, 65536
+    B = 8
     student = MultiCropWrapper(vits.vit_tiny(patch_size=8, drop_path_rate=0.0), vits.DINOHead(192, K, use_bn=False, norm_last_layer=True))
     teacher = MultiCropWrapper(vits.vit_tiny(patch_size=8), vits.DINOHead(192, K, use_bn=False))
     teacher.load_state_dict(student.state_dict())
