@@ -240,9 +240,11 @@ int lafs_center_ema(float* center, const float* colsum, int K, float inv_rows_to
  * ------------------------------------------------------------------------------------------------ */
 #define LAFS_N_XCD 8          /* XCDs (L2 domains) of an MI355X */
 #define LAFS_CHUNK 1024
-enum { LAFS_SEG_DECAY = 1, LAFS_SEG_LAST_LAYER = 2, LAFS_SEG_TRAINABLE = 4 };
+enum { LAFS_SEG_DECAY = 1, LAFS_SEG_LAST_LAYER = 2, LAFS_SEG_TRAINABLE = 4,
+       LAFS_SEG_LOW_DECAY = 8 /* decays at hyper[LAFS_HP_WD_LOW] instead of hyper[LAFS_HP_WD]: the `stn*` matrices of the
+                                  fine-tune step, train_largescale.py:143-145 (5e-2 against 1e-1) */ };
 enum { LAFS_HP_LR = 0, LAFS_HP_WD, LAFS_HP_BETA1, LAFS_HP_BETA2, LAFS_HP_EPS, LAFS_HP_CLIP, LAFS_HP_EMA_M,
-       LAFS_HP_FREEZE_LAST, LAFS_HP_GRAD_SCALE, LAFS_HP_COUNT = 16 };
+       LAFS_HP_FREEZE_LAST, LAFS_HP_GRAD_SCALE, LAFS_HP_WD_LOW, LAFS_HP_COUNT = 16 };
 /* seg_sumsq(f32)[n_seg] += sum of (grad_scale*g)^2 per segment (seg_sumsq must be pre-zeroed). */
 int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, const float* hyper,
                     float* seg_sumsq, hipStream_t stream);

@@ -49,8 +49,8 @@ EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32,
 ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = range(4)
 PATCH_ORDER_CHW, PATCH_ORDER_HWC = 0, 1
 CHUNK = 1024
-SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE = 1, 2, 4
-HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE = range(9)
+SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE, SEG_LOW_DECAY = 1, 2, 4, 8
+HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE, HP_WD_LOW = range(10)
 HP_COUNT = 16
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32

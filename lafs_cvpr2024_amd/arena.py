@@ -76,6 +76,22 @@ class ParamArena:
         self._versions = None
         self.refresh_shadows()
 
+    def set_decay_groups(self, rule):
+        """Re-assign the weight-decay class of every tensor: rule(name, param) -> 'decay' | 'low' | 'none'.  The default (set in
+        __init__) is utils.get_params_groups of the LAFS step; the fine-tune step uses param_groups_lrd (finetune_decay_group)."""
+        flags = self.seg_flags.cpu().tolist()
+        for i, (name, p) in enumerate(zip(self.names, self.params)):
+            f = flags[i] & ~(_lib.SEG_DECAY | _lib.SEG_LOW_DECAY)
+            g = rule(name, p)
+            if g == "decay":
+                f |= _lib.SEG_DECAY
+            elif g == "low":
+                f |= _lib.SEG_LOW_DECAY
+            elif g != "none":
+                raise ValueError(f"unknown decay group {g!r} for {name}")
+            flags[i] = f
+        self.seg_flags.copy_(torch.tensor(flags, dtype=torch.int32))
+
     # ------------------------------------------------------------------ views / pointers
     def view(self, buf, name, shape=None):
         o, n = self.offsets[name], self.numels[name]

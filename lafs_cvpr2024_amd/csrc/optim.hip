@@ -61,7 +61,8 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(float* __restrict__
   const bool update = (flags & LAFS_SEG_TRAINABLE) && !frozen;
   float4 p = *reinterpret_cast<const float4*>(param + i);
   if (update) {
-    const float lr = hyper[LAFS_HP_LR], wd = (flags & LAFS_SEG_DECAY) ? hyper[LAFS_HP_WD] : 0.f;
+    const float lr = hyper[LAFS_HP_LR];
+    const float wd = (flags & LAFS_SEG_LOW_DECAY) ? hyper[LAFS_HP_WD_LOW] : ((flags & LAFS_SEG_DECAY) ? hyper[LAFS_HP_WD] : 0.f);
     const float b1 = hyper[LAFS_HP_BETA1], b2 = hyper[LAFS_HP_BETA2], eps = hyper[LAFS_HP_EPS], clip = hyper[LAFS_HP_CLIP];
     float gsc = hyper[LAFS_HP_GRAD_SCALE];
     if (clip > 0.f) {

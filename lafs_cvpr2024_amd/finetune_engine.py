@@ -18,6 +18,18 @@ from .vision_transformer import attach_arena
 f32, bf16 = torch.float32, torch.bfloat16
 
 
+LOW_WEIGHT_DECAY = 5e-2
+
+
+def finetune_decay_group(name, param):
+    """Weight-decay class of a fine-tune parameter, as param_groups_lrd assigns it (reference train_largescale.py:139-149):
+    1-D tensors do not decay, the landmark CNN's matrices (`stn*`) decay at 5e-2, everything else at the configured rate
+    (1e-1).  The `lr_scale` the reference also stores per group is never applied by torch's AdamW."""
+    if param.dim() == 1:
+        return "none"
+    return "low" if name.startswith("stn") else "decay"
+
+
 class FinetuneEngine:
     def __init__(self, backbone: ViT_face_landmark_patch8, batch_size, acc_step=3, mixup_alpha=0.2, mixup_prob=0.1,
                  s=64.0, m=0.4, margin_type=0, image_size=112, device=None, sharded_head=None):
@@ -33,6 +45,7 @@ class FinetuneEngine:
         self.s, self.m, self.margin_type = float(s), float(m), margin_type
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena = attach_arena(backbone, self.device)
+        self.arena.set_decay_groups(finetune_decay_group)
         self.head = sharded_head
         self.C = backbone.loss.out_features if sharded_head is None else 8
         self.Cpad = (self.C + 127) // 128 * 128
@@ -132,6 +145,7 @@ class FinetuneEngine:
         # dense head: every rank's loss is its local mean -> average; sharded head: gradients of the global mean -> sum
         gscale = 1.0 if self.head is not None else 1.0 / self.world
         h[_lib.HP_CLIP], h[_lib.HP_EMA_M], h[_lib.HP_FREEZE_LAST], h[_lib.HP_GRAD_SCALE] = 0.0, 0.0, 0.0, gscale
+        h[_lib.HP_WD_LOW] = LOW_WEIGHT_DECAY
         self.hyper.copy_(h)
         if self.head is not None:
             self.head.optimizer_step(lr, weight_decay, beta1, beta2, eps)

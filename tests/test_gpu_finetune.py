@@ -430,3 +430,27 @@ def test_finetune_engine_dense_arcface_matches_oracle():
     named = dict(model.named_parameters())
     gate_errors("ArcFace micro step vs oracle", {k: rel_l2(named[k].grad, P[k].grad)
                                                   for k in ("loss.weight", "patch_to_embedding.weight", "transformer.layers.1.1.fn.fn.net.3.weight")}, GATE_FT)
+
+
+def test_f12_arena_applies_the_reference_weight_decay_groups():
+    """One fused AdamW step with zero gradients is a pure decoupled decay p <- p (1 - lr wd): every tensor of a with_land
+    Part-fViT must shrink by exactly the rate param_groups_lrd gives it in the reference (F12: stn* matrices 5e-2, other
+    matrices 1e-1, 1-D tensors 0)."""
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    fx = load_golden("f12_param_groups_lrd")
+    torch.manual_seed(0)
+    model = ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=50, image_size=112, patch_size=8, dim=64, depth=2, heads=2,
+                                     mlp_dim=128, dropout=0.1, emb_dropout=0.1, with_land=True)
+    eng = FinetuneEngine(model, 8, acc_step=1, device=DEV)
+    named = dict(model.named_parameters())
+    assert sorted(named) == sorted(str(n) for n in fx["names"])
+    with torch.no_grad():
+        for p in named.values():
+            p.add_(1.0)                                   # keep every element away from 0
+    eng.arena.refresh_shadows()
+    before = {k: v.detach().clone() for k, v in named.items()}
+    lr = 0.5
+    eng.optimizer_step(lr=lr, weight_decay=1e-1)
+    for n, wd in zip([str(n) for n in fx["names"]], fx["weight_decay"].tolist()):
+        ratio = (named[n].detach() / before[n]).flatten()
+        assert float((ratio - (1 - lr * wd)).abs().max()) < 1e-6, (n, wd, float(ratio.mean()))

@@ -1,5 +1,6 @@
 """CPU tests of the host-side logic (packing geometry, crop grouping, schedules, mixup, FLOP model)."""
 import numpy as np
+import pytest
 import torch
 
 from conftest import load_golden
@@ -111,3 +112,19 @@ def test_f15_checkpoint_layout_matches_reference_at_full_scale():
         assert not missing and not extra, (name, missing[:5], extra[:5])
         bad = {k: (mine[name][k], v) for k, v in ref[name].items() if mine[name][k] != v}
         assert not bad, (name, dict(list(bad.items())[:5]))
+
+
+def test_f12_finetune_weight_decay_groups_match_param_groups_lrd():
+    """F12: the reference's own param_groups_lrd (train_largescale.py:122-173, exec'ed out of the reference file by
+    tools/make_golden.py on a with_land Part-fViT) against finetune_decay_group: 1-D tensors 0, `stn*` matrices 5e-2, the rest 1e-1.
+    (The per-group lr_scale = 0.58^k the reference also stores is recorded but never applied by torch.optim.AdamW.)"""
+    import types
+    from lafs_cvpr2024_amd.finetune_engine import LOW_WEIGHT_DECAY, finetune_decay_group
+    fx = load_golden("f12_param_groups_lrd")
+    wd_of = {"none": 0.0, "low": LOW_WEIGHT_DECAY, "decay": 1e-1}
+    names = [str(n) for n in fx["names"]]
+    assert len(names) == 185 and any(n.startswith("stn.") for n in names)
+    for n, wd, nd in zip(names, fx["weight_decay"].tolist(), fx["ndim"].tolist()):
+        p = types.SimpleNamespace(dim=lambda nd=nd: nd)
+        assert wd_of[finetune_decay_group(n, p)] == pytest.approx(wd), (n, wd)
+    assert {0.0, 0.05, 0.1} == {round(float(w), 6) for w in fx["weight_decay"].tolist()}

@@ -259,6 +259,30 @@ def main():
     fx["teacher_backbone_keys"] = np.array([k[len("backbone."):] for k in teacher.state_dict() if k.startswith("backbone.")])
     save("f16_lafs_step_partfvit", **fx)
 
+    # ---------------------------------------------------------------- F12 param_groups_lrd (train_largescale.py:122-196)
+    # train_largescale.py is a script with top-level side effects (argparse, NCCL init) and cannot be imported; its two grouping
+    # functions are pure, so their source lines are exec'ed straight out of the reference file here (nothing of it is stored).
+    print("F12 param_groups_lrd")
+    src = open(os.path.join(REF, "train_largescale.py")).read().split("\n")
+    def grab(fn):
+        i = next(k for k, l in enumerate(src) if l.startswith(f"def {fn}("))
+        j = next(k for k in range(i + 1, len(src)) if src[k].startswith(("def ", "class ")) or (src[k] and not src[k][0].isspace() and not src[k].startswith("#")))
+        return "\n".join(src[i:j])
+    ns = {}
+    exec(grab("get_layer_id_for_vit"), ns); exec(grab("param_groups_lrd"), ns)
+    torch.manual_seed(12)
+    ft = ref_face.ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=50, image_size=112, patch_size=8, dim=64, depth=2,
+                                           heads=2, mlp_dim=128, dropout=0.1, emb_dropout=0.1, with_land=True)
+    groups = ns["param_groups_lrd"](ft, 1e-1, no_weight_decay_list=[], layer_decay=0.58)          # the call at :619-621
+    by_id = {id(p): n for n, p in ft.named_parameters()}
+    names, wds, lrs = [], [], []
+    for gp in groups:
+        for p in gp["params"]:
+            names.append(by_id[id(p)]); wds.append(gp["weight_decay"]); lrs.append(gp["lr_scale"])
+    assert sorted(names) == sorted(n for n, p in ft.named_parameters() if p.requires_grad)
+    save("f12_param_groups_lrd", names=np.array(names), weight_decay=np.array(wds), lr_scale=np.array(lrs),
+         ndim=np.array([dict(ft.named_parameters())[n].dim() for n in names]))
+
     # ---------------------------------------------------------------- F6 schedules
     print("F6 schedules")
     save("f6_schedules",
