@@ -296,14 +296,58 @@ class LafsPretrainEngine:
         torch.cuda.set_rng_state(rng, self.device)
 
     # ------------------------------------------------------------------ checkpoint helpers (reference layout)
+    def _adamw_order(self):
+        """Parameter names in torch.optim.AdamW(utils.get_params_groups(student)) index order: the regularised group first
+        (>= 2-D non-bias tensors), then the rest, each in named_parameters order, trainable tensors only (reference
+        lafs_train.py:385-392, utils.py:662-673)."""
+        reg, noreg = [], []
+        for name, p in self.student.named_parameters():
+            if p.requires_grad:
+                (noreg if (name.endswith(".bias") or p.dim() == 1) else reg).append(name)
+        return reg, noreg
+
     def optimizer_state_dict(self):
+        """The state_dict torch.optim.AdamW(get_params_groups(student)) would have at this point -- the format the reference
+        stores under checkpoint['optimizer'] and restores with optimizer.load_state_dict (lafs_train.py:428-463,
+        utils.py:152-184): per-parameter {step, exp_avg, exp_avg_sq} (only for tensors that have been stepped, like torch:
+        the last layer has none while it is frozen) and the two param_groups."""
         sa = self.sa
-        return {"lafs_arena": {"exp_avg": sa.exp_avg.cpu(), "exp_avg_sq": sa.exp_avg_sq.cpu(), "seg_step": sa.seg_step.cpu(),
-                               "names": list(sa.names)}}
+        reg, noreg = self._adamw_order()
+        steps = sa.seg_step.cpu().tolist()
+        h = self.hyper.cpu().tolist()
+        state = {}
+        for idx, name in enumerate(reg + noreg):
+            t = steps[sa.names.index(name)]
+            if t > 0:
+                shape = sa.params[sa.names.index(name)].shape
+                state[idx] = {"step": torch.tensor(float(t)), "exp_avg": sa.view(sa.exp_avg, name, shape).detach().cpu().clone(),
+                              "exp_avg_sq": sa.view(sa.exp_avg_sq, name, shape).detach().cpu().clone()}
+        common = {"lr": h[_lib.HP_LR], "betas": (h[_lib.HP_BETA1] or 0.9, h[_lib.HP_BETA2] or 0.999), "eps": h[_lib.HP_EPS] or 1e-8,
+                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None}
+        groups = [dict(common, weight_decay=h[_lib.HP_WD], params=list(range(len(reg)))),
+                  dict(common, weight_decay=0.0, params=list(range(len(reg), len(reg) + len(noreg))))]
+        return {"state": state, "param_groups": groups}
 
     def load_optimizer_state_dict(self, sd):
-        a = sd.get("lafs_arena")
-        if a is None or a["names"] != list(self.sa.names):
-            print("=> optimizer state in checkpoint is not a lafs arena state; moments start from zero")
-            return
-        self.sa.exp_avg.copy_(a["exp_avg"]); self.sa.exp_avg_sq.copy_(a["exp_avg_sq"]); self.sa.seg_step.copy_(a["seg_step"])
+        """Inverse of optimizer_state_dict; also accepts a checkpoint written by the reference itself (same format)."""
+        if "state" not in sd or "param_groups" not in sd:
+            raise _lib.LafsHipError("checkpoint['optimizer'] is not a torch.optim.AdamW state_dict (keys: %s)" % sorted(sd))
+        sa = self.sa
+        reg, noreg = self._adamw_order()
+        names = reg + noreg
+        sizes = [len(g["params"]) for g in sd["param_groups"]]
+        if sizes != [len(reg), len(noreg)]:
+            raise _lib.LafsHipError(f"optimizer param_groups of sizes {sizes} do not fit this model ({len(reg)} regularised + "
+                                    f"{len(noreg)} other tensors)")
+        sa.exp_avg.zero_(); sa.exp_avg_sq.zero_(); sa.seg_step.zero_()
+        steps = sa.seg_step.cpu()
+        flat = [i for g in sd["param_groups"] for i in g["params"]]
+        for pos, idx in enumerate(flat):
+            st = sd["state"].get(idx)
+            if st is None:
+                continue
+            name = names[pos]
+            shape = sa.params[sa.names.index(name)].shape
+            sa.view(sa.exp_avg, name, shape).copy_(st["exp_avg"]); sa.view(sa.exp_avg_sq, name, shape).copy_(st["exp_avg_sq"])
+            steps[sa.names.index(name)] = int(float(st["step"]))
+        sa.seg_step.copy_(steps)

@@ -333,3 +333,104 @@ def test_partfvit_pair_runs_with_live_dropout_and_droppath():
     l1 = float(eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item())
     assert math.isfinite(l0) and math.isfinite(l1) and l0 != l1
     assert not torch.equal(t0, eng.logits_t)
+
+
+# ------------------------------------------------------------------------------------------------ checkpoint layout / resume
+def _fresh_pair(drop_path=0.1):
+    torch.manual_seed(21)
+    mk = lambda dpr: vits.VisionTransformer(img_size=[112], patch_size=8, embed_dim=64, depth=3, num_heads=1, qkv_bias=True,
+                                            drop_path_rate=dpr, norm_layer=LN6)
+    student = MultiCropWrapper(mk(drop_path), vits.DINOHead(64, 512, hidden_dim=128, bottleneck_dim=64, norm_last_layer=True))
+    teacher = MultiCropWrapper(mk(0.0), vits.DINOHead(64, 512, hidden_dim=128, bottleneck_dim=64))
+    teacher.load_state_dict(student.state_dict())
+    return student, teacher
+
+
+def test_optimizer_state_is_a_torch_adamw_state_dict():
+    """checkpoint['optimizer'] must be what the reference stores and restores: a torch.optim.AdamW(get_params_groups(student))
+    state_dict (lafs_train.py:385-392, 428-463; utils.py:152-184).  torch's own optimizer must load it, hold the engine's moments
+    and step counts (the last layer, frozen during step 0, is one step behind), and the engine must read its own output back."""
+    from lafs_cvpr2024_amd.utils import get_params_groups
+    student, teacher = _fresh_pair()
+    crit = DINOLoss(512, 4, 0.07, 0.04, 3, 10)
+    eng = LafsPretrainEngine(student, teacher, crit, 2, n_local=2, use_graph=True, device=DEV)
+    g = torch.Generator().manual_seed(0)
+    crops = [torch.randn(2, 3, 112, 112, generator=g) for _ in range(2)] + [torch.randn(2, 3, 48, 48, generator=g) for _ in range(2)]
+    for ep in (0, 1):
+        eng.step(crops, lr=1e-3, wd=0.05, momentum=0.99, teacher_temp=0.05, epoch=ep)
+    torch.cuda.synchronize()
+    sd = eng.optimizer_state_dict()
+    ref_model, _ = _fresh_pair()
+    opt = torch.optim.AdamW(get_params_groups(ref_model))
+    opt.load_state_dict(sd)                                           # the reference's restart_from_checkpoint does exactly this
+    named = [(n, p) for n, p in ref_model.named_parameters() if p.requires_grad]
+    reg = [n for n, p in named if not (n.endswith(".bias") or p.dim() == 1)]
+    order = reg + [n for n, _ in named if n not in reg]
+    flat = [p for gq in opt.param_groups for p in gq["params"]]
+    assert len(flat) == len(order) and opt.param_groups[1]["weight_decay"] == 0.0 and abs(opt.param_groups[0]["weight_decay"] - 0.05) < 1e-7
+    sa = eng.sa
+    for name, p in zip(order, flat):
+        st = opt.state[p]
+        assert float(st["step"]) == (1.0 if "last_layer" in name else 2.0), name
+        assert torch.equal(st["exp_avg"], sa.view(sa.exp_avg, name, p.shape).cpu())
+        assert torch.equal(st["exp_avg_sq"], sa.view(sa.exp_avg_sq, name, p.shape).cpu())
+    m0, v0, s0 = sa.exp_avg.clone(), sa.exp_avg_sq.clone(), sa.seg_step.clone()
+    sa.exp_avg.fill_(7.0); sa.exp_avg_sq.fill_(7.0); sa.seg_step.fill_(9)
+    eng.load_optimizer_state_dict(opt.state_dict())                   # and back, through torch's own re-serialisation
+    assert torch.equal(sa.exp_avg, m0) and torch.equal(sa.exp_avg_sq, v0)
+    trainable = torch.tensor([p.requires_grad for p in sa.params], device=DEV)
+    assert torch.equal(sa.seg_step[trainable], s0[trainable])
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_checkpoint_resume_continues_the_uninterrupted_run(use_graph, tmp_path):
+    """3 steps -> checkpoint.pth (reference layout, lafs_train.py:451-460) -> brand-new modules + engine (new arenas, new
+    graphs) -> _load_checkpoint -> step 4 must equal step 4 of the uninterrupted run: loss, student master weights, both AdamW
+    moments, per-tensor step counters, teacher, center.  The device RNG is re-seeded before step 4 on both sides (DropPath masks;
+    the reference does not checkpoint RNG state either).  Equality is up to the order of the fp32 atomics that accumulate bias /
+    LayerNorm gradients (1e-6 relative); everything written without atomics is compared bit for bit through the loss."""
+    from lafs_cvpr2024_amd.lafs_train import _load_checkpoint
+    g = torch.Generator().manual_seed(5)
+    batches = [[torch.randn(2, 3, 112, 112, generator=g) for _ in range(2)] + [torch.randn(2, 3, 48, 48, generator=g) for _ in range(2)]
+               for _ in range(4)]
+    hp = lambda it: dict(lr=1e-3 * (1 + it), wd=0.04 + 0.01 * it, momentum=0.99, teacher_temp=0.05, epoch=1 if it else 0)
+
+    def run(n_from, eng):
+        out = None
+        for it in range(n_from, 4):
+            if it == 3:
+                torch.cuda.manual_seed(99)
+            out = eng.step(batches[it], **hp(it))
+        torch.cuda.synchronize()
+        return float(out.item())
+
+    student, teacher = _fresh_pair()
+    crit = DINOLoss(512, 4, 0.07, 0.04, 3, 10)
+    eng = LafsPretrainEngine(student, teacher, crit, 2, n_local=2, use_graph=use_graph, device=DEV)
+    for it in range(3):
+        eng.step(batches[it], **hp(it))
+    torch.cuda.synchronize()
+    ck = tmp_path / "checkpoint.pth"
+    torch.save({"student": {"module." + k: v.cpu() for k, v in student.state_dict().items()},
+                "teacher": {k: v.cpu() for k, v in teacher.state_dict().items()},
+                "optimizer": eng.optimizer_state_dict(), "epoch": 1, "dino_loss": {k: v.cpu() for k, v in crit.state_dict().items()}}, ck)
+    loss_a = run(3, eng)
+    snap_a = [t.clone() for t in (eng.sa.master, eng.sa.exp_avg, eng.sa.exp_avg_sq, eng.ta.master, crit.center)]
+    steps_a = eng.sa.seg_step.clone()
+
+    student2, teacher2 = _fresh_pair()
+    with torch.no_grad():                                             # a different init: everything must come from the file
+        for p in list(student2.parameters()) + list(teacher2.parameters()):
+            p.add_(0.123)
+    crit2 = DINOLoss(512, 4, 0.07, 0.04, 3, 10)
+    eng2 = LafsPretrainEngine(student2, teacher2, crit2, 2, n_local=2, use_graph=use_graph, device=DEV)
+    state = {"epoch": 0}
+    _load_checkpoint(str(ck), student2, teacher2, crit2, eng2, state)
+    assert state["epoch"] == 1
+    loss_b = run(3, eng2)
+    assert abs(loss_a - loss_b) <= 1e-6 * abs(loss_a), (loss_a, loss_b)
+    assert torch.equal(steps_a, eng2.sa.seg_step)
+    for name, a, b in zip(("student", "exp_avg", "exp_avg_sq", "teacher", "center"), snap_a,
+                          (eng2.sa.master, eng2.sa.exp_avg, eng2.sa.exp_avg_sq, eng2.ta.master, crit2.center)):
+        d = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-30)
+        assert d < 2e-5, (name, d)
