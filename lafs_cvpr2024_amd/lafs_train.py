@@ -140,6 +140,14 @@ class SyntheticU8Views:
             yield self.aug(u8), None
 
 
+def epoch_shard(n, rank, world, seed, epoch):
+    """Indices of this rank's samples in one epoch, torch DistributedSampler style: a permutation of range(n) seeded with
+    (seed, epoch) -- the same on every rank --, cut to world * (n // world) and dealt out round-robin."""
+    g = torch.Generator().manual_seed(int(seed) * 1000003 + int(epoch))
+    perm = torch.randperm(n, generator=g).tolist()
+    return perm[rank: (n // world) * world: world]
+
+
 class RecordIOViews:
     """--data_path/train.rec (reference lafs_train.py:157-191: FaceDataset over MXNet recordio + DataLoader) -> decoded uint8
     batches -> device-side DataAugmentation_LAFS.  One pass over the dataset per epoch, sharded over the ranks."""
@@ -148,19 +156,29 @@ class RecordIOViews:
         from .augment import DeviceAugmenter
         from .recordio import FaceRecordDataset
         self.ds = FaceRecordDataset(os.path.join(path, 'train.rec'))
-        if world > 1:                                        # DistributedSampler-style strided shard
-            self.ds.seq = self.ds.seq[rank::world]
+        self.all_seq = list(self.ds.seq)
+        self.rank, self.world = rank, world
+        # torch DistributedSampler semantics (reference lafs_train.py:186-191): every rank gets the SAME number of samples
+        # (len // world, the tail dropped), so all ranks run the same number of steps -- unequal shards would leave the last
+        # gradient all-reduce of the longer ranks waiting for ever -- and the partition is re-drawn every epoch from a
+        # permutation seeded with (seed, epoch), identical on all ranks (set_epoch)
+        self.per_rank = len(self.all_seq) // world
         self.batch, self.device, self.seed, self.workers = batch, device, seed, num_workers
         self.aug = DeviceAugmenter(batch, n_local=n_local, device=device, seed=seed)
         self.epoch = 0
-        print(f"Data loaded: there are {len(self.ds)} images.")
+        self.set_epoch(0)
+        print(f"Data loaded: there are {len(self.all_seq)} images ({self.per_rank} per rank).")
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+        mine = epoch_shard(len(self.all_seq), self.rank, self.world, self.seed - self.rank, self.epoch)   # `seed` arrives as base + rank
+        self.ds.seq = [self.all_seq[i] for i in mine]
 
     def __len__(self):
-        return len(self.ds) // self.batch
+        return self.per_rank // self.batch
 
     def __iter__(self):
         from .recordio import device_batches
-        self.epoch += 1
         for u8, _ in device_batches(self.ds, self.batch, self.device, num_workers=self.workers, shuffle=True,
                                     seed=self.seed + self.epoch):
             yield self.aug(u8), None
@@ -253,6 +271,8 @@ def train_lafs(args, dataset=None):
     start = time.time()
     print("Starting LAFS training !")
     for epoch in range(start_epoch, args.epochs):
+        if hasattr(data_loader, "set_epoch"):
+            data_loader.set_epoch(epoch)                      # data_loader.sampler.set_epoch(epoch), reference :440
         stats = train_one_epoch(engine, dino_loss, data_loader, lr_schedule, wd_schedule, momentum_schedule, epoch, args,
                                 frontend=frontend)
         save_dict = {

@@ -102,7 +102,11 @@ class PartialFC:
         self.gen = torch.Generator(device=self.device).manual_seed(seed + 1000 + self.rank)
         dev, N = self.device, batch_size * self.world
         self.N = N
-        self.Spad = (self.num_sample + 127) // 128 * 128
+        # a rank scores the batch against max(num_sample, #positive classes it owns) centres: every positive is kept even when
+        # there are more of them than num_sample (small shards, low sample rates, large global batches); at most N distinct
+        # labels exist, so this bound holds on every rank and no buffer can overflow on one rank while the others wait in a
+        # collective
+        self.Spad = (max(self.num_sample, min(self.num_local, N)) + 127) // 128 * 128
         self.ones = torch.ones(self.Spad, device=dev, dtype=f32)
         self.cos = torch.empty(N, self.Spad, device=dev, dtype=f32)
         self.dcos = torch.zeros(N, self.Spad, device=dev, dtype=bf16)

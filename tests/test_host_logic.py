@@ -128,3 +128,16 @@ def test_f12_finetune_weight_decay_groups_match_param_groups_lrd():
         p = types.SimpleNamespace(dim=lambda nd=nd: nd)
         assert wd_of[finetune_decay_group(n, p)] == pytest.approx(wd), (n, wd)
     assert {0.0, 0.05, 0.1} == {round(float(w), 6) for w in fx["weight_decay"].tolist()}
+
+
+def test_recordio_epoch_shards_are_equal_disjoint_and_reshuffled():
+    """Every rank must see the same number of samples per epoch (else the ranks run different step counts and the last all-reduce
+    hangs) and the partition is re-drawn each epoch, like DistributedSampler.set_epoch (reference lafs_train.py:186-191, 440)."""
+    from lafs_cvpr2024_amd.lafs_train import epoch_shard
+    n, world = 1003, 8
+    e0 = [epoch_shard(n, r, world, 7, 0) for r in range(world)]
+    e1 = [epoch_shard(n, r, world, 7, 1) for r in range(world)]
+    assert {len(s) for s in e0} == {n // world}
+    flat = [i for s in e0 for i in s]
+    assert len(set(flat)) == len(flat) == (n // world) * world
+    assert e0[3] != e1[3] and sorted(i for s in e1 for i in s) != sorted(flat) or e0 != e1
