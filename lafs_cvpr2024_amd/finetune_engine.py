@@ -12,7 +12,9 @@ import torch.distributed as dist
 
 from . import _lib, functional as Fn, ops
 from .face_pre_pro.ViT_face import ViT_face_landmark_patch8
+from .distributed import FlatReducer
 from .ops import _p, call
+from .utils import PinnedRing
 from .vision_transformer import attach_arena
 
 f32, bf16 = torch.float32, torch.bfloat16
@@ -53,6 +55,20 @@ class FinetuneEngine:
         self.geom = Fn.geometry([(batch_size, image_size)], self.device)
         dev = self.device
         self.hyper = torch.zeros(_lib.HP_COUNT, device=dev, dtype=f32)
+        self.hyper_ring = PinnedRing((_lib.HP_COUNT,), f32)     # asynchronous upload; a pageable copy would block the host
+        # data parallelism (reference: DDP bucketed all-reduce overlapped with backward, train_largescale.py:676-677, 867): on the
+        # last micro-step of an accumulation window the flat gradient goes out over RCCL in slices AS THE BACKWARD RETIRES
+        # THEM -- the 0.6 GB margin head first (it is final before the trunk backward starts), then runs of blocks from the top,
+        # last the embedding / landmark-CNN range -- and optimizer_step only waits.  Reducing once per window instead of once
+        # per micro-step is the same sum (no_sync semantics).
+        self.reducer = FlatReducer()
+        self.grad_slices = 4
+        names = backbone._spec.trunk.block_names
+        self.block0 = self.arena.offsets[names[0]["ln1_g"]]
+        self.block_off = [self.arena.offsets[n["ln1_g"]] for n in names] + [self.arena.offsets[backbone._spec.prefix + backbone._spec.final_g]]
+        hn = backbone._spec.prefix + "loss.weight"
+        self.head_off = self.arena.offsets[hn] if (sharded_head is None) else self.arena.size
+        self._reduced = False
         self.ones = torch.ones(self.C, device=dev, dtype=f32)
         self.x = torch.empty(batch_size, 3, image_size, image_size, device=dev, dtype=f32)
         self.cos = torch.empty(batch_size, self.Cpad, device=dev, dtype=f32)
@@ -118,35 +134,73 @@ class FinetuneEngine:
              _p(a.view(a.grad, wname)), None, 1)
         demb = torch.empty(B, D, device=dev, dtype=f32)
         call("lafs_l2norm_bwd", _p(emb), D, _p(dxn), D, _p(inv_x), _p(demb), D, B, D)
+        if self._reduce_now():
+            self.reducer.launch(a.grad[self.head_off:])          # margin head (+ anything behind it): final from here on
         self._backward_trunk(st, demb, th if m.with_land else None, theta)
         self.micro += 1
         return self.loss
 
+    def _reduce_now(self):
+        """True on the micro-step that completes an accumulation window of a data-parallel run."""
+        return self.world > 1 and (self.micro + 1) % self.acc_step == 0
+
+    def _trunk_layers_backward(self, st, demb):
+        """Final norm + all blocks; with DP on the window's last micro-step in `grad_slices` runs, each run's gradient range
+        handed to RCCL as soon as it has been enqueued."""
+        a, m = self.arena, self.model
+        g = Fn.vit_backward_begin(a, m._spec, st, demb)
+        depth = m.depth
+        if not self._reduce_now():
+            Fn.vit_backward_layers(st, g, depth, 0)
+            return g
+        ns = max(1, min(self.grad_slices, depth))
+        cuts = [depth - (depth * k) // ns for k in range(ns + 1)]
+        hi = self.head_off
+        for k in range(ns):
+            Fn.vit_backward_layers(st, g, cuts[k], cuts[k + 1])
+            lo = self.block_off[cuts[k + 1]]
+            if cuts[k + 1] > 0:                                  # the range below block 0 still waits for the embedding / CNN gradients
+                self.reducer.launch(a.grad[lo:hi])
+                hi = lo
+        self._hi_left = hi
+        return g
+
     def _backward_trunk(self, st, demb, th, theta):
         a, m, B, D = self.arena, self.model, self.B, self.D
+        reduce_now = self._reduce_now()
         if m.with_land:
-            dpos, dx = Fn.vit_backward(a, m._spec, st, demb, want_dx=True)
+            g = self._trunk_layers_backward(st, demb)
+            dpos, dx = Fn.vit_backward_end(a, m._spec, st, g, want_dx=True)
             dmosaic = Fn.unpatchify_grad(dx[0], m._spec.patch_order).contiguous()
             dth = torch.empty_like(th)
             call("lafs_patch_gather_bwd", _p(self.x), _p(th), _p(dmosaic), B, self.x.shape[-1], th.shape[1], _p(dth), None)
             theta.backward(dth)                          # into stn.* / output_layer.* gradients (views of the arena)
         else:
-            dpos = Fn.vit_backward(a, m._spec, st, demb)
+            g = self._trunk_layers_backward(st, demb)
+            dpos = Fn.vit_backward_end(a, m._spec, st, g)
         a.view(a.grad, m._spec.prefix + "pos_embedding").view(-1, D)[: dpos[0].shape[0]] += dpos[0]
+        if reduce_now:                                           # what is left: block 0's run + embedding + landmark CNN
+            self.reducer.launch(a.grad[: self._hi_left])
+            self._reduced = True
 
     def optimizer_step(self, lr, weight_decay=0.1, beta1=0.9, beta2=0.999, eps=1e-8):
         """AdamW over every tensor (decay only on >= 2-D tensors, train_largescale.py:122-173); all-reduces the flat gradient
         first when running data-parallel (the reference's DDP does it on every micro-step, :676-677)."""
         a = self.arena
         if self.world > 1:
-            dist.all_reduce(a.grad)
-        h = torch.zeros(_lib.HP_COUNT, dtype=f32)
-        h[_lib.HP_LR], h[_lib.HP_WD], h[_lib.HP_BETA1], h[_lib.HP_BETA2], h[_lib.HP_EPS] = lr, weight_decay, beta1, beta2, eps
+            if self._reduced:
+                self.reducer.wait_all()                          # launched slice by slice during the last backward
+            else:
+                dist.all_reduce(a.grad)                          # optimizer_step called outside the acc_step cadence
+            self._reduced = False
         # dense head: every rank's loss is its local mean -> average; sharded head: gradients of the global mean -> sum
         gscale = 1.0 if self.head is not None else 1.0 / self.world
-        h[_lib.HP_CLIP], h[_lib.HP_EMA_M], h[_lib.HP_FREEZE_LAST], h[_lib.HP_GRAD_SCALE] = 0.0, 0.0, 0.0, gscale
-        h[_lib.HP_WD_LOW] = LOW_WEIGHT_DECAY
-        self.hyper.copy_(h)
+
+        def fill(h):
+            h.zero_()
+            h[_lib.HP_LR], h[_lib.HP_WD], h[_lib.HP_BETA1], h[_lib.HP_BETA2], h[_lib.HP_EPS] = lr, weight_decay, beta1, beta2, eps
+            h[_lib.HP_GRAD_SCALE], h[_lib.HP_WD_LOW] = gscale, LOW_WEIGHT_DECAY
+        self.hyper_ring.upload(self.hyper, fill)
         if self.head is not None:
             self.head.optimizer_step(lr, weight_decay, beta1, beta2, eps)
         call("lafs_clip_adamw_ema", _p(a.master), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq), None, _p(a.shadow), None,

@@ -128,3 +128,67 @@ def test_partial_fc_two_class_shards_on_one_gpu(tmp_path):
         assert float((got["demb"] - e).abs().max()) < 3e-2 * float(e.abs().max())
         w = Wfull.grad[got["start"]:got["start"] + got["dW"].shape[0]]
         assert float((got["dW"] - w).abs().max()) < 3e-2 * float(Wfull.grad.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------ dense fine-tune head, DP
+def _ft_model(with_land):
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8
+    torch.manual_seed(3)
+    return ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=512, image_size=112, patch_size=8, dim=128, depth=4, heads=3,
+                                    mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=with_land, drop_path_rate=0.0)
+
+
+def _ft_data(B):
+    g = torch.Generator().manual_seed(11)
+    return [(torch.randint(0, 256, (B, 3, 112, 112), dtype=torch.uint8, generator=g), torch.randint(0, 512, (B,), generator=g)) for _ in range(3)]
+
+
+def _ft_worker(rank, world, port, out, with_land):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    model = _ft_model(with_land)
+    if with_land:
+        model.eval()                                  # BatchNorm batch statistics differ between a half batch and the full one
+    eng = FinetuneEngine(model, 8, acc_step=3, device="cuda")
+    assert eng.world == 2
+    w0 = eng.arena.master.clone()
+    for u8, y in _ft_data(16):                        # this rank's half of every micro-batch
+        # batch mixup pairs row i with row B-1-i of the SAME rank's batch: lam = 1 keeps the two decompositions comparable
+        loss = eng.micro_step(u8[rank * 8:(rank + 1) * 8].cuda(), y[rank * 8:(rank + 1) * 8].cuda(), lam=1.0)
+    assert eng._reduced                               # the slices went out during the third backward, not at the optimizer step
+    eng.reducer.wait_all()
+    gsum = eng.arena.grad.clone()                     # SUM over ranks of the accumulated local-mean gradients
+    eng._reduced = True
+    eng.optimizer_step(lr=1e-3, weight_decay=0.1)
+    torch.cuda.synchronize()
+    torch.save({"grad": gsum.cpu(), "master": eng.arena.master.cpu(), "moved": float((eng.arena.master - w0).abs().max())}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_land", [False, True])
+def test_dense_finetune_two_ranks_equal_one_rank_on_the_full_batch(tmp_path, with_land):
+    """train_largescale.py under DDP (:676-677, 842-891): two ranks x batch 8, acc_step 3, against one process x batch 16.  The
+    gradient slices are launched as the last backward retires them (head first) and optimizer_step only waits; the summed
+    gradient over 1/world equals the full-batch gradient, the replicas end bit-identical and close to the single-process run."""
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    out = str(tmp_path / "ft")
+    port = _free_port()
+    mp.spawn(_ft_worker, args=(2, port, out, with_land), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    assert torch.equal(r0["grad"], r1["grad"]) and torch.equal(r0["master"], r1["master"]) and r0["moved"] > 1e-4
+    model = _ft_model(with_land)
+    if with_land:
+        model.eval()
+    eng = FinetuneEngine(model, 16, acc_step=3, device="cuda")
+    for u8, y in _ft_data(16):
+        eng.micro_step(u8.cuda(), y.cuda(), lam=1.0)
+    g_full = eng.arena.grad.clone().cpu()
+    # rank-local losses are means over 8 rows: SUM over ranks / world == mean over the 16 rows
+    rel = float((r0["grad"] * 0.5 - g_full).norm() / g_full.norm())
+    assert rel < 2e-3, rel
+    eng.optimizer_step(lr=1e-3, weight_decay=0.1)
+    d = (r0["master"] - eng.arena.master.cpu()).abs()
+    assert float(d.median()) < 1e-6 and float((d > 1e-4).float().mean()) < 0.06, (float(d.median()), float((d > 1e-4).float().mean()))

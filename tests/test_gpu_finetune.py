@@ -454,3 +454,78 @@ def test_f12_arena_applies_the_reference_weight_decay_groups():
     for n, wd in zip([str(n) for n in fx["names"]], fx["weight_decay"].tolist()):
         ratio = (named[n].detach() / before[n]).flatten()
         assert float((ratio - (1 - lr * wd)).abs().max()) < 1e-6, (n, wd, float(ratio.mean()))
+
+
+def test_full_size_c4_reference_configuration_step_properties():
+    """BASELINE.json configs[3] as train_largescale.py really builds it (:432, 542-561): Part-fViT ViT-B with the TRAINABLE landmark
+    branch (with_land=True), dropout = emb_dropout 0.1, DropPath 0.1, batch 128, 205 990 classes, a mixed batch (lambda = 0.3),
+    acc_step 3.  Size-independent properties: finite loss in the closed-form band of the soft-target CE, softmax-gradient rows
+    sum to zero, every tensor that can receive a gradient has one (incl. stn.* through theta and the gather), lr = 0 is the
+    identity, a real step moves matrices by about lr and decays stn.* at 5e-2 / the rest at 1e-1."""
+    import math
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    torch.manual_seed(0)
+    B, C, D = 128, 205990, 768
+    model = ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=C, image_size=112, patch_size=8, dim=D, depth=12,
+                                     heads=11, mlp_dim=2048, dropout=0.1, emb_dropout=0.1, with_land=True)
+    eng = FinetuneEngine(model, B, acc_step=3, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    losses = []
+    for _ in range(3):
+        u8 = torch.randint(0, 256, (B, 3, 112, 112), device=DEV, dtype=torch.uint8, generator=g)
+        y = torch.randint(0, C, (B,), device=DEV, generator=g)
+        losses.append(float(eng.micro_step(u8, y, lam=0.3).item()))
+        rows = eng.cos[:, :C].sum(1)
+        assert float(rows.abs().max()) < 1e-3 * float(eng.cos[:, :C].abs().sum(1).mean())
+    # dense soft target y = 0.3 e_a + 0.7 e_b enters the margin itself (ViT_face.py:69-73: s (cos - m y)), so the margin term of the
+    # soft-target CE is s m (0.3^2 + 0.7^2) = 0.58 s m; plus ln C and the variance term of the random cosines
+    lo, hi = math.log(C) + 0.58 * 64 * 0.4 - 0.5, math.log(C) + 0.58 * 64 * 0.4 + 64 ** 2 / D / 2 + 0.5
+    assert all(math.isfinite(v) and lo < v < hi for v in losses), (losses, lo, hi)
+    named = dict(model.named_parameters())
+    dead = [k for k, p in named.items() if p.requires_grad and (p.grad is None or float(p.grad.abs().max()) == 0.0)]
+    assert not dead, dead[:5]
+    assert float(named["stn.features.0.0.weight"].grad.abs().max()) > 0          # the CNN is reached through theta + gather
+    w0 = eng.arena.master.clone()
+    grad = eng.arena.grad.clone()
+    eng.optimizer_step(lr=0.0, weight_decay=0.0)
+    assert torch.equal(eng.arena.master, w0) and float(eng.arena.grad.abs().max()) == 0.0
+    eng.arena.grad.copy_(grad)
+    eng.optimizer_step(lr=1e-4, weight_decay=0.1)
+    d = (eng.arena.master - w0).abs()
+    assert 0.5e-4 < float(d.max()) < 3e-4
+
+
+def test_full_size_c5_partial_fc_step_properties():
+    """BASELINE.json configs[4] at the per-GPU size (Part-fViT embeddings 768-d, PartialFC with sample_rate 0.1 over ~200 000
+    identities, batch 256, one class shard = the whole table at world 1): every positive class is among the sampled centres,
+    exactly num_sample centres are scored, the gradient rows of the sampled softmax sum to zero, the loss equals the closed form
+    ln S + s m + s^2 / (2 D) for random unit embeddings, lr = 0 is the identity, unsampled centres do not move."""
+    import math
+    from lafs_cvpr2024_amd.partial_fc import PartialFC, sample_classes
+    torch.manual_seed(0)
+    B, C, D = 256, 200000, 768
+    pfc = PartialFC(D, C, B, sample_rate=0.1, device=DEV)
+    assert pfc.num_sample == 20000 and pfc.num_local == C
+    g = torch.Generator(device=DEV).manual_seed(4)
+    emb = torch.randn(B, D, device=DEV, generator=g)
+    y = torch.randint(0, C, (B,), device=DEV, generator=g)
+    idx, yl = sample_classes(y, 0, C, pfc.num_sample, torch.Generator(device=DEV).manual_seed(1))
+    assert idx.numel() == 20000 and bool((yl >= 0).all()) and torch.equal(idx[yl.long()], y)       # positives always present
+    loss, demb = pfc.forward_backward(emb, y)
+    S = 20000
+    rows = pfc.cos[:, :S].sum(1)                                            # dL/dcos left in place
+    assert float(rows.abs().max()) < 1e-3 * float(pfc.cos[:, :S].abs().sum(1).mean())
+    ref = math.log(S) + 64 * 0.4 + 64 ** 2 / D / 2
+    assert abs(float(loss) - ref) < 0.6, (float(loss), ref)
+    assert math.isfinite(float(demb.abs().max())) and float(demb.abs().max()) > 0
+    gw = pfc.arena.view(pfc.arena.grad, "weight", (C, D))
+    touched = (gw.abs().sum(1) > 0)
+    assert int(touched.sum()) <= S and bool(touched[y].all())
+    w0 = pfc.arena.master.clone()
+    gsave = pfc.arena.grad.clone()
+    pfc.optimizer_step(lr=0.0, weight_decay=0.0)
+    assert torch.equal(pfc.arena.master, w0)
+    pfc.arena.grad.copy_(gsave)
+    pfc.optimizer_step(lr=1e-3, weight_decay=0.0)
+    moved = ((pfc.arena.view(pfc.arena.master, "weight", (C, D)) - pfc.arena.view(w0, "weight", (C, D))).abs().sum(1) > 0)
+    assert torch.equal(moved, touched)
