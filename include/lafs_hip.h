@@ -168,6 +168,8 @@ int lafs_debug_dropout_mask(int rows, int cols, float drop_p, uint32_t drop_seed
 int lafs_attention_fwd(const void* qkv, int ldqkv, const int32_t* cu_seqlens, int n_seq, int max_len, int heads,
                        float scale, void* out_bf16, int ldo, float* lse, hipStream_t stream);
 /* dqkv(bf16) [T, 3*H*64] from dout(bf16) [T, H*64]; `delta` is an f32 [T, H] scratch; n_tok = T. */
+/* (n_tok == 0 skips the delta = rowsum(dO * O) pre-pass: for the second and later sequence groups of one batch, whose delta
+ * the first group's call has already produced.) */
 int lafs_attention_bwd(const void* qkv, int ldqkv, const void* out_bf16, int ldo, const void* dout_bf16, int lddo,
                        const float* lse, float* delta, const int32_t* cu_seqlens, int n_seq, int n_tok, int max_len,
                        int heads, float scale, void* dqkv, int lddqkv, hipStream_t stream);
@@ -286,6 +288,11 @@ typedef struct lafs_trunk_desc {
   uint32_t dropout_seed;
   const float* master; const void* shadow; const void* shadow_t; float* grad;
   const lafs_block_offsets* blocks;   /* HOST array [depth] */
+  /* Sequence groups of equal length (the crop resolutions of a packed multi-crop batch, in packing order): attention is
+   * launched once per group with the tile configuration of THAT length (197-token global crops: one (sequence, head) pair
+   * per workgroup, 53 KB of LDS; 37-token local crops: four pairs per workgroup) instead of once with the longest one.
+   * n_groups = 0: a single launch over all sequences with max_len. */
+  int n_groups; int group_n_seq[4]; int group_max_len[4];
 } lafs_trunk_desc;
 
 /* Bytes of activation workspace for a forward with (1) / without (0) saving activations for backward. */

@@ -42,7 +42,8 @@ class TrunkDesc(C.Structure):
                 ("cu_seqlens", C.c_void_p), ("row2seq", C.c_void_p), ("drop_scales", C.c_void_p),
                 ("dropout_p", C.c_float), ("dropout_seed", C.c_uint32),
                 ("master", C.c_void_p), ("shadow", C.c_void_p), ("shadow_t", C.c_void_p), ("grad", C.c_void_p),
-                ("blocks", C.POINTER(BlockOffsets))]
+                ("blocks", C.POINTER(BlockOffsets)),
+                ("n_groups", C.c_int), ("group_n_seq", C.c_int * 4), ("group_max_len", C.c_int * 4)]
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32, EPI_BF16_ACT = range(8)

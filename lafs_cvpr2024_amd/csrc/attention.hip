@@ -507,15 +507,17 @@ extern "C" int lafs_attention_bwd(const void* qkv, int ldqkv, const void* out_bf
                                   int heads, float scale, void* dqkv, int lddqkv, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(qkv && out_bf16 && dout_bf16 && lse && delta && cu_seqlens && dqkv, "null operand");
-  LAFS_CHECK_ARG(n_seq > 0 && n_tok > 0 && heads > 0 && max_len > 0 && max_len <= 256, "sequence length must be in 1..256");
+  LAFS_CHECK_ARG(n_seq > 0 && n_tok >= 0 && heads > 0 && max_len > 0 && max_len <= 256, "sequence length must be in 1..256");
   LAFS_CHECK_ARG(ldqkv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0, "row strides must be multiples of 8");
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ldqkv = ldqkv; a.cu = cu_seqlens; a.n_seq = n_seq; a.heads = heads; a.scale = scale;
   a.out = (bf16_t*)out_bf16; a.ldo = ldo; a.lse = const_cast<float*>(lse);
   a.dout = (const bf16_t*)dout_bf16; a.lddo = lddo; a.delta = delta; a.dqkv = (bf16_t*)dqkv; a.lddqkv = lddqkv;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div(n_tok * heads, 256)), dim3(256), 0, stream, a.out, ldo, a.dout, lddo,
-                     delta, n_tok, heads);
-  LAFS_LAUNCH_CHECK();
+  if (n_tok > 0) {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div(n_tok * heads, 256)), dim3(256), 0, stream, a.out, ldo, a.dout, lddo,
+                       delta, n_tok, heads);
+    LAFS_LAUNCH_CHECK();
+  }
   const int rc = dispatch_len(1, max_len, a, stream);
   if (rc != LAFS_OK) return rc;
   return dispatch_len(2, max_len, a, stream);

@@ -90,6 +90,15 @@ int check_desc(const lafs_trunk_desc* d) {
   LAFS_CHECK_ARG(d->depth > 0 && d->n_tok > 0 && d->n_seq > 0 && d->max_len > 0 && d->max_len <= 256, "bad geometry");
   LAFS_CHECK_ARG(d->cu_seqlens && d->row2seq && d->master && d->shadow && d->blocks, "null pointer in descriptor");
   LAFS_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "dropout_p must be in [0, 1)");
+  LAFS_CHECK_ARG(d->n_groups >= 0 && d->n_groups <= 4, "at most 4 sequence groups");
+  if (d->n_groups > 0) {
+    int ns = 0;
+    for (int gi = 0; gi < d->n_groups; ++gi) {
+      LAFS_CHECK_ARG(d->group_n_seq[gi] > 0 && d->group_max_len[gi] > 0 && d->group_max_len[gi] <= d->max_len, "bad sequence group");
+      ns += d->group_n_seq[gi];
+    }
+    LAFS_CHECK_ARG(ns == d->n_seq, "sequence groups must cover n_seq");
+  }
   return LAFS_OK;
 }
 
@@ -138,7 +147,16 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
     else nxt = (cur == c.xalt) ? x_out : c.xalt;            // ping-pong; never aliases x_in
     RUN(lafs_layernorm_fwd(cur, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1, D, nullptr, 0, b.st1, T, D, stream));
     RUN(gemm(b.h1, D, sh + o.w_qkv, D, T, 3 * I, D, LAFS_EPI_BF16, b.qkv, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, stream));
-    RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, stream));
+    if (d->n_groups > 1) {                                  // one launch per crop resolution, each with its own tile shape
+      int s0 = 0;
+      for (int gi = 0; gi < d->n_groups; ++gi) {
+        RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads, d->attn_scale,
+                               b.o, I, b.lse, stream));
+        s0 += d->group_n_seq[gi];
+      }
+    } else {
+      RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, stream));
+    }
     const float dp = d->dropout_p;
     const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
     RUN(gemm(b.o, I, sh + o.w_proj, I, T, D, I, LAFS_EPI_RESID_F32, b.x1, D, d->master + o.b_proj, stream, nullptr, 0, cur, D, sa,
@@ -209,8 +227,17 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
                            gr + o.ln2_g, gr + o.ln2_b, T, D, dp, dseed(l, 0), stream));
     // ---- attention branch ----
     RUN(gemm(s.gba[p], D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
-    RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens, d->n_seq, T, d->max_len, d->heads,
-                           d->attn_scale, s.dqkv[p], 3 * I, stream));
+    if (d->n_groups > 1) {
+      int s0 = 0;
+      for (int gi = 0; gi < d->n_groups; ++gi) {             // delta for ALL tokens rides with the first group's call
+        RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens + s0, d->group_n_seq[gi], gi == 0 ? T : 0,
+                               d->group_max_len[gi], d->heads, d->attn_scale, s.dqkv[p], 3 * I, stream));
+        s0 += d->group_n_seq[gi];
+      }
+    } else {
+      RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens, d->n_seq, T, d->max_len, d->heads,
+                             d->attn_scale, s.dqkv[p], 3 * I, stream));
+    }
     // ---- the block's four weight gradients: ONE grouped launch on the side stream, once all their operands exist.  Its
     // 48 (ViT-S) output tiles x 5 token slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four
     // separate launches (csrc/wgrad.hip)

@@ -99,6 +99,10 @@ def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=No
     d.master, d.shadow, d.shadow_t = arena.master.data_ptr(), arena.shadow.data_ptr(), arena.shadow_t.data_ptr()
     d.grad = arena.grad.data_ptr() if (with_grad and arena.grad is not None) else None
     d.blocks = C.cast(blocks, C.POINTER(_lib.BlockOffsets))
+    if 1 < len(geom.groups) <= 4:                        # one attention launch per crop resolution
+        d.n_groups = len(geom.groups)
+        for gi, (n_img, side) in enumerate(geom.groups):
+            d.group_n_seq[gi], d.group_max_len[gi] = n_img, (side // geom.patch) ** 2 + 1
     d._keep = (blocks, drop_scales, geom, arena)
     return d
 
