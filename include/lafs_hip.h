@@ -243,10 +243,14 @@ int lafs_center_ema(float* center, const float* colsum, int K, float inv_rows_to
 #define LAFS_N_XCD 8          /* XCDs (L2 domains) of an MI355X */
 #define LAFS_CHUNK 1024
 enum { LAFS_SEG_DECAY = 1, LAFS_SEG_LAST_LAYER = 2, LAFS_SEG_TRAINABLE = 4,
+       LAFS_SEG_OVERWRITTEN = 16 /* the step's first gradient writer of this tensor OVERWRITES it (wgrad fold with accumulate = 0,
+                                     weight-norm backward): lafs_zero_chunks(skip_mask = 16) leaves it alone */,
        LAFS_SEG_LOW_DECAY = 8 /* decays at hyper[LAFS_HP_WD_LOW] instead of hyper[LAFS_HP_WD]: the `stn*` matrices of the
                                   fine-tune step, train_largescale.py:143-145 (5e-2 against 1e-1) */ };
 enum { LAFS_HP_LR = 0, LAFS_HP_WD, LAFS_HP_BETA1, LAFS_HP_BETA2, LAFS_HP_EPS, LAFS_HP_CLIP, LAFS_HP_EMA_M,
-       LAFS_HP_FREEZE_LAST, LAFS_HP_GRAD_SCALE, LAFS_HP_WD_LOW, LAFS_HP_COUNT = 16 };
+       LAFS_HP_FREEZE_LAST, LAFS_HP_GRAD_SCALE, LAFS_HP_WD_LOW,
+       LAFS_HP_STEP /* optimisation step count (as a float): seeds the per-step DropPath masks of a replayed graph */,
+       LAFS_HP_COUNT = 16 };
 /* seg_sumsq(f32)[n_seg] += sum of (grad_scale*g)^2 per segment (seg_sumsq must be pre-zeroed). */
 int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, const float* hyper,
                     float* seg_sumsq, hipStream_t stream);
@@ -293,6 +297,8 @@ typedef struct lafs_trunk_desc {
    * per workgroup, 53 KB of LDS; 37-token local crops: four pairs per workgroup) instead of once with the longest one.
    * n_groups = 0: a single launch over all sequences with max_len. */
   int n_groups; int group_n_seq[4]; int group_max_len[4];
+  int wgrad_overwrite;                /* != 0: the block weight gradients are WRITTEN (not accumulated): the caller zeroes only the
+                                         other tensors (lafs_zero_chunks, LAFS_SEG_OVERWRITTEN) and runs one backward per step */
 } lafs_trunk_desc;
 
 /* Bytes of activation workspace for a forward with (1) / without (0) saving activations for backward. */
@@ -309,6 +315,25 @@ int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, float* x_out
  * events, so the call is still hipGraph-capturable and complete on `stream` when it returns to stream order). */
 int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
                         int layer_lo, hipStream_t wgrad_stream, hipStream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Step glue that used to run on ATen / rocBLAS inside the captured step (csrc/stepglue.hip)
+ * ------------------------------------------------------------------------------------------------ */
+/* Stochastic depth (vision_transformer.py:27-35; ViT_face.py:106-112): scales(f32)[depth, 2, n_seq] = 1/keep_l with probability
+ * keep_l, else 0; keep_prob f32 [depth] on the device.  Counter-based: hash(seed, step, index), `step_dev` (device f32, may be
+ * NULL) = &hyper[LAFS_HP_STEP], so a replayed hipGraph draws new masks every step.  Same distribution as torch.rand-based
+ * drop_path, different random stream. */
+int lafs_droppath_scales(const float* keep_prob, int depth, int n_seq, uint32_t seed, const float* step_dev, float* scales,
+                         hipStream_t stream);
+/* interpolate_pos_encoding (vision_transformer.py:174-194) as its fixed linear map: out(f32)[1+R, D]: row 0 = cls row of the
+ * table, rows 1.. = interp(f32 [R, G]) @ table[1:, :]  (table f32 [1+G, D]).  bwd: grad_table += the transposed map of dpos. */
+int lafs_pos_interp_fwd(const float* pos_table, const float* interp, float* out, int R, int G, int D, hipStream_t stream);
+int lafs_pos_interp_bwd(const float* dpos, const float* interp, float* grad_table, int R, int G, int D, hipStream_t stream);
+/* Zero the 1024-float chunks of a gradient arena whose segment flags do not intersect skip_mask. */
+int lafs_zero_chunks(float* buf, const int32_t* chunk_seg, const int32_t* seg_flags, int64_t n_chunks, int skip_mask,
+                     hipStream_t stream);
+/* hipMemsetAsync(buf, 0, bytes) on `stream` (a memset node under graph capture). */
+int lafs_fill_zero(void* buf, int64_t bytes, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fine-tune path (train_largescale.py): margin-softmax head, mixup, landmark patch gather

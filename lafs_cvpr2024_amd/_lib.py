@@ -43,15 +43,15 @@ class TrunkDesc(C.Structure):
                 ("dropout_p", C.c_float), ("dropout_seed", C.c_uint32),
                 ("master", C.c_void_p), ("shadow", C.c_void_p), ("shadow_t", C.c_void_p), ("grad", C.c_void_p),
                 ("blocks", C.POINTER(BlockOffsets)),
-                ("n_groups", C.c_int), ("group_n_seq", C.c_int * 4), ("group_max_len", C.c_int * 4)]
+                ("n_groups", C.c_int), ("group_n_seq", C.c_int * 4), ("group_max_len", C.c_int * 4), ("wgrad_overwrite", C.c_int)]
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32, EPI_BF16_ACT = range(8)
 ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = range(4)
 PATCH_ORDER_CHW, PATCH_ORDER_HWC = 0, 1
 CHUNK = 1024
-SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE, SEG_LOW_DECAY = 1, 2, 4, 8
-HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE, HP_WD_LOW = range(10)
+SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE, SEG_LOW_DECAY, SEG_OVERWRITTEN = 1, 2, 4, 8, 16
+HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE, HP_WD_LOW, HP_STEP = range(11)
 HP_COUNT = 16
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -88,6 +88,11 @@ _PROTOS = {
     "lafs_grad_sumsq": [vp, vp, i64, vp, vp],
     "lafs_clip_adamw_ema": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp],
     "lafs_cast_bf16": [vp, vp, i64],
+    "lafs_droppath_scales": [vp, i32, i32, u32, vp, vp],
+    "lafs_pos_interp_fwd": [vp, vp, vp, i32, i32, i32],
+    "lafs_pos_interp_bwd": [vp, vp, vp, i32, i32, i32],
+    "lafs_zero_chunks": [vp, vp, vp, i64, i32],
+    "lafs_fill_zero": [vp, i64],
     "lafs_transpose_cast_bf16": [vp, i32, i32, vp, i32],
     "lafs_transpose_cast_table": [vp, vp, vp, vp, i32, i32],
     "lafs_trunk_forward": [C.POINTER(TrunkDesc), vp, vp, vp, i32],

@@ -249,7 +249,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
       it[1].A = s.du[p]; it[1].B = b.h2; it[1].C = gr + o.w_fc1; it[1].colsum_a = gr + o.b_fc1;
       it[2].A = s.gba[p]; it[2].B = b.o; it[2].C = gr + o.w_proj; it[2].colsum_a = gr + o.b_proj;
       it[3].A = s.dqkv[p]; it[3].B = b.h1; it[3].C = gr + o.w_qkv; it[3].colsum_a = o.b_qkv >= 0 ? gr + o.b_qkv : nullptr;
-      for (auto& x : it) x.accumulate = 1;
+      for (auto& x : it) x.accumulate = d->wgrad_overwrite ? 0 : 1;
       RUN(lafs_wgrad_group(it, 4, T, c.wg_ws, (int64_t)c.wg_bytes, s2));
     }
     if (two) { done[l] = ev[evi++]; (void)hipEventRecord(done[l], s2); }

@@ -117,6 +117,27 @@ class LafsPretrainEngine:
         self.in_local_all = torch.zeros(max(n_local, 1) * B, 3, local_size, local_size, device=dev)
         self.in_global = list(self.in_global_all.split(B))
         self.in_local = list(self.in_local_all.split(B))[:n_local]
+        # DropPath scales are drawn by lafs_droppath_scales from (seed, hyper[HP_STEP]): new masks on every graph replay without
+        # an ATen RNG kernel; keep probabilities per block on the device, None when every rate is 0
+        def keep_probs(v):
+            rates = [v.drop_path_rate] * v.depth if self.partfvit else list(v.drop_path_rates)
+            return torch.tensor([1.0 - r for r in rates], device=dev, dtype=f32) if any(rates) else None
+        self.keep_s, self.keep_t = keep_probs(vit_s), keep_probs(vit_t)
+        self.drop_s = torch.empty(vit_s.depth, 2, self.geom_s.n_seq, device=dev, dtype=f32)
+        self.drop_t = torch.empty(vit_t.depth, 2, self.geom_t.n_seq, device=dev, dtype=f32)
+        self.drop_seed = 0x0D20FA7
+        # resampled position tables (static: [1 + r*r, D] per crop size and network)
+        self.pos_s = [torch.empty(r * r + 1, D, device=dev, dtype=f32) for r in self.grids]
+        self.pos_t = [torch.empty(self.grids[0] ** 2 + 1, D, device=dev, dtype=f32)]
+        # tensors whose gradient is WRITTEN by its first producer (block weights: wgrad fold with accumulate = 0; last layer:
+        # weight-norm backward): the per-step zeroing skips them (lafs_zero_chunks)
+        flags = self.sa.seg_flags.cpu().tolist()
+        over = {nm[k] for nm in self.spec_s.trunk.block_names for k in ("w_qkv", "w_proj", "w_fc1", "w_fc2")}
+        over.add(self.head_prefix_s + "last_layer.weight_v")
+        for i, name in enumerate(self.sa.names):
+            if name in over:
+                flags[i] |= _lib.SEG_OVERWRITTEN
+        self.sa.seg_flags.copy_(torch.tensor(flags, dtype=torch.int32))
         # gradient ranges for the two all-reduces: [trunk | head]
         self.head_start = min(o for n, o in self.sa.offsets.items() if n.startswith(self.head_prefix_s))
         self.depth = vit_s.depth
@@ -138,37 +159,47 @@ class LafsPretrainEngine:
         self.step_count = 0
 
     # ------------------------------------------------------------------ pieces (all capturable)
-    def _pos_tokens(self, arena, spec):
+    def _pos_tokens(self, arena, spec, bufs):
         pe = arena.view(arena.master, spec.prefix + spec.pos).view(-1, spec.trunk.dim)
         out = []
-        for M, r in zip(self.interp, self.grids):
+        for M, r, buf in zip(self.interp, self.grids, bufs):
             if self.partfvit:
                 out.append(pe[:r * r + 1])                 # pos_embedding[:, :n+1] (reference ViT_face.py:766)
-            else:
-                out.append(pe if M is None else torch.cat((pe[:1], M @ pe[1:])))
+            elif M is None:
+                out.append(pe)
+            else:                                          # bicubic resampling as its fixed linear map, one small launch
+                call("lafs_pos_interp_fwd", _p(pe), _p(M), _p(buf), M.shape[0], M.shape[1], spec.trunk.dim)
+                out.append(buf)
+        return out
+
+    def _drop_scales(self, keep, out, salt):
+        if keep is None:
+            return None
+        call("lafs_droppath_scales", _p(keep), out.shape[0], out.shape[2], (self.drop_seed + salt) & 0xFFFFFFFF,
+             _p(self.hyper[_lib.HP_STEP:]), _p(out))
         return out
 
     def _seg_forward(self):
         sa, ta, B = self.sa, self.ta, self.B
-        sa.grad.zero_()
+        call("lafs_zero_chunks", _p(sa.grad), _p(sa.chunk_seg), _p(sa.seg_flags), sa.n_chunks, _lib.SEG_OVERWRITTEN)
         # teacher (two global views, no activations kept) runs on the side stream, concurrently with the student
         cur = torch.cuda.current_stream()
         side = self.side_stream if self.side_stream is not None else cur
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            pos_t = self._pos_tokens(ta, self.spec_t)[:1]
+            pos_t = self._pos_tokens(ta, self.spec_t, self.pos_t)[:1]
             vit_t = self.teacher.backbone
-            drop_t = vit_t._sample_drop_scales(self.geom_t) if vit_t.training else None      # rate 0 for the DINO ViT teacher
+            drop_t = self._drop_scales(self.keep_t, self.drop_t, 1) if vit_t.training else None   # rate 0 for the DINO ViT teacher
             dd_t = vit_t._next_dropout() if self.partfvit else None
             feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, drop_t, save=False, dropout=dd_t)
             Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self.logits_t)
         # student: all views in one packed pass
         vit = self.student.backbone
-        drop = vit._sample_drop_scales(self.geom_s) if vit.training else None
+        drop = self._drop_scales(self.keep_s, self.drop_s, 0) if vit.training else None
         imgs = [self.in_global_all] + ([self.in_local_all] if self.n_local else [])
         dd_s = vit._next_dropout() if self.partfvit else None
-        feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s), drop, save=True,
-                                         dropout=dd_s)
+        feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s, self.pos_s), drop,
+                                         save=True, dropout=dd_s, wgrad_overwrite=True)
         _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self.logits_s)
         cur.wait_stream(side)
         # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
@@ -177,7 +208,7 @@ class LafsPretrainEngine:
                               loss=self.loss, dev_temps=self.temps)
         call("lafs_colsum_f32", _p(self.logits_t), self.Kpad, 2 * B, self.K, _p(self.colsum))
         train_g = self.student.head.last_layer.weight_g.requires_grad
-        dfeat = Fn.head_backward(sa, self.head_prefix_s, st_h, self.dlogits, train_g=train_g)
+        dfeat = Fn.head_backward(sa, self.head_prefix_s, st_h, self.dlogits, train_g=train_g, overwrite_last=True)
         self._st = dict(vit=st_v, dfeat=dfeat)
 
     def _seg_trunk_backward(self, k):
@@ -188,22 +219,20 @@ class LafsPretrainEngine:
             self._st["g"] = Fn.vit_backward_begin(sa, self.spec_s, self._st["vit"], self._st["dfeat"])
         Fn.vit_backward_layers(self._st["vit"], self._st["g"], self.cuts[k], self.cuts[k + 1], wgrad_stream=self.side_stream)
         if k == len(self.cuts) - 2:
-            dpos = Fn.vit_backward_end(sa, self.spec_s, self._st["vit"], self._st["g"])
             gpe = sa.view(sa.grad, self.spec_s.prefix + self.pos_name).view(-1, self.spec_s.trunk.dim)
-            for M, dp in zip(self.interp, dpos):
-                if self.partfvit:
-                    gpe[:dp.shape[0]] += dp
-                elif M is None:
-                    gpe += dp
-                else:
-                    gpe[:1] += dp[:1]
-                    gpe[1:] += M.t() @ dp[1:]
+            # a table that is used as stored (Part-fViT slices, or a crop size equal to the table's grid) takes its gradient rows
+            # directly; a resampled one goes through the transposed interpolation map
+            direct = [gpe[:r * r + 1] if (self.partfvit or M is None) else None for M, r in zip(self.interp, self.grids)]
+            dpos = Fn.vit_backward_end(sa, self.spec_s, self._st["vit"], self._st["g"], dpos_out=direct)
+            for M, dp, dr in zip(self.interp, dpos, direct):
+                if dr is None:
+                    call("lafs_pos_interp_bwd", _p(dp), _p(M), _p(gpe), M.shape[0], M.shape[1], self.spec_s.trunk.dim)
 
     def _seg_update(self):
         sa, ta = self.sa, self.ta
         call("lafs_center_ema", _p(self.dino_loss.center), _p(self.colsum), self.K, 1.0 / (2 * self.B * self.world),
              float(self.dino_loss.center_momentum))
-        sa.seg_sumsq.zero_()
+        ops.zero_(sa.seg_sumsq)
         call("lafs_grad_sumsq", _p(sa.grad), _p(sa.chunk_seg), sa.n_chunks, _p(self.hyper), _p(sa.seg_sumsq))
         call("lafs_clip_adamw_ema", _p(sa.master), _p(sa.grad), _p(sa.exp_avg), _p(sa.exp_avg_sq), _p(ta.master),
              _p(sa.shadow), _p(ta.shadow), _p(sa.chunk_seg), sa.n_chunks, _p(sa.seg_flags), _p(sa.seg_step), sa.n_seg,
@@ -251,6 +280,7 @@ class LafsPretrainEngine:
             h[_lib.HP_CLIP], h[_lib.HP_EMA_M] = self.clip_grad, momentum
             h[_lib.HP_FREEZE_LAST] = 1.0 if epoch < self.freeze_last_layer else 0.0
             h[_lib.HP_GRAD_SCALE] = 1.0 / self.world        # DDP mean of the summed gradients
+            h[_lib.HP_STEP] = float(self.step_count % (1 << 24))
 
         def fill_temps(t):
             t[0], t[1] = float(self.dino_loss.student_temp), teacher_temp
@@ -351,3 +381,5 @@ class LafsPretrainEngine:
             sa.view(sa.exp_avg, name, shape).copy_(st["exp_avg"]); sa.view(sa.exp_avg_sq, name, shape).copy_(st["exp_avg_sq"])
             steps[sa.names.index(name)] = int(float(st["step"]))
         sa.seg_step.copy_(steps)
+        # the per-step DropPath masks are seeded with the step count: continue the sequence of the interrupted run
+        self.step_count = int(steps.max()) if steps.numel() else 0

@@ -79,7 +79,8 @@ class TrunkSpec:
         return self.heads * 64
 
 
-def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=None, with_grad=True, dropout_p=0.0, dropout_seed=0):
+def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=None, with_grad=True, dropout_p=0.0, dropout_seed=0,
+                    wgrad_overwrite=False):
     """Build the C descriptor (keeps the ctypes block array alive on the returned object)."""
     blocks = (_lib.BlockOffsets * spec.depth)()
     for i, nm in enumerate(spec.block_names):
@@ -99,6 +100,7 @@ def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=No
     d.master, d.shadow, d.shadow_t = arena.master.data_ptr(), arena.shadow.data_ptr(), arena.shadow_t.data_ptr()
     d.grad = arena.grad.data_ptr() if (with_grad and arena.grad is not None) else None
     d.blocks = C.cast(blocks, C.POINTER(_lib.BlockOffsets))
+    d.wgrad_overwrite = 1 if wgrad_overwrite else 0
     if 1 < len(geom.groups) <= 4:                        # one attention launch per crop resolution
         d.n_groups = len(geom.groups)
         for gi, (n_img, side) in enumerate(geom.groups):
@@ -137,7 +139,7 @@ EMB_DROP_SITE = 0x40000000          # seed offset of the embedding dropout (the 
 
 
 def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, drop_scales=None, save=True,
-                ws=None, x_in=None, x_out=None, dropout=None):
+                ws=None, x_in=None, x_out=None, dropout=None, wgrad_overwrite=False):
     """imgs: list of fp32 NCHW tensors (one per group); pos_tokens: list of fp32 [npatch+1, D] per group.
     dropout: None or (p_trunk, p_embedding, seed): element dropout of Part-fViT (counter-based masks, see lafs_hip.h).
     Returns (feat f32 [n_seq, D], state)."""
@@ -148,7 +150,8 @@ def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, dr
     st.geom = geom
     p_trunk, p_emb, dseed = dropout if dropout is not None else (0.0, 0.0, 0)
     st.dropout = (p_trunk, p_emb, dseed)
-    st.desc = make_trunk_desc(arena, spec.trunk, geom, drop_scales, with_grad=save, dropout_p=p_trunk, dropout_seed=dseed)
+    st.desc = make_trunk_desc(arena, spec.trunk, geom, drop_scales, with_grad=save, dropout_p=p_trunk, dropout_seed=dseed,
+                              wgrad_overwrite=wgrad_overwrite)
     st.ws = ws if ws is not None else trunk_workspace(st.desc, save, dev)
     st.x_in = x_in if x_in is not None else torch.empty(geom.n_tok, D, device=dev, dtype=f32)
     if x_out is None:
@@ -187,7 +190,7 @@ def vit_backward_begin(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None):
     ops.layernorm_bwd(dfeat.contiguous(), st.cls_rows, st.stats, arena.view(arena.master, pre + spec.final_g), dcls_rows,
                       gv(spec.final_g), gv(spec.final_b), accumulate=False)
     g = g_buf if g_buf is not None else torch.empty(geom.n_tok, D, device=dev, dtype=f32)
-    g.zero_()
+    ops.zero_(g)
     call("lafs_scatter_cls", _p(dcls_rows), _p(geom.cu_seqlens), geom.n_seq, D, _p(g), D)
     return g
 
@@ -198,7 +201,7 @@ def vit_backward_layers(st: ViTState, g, hi, lo, wgrad_stream=None):
     call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo, ws2)
 
 
-def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g, want_dx=False):
+def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g, want_dx=False, dpos_out=None):
     """Token-assembly / patch-embedding backward.  Returns the list of dpos f32 [npatch+1, D] per group (the bicubic
     resampling of the position table lives in torch); with ``want_dx`` also the gradient of the patch vectors
     f32 [n_img, npatch, 192] per group (the landmark branch of Part-fViT differentiates through the patches,
@@ -218,7 +221,9 @@ def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g, want_dx=False):
         n_img, np_ = geom.groups[gi][0], geom.npatch(gi)
         rows = g[geom.tok_start[gi]: geom.tok_start[gi] + n_img * (np_ + 1)]
         gp = torch.empty(n_img * np_, D, device=dev, dtype=bf16)
-        dp = torch.zeros(np_ + 1, D, device=dev, dtype=f32)
+        # dpos_out[gi]: accumulate this group's position gradient straight into a caller buffer (e.g. the arena's gradient rows of
+        # a table that needs no resampling) instead of a fresh zeroed temporary
+        dp = dpos_out[gi] if (dpos_out is not None and dpos_out[gi] is not None) else ops.zeros(np_ + 1, D, device=dev)
         call("lafs_embed_bwd", _p(rows), D, n_img, np_, D, _p(gp), _p(dp), _p(gv(spec.cls)))
         ops.gemm_tn_acc(gp, st.patches[gi], gv(spec.w_patch).view(D, -1), colsum=gv(spec.b_patch))
         dpos.append(dp)
@@ -276,8 +281,10 @@ def head_forward(arena, prefix, x, K, save=True, logits=None):
     return logits, st
 
 
-def head_backward(arena, prefix, st: HeadState, dlogits_bf, train_g=False):
-    """dlogits_bf: bf16 [n, Kpad] (pad columns zero).  Accumulates into arena.grad; returns dx f32 [n, in_dim]."""
+def head_backward(arena, prefix, st: HeadState, dlogits_bf, train_g=False, overwrite_last=False):
+    """dlogits_bf: bf16 [n, Kpad] (pad columns zero).  Accumulates into arena.grad; returns dx f32 [n, in_dim].
+    overwrite_last: WRITE the last layer's weight_v (and weight_g) gradient instead of accumulating -- the training engine runs
+    one backward per step and skips zeroing that 100 MB tensor (LAFS_SEG_OVERWRITTEN)."""
     n, dev = dlogits_bf.shape[0], dlogits_bf.device
     K, Kpad = st.K, st.Kpad
     Db = st.z.shape[1]
@@ -285,11 +292,13 @@ def head_backward(arena, prefix, st: HeadState, dlogits_bf, train_g=False):
     gv = lambda k: arena.view(arena.grad, prefix + k)
     p2 = lambda k: arena.params[arena.names.index(prefix + k)].shape
     dzn = ops.gemm_nt(dlogits_bf, st.wn_t, _lib.EPI_ATOMIC_F32, splits=max(1, min(64, Kpad // 1024)))
-    dwn = torch.zeros(Kpad, Db, device=dev, dtype=f32)
-    ops.gemm_tn_acc(dlogits_bf, st.zn, dwn, splits=1)
+    # d(normalised weights) = dlogits^T zn: M = n rows is a single token slice of the wide-tile kernel -> written directly, no
+    # zero-fill of the 100 MB buffer and no atomics
+    dwn = torch.empty(Kpad, Db, device=dev, dtype=f32)
+    ops.wgrad(dlogits_bf, st.zn, dwn, accumulate=False)
     dg = gv("last_layer.weight_g") if train_g else None
     call("lafs_weightnorm_bwd", _p(dwn), _p(m("last_layer.weight_v")), _p(m("last_layer.weight_g")), _p(st.inv_v), K, Db,
-         _p(gv("last_layer.weight_v")), _p(dg), 1)
+         _p(gv("last_layer.weight_v")), _p(dg), 0 if overwrite_last else 1)
     dz = torch.empty(n, Db, device=dev, dtype=f32)
     call("lafs_l2norm_bwd", _p(st.z), Db, _p(dzn), Db, _p(st.inv_z), _p(dz), Db, n, Db)
     dz_bf = ops.scale_cast_bf16(dz)

@@ -32,6 +32,17 @@ def _ld(t):
     return t.stride(0) if t.dim() >= 2 else t.numel()
 
 
+def zero_(t):
+    """t.zero_() through hipMemsetAsync (no ATen fill kernel: keeps the captured step free of at::native launches)."""
+    if t.numel():
+        call("lafs_fill_zero", _p(t), t.numel() * t.element_size())
+    return t
+
+
+def zeros(*shape, device, dtype=torch.float32):
+    return zero_(torch.empty(*shape, device=device, dtype=dtype))
+
+
 def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=None, seq_scale=None, row2seq=None,
             aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0, act=0):
     """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*)."""
