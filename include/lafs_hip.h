@@ -117,9 +117,12 @@ typedef struct lafs_wgrad_item {
   int accumulate;                  /* 0: C = A^T B ; 1: C += A^T B                  */
   float* colsum_a;                 /* f32 [N1] += column sums of A (bias gradient), or NULL */
 } lafs_wgrad_item;
-int64_t lafs_wgrad_group_workspace_bytes(const lafs_wgrad_item* items, int n_items, int M);
-int lafs_wgrad_group(const lafs_wgrad_item* items, int n_items, int M, void* workspace, int64_t workspace_bytes,
-                     hipStream_t stream);
+/* max_workgroups: how many workgroups (= CUs) the launch may occupy, 8..256; 0 = the whole chip.  A backward pass that runs
+ * its weight gradients on a side stream keeps part of the chip free for the HBM-bound kernels of the main stream this way
+ * (the LAFS step: 160 of 256, 18.8 -> 18.5 ms).  The workspace size depends on it. */
+int64_t lafs_wgrad_group_workspace_bytes(const lafs_wgrad_item* items, int n_items, int M, int max_workgroups);
+int lafs_wgrad_group(const lafs_wgrad_item* items, int n_items, int M, int max_workgroups, void* workspace,
+                     int64_t workspace_bytes, hipStream_t stream);
 int64_t lafs_wgrad_workspace_bytes(int M, int N1, int N2);
 int lafs_wgrad(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
                int accumulate, float* colsum_a, void* workspace, int64_t workspace_bytes, hipStream_t stream);
@@ -251,9 +254,11 @@ enum { LAFS_HP_LR = 0, LAFS_HP_WD, LAFS_HP_BETA1, LAFS_HP_BETA2, LAFS_HP_EPS, LA
        LAFS_HP_FREEZE_LAST, LAFS_HP_GRAD_SCALE, LAFS_HP_WD_LOW,
        LAFS_HP_STEP /* optimisation step count (as a float): seeds the per-step DropPath masks of a replayed graph */,
        LAFS_HP_COUNT = 16 };
-/* seg_sumsq(f32)[n_seg] += sum of (grad_scale*g)^2 per segment (seg_sumsq must be pre-zeroed). */
-int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, const float* hyper,
-                    float* seg_sumsq, hipStream_t stream);
+/* seg_sumsq(f32)[n_seg] = sum of (grad_scale*g)^2 per segment -- the per-tensor norms of utils.clip_gradients
+ * (utils.py:132-141).  Two passes through chunk_sumsq(f32)[n_chunks] scratch, fixed summation order: no atomics, nothing
+ * to pre-zero, bitwise reproducible. */
+int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int n_seg, const float* hyper,
+                    float* chunk_sumsq, float* seg_sumsq, hipStream_t stream);
 /* Fused per-tensor clip + AdamW + teacher EMA + bf16 shadow refresh.  seg_step(i32)[n_seg] counts the
  * optimizer steps each tensor has actually taken.  teacher/shadow pointers may be NULL. */
 int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* teacher,
@@ -297,6 +302,7 @@ typedef struct lafs_trunk_desc {
    * per workgroup, 53 KB of LDS; 37-token local crops: four pairs per workgroup) instead of once with the longest one.
    * n_groups = 0: a single launch over all sequences with max_len. */
   int n_groups; int group_n_seq[4]; int group_max_len[4];
+  int wgrad_workgroups;               /* CUs the grouped weight-gradient launch may occupy (0 = all 256), see lafs_wgrad_group */
   int wgrad_overwrite;                /* != 0: the block weight gradients are WRITTEN (not accumulated): the caller zeroes only the
                                          other tensors (lafs_zero_chunks, LAFS_SEG_OVERWRITTEN) and runs one backward per step */
 } lafs_trunk_desc;
@@ -332,7 +338,7 @@ int lafs_pos_interp_bwd(const float* dpos, const float* interp, float* grad_tabl
 /* Zero the 1024-float chunks of a gradient arena whose segment flags do not intersect skip_mask. */
 int lafs_zero_chunks(float* buf, const int32_t* chunk_seg, const int32_t* seg_flags, int64_t n_chunks, int skip_mask,
                      hipStream_t stream);
-/* hipMemsetAsync(buf, 0, bytes) on `stream` (a memset node under graph capture). */
+/* buf[0 .. bytes) = 0 as a kernel launch on `stream` (16-byte aligned buffer). */
 int lafs_fill_zero(void* buf, int64_t bytes, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -43,7 +43,8 @@ class TrunkDesc(C.Structure):
                 ("dropout_p", C.c_float), ("dropout_seed", C.c_uint32),
                 ("master", C.c_void_p), ("shadow", C.c_void_p), ("shadow_t", C.c_void_p), ("grad", C.c_void_p),
                 ("blocks", C.POINTER(BlockOffsets)),
-                ("n_groups", C.c_int), ("group_n_seq", C.c_int * 4), ("group_max_len", C.c_int * 4), ("wgrad_overwrite", C.c_int)]
+                ("n_groups", C.c_int), ("group_n_seq", C.c_int * 4), ("group_max_len", C.c_int * 4), ("wgrad_workgroups", C.c_int),
+                ("wgrad_overwrite", C.c_int)]
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32, EPI_BF16_ACT = range(8)
@@ -64,7 +65,7 @@ _PROTOS = {
     "lafs_gemm_tn_part": [vp, i32, vp, i32, vp, i32, i64, i32, i32, i32, i32, vp],
     "lafs_reduce_partials": [vp, i64, i32, i64, vp],
     "lafs_wgrad": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i64],
-    "lafs_wgrad_group": [C.POINTER(WgradItem), i32, i32, vp, i64],
+    "lafs_wgrad_group": [C.POINTER(WgradItem), i32, i32, i32, vp, i64],
     "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
     "lafs_layernorm_fwd": [vp, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32],
     "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, u32],
@@ -85,7 +86,7 @@ _PROTOS = {
     "lafs_dino_loss_fwd_bwd": [vp, vp, i32, vp, i32, i32, i32, f32, f32, vp, vp, i32, i32, f32, vp, vp],
     "lafs_colsum_f32": [vp, i32, i32, i32, vp],
     "lafs_center_ema": [vp, vp, i32, f32, f32],
-    "lafs_grad_sumsq": [vp, vp, i64, vp, vp],
+    "lafs_grad_sumsq": [vp, vp, i64, i32, vp, vp, vp],
     "lafs_clip_adamw_ema": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp],
     "lafs_cast_bf16": [vp, vp, i64],
     "lafs_droppath_scales": [vp, i32, i32, u32, vp, vp],
@@ -125,7 +126,7 @@ _NO_STREAM = {
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),
     "lafs_wgrad_workspace_bytes": ([i32, i32, i32], i64),
-    "lafs_wgrad_group_workspace_bytes": ([C.POINTER(WgradItem), i32, i32], i64),
+    "lafs_wgrad_group_workspace_bytes": ([C.POINTER(WgradItem), i32, i32, i32], i64),
 }
 EXPORTED = sorted(list(_PROTOS) + list(_NO_STREAM))
 

@@ -57,6 +57,7 @@ class ParamArena:
         self.seg_flags = torch.tensor(flags, dtype=torch.int32, device=dev)
         self.seg_step = torch.zeros(self.n_seg, dtype=torch.int32, device=dev)
         self.seg_sumsq = torch.zeros(self.n_seg, dtype=torch.float32, device=dev)
+        self.chunk_sumsq = torch.zeros(self.n_chunks, dtype=torch.float32, device=dev) if with_grad else None
         # transposed bf16 shadows for the 2-D weights named in `transposed` (name -> True)
         self.t_offsets = {}
         toff = 0

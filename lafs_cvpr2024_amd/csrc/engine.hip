@@ -6,6 +6,7 @@
 // Mirrors Block.forward (vision_transformer.py:107-113) / Residual_droppath(PreNorm(.)) (face_pre_pro/ViT_face.py:106-120):
 //   x1 = x0 + s_a * proj(attn(LN1(x0)));   x0' = x1 + s_m * fc2(gelu(fc1(LN2(x1))))
 // The residual stream is fp32; GEMM operands are bf16 (fp32 accumulate).
+#include <algorithm>
 #include <vector>
 #include "common.hpp"
 #include "lafs_hip.h"
@@ -73,7 +74,9 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
     c.s.delta = (float*)take(T * H * 4);
     lafs_wgrad_item it[4];
     block_wgrad_shapes(d, it);
-    const int64_t wb = lafs_wgrad_group_workspace_bytes(it, 4, d->n_tok);
+    // (the single-stream backward uses the whole chip: size for whichever plan needs more)
+    const int64_t wb = std::max(lafs_wgrad_group_workspace_bytes(it, 4, d->n_tok, d->wgrad_workgroups),
+                                lafs_wgrad_group_workspace_bytes(it, 4, d->n_tok, 0));
     c.wg_bytes = wb > 0 ? (size_t)wb : 0;
     c.wg_ws = take(c.wg_bytes > 0 ? c.wg_bytes : 256);
   } else {
@@ -250,7 +253,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
       it[2].A = s.gba[p]; it[2].B = b.o; it[2].C = gr + o.w_proj; it[2].colsum_a = gr + o.b_proj;
       it[3].A = s.dqkv[p]; it[3].B = b.h1; it[3].C = gr + o.w_qkv; it[3].colsum_a = o.b_qkv >= 0 ? gr + o.b_qkv : nullptr;
       for (auto& x : it) x.accumulate = d->wgrad_overwrite ? 0 : 1;
-      RUN(lafs_wgrad_group(it, 4, T, c.wg_ws, (int64_t)c.wg_bytes, s2));
+      RUN(lafs_wgrad_group(it, 4, T, two ? d->wgrad_workgroups : 0, c.wg_ws, (int64_t)c.wg_bytes, s2));
     }
     if (two) { done[l] = ev[evi++]; (void)hipEventRecord(done[l], s2); }
     RUN(gemm(s.dqkv[p], 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));

@@ -11,32 +11,47 @@
 
 namespace {
 
-// Each workgroup walks SUMSQ_SPAN consecutive chunks and only touches the per-tensor accumulator when the tensor
-// changes (or at the end): the 25k chunks of the DINO last layer would otherwise serialise 25k same-address atomics.
-constexpr int SUMSQ_SPAN = 32;
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ grad, const int* __restrict__ chunk_seg,
-                                                   long n_chunks, const float* __restrict__ hyper, float* __restrict__ seg_sumsq) {
-  __shared__ float red[4];
-  const float gs = hyper[LAFS_HP_GRAD_SCALE];
-  const long c0 = (long)blockIdx.x * SUMSQ_SPAN;
-  const long c1 = c0 + SUMSQ_SPAN < n_chunks ? c0 + SUMSQ_SPAN : n_chunks;
+// Per-tensor squared norms in two passes, no atomics and no pre-zeroed accumulator: one wave per chunk writes the chunk's sum
+// of squares, then one workgroup per tensor adds its chunks in a fixed order (chunk_seg is ascending, so a tensor's chunks are
+// the run [lower_bound(seg), lower_bound(seg+1))).  The norms -- and with them the clip coefficients and the whole update --
+// are bitwise reproducible from the gradients.
+__global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restrict__ grad, long n_chunks, float* __restrict__ chunk_sumsq) {
+  const long c = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_chunks) return;
+  const float* g = grad + c * LAFS_CHUNK + (threadIdx.x & 63) * 4;
   float s = 0.f;
-  int seg = chunk_seg[c0];
-  auto flush = [&](int sg) {
-    float t = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(seg_sumsq + sg, (red[0] + red[1] + red[2] + red[3]) * gs * gs);
-    __syncthreads();
-    s = 0.f;
-  };
-  for (long c = c0; c < c1; ++c) {
-    const int sg = chunk_seg[c];
-    if (sg != seg) { flush(seg); seg = sg; }
-    const float4 g = *reinterpret_cast<const float4*>(grad + c * LAFS_CHUNK + threadIdx.x * 4);
-    s += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+#pragma unroll
+  for (int i = 0; i < LAFS_CHUNK / 256; ++i) {
+    const float4 v = *reinterpret_cast<const float4*>(g + i * 256);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
   }
-  flush(seg);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) chunk_sumsq[c] = s;
+}
+
+__device__ __forceinline__ long first_chunk_of(const int* __restrict__ chunk_seg, long n_chunks, int seg) {
+  long lo = 0, hi = n_chunks;
+  while (lo < hi) {
+    const long mid = (lo + hi) >> 1;
+    if (chunk_seg[mid] < seg) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void seg_sumsq_kernel(const float* __restrict__ chunk_sumsq, const int* __restrict__ chunk_seg,
+                                                       long n_chunks, const float* __restrict__ hyper, float* __restrict__ seg_sumsq) {
+  __shared__ float red[4];
+  const int seg = blockIdx.x;
+  const long c0 = first_chunk_of(chunk_seg, n_chunks, seg), c1 = first_chunk_of(chunk_seg, n_chunks, seg + 1);
+  float s = 0.f;
+  for (long c = c0 + threadIdx.x; c < c1; c += 256) s += chunk_sumsq[c];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float gs = hyper[LAFS_HP_GRAD_SCALE];
+    seg_sumsq[seg] = (red[0] + red[1] + red[2] + red[3]) * gs * gs;
+  }
 }
 
 __global__ __launch_bounds__(256) void seg_step_kernel(const int* __restrict__ seg_flags, int* __restrict__ seg_step, int n_seg,
@@ -131,12 +146,15 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, const float* hyper,
-                               float* seg_sumsq, hipStream_t stream) {
+extern "C" int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int n_seg, const float* hyper,
+                               float* chunk_sumsq, float* seg_sumsq, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
-  LAFS_CHECK_ARG(grad && chunk_seg && hyper && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31), "bad operand");
-  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)((n_chunks + SUMSQ_SPAN - 1) / SUMSQ_SPAN)), dim3(256), 0, stream, grad, chunk_seg,
-                     (long)n_chunks, hyper, seg_sumsq);
+  LAFS_CHECK_ARG(grad && chunk_seg && hyper && chunk_sumsq && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31) && n_seg > 0,
+                 "bad operand");
+  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, grad, (long)n_chunks, chunk_sumsq);
+  LAFS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_sumsq_kernel, dim3((unsigned)n_seg), dim3(256), 0, stream, chunk_sumsq, chunk_seg, (long)n_chunks, hyper,
+                     seg_sumsq);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

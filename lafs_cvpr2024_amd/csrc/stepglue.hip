@@ -108,11 +108,24 @@ extern "C" int lafs_zero_chunks(float* buf, const int32_t* chunk_seg, const int3
   return LAFS_OK;
 }
 
-// hipMemsetAsync node: zeroing scratch buffers inside the captured step without an ATen fill kernel
+// Zeroing of scratch buffers inside the captured step, as a plain kernel node (no at::native fill, no memset node).
+namespace {
+__global__ __launch_bounds__(256) void fill_zero_kernel(unsigned char* __restrict__ p, size_t bytes) {
+  const size_t n16 = bytes / 16;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+    reinterpret_cast<uint4*>(p)[i] = make_uint4(0, 0, 0, 0);
+  if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) p[n16 * 16 + threadIdx.x] = 0;
+}
+}  // namespace
+
 extern "C" int lafs_fill_zero(void* buf, int64_t bytes, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
-  LAFS_CHECK_ARG(buf && bytes > 0, "bad argument");
-  const hipError_t e = hipMemsetAsync(buf, 0, (size_t)bytes, stream);
-  if (e != hipSuccess) { lafs_set_error("lafs_fill_zero: %s", hipGetErrorString(e)); return (int)e; }
+  LAFS_CHECK_ARG(buf && bytes > 0 && ((uintptr_t)buf & 15) == 0, "buffer must be 16-byte aligned");
+  const size_t n16 = (size_t)bytes / 16;
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (unsigned char*)buf, (size_t)bytes);
+  LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -336,7 +336,10 @@ struct Plan { int fa, fb, tiles, slices, mlen; int tile0[MAXG], tiles_n2[MAXG]; 
 
 // One tile shape for the whole group: the one with the least matrix work per workgroup (padding included) when the tiles of
 // all GEMMs times the token slices fill the 256 CUs once.
-Plan make_plan(const lafs_wgrad_item* items, int n, int M) {
+// max_wg: workgroups (= CUs, one 512-register workgroup each) the launch may occupy; a two-stream backward keeps part of the
+// chip free for the HBM-bound kernels of its other stream this way (0 = the whole chip)
+Plan make_plan(const lafs_wgrad_item* items, int n, int M, int max_wg) {
+  const int g_wgrad_cus = (max_wg >= 8 && max_wg <= 256) ? max_wg : 256;
   // (4x4 blocks per wave = 256 accumulators leave hipcc no room: it spills the accumulators around the loop nest)
   static const int cand[4][2] = {{3, 3}, {4, 3}, {3, 4}, {2, 2}};
   Plan best = {};
@@ -350,12 +353,12 @@ Plan make_plan(const lafs_wgrad_item* items, int n, int M) {
       pl.tiles_n2[g] = ceil_div(items[g].N2, 64 * pl.fb);
       pl.tiles += ceil_div(items[g].N1, 64 * pl.fa) * pl.tiles_n2[g];
     }
-    int slices = 256 / pl.tiles;
+    int slices = g_wgrad_cus / pl.tiles;
     if (slices < 1) slices = 1;
     if (slices > msteps / 4) slices = msteps / 4 > 0 ? msteps / 4 : 1;     // at least 4 stages per workgroup
     pl.mlen = ceil_div(msteps, slices) * KB;
     pl.slices = ceil_div(M, pl.mlen);
-    const long rounds = ceil_div(pl.tiles * pl.slices, 256);
+    const long rounds = ceil_div(pl.tiles * pl.slices, g_wgrad_cus);
     long cost = rounds * (2L * (pl.mlen / KB) + 10) * pl.fa * pl.fb;
     if (pl.fa * pl.fb < 9) cost += cost / 2;          // 128x128 tiles: 2.25x the L2->LDS traffic and LDS reads per MFMA of 192x192
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = pl; }
@@ -379,7 +382,8 @@ int launch(const WgArgs& a, hipStream_t s) {
 }
 
 template <int ABL>
-int group_impl(const lafs_wgrad_item* items, int n_items, int M, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+int group_impl(const lafs_wgrad_item* items, int n_items, int M, int max_workgroups, void* workspace, int64_t workspace_bytes,
+               hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(items != nullptr && n_items > 0 && n_items <= MAXG, "1..8 GEMMs per group");
   LAFS_CHECK_ARG(M > 0, "empty problem");
@@ -390,7 +394,7 @@ int group_impl(const lafs_wgrad_item* items, int n_items, int M, void* workspace
     LAFS_CHECK_ARG(it.lda % 8 == 0 && it.ldb % 8 == 0 && it.N1 % 8 == 0 && it.N2 % 8 == 0 && it.ldc % 4 == 0,
                    "N1/N2/lda/ldb must be multiples of 8, ldc of 4");
   }
-  const Plan pl = make_plan(items, n_items, M);
+  const Plan pl = make_plan(items, n_items, M, max_workgroups);
   const int64_t need = plan_bytes(pl, items, n_items);
   LAFS_CHECK_ARG(need == 0 || (workspace != nullptr && workspace_bytes >= need), "workspace too small (lafs_wgrad_group_workspace_bytes)");
   WgArgs a = {};
@@ -429,22 +433,22 @@ int group_impl(const lafs_wgrad_item* items, int n_items, int M, void* workspace
 
 }  // namespace
 
-extern "C" int64_t lafs_wgrad_group_workspace_bytes(const lafs_wgrad_item* items, int n_items, int M) {
+extern "C" int64_t lafs_wgrad_group_workspace_bytes(const lafs_wgrad_item* items, int n_items, int M, int max_workgroups) {
   if (items == nullptr || n_items <= 0 || n_items > MAXG || M <= 0) return -1;
   for (int g = 0; g < n_items; ++g)
     if (items[g].N1 <= 0 || items[g].N2 <= 0) return -1;
-  return plan_bytes(make_plan(items, n_items, M), items, n_items);
+  return plan_bytes(make_plan(items, n_items, M, max_workgroups), items, n_items);
 }
 
-extern "C" int lafs_wgrad_group(const lafs_wgrad_item* items, int n_items, int M, void* workspace, int64_t workspace_bytes,
-                                hipStream_t stream) {
-  return group_impl<0>(items, n_items, M, workspace, workspace_bytes, stream);
+extern "C" int lafs_wgrad_group(const lafs_wgrad_item* items, int n_items, int M, int max_workgroups, void* workspace,
+                                int64_t workspace_bytes, hipStream_t stream) {
+  return group_impl<0>(items, n_items, M, max_workgroups, workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t lafs_wgrad_workspace_bytes(int M, int N1, int N2) {
   lafs_wgrad_item it = {};
   it.N1 = N1; it.N2 = N2;
-  return lafs_wgrad_group_workspace_bytes(&it, 1, M);
+  return lafs_wgrad_group_workspace_bytes(&it, 1, M, 0);
 }
 
 extern "C" int lafs_wgrad(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
@@ -452,5 +456,5 @@ extern "C" int lafs_wgrad(const void* A, int lda, const void* B, int ldb, float*
   lafs_wgrad_item it = {};
   it.A = A; it.lda = lda; it.B = B; it.ldb = ldb; it.C = C; it.ldc = ldc; it.N1 = N1; it.N2 = N2;
   it.accumulate = accumulate; it.colsum_a = colsum_a;
-  return lafs_wgrad_group(&it, 1, M, workspace, workspace_bytes, stream);
+  return lafs_wgrad_group(&it, 1, M, 0, workspace, workspace_bytes, stream);
 }

@@ -199,7 +199,8 @@ class LafsPretrainEngine:
         imgs = [self.in_global_all] + ([self.in_local_all] if self.n_local else [])
         dd_s = vit._next_dropout() if self.partfvit else None
         feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s, self.pos_s), drop,
-                                         save=True, dropout=dd_s, wgrad_overwrite=True)
+                                         save=True, dropout=dd_s, wgrad_overwrite=True,
+                                         wgrad_workgroups=160 if self.side_stream is not None else 0)
         _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self.logits_s)
         cur.wait_stream(side)
         # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
@@ -232,8 +233,8 @@ class LafsPretrainEngine:
         sa, ta = self.sa, self.ta
         call("lafs_center_ema", _p(self.dino_loss.center), _p(self.colsum), self.K, 1.0 / (2 * self.B * self.world),
              float(self.dino_loss.center_momentum))
-        ops.zero_(sa.seg_sumsq)
-        call("lafs_grad_sumsq", _p(sa.grad), _p(sa.chunk_seg), sa.n_chunks, _p(self.hyper), _p(sa.seg_sumsq))
+        call("lafs_grad_sumsq", _p(sa.grad), _p(sa.chunk_seg), sa.n_chunks, sa.n_seg, _p(self.hyper), _p(sa.chunk_sumsq),
+             _p(sa.seg_sumsq))
         call("lafs_clip_adamw_ema", _p(sa.master), _p(sa.grad), _p(sa.exp_avg), _p(sa.exp_avg_sq), _p(ta.master),
              _p(sa.shadow), _p(ta.shadow), _p(sa.chunk_seg), sa.n_chunks, _p(sa.seg_flags), _p(sa.seg_step), sa.n_seg,
              _p(sa.seg_sumsq), _p(self.hyper))

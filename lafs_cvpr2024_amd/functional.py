@@ -80,7 +80,7 @@ class TrunkSpec:
 
 
 def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=None, with_grad=True, dropout_p=0.0, dropout_seed=0,
-                    wgrad_overwrite=False):
+                    wgrad_overwrite=False, wgrad_workgroups=0):
     """Build the C descriptor (keeps the ctypes block array alive on the returned object)."""
     blocks = (_lib.BlockOffsets * spec.depth)()
     for i, nm in enumerate(spec.block_names):
@@ -101,6 +101,7 @@ def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=No
     d.grad = arena.grad.data_ptr() if (with_grad and arena.grad is not None) else None
     d.blocks = C.cast(blocks, C.POINTER(_lib.BlockOffsets))
     d.wgrad_overwrite = 1 if wgrad_overwrite else 0
+    d.wgrad_workgroups = int(wgrad_workgroups)
     if 1 < len(geom.groups) <= 4:                        # one attention launch per crop resolution
         d.n_groups = len(geom.groups)
         for gi, (n_img, side) in enumerate(geom.groups):
@@ -139,7 +140,7 @@ EMB_DROP_SITE = 0x40000000          # seed offset of the embedding dropout (the 
 
 
 def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, drop_scales=None, save=True,
-                ws=None, x_in=None, x_out=None, dropout=None, wgrad_overwrite=False):
+                ws=None, x_in=None, x_out=None, dropout=None, wgrad_overwrite=False, wgrad_workgroups=0):
     """imgs: list of fp32 NCHW tensors (one per group); pos_tokens: list of fp32 [npatch+1, D] per group.
     dropout: None or (p_trunk, p_embedding, seed): element dropout of Part-fViT (counter-based masks, see lafs_hip.h).
     Returns (feat f32 [n_seq, D], state)."""
@@ -151,7 +152,7 @@ def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, dr
     p_trunk, p_emb, dseed = dropout if dropout is not None else (0.0, 0.0, 0)
     st.dropout = (p_trunk, p_emb, dseed)
     st.desc = make_trunk_desc(arena, spec.trunk, geom, drop_scales, with_grad=save, dropout_p=p_trunk, dropout_seed=dseed,
-                              wgrad_overwrite=wgrad_overwrite)
+                              wgrad_overwrite=wgrad_overwrite, wgrad_workgroups=wgrad_workgroups)
     st.ws = ws if ws is not None else trunk_workspace(st.desc, save, dev)
     st.x_in = x_in if x_in is not None else torch.empty(geom.n_tok, D, device=dev, dtype=f32)
     if x_out is None:

@@ -33,7 +33,7 @@ def _ld(t):
 
 
 def zero_(t):
-    """t.zero_() through hipMemsetAsync (no ATen fill kernel: keeps the captured step free of at::native launches)."""
+    """t.zero_() as a lafs_fill_zero launch (keeps the captured step free of at::native kernels)."""
     if t.numel():
         call("lafs_fill_zero", _p(t), t.numel() * t.element_size())
     return t
@@ -122,13 +122,13 @@ def _wgrad_items(problems):
     return items, M
 
 
-def wgrad_group(problems, workspace=None):
+def wgrad_group(problems, workspace=None, max_workgroups=0):
     """problems: list of (A[M,N1] bf16, B[M,N2] bf16, C[N1,N2] f32, accumulate, colsum or None); one launch + one fold."""
     items, M = _wgrad_items(problems)
     if workspace is None:
-        n = int(_lib.lib().lafs_wgrad_group_workspace_bytes(items, len(problems), M))
+        n = int(_lib.lib().lafs_wgrad_group_workspace_bytes(items, len(problems), M, max_workgroups))
         workspace = torch.empty(max(n, 16) // 4, device=problems[0][0].device, dtype=torch.float32)
-    call("lafs_wgrad_group", items, len(problems), M, _p(workspace), workspace.numel() * workspace.element_size())
+    call("lafs_wgrad_group", items, len(problems), M, max_workgroups, _p(workspace), workspace.numel() * workspace.element_size())
     return workspace
 
 

@@ -123,7 +123,7 @@ def test_partial_fc_two_class_shards_on_one_gpu(tmp_path):
     ref.backward()
     for r in range(2):
         got = torch.load(out + f".{r}", weights_only=False)
-        assert abs(float(got["loss"]) - float(ref)) < 2e-2 * abs(float(ref))
+        assert abs(float(got["loss"].detach()) - float(ref)) < 2e-2 * abs(float(ref))
         e = emb.grad[r * B:(r + 1) * B]
         assert float((got["demb"] - e).abs().max()) < 3e-2 * float(e.abs().max())
         w = Wfull.grad[got["start"]:got["start"] + got["dW"].shape[0]]

@@ -210,6 +210,28 @@ def test_depthwise_conv_nchw_forward_and_gradients(k, stride, H):
     torch.testing.assert_close(conv.weight.grad, wr.grad, rtol=1e-4, atol=1e-4)
 
 
+def test_per_tensor_grad_norms_need_no_zeroing_and_repeat_bitwise():
+    """utils.clip_gradients' per-tensor norms (reference utils.py:132-141) over a flat arena of ragged tensors: equal to the
+    per-tensor fp64 sums, independent of what the output and scratch buffers held before, and bitwise equal from call to call."""
+    from lafs_cvpr2024_amd.ops import _p, call
+    g = torch.Generator().manual_seed(3)
+    chunks = [1, 13, 12, 1, 40, 3, 1, 700, 2]                              # chunks per tensor; one block of the old kernel saw many
+    n_seg, n_chunks = len(chunks), sum(chunks)
+    grad = torch.randn(n_chunks * _lib.CHUNK, generator=g).to(DEV)
+    chunk_seg = torch.tensor(sum(([i] * c for i, c in enumerate(chunks)), []), dtype=torch.int32, device=DEV)
+    hyper = torch.zeros(_lib.HP_COUNT, device=DEV); hyper[_lib.HP_GRAD_SCALE] = 0.5
+    outs = []
+    for junk in (float("nan"), -7.0):
+        seg = torch.full((n_seg,), junk, device=DEV); scratch = torch.full((n_chunks,), junk, device=DEV)
+        call("lafs_grad_sumsq", _p(grad), _p(chunk_seg), n_chunks, n_seg, _p(hyper), _p(scratch), _p(seg))
+        outs.append(seg.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.stack([t.double().pow(2).sum() * 0.25 for t in grad.cpu().split([c * _lib.CHUNK for c in chunks])])
+    err = ((outs[0].double() - ref).abs() / ref).max().item()
+    print(f"per-tensor sumsq max rel err {err:.2e}")
+    assert err < 1e-5
+
+
 def test_invalid_arguments_fail_loudly():
     """Unsupported shapes are rejected by the C entry points (negative return code -> LafsHipError with the reason), never
     silently mis-computed or routed to another implementation."""

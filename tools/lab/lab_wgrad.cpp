@@ -17,11 +17,11 @@ void run(const char* name, int M, std::vector<std::pair<int, int>> dims, const b
     it[g].C = C + g * (4 << 20); it[g].ldc = dims[g].second; it[g].N1 = dims[g].first; it[g].N2 = dims[g].second; it[g].accumulate = 0;
     fl += 2.0 * M * dims[g].first * dims[g].second;
   }
-  const Plan pl = make_plan(it.data(), (int)it.size(), M);
+  const Plan pl = make_plan(it.data(), (int)it.size(), M, 0);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) group_impl<ABL>(it.data(), (int)it.size(), M, ws, 256 << 20, 0);
+  for (int i = 0; i < 3; ++i) group_impl<ABL>(it.data(), (int)it.size(), M, 0, ws, 256 << 20, 0);
   hipEventRecord(e0, 0);
-  for (int i = 0; i < iters; ++i) group_impl<ABL>(it.data(), (int)it.size(), M, ws, 256 << 20, 0);
+  for (int i = 0; i < iters; ++i) group_impl<ABL>(it.data(), (int)it.size(), M, 0, ws, 256 << 20, 0);
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const float us = ms * 1e3f / iters;
