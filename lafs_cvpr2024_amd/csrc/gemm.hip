@@ -129,6 +129,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
   const int kbeg = blockIdx.z * p.klen;
   const int kend = min(p.K, kbeg + p.klen);
   const int nk = (kend - kbeg) / BK;
+#ifdef LAFS_ABLATE
+  // phase-lock experiment: hold back every second round-robin slot of a CU by (dbg >> 20) & 15 sleeps of ~4 us
+  if ((((blockIdx.x >> 3) >> 5) & 1) && ((p.dbg >> 20) & 15)) {
+    for (int z = 0; z < ((p.dbg >> 20) & 15); ++z) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
   // ---- async global -> LDS staging (LDS-DMA).  The LDS image is lane-linear (wave base + lane*16), so the XOR
   // swizzle is applied to the SOURCE column instead. ----
@@ -141,6 +147,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
     ldsoff[i] = (i * THREADS + wave * 64) * 16;       // wave-uniform
   }
   auto issue = [&](int t) {
+    if DBG(p, 524288) return;                        // ablation: no operand loads (the epilogue works on whatever LDS holds)
     unsigned char* st = smem + (t % NSTG) * STAGE;
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
@@ -285,6 +292,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
       if (n >= p.N) continue;
       const bool full = (n + VPL <= p.N);
       float* w = v + q * VPL;
+#ifdef LAFS_ABLATE
+      // pacing experiment: (dbg >> 24) & 31 sleeps of 128 clocks before every store group, so that a workgroup's stores enter
+      // the CU's in-order memory pipeline spread out instead of as one burst in front of the neighbour workgroup's loads
+      for (int z = 0; z < ((p.dbg >> 24) & 31); ++z) __builtin_amdgcn_s_sleep(2);
+#endif
       const bool legacy = DBG(p, 32768) != 0;
       const bool do_first = legacy ? (pass == 0) : (pass == 0), do_second = legacy ? (pass == 0) : (pass == NPASS - 1);
       if (legacy && pass > 0) continue;
@@ -314,6 +326,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
           }
         }
         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
+#ifdef LAFS_ABLATE
+        // ablation (timing only, values land in the wrong places): every store instruction covers 8 full 128-byte lines
+        // (8 rows x 64 columns of the wave's 64x64 tile) instead of 16 half lines
+        const bool fullline = DBG(p, 2097152) && VPL == 8;
+        const size_t flrow = (size_t)(m0 + wr * 64 + (i * NG + q) * 8 + (lane >> 3));
+        if (fullline) c = reinterpret_cast<bf16_t*>(p.C) + min(flrow, (size_t)p.M - 1) * p.ldc + n0 + wc * 64 + (lane & 7) * 8;
+#endif
         // experiment (debug flag 16384): u and GELU(u) interleaved in 64-byte pieces of ONE [M, 2N] buffer, so the two stores
         // of a lane group complete a 128-byte line
         if (EPI == EPI_BF16_GELU && DBG(p, 16384)) c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc * 2 + (n >> 5) * 64 + (n & 31);
@@ -327,6 +346,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
         }
         if (EPI == EPI_BF16_GELU && !DBG(p, 64) && do_second) {
           bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n;
+#ifdef LAFS_ABLATE
+          if (fullline) c2 = reinterpret_cast<bf16_t*>(p.C2) + min(flrow, (size_t)p.M - 1) * p.ldc2 + n0 + wc * 64 + (lane & 7) * 8;
+#endif
           if DBG(p, 16384) c2 = c + 32;
           if (full && DBG(p, 128)) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));

@@ -118,6 +118,20 @@ if "tnpart" in which:
         t2 = timeit(lambda: ops.reduce_partials(part, out))
         _lib.lib().lafs_debug_set(1); t3 = timeit(lambda: ops.gemm_tn_acc(A, B, Cd)); _lib.lib().lafs_debug_set(0)
         print(f"   {name}: atomics {t0*1e6:7.1f} us | partial {t1*1e6:7.1f} us + fold {t2*1e6:6.1f} us | stores {t3*1e6:7.1f} us")
+if "stagger" in which:
+    print("--- NT GEMMs (LAFS_USE_ABLATE_LIB=1): second round-robin slot of each CU held back by n x ~4 us; 16 = no stores, 32 = no MFMA")
+    for flag in (0, 1 << 20, 2 << 20, 3 << 20, 16, 32, 48):
+        _lib.lib().lafs_debug_set(flag)
+        for M, N, K, e, n in SHAPES[:8]:
+            nt(M, N, K, e, f"{n} f{flag}")
+    _lib.lib().lafs_debug_set(0)
+if "gelucost" in which:
+    print("--- fc1 forward (LAFS_USE_ABLATE_LIB=1): 0 product | 128 second tensor stored without the GELU math | 64 no second store")
+    for flag in (0, 1 << 24, 2 << 24, 4 << 24, 6 << 24, 8 << 24, 12 << 24):
+        _lib.lib().lafs_debug_set(flag)
+        nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd f{flag}")
+        nt(25216, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd teacher-size f{flag}")
+    _lib.lib().lafs_debug_set(0)
 if "ntstore" in which:
     print("--- NT epilogue stores: normal (default) vs non-temporal (flag 256)")
     for flag in (0, 256):
