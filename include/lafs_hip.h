@@ -170,12 +170,11 @@ int lafs_debug_dropout_mask(int rows, int cols, float drop_p, uint32_t drop_seed
  * ------------------------------------------------------------------------------------------------ */
 int lafs_attention_fwd(const void* qkv, int ldqkv, const int32_t* cu_seqlens, int n_seq, int max_len, int heads,
                        float scale, void* out_bf16, int ldo, float* lse, hipStream_t stream);
-/* dqkv(bf16) [T, 3*H*64] from dout(bf16) [T, H*64]; `delta` is an f32 [T, H] scratch; n_tok = T. */
-/* (n_tok == 0 skips the delta = rowsum(dO * O) pre-pass: for the second and later sequence groups of one batch, whose delta
- * the first group's call has already produced.) */
+/* dqkv(bf16) [T, 3*H*64] from dout(bf16) [T, H*64], out(bf16) and lse(f32) [T, H] of the forward: one launch per call (Q, K, V,
+ * dO of a (sequence, head) staged once; delta = rowsum(dO * O) formed on the way in). */
 int lafs_attention_bwd(const void* qkv, int ldqkv, const void* out_bf16, int ldo, const void* dout_bf16, int lddo,
-                       const float* lse, float* delta, const int32_t* cu_seqlens, int n_seq, int n_tok, int max_len,
-                       int heads, float scale, void* dqkv, int lddqkv, hipStream_t stream);
+                       const float* lse, const int32_t* cu_seqlens, int n_seq, int max_len, int heads, float scale,
+                       void* dqkv, int lddqkv, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Patch embedding front end  (vision_transformer.py:126-131, 196-207; face_pre_pro/ViT_face.py:760-766)

@@ -73,7 +73,7 @@ _PROTOS = {
     "lafs_dropout_f32": [vp, i32, i32, i32, f32, u32],
     "lafs_debug_dropout_mask": [i32, i32, f32, u32, vp],
     "lafs_attention_fwd": [vp, i32, vp, i32, i32, i32, f32, vp, i32, vp],
-    "lafs_attention_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp, i32],
+    "lafs_attention_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, vp, i32],
     "lafs_patchify": [vp, i32, i32, i32, vp],
     "lafs_embed_cls": [vp, vp, vp, i32, i32, i32, i32],
     "lafs_embed_bwd": [vp, i32, i32, i32, i32, vp, vp, vp],

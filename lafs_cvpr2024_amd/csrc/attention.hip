@@ -12,8 +12,9 @@
 //   so P feeds  O^T = V^T P^T  straight from registers; V^T (A-operand) comes from a row-major V tile via the
 //   gfx950 LDS transpose read (ds_read_b64_tr_b16).  The d-columns are permuted in that read so each lane
 //   ends with 16 contiguous output channels (two 16-byte stores).
-// The backward uses the same trick in two kernels: dQ (one wave per 16-query tile, streams key tiles) and
-// dK/dV (one wave per 16-key tile, streams query tiles); P is recomputed from the saved log-sum-exp.
+// The backward uses the same trick in two phases of ONE kernel over the LDS-resident Q, K, V, dO of a (sequence, head):
+// dK/dV (a wave per run of key tiles, streams the query tiles) and dQ (a wave per run of query tiles, streams the key
+// tiles); P is recomputed from the saved log-sum-exp, delta = rowsum(O * dO) is formed while staging.
 //
 // LDS layouts for a [rows][64] bf16 tile (128-byte rows):
 //   R (row fragments, ds_read_b128): 16-byte chunk c of row r stored at chunk c ^ (r & 7)
@@ -120,7 +121,7 @@ struct AttnArgs {
   const bf16_t* qkv; int ldqkv;
   const int* cu; int n_seq, heads; float scale;
   bf16_t* out; int ldo; float* lse;
-  const bf16_t* dout; int lddo; const float* delta; bf16_t* dqkv; int lddqkv;
+  const bf16_t* dout; int lddo; bf16_t* dqkv; int lddqkv;
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -226,124 +227,26 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------ backward: delta
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int ldo, const bf16_t* __restrict__ d_o,
-                                                        int lddo, float* __restrict__ delta, int T, int heads) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= T * heads) return;
-  const int t = i / heads, h = i % heads;
-  const uint4* po = reinterpret_cast<const uint4*>(o + (size_t)t * ldo + h * 64);
-  const uint4* pd = reinterpret_cast<const uint4*>(d_o + (size_t)t * lddo + h * 64);
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const uint4 x = po[c], y = pd[c];
-    s += bf_lo(x.x) * bf_lo(y.x) + bf_hi(x.x) * bf_hi(y.x) + bf_lo(x.y) * bf_lo(y.y) + bf_hi(x.y) * bf_hi(y.y) +
-         bf_lo(x.z) * bf_lo(y.z) + bf_hi(x.z) * bf_hi(y.z) + bf_lo(x.w) * bf_lo(y.w) + bf_hi(x.w) * bf_hi(y.w);
-  }
-  delta[i] = s;
-}
-
-// ------------------------------------------------------------------------------------------------ backward: dQ
-// LDS per pair: K (F: row fragments and transpose reads), V (R)
-template <int NT, int PPB, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnArgs a) {
+// ------------------------------------------------------------------------------------------------ backward, one launch
+// Q (F), dO (F), K (F) and V (R) of a (sequence, head) pair are staged ONCE; delta = rowsum(O * dO) is formed while staging
+// (the 8 threads that carry a row's eight 16-byte chunks reduce their partial dot products with three shuffles).  Phase A is
+// the dK/dV loop (one wave per 16-key tile, streams the query tiles), phase B the dQ loop (one wave per 16-query tile,
+// streams the key tiles); both only read LDS, so no barrier separates them.  Against the three-kernel form (delta, dQ,
+// dK/dV) the pair's operands cross HBM once instead of 2-3 times: 4.4 -> 3.1 bytes per token-channel.
+// LDS per pair: Q | dO | K | V tiles, then lse[NT*16] and delta[NT*16] (f32).
+template <int NT, int PPB, int NW, int TPI>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int TILE = NT * 16 * 128;
+  constexpr int PAIR_BYTES = 4 * TILE + 2 * NT * 16 * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, c16 = lane & 15;
   const int inner = a.heads * 64;
   const int n_pairs = a.n_seq * a.heads;
   {
     constexpr int TPP = (NW * 64) / PPB;
-    const int pl = tid / TPP, lt = tid % TPP;
-    const int pair = blockIdx.x * PPB + pl;
-    if (pair < n_pairs) {
-      const int seq = pair / a.heads, h = pair % a.heads;
-      const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
-      const bf16_t* base = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
-      unsigned char* s0 = smem + pl * 2 * TILE;
-      stage_pair<2, 0, NT * 16, TPP>(s0, base + inner, a.ldqkv, s0 + TILE, base + 2 * inner, a.ldqkv, len, lt);
-    }
-  }
-  __syncthreads();
-  for (int item = wave; item < PPB * NT; item += NW) {
-    const int pl = item % PPB, qt = item / PPB;
-    const int pair = blockIdx.x * PPB + pl;
-    if (pair >= n_pairs) continue;
-    const int seq = pair / a.heads, h = pair % a.heads;
-    const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
-    if (qt * 16 >= len) continue;
-    const unsigned char* KsF = smem + pl * 2 * TILE;
-    const unsigned char* VsR = KsF + TILE;
-    const bool swp = (lds_f(c16) & 1) != 0;
-    const int q = qt * 16 + c16;
-    const int qc = min(q, len - 1);
-    const bf16_t* qp = a.qkv + (size_t)(tok0 + qc) * a.ldqkv + h * 64 + g * 8;
-    const bf16_t* dp_ = a.dout + (size_t)(tok0 + qc) * a.lddo + h * 64 + g * 8;
-    const bf16x8_t qf0 = *reinterpret_cast<const bf16x8_t*>(qp), qf1 = *reinterpret_cast<const bf16x8_t*>(qp + 32);
-    const bf16x8_t df0 = *reinterpret_cast<const bf16x8_t*>(dp_), df1 = *reinterpret_cast<const bf16x8_t*>(dp_ + 32);
-    const float lse_q = a.lse[(size_t)(tok0 + qc) * a.heads + h];
-    const float del_q = a.delta[(size_t)(tok0 + qc) * a.heads + h];
-
-    f32x4_t dq[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < (NT + 1) / 2; ++u) {
-      float ds[8];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * u + tt;
-        if (t < NT) {
-          const int krow = t * 16 + c16;
-          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(rfrag_f(KsF, krow, g, swp), qf0, s);
-          s = mfma16(rfrag_f(KsF, krow, 4 + g, swp), qf1, s);
-          dp = mfma16(rfrag(VsR, krow, g), df0, dp);
-          dp = mfma16(rfrag(VsR, krow, 4 + g), df1, dp);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = (t * 16 + g * 4 + r < len) ? __expf(s[r] * a.scale - lse_q) : 0.f;
-            ds[tt * 4 + r] = p * (dp[r] - del_q) * a.scale;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ds[tt * 4 + r] = 0.f;
-        }
-      }
-      const bf16x8_t dsf = pack_frag(ds);
-      const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(tfrag_f(KsF, t0, t1, dt, lane), dsf, dq[dt]);
-    }
-    if (q < len) {
-      uint32_t w[8];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        w[2 * dt] = pack_bf2(dq[dt][0], dq[dt][1]);
-        w[2 * dt + 1] = pack_bf2(dq[dt][2], dq[dt][3]);
-      }
-      bf16_t* op = a.dqkv + (size_t)(tok0 + q) * a.lddqkv + h * 64 + g * 16;
-      reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ backward: dK, dV
-// LDS per pair: Q (F), dO (F), then lse[NT*16] and delta[NT*16] (f32)
-template <int NT, int PPB, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int TILE = NT * 16 * 128;
-  constexpr int PAIR_BYTES = 2 * TILE + 2 * NT * 16 * 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, c16 = lane & 15;
-  const int inner = a.heads * 64;
-  const int n_pairs = a.n_seq * a.heads;
-  {
-    constexpr int TPP = (NW * 64) / PPB;
+    constexpr int ROWS = NT * 16;
+    constexpr int IT = (ROWS * 8 + TPP - 1) / TPP;
     const int pl = tid / TPP, lt = tid % TPP;
     const int pair = blockIdx.x * PPB + pl;
     if (pair < n_pairs) {
@@ -351,93 +254,222 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnArgs a) {
       const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
       const bf16_t* qb = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
       const bf16_t* db = a.dout + (size_t)tok0 * a.lddo + h * 64;
+      const bf16_t* ob = a.out + (size_t)tok0 * a.ldo + h * 64;
       unsigned char* s0 = smem + pl * PAIR_BYTES;
-      stage_pair<2, 2, NT * 16, TPP>(s0, qb, a.ldqkv, s0 + TILE, db, a.lddo, len, lt);
-      float* lsd = reinterpret_cast<float*>(s0 + 2 * TILE);
-      for (int r = lt; r < NT * 16; r += TPP) {
-        const bool ok = r < len;
-        lsd[r] = ok ? a.lse[(size_t)(tok0 + r) * a.heads + h] : 0.f;
-        lsd[NT * 16 + r] = ok ? a.delta[(size_t)(tok0 + r) * a.heads + h] : 0.f;
+      float* lsd = reinterpret_cast<float*>(s0 + 4 * TILE);
+      uint4 vq[IT], vd[IT], vk[IT], vv[IT], vo[IT];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int idx = lt + i * TPP, row = idx >> 3, ch = idx & 7;
+        vq[i] = make_uint4(0, 0, 0, 0); vd[i] = vq[i]; vk[i] = vq[i]; vv[i] = vq[i]; vo[i] = vq[i];
+        if (idx < ROWS * 8 && row < len) {
+          const bf16_t* qr = qb + (size_t)row * a.ldqkv + ch * 8;
+          vq[i] = *reinterpret_cast<const uint4*>(qr);
+          vk[i] = *reinterpret_cast<const uint4*>(qr + inner);
+          vv[i] = *reinterpret_cast<const uint4*>(qr + 2 * inner);
+          vd[i] = *reinterpret_cast<const uint4*>(db + (size_t)row * a.lddo + ch * 8);
+          vo[i] = *reinterpret_cast<const uint4*>(ob + (size_t)row * a.ldo + ch * 8);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int idx = lt + i * TPP, row = idx >> 3, ch = idx & 7;
+        const uint4 x = vo[i], y = vd[i];
+        float d = bf_lo(x.x) * bf_lo(y.x) + bf_hi(x.x) * bf_hi(y.x) + bf_lo(x.y) * bf_lo(y.y) + bf_hi(x.y) * bf_hi(y.y) +
+                  bf_lo(x.z) * bf_lo(y.z) + bf_hi(x.z) * bf_hi(y.z) + bf_lo(x.w) * bf_lo(y.w) + bf_hi(x.w) * bf_hi(y.w);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if (idx < ROWS * 8) {
+          lds_put<2>(s0, row, ch, vq[i]); lds_put<2>(s0 + TILE, row, ch, vd[i]);
+          lds_put<2>(s0 + 2 * TILE, row, ch, vk[i]); lds_put<0>(s0 + 3 * TILE, row, ch, vv[i]);
+          if (ch == 0) {                                   // stored negated and pre-scaled: the loops use them as FMA addends
+            lsd[row] = (row < len) ? -1.4426950408889634f * a.lse[(size_t)(tok0 + row) * a.heads + h] : 0.f;
+            lsd[ROWS + row] = -a.scale * d;
+          }
+        }
       }
     }
   }
   __syncthreads();
-  for (int item = wave; item < PPB * NT; item += NW) {
-    const int pl = item % PPB, kt = item / PPB;
+  const bool swp = (lds_f(c16) & 1) != 0;
+  const float c2 = a.scale * 1.4426950408889634f;      // softmax scale folded with log2(e): p = exp2(s * c2 - lse * log2(e))
+  // No masks in either phase: rows beyond the sequence are ZERO in all four tiles, so an out-of-range query contributes
+  // dO = 0 / Q = 0 to dV / dK, an out-of-range key contributes K = 0 to dQ, and out-of-range outputs are never stored; the
+  // probabilities of padded positions only have to stay finite (their lse entry is 0).
+  // Each wave item covers TPI consecutive 16-row tiles, so every LDS fragment (the MFMA A operand) feeds TPI MFMAs: with one
+  // tile per item the loops ask the LDS for 256 B/clk/CU at MFMA rate -- twice what it delivers -- and sit in LDS issue stalls.
+  constexpr int NI = (NT + TPI - 1) / TPI;              // items per pair and phase
+  // ---- phase A: dK, dV
+  for (int item = wave; item < PPB * NI; item += NW) {
+    const int pl = item % PPB, it = item / PPB;
     const int pair = blockIdx.x * PPB + pl;
     if (pair >= n_pairs) continue;
     const int seq = pair / a.heads, h = pair % a.heads;
     const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
-    if (kt * 16 >= len) continue;
+    if (it * TPI * 16 >= len) continue;
     const unsigned char* QsF = smem + pl * PAIR_BYTES;
     const unsigned char* DsF = QsF + TILE;
-    const float* lsd = reinterpret_cast<const float*>(QsF + 2 * TILE);
-    const bool swp = (lds_f(c16) & 1) != 0;
-    const int key = kt * 16 + c16;
-    const int kc = min(key, len - 1);
-    const bf16_t* kp = a.qkv + (size_t)(tok0 + kc) * a.ldqkv + inner + h * 64 + g * 8;
-    const bf16_t* vp = kp + inner;
-    const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t*>(kp), kf1 = *reinterpret_cast<const bf16x8_t*>(kp + 32);
-    const bf16x8_t vf0 = *reinterpret_cast<const bf16x8_t*>(vp), vf1 = *reinterpret_cast<const bf16x8_t*>(vp + 32);
-    const bool key_ok = key < len;
-
-    f32x4_t dk[4], dv[4];
+    const unsigned char* KsF = QsF + 2 * TILE;
+    const unsigned char* VsR = QsF + 3 * TILE;
+    const float* lsd = reinterpret_cast<const float*>(QsF + 4 * TILE);
+    bf16x8_t kf[TPI][2], vf[TPI][2];
+    f32x4_t dk[TPI][4], dv[TPI][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[dt] = dk[dt]; }
+    for (int x = 0; x < TPI; ++x) {
+      const int key = min(it * TPI + x, NT - 1) * 16 + c16;      // a tile index past NT only occurs in the last item: its results are dropped
+      kf[x][0] = rfrag_f(KsF, key, g, swp); kf[x][1] = rfrag_f(KsF, key, 4 + g, swp);
+      vf[x][0] = rfrag(VsR, key, g); vf[x][1] = rfrag(VsR, key, 4 + g);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { dk[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[x][dt] = dk[x][dt]; }
+    }
 #pragma unroll
     for (int u = 0; u < (NT + 1) / 2; ++u) {
-      float pv[8], ds[8];
+      float pv[TPI][8], ds[TPI][8];
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int qt = 2 * u + tt;
         if (qt < NT) {
           const int qrow = qt * 16 + c16;
-          f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s = mfma16(rfrag_f(QsF, qrow, g, swp), kf0, s);
-          s = mfma16(rfrag_f(QsF, qrow, 4 + g, swp), kf1, s);
-          dp = mfma16(rfrag_f(DsF, qrow, g, swp), vf0, dp);
-          dp = mfma16(rfrag_f(DsF, qrow, 4 + g, swp), vf1, dp);
+          const bf16x8_t qa0 = rfrag_f(QsF, qrow, g, swp), qa1 = rfrag_f(QsF, qrow, 4 + g, swp);
+          const bf16x8_t da0 = rfrag_f(DsF, qrow, g, swp), da1 = rfrag_f(DsF, qrow, 4 + g, swp);
           const float4 l4 = *reinterpret_cast<const float4*>(lsd + qt * 16 + g * 4);
           const float4 d4 = *reinterpret_cast<const float4*>(lsd + NT * 16 + qt * 16 + g * 4);
           const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int q = qt * 16 + g * 4 + r;
-            const float del_q = dq4[r];
-            const float p = (q < len && key_ok) ? __expf(s[r] * a.scale - lq[r]) : 0.f;
-            pv[tt * 4 + r] = p;
-            ds[tt * 4 + r] = p * (dp[r] - del_q) * a.scale;
+          for (int x = 0; x < TPI; ++x) {
+            f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            sx = mfma16(qa0, kf[x][0], sx);
+            sx = mfma16(qa1, kf[x][1], sx);
+            dp = mfma16(da0, vf[x][0], dp);
+            dp = mfma16(da1, vf[x][1], dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, lq[r]));
+              pv[x][tt * 4 + r] = p;
+              ds[x][tt * 4 + r] = p * fmaf(dp[r], a.scale, dq4[r]);
+            }
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { pv[tt * 4 + r] = 0.f; ds[tt * 4 + r] = 0.f; }
+          for (int x = 0; x < TPI; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pv[x][tt * 4 + r] = 0.f; ds[x][tt * 4 + r] = 0.f; }
         }
       }
-      const bf16x8_t pf = pack_frag(pv), dsf = pack_frag(ds);
+      bf16x8_t pf[TPI], dsf[TPI];
+#pragma unroll
+      for (int x = 0; x < TPI; ++x) { pf[x] = pack_frag(pv[x]); dsf[x] = pack_frag(ds[x]); }
       const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        dv[dt] = mfma16(tfrag_f(DsF, t0, t1, dt, lane), pf, dv[dt]);
-        dk[dt] = mfma16(tfrag_f(QsF, t0, t1, dt, lane), dsf, dk[dt]);
+        const bf16x8_t td = tfrag_f(DsF, t0, t1, dt, lane), tq = tfrag_f(QsF, t0, t1, dt, lane);
+#pragma unroll
+        for (int x = 0; x < TPI; ++x) {
+          dv[x][dt] = mfma16(td, pf[x], dv[x][dt]);
+          dk[x][dt] = mfma16(tq, dsf[x], dk[x][dt]);
+        }
       }
     }
-    if (key_ok) {
-      uint32_t w[8];
-      bf16_t* op = a.dqkv + (size_t)(tok0 + key) * a.lddqkv + inner + h * 64 + g * 16;
+#pragma unroll
+    for (int x = 0; x < TPI; ++x) {
+      const int key = (it * TPI + x) * 16 + c16;
+      if (it * TPI + x < NT && key < len) {
+        uint32_t w[8];
+        bf16_t* op = a.dqkv + (size_t)(tok0 + key) * a.lddqkv + inner + h * 64 + g * 16;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          w[2 * dt] = pack_bf2(dk[x][dt][0], dk[x][dt][1]);
+          w[2 * dt + 1] = pack_bf2(dk[x][dt][2], dk[x][dt][3]);
+        }
+        reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          w[2 * dt] = pack_bf2(dv[x][dt][0], dv[x][dt][1]);
+          w[2 * dt + 1] = pack_bf2(dv[x][dt][2], dv[x][dt][3]);
+        }
+        reinterpret_cast<uint4*>(op + inner)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        reinterpret_cast<uint4*>(op + inner)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      }
+    }
+  }
+  // ---- phase B: dQ (waves take the items in the opposite order, which evens out the two phases' remainders)
+  for (int item = NW - 1 - wave; item < PPB * NI; item += NW) {
+    const int pl = item % PPB, it = item / PPB;
+    const int pair = blockIdx.x * PPB + pl;
+    if (pair >= n_pairs) continue;
+    const int seq = pair / a.heads, h = pair % a.heads;
+    const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
+    if (it * TPI * 16 >= len) continue;
+    const unsigned char* QsF = smem + pl * PAIR_BYTES;
+    const unsigned char* DsF = QsF + TILE;
+    const unsigned char* KsF = QsF + 2 * TILE;
+    const unsigned char* VsR = QsF + 3 * TILE;
+    const float* lsd = reinterpret_cast<const float*>(QsF + 4 * TILE);
+    bf16x8_t qf[TPI][2], df[TPI][2];
+    float nlse_q[TPI], ndel_q[TPI];
+    f32x4_t dq[TPI][4];
+#pragma unroll
+    for (int x = 0; x < TPI; ++x) {
+      const int q = min(it * TPI + x, NT - 1) * 16 + c16;
+      qf[x][0] = rfrag_f(QsF, q, g, swp); qf[x][1] = rfrag_f(QsF, q, 4 + g, swp);
+      df[x][0] = rfrag_f(DsF, q, g, swp); df[x][1] = rfrag_f(DsF, q, 4 + g, swp);
+      nlse_q[x] = lsd[q]; ndel_q[x] = lsd[NT * 16 + q];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) dq[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < (NT + 1) / 2; ++u) {
+      float ds[TPI][8];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const int t = 2 * u + tt;
+        if (t < NT) {
+          const int krow = t * 16 + c16;
+          const bf16x8_t ka0 = rfrag_f(KsF, krow, g, swp), ka1 = rfrag_f(KsF, krow, 4 + g, swp);
+          const bf16x8_t va0 = rfrag(VsR, krow, g), va1 = rfrag(VsR, krow, 4 + g);
+#pragma unroll
+          for (int x = 0; x < TPI; ++x) {
+            f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            sx = mfma16(ka0, qf[x][0], sx);
+            sx = mfma16(ka1, qf[x][1], sx);
+            dp = mfma16(va0, df[x][0], dp);
+            dp = mfma16(va1, df[x][1], dp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              ds[x][tt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, nlse_q[x])) * fmaf(dp[r], a.scale, ndel_q[x]);
+          }
+        } else {
+#pragma unroll
+          for (int x = 0; x < TPI; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[x][tt * 4 + r] = 0.f;
+        }
+      }
+      bf16x8_t dsf[TPI];
+#pragma unroll
+      for (int x = 0; x < TPI; ++x) dsf[x] = pack_frag(ds[x]);
+      const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        w[2 * dt] = pack_bf2(dk[dt][0], dk[dt][1]);
-        w[2 * dt + 1] = pack_bf2(dk[dt][2], dk[dt][3]);
-      }
-      reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        const bf16x8_t tk = tfrag_f(KsF, t0, t1, dt, lane);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        w[2 * dt] = pack_bf2(dv[dt][0], dv[dt][1]);
-        w[2 * dt + 1] = pack_bf2(dv[dt][2], dv[dt][3]);
+        for (int x = 0; x < TPI; ++x) dq[x][dt] = mfma16(tk, dsf[x], dq[x][dt]);
       }
-      reinterpret_cast<uint4*>(op + inner)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      reinterpret_cast<uint4*>(op + inner)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+#pragma unroll
+    for (int x = 0; x < TPI; ++x) {
+      const int q = (it * TPI + x) * 16 + c16;
+      if (it * TPI + x < NT && q < len) {
+        uint32_t w[8];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          w[2 * dt] = pack_bf2(dq[x][dt][0], dq[x][dt][1]);
+          w[2 * dt + 1] = pack_bf2(dq[x][dt][2], dq[x][dt][3]);
+        }
+        bf16_t* op = a.dqkv + (size_t)(tok0 + q) * a.lddqkv + h * 64 + g * 16;
+        reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      }
     }
   }
 }
@@ -464,16 +496,20 @@ int launch_attn(K kernel, int n_pairs, int ppb, int threads, size_t lds, const A
   return LAFS_OK;
 }
 
-// which: 0 = fwd (2 tiles/pair), 1 = dq (3), 2 = dkv (4)
+// which: 0 = forward (2 tiles per pair), 1 = backward (4 tiles + lse/delta per pair)
 template <int NT, int PPB>
 int dispatch(int which, const AttnArgs& a, hipStream_t s) {
-  // 8 waves per workgroup for long sequences: 13 query/key tiles spread over 8 waves (2 rounds) instead of 4 (4 rounds)
   constexpr int NW = 4;          // measured: 8 waves/workgroup is slower (36.7 vs 31.0 us fwd at 128 x 197)
   const int n_pairs = a.n_seq * a.heads;
   const size_t tile = (size_t)NT * 16 * 128;
   if (which == 0) return launch_attn(attn_fwd_kernel<NT, PPB, NW>, n_pairs, PPB, NW * 64, PPB * 2 * tile, a, s);
-  if (which == 1) return launch_attn(attn_bwd_dq_kernel<NT, PPB, NW>, n_pairs, PPB, NW * 64, PPB * 2 * tile, a, s);
-  return launch_attn(attn_bwd_dkv_kernel<NT, PPB, NW>, n_pairs, PPB, NW * 64, PPB * (2 * tile + 2 * NT * 16 * 4), a, s);
+  // Backward (tools/bench_kernels.py attn, 6 heads): long sequences take one pair per 8-wave workgroup (108 KB of LDS at 197
+  // tokens: one workgroup per CU) with two tiles per wave item: 128 x 197 in 74 us against 97 (one tile per item) and 99 for
+  // the former delta + dQ + dK/dV kernels; short ones two pairs per 4-wave workgroup, one tile per item: 512 x 37 in 32 us
+  // against 42.
+  const size_t pair_bytes = 4 * tile + 2 * NT * 16 * 4;
+  if constexpr (NT >= 7) return launch_attn(attn_bwd_fused_kernel<NT, 1, 8, 2>, n_pairs, 1, 512, pair_bytes, a, s);
+  else return launch_attn(attn_bwd_fused_kernel<NT, 2, 4, 1>, n_pairs, 2, 256, 2 * pair_bytes, a, s);
 }
 
 int dispatch_len(int which, int max_len, const AttnArgs& a, hipStream_t s) {
@@ -503,22 +539,15 @@ extern "C" int lafs_attention_fwd(const void* qkv, int ldqkv, const int32_t* cu_
 }
 
 extern "C" int lafs_attention_bwd(const void* qkv, int ldqkv, const void* out_bf16, int ldo, const void* dout_bf16, int lddo,
-                                  const float* lse, float* delta, const int32_t* cu_seqlens, int n_seq, int n_tok, int max_len,
-                                  int heads, float scale, void* dqkv, int lddqkv, hipStream_t stream) {
+                                  const float* lse, const int32_t* cu_seqlens, int n_seq, int max_len, int heads, float scale,
+                                  void* dqkv, int lddqkv, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
-  LAFS_CHECK_ARG(qkv && out_bf16 && dout_bf16 && lse && delta && cu_seqlens && dqkv, "null operand");
-  LAFS_CHECK_ARG(n_seq > 0 && n_tok >= 0 && heads > 0 && max_len > 0 && max_len <= 256, "sequence length must be in 1..256");
+  LAFS_CHECK_ARG(qkv && out_bf16 && dout_bf16 && lse && cu_seqlens && dqkv, "null operand");
+  LAFS_CHECK_ARG(n_seq > 0 && heads > 0 && max_len > 0 && max_len <= 256, "sequence length must be in 1..256");
   LAFS_CHECK_ARG(ldqkv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddqkv % 8 == 0, "row strides must be multiples of 8");
   AttnArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ldqkv = ldqkv; a.cu = cu_seqlens; a.n_seq = n_seq; a.heads = heads; a.scale = scale;
   a.out = (bf16_t*)out_bf16; a.ldo = ldo; a.lse = const_cast<float*>(lse);
-  a.dout = (const bf16_t*)dout_bf16; a.lddo = lddo; a.delta = delta; a.dqkv = (bf16_t*)dqkv; a.lddqkv = lddqkv;
-  if (n_tok > 0) {
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div(n_tok * heads, 256)), dim3(256), 0, stream, a.out, ldo, a.dout, lddo,
-                       delta, n_tok, heads);
-    LAFS_LAUNCH_CHECK();
-  }
-  const int rc = dispatch_len(1, max_len, a, stream);
-  if (rc != LAFS_OK) return rc;
-  return dispatch_len(2, max_len, a, stream);
+  a.dout = (const bf16_t*)dout_bf16; a.lddo = lddo; a.dqkv = (bf16_t*)dqkv; a.lddqkv = lddqkv;
+  return dispatch_len(1, max_len, a, stream);
 }

@@ -19,7 +19,7 @@ struct LayerBuf {
   float* x0; float* st1; bf16_t* h1; bf16_t* qkv; float* lse; bf16_t* o; float* x1; float* st2; bf16_t* h2; bf16_t* u; bf16_t* a;
 };
 struct Scratch {             // [2]: alternate by layer parity so the wgrad stream may lag one layer behind
-  bf16_t* gbm[2]; bf16_t* gba[2]; bf16_t* du[2]; bf16_t* dqkv[2]; bf16_t* dh; bf16_t* d_o; float* delta;
+  bf16_t* gbm[2]; bf16_t* gba[2]; bf16_t* du[2]; bf16_t* dqkv[2]; bf16_t* dh; bf16_t* d_o;
 };
 struct Carve {
   std::vector<LayerBuf> layers;   // depth entries when saving, 1 otherwise (reused)
@@ -71,7 +71,6 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
     }
     c.s.dh = (bf16_t*)take(T * D * 2);
     c.s.d_o = (bf16_t*)take(T * I * 2);
-    c.s.delta = (float*)take(T * H * 4);
     lafs_wgrad_item it[4];
     block_wgrad_shapes(d, it);
     // (the single-stream backward uses the whole chip: size for whichever plan needs more)
@@ -232,14 +231,14 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     RUN(gemm(s.gba[p], D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
     if (d->n_groups > 1) {
       int s0 = 0;
-      for (int gi = 0; gi < d->n_groups; ++gi) {             // delta for ALL tokens rides with the first group's call
-        RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens + s0, d->group_n_seq[gi], gi == 0 ? T : 0,
-                               d->group_max_len[gi], d->heads, d->attn_scale, s.dqkv[p], 3 * I, stream));
+      for (int gi = 0; gi < d->n_groups; ++gi) {
+        RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi],
+                               d->heads, d->attn_scale, s.dqkv[p], 3 * I, stream));
         s0 += d->group_n_seq[gi];
       }
     } else {
-      RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, s.delta, d->cu_seqlens, d->n_seq, T, d->max_len, d->heads,
-                             d->attn_scale, s.dqkv[p], 3 * I, stream));
+      RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale,
+                             s.dqkv[p], 3 * I, stream));
     }
     // ---- the block's four weight gradients: ONE grouped launch on the side stream, once all their operands exist.  Its
     // 48 (ViT-S) output tiles x 5 token slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four

@@ -205,11 +205,9 @@ def attention_fwd(qkv, cu_seqlens, max_len, heads, scale):
 
 def attention_bwd(qkv, out, dout, lse, cu_seqlens, max_len, heads, scale):
     _chk(dout, bf16, "dout")
-    T = qkv.shape[0]
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(T, heads, device=qkv.device, dtype=torch.float32)
-    call("lafs_attention_bwd", _p(qkv), _ld(qkv), _p(out), _ld(out), _p(dout), _ld(dout), _p(lse), _p(delta),
-         _p(cu_seqlens), cu_seqlens.numel() - 1, T, max_len, heads, scale, _p(dqkv), _ld(dqkv))
+    call("lafs_attention_bwd", _p(qkv), _ld(qkv), _p(out), _ld(out), _p(dout), _ld(dout), _p(lse),
+         _p(cu_seqlens), cu_seqlens.numel() - 1, max_len, heads, scale, _p(dqkv), _ld(dqkv))
     return dqkv
 
 

@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage (on the GPU box): tools/lab/pmc.sh <binary> [args]   -> per-kernel SQ counter table (two passes)
+# usage (on the GPU box): tools/lab/pmc.sh <binary | script.py> [args]   -> per-kernel SQ counter table (two passes)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/labpmc; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 BIN=$R/$1; shift
+case "$BIN" in *.py) set -- "$BIN" "$@"; BIN=python3;; esac
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d $O/p1 -o g --output-format csv -- $BIN "$@" > $O/out1.txt 2> $O/err1.txt
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INST_CYCLES_SALU -d $O/p2 -o g --output-format csv -- $BIN "$@" > $O/out2.txt 2> $O/err2.txt
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU -d $O/p2 -o g --output-format csv -- $BIN "$@" > $O/out2.txt 2> $O/err2.txt
 python3 - <<PY
 import csv, glob, collections, re
 for pas in ("p1", "p2"):
