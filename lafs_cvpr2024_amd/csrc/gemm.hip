@@ -28,6 +28,13 @@
 
 namespace {
 
+#ifdef LAFS_ABLATE
+unsigned long long* g_stamps = nullptr;                // lab: per-workgroup phase time stamps of the next NT launches
+#define STAMP(slot) do { if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)(stamp_id + n_vb * blockIdx.z) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 enum {
   EPI_BF16 = LAFS_EPI_BF16,
   EPI_BF16_GELU = LAFS_EPI_BF16_GELU,
@@ -42,6 +49,7 @@ enum {
 struct NTArgs {
   const bf16_t* A; const bf16_t* B;
   int M, N, K, lda, ldb, klen;
+  int n_tiles;                      // persistent variants: output tiles to walk (the grid is one residency wave)
   void* C; int ldc; void* C2; int ldc2;
   const float* bias; const float* resid; int ldr;
   const float* seq_scale; const int* row2seq;
@@ -50,6 +58,9 @@ struct NTArgs {
   int dbg;                          // timing ablations (lafs_debug_set): 16 = no epilogue stores, 32 = no MFMA/ds_read
   DropCfg drop;                     // element dropout on the linear's output (RESID_F32) / on GELU(u) (BF16_GELU, DGELU_BF16)
   int act;                          // BF16_ACT: LAFS_ACT_*
+#ifdef LAFS_ABLATE
+  unsigned long long* stamps;
+#endif
 };
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -109,7 +120,9 @@ template <int BK> __device__ __forceinline__ int nt_swzk(int row) { return BK ==
 
 // WN = wave columns: 2 -> 128-wide tiles (default), 4 -> 256-wide (256x256 with WM = 4: 16 waves, one workgroup per CU, half the
 // L2->LDS traffic of 128x128 per flop).
-template <int EPI, int WM, int BK, int WN = 2>
+// PERSIST (lab build only, see launch_nt): the grid is one residency wave of workgroups and each walks virtual blocks b,
+// b + grid, b + 2 grid, ...; while a workgroup stores tile j it already has the first ring stages of tile j+1 in flight.
+template <int EPI, int WM, int BK, int WN = 2, bool PERSIST = false>
 __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2))) void gemm_nt_kernel(NTArgs p) {
   constexpr int THREADS = WM * WN * 64, BMT = WM * 64, BN = WN * 64;
   constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
@@ -123,9 +136,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / WN, wc = wave % WN;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int m0 = tm * BMT, n0 = tn * BN;
+  const int n_vb = PERSIST ? p.n_tiles : (int)gridDim.x;     // virtual blocks = output tiles (per k-split)
+  int m0, n0;
   const int kbeg = blockIdx.z * p.klen;
   const int kend = min(p.K, kbeg + p.klen);
   const int nk = (kend - kbeg) / BK;
@@ -138,34 +150,34 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
 
   // ---- async global -> LDS staging (LDS-DMA).  The LDS image is lane-linear (wave base + lane*16), so the XOR
   // swizzle is applied to the SOURCE column instead. ----
-  const bf16_t* ga[NA]; const bf16_t* gb[NB]; int ldsoff[NMAX];
+  struct Src { const bf16_t* a[NA]; const bf16_t* b[NB]; int m0, n0; };
+  int ldsoff[NMAX];
+  auto locate = [&](int vb, Src& o) {               // operand pointers of virtual block vb
+    const int tile = xcd_tile(vb, n_vb);
+    const int tm = tile / tiles_n, tn = tile % tiles_n;
+    o.m0 = tm * BMT; o.n0 = tn * BN;
 #pragma unroll
-  for (int i = 0; i < NMAX; ++i) {
-    const int q = i * THREADS + tid, row = q / CPR, ch = (q % CPR) ^ nt_swzk<BK>(row);
-    if (i < NA) ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + kbeg + ch * 8;
-    if (i < NB) gb[i] = p.B + (size_t)min(n0 + nt_perm<EpiTraits<EPI>::VPL>(row), p.N - 1) * p.ldb + kbeg + ch * 8;
-    ldsoff[i] = (i * THREADS + wave * 64) * 16;       // wave-uniform
-  }
-  auto issue = [&](int t) {
+    for (int i = 0; i < NMAX; ++i) {
+      const int q = i * THREADS + tid, row = q / CPR, ch = (q % CPR) ^ nt_swzk<BK>(row);
+      if (i < NA) o.a[i] = p.A + (size_t)min(o.m0 + row, p.M - 1) * p.lda + kbeg + ch * 8;
+      if (i < NB) o.b[i] = p.B + (size_t)min(o.n0 + nt_perm<EpiTraits<EPI>::VPL>(row), p.N - 1) * p.ldb + kbeg + ch * 8;
+    }
+  };
+  auto issue = [&](const Src& o, int t) {
     if DBG(p, 524288) return;                        // ablation: no operand loads (the epilogue works on whatever LDS holds)
     unsigned char* st = smem + (t % NSTG) * STAGE;
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
-      if (i < NA) glds16(ga[i] + t * BK, st + ldsoff[i]);
-      if (i < NB) glds16(gb[i] + t * BK, st + BMT * ROWB + ldsoff[i]);
+      if (i < NA) glds16(o.a[i] + t * BK, st + ldsoff[i]);
+      if (i < NB) glds16(o.b[i] + t * BK, st + BMT * ROWB + ldsoff[i]);
     }
   };
+  Src src;
 
   f32x4_t acc[4][4];                                 // [j: column group][i: row tile]
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
   int arow[4], brow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { arow[i] = wr * 64 + i * 16 + frow; brow[i] = wc * 64 + i * 16 + frow; }
 
   auto compute = [&](int t) {
     if DBG(p, 32) return;
@@ -185,30 +197,71 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
     }
   };
 
+  bool primed = false;                               // the first ring stages of this tile were issued before the previous epilogue
+  for (int vb = blockIdx.x; vb < n_vb; vb += (int)gridDim.x) {
+#ifdef LAFS_ABLATE
+  const int stamp_id = vb;
+  STAMP(0);
+  if (p.stamps && threadIdx.x == 0) {
+    p.stamps[(size_t)(stamp_id + n_vb * blockIdx.z) * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+    p.stamps[(size_t)(stamp_id + n_vb * blockIdx.z) * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+  }
+#endif
+  {
+    // k-loop addressing is re-derived per tile from an opaque copy of the thread id: hoisted out of the loop it would stay live
+    // across the epilogue, which has no registers to spare at 4 waves per SIMD
+    int t_ = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(t_));
+    const int w_ = t_ >> 6, l_ = t_ & 63;
+#pragma unroll
+    for (int i = 0; i < NMAX; ++i) ldsoff[i] = (i * THREADS + w_ * 64) * 16;       // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { arow[i] = (w_ / WN) * 64 + i * 16 + (l_ & 15); brow[i] = (w_ % WN) * 64 + i * 16 + (l_ & 15); }
+  }
+  if (!PERSIST || !primed) locate(vb, src);
+  m0 = src.m0; n0 = src.n0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (NSTG == 3) {
-    if (nk > 0) issue(0);
-    if (nk > 1) issue(1);
+    if (!primed) {
+      if (nk > 0) issue(src, 0);
+      if (nk > 1) issue(src, 1);
+    }
     for (int t = 0; t < nk; ++t) {
-      // stage t has landed once at most the NA+NB loads of stage t+1 are still in flight (loads retire in order)
-      if (t + 1 < nk) {
+      // stage t has landed once at most the NA+NB loads of stage t+1 are still in flight (loads retire in order).  The first
+      // step of a primed tile drains everything instead: the previous tile's stores are younger than its two stages.
+      if (t + 1 < nk && !(PERSIST && primed && t == 0)) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();                  // everyone's part of stage t landed; stage (t-1)%3 is free again
-      if (t + 2 < nk) issue(t + 2);
+      if (t + 2 < nk) issue(src, t + 2);
       compute(t);
     }
   } else {
-    if (nk > 0) issue(0);
+    if (!primed && nk > 0) issue(src, 0);
     for (int t = 0; t < nk; ++t) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                  // stage t landed everywhere; the other buffer is free again
-      if (t + 1 < nk) issue(t + 1);
+      if (t + 1 < nk) issue(src, t + 1);
       compute(t);
     }
   }
+  if (PERSIST) {
+    primed = vb + (int)gridDim.x < n_vb;
+    if (primed) {
+      locate(vb + gridDim.x, src);                   // (m0, n0 keep this tile's origin for the epilogue)
+      __builtin_amdgcn_s_barrier();                  // every wave is out of the ring before the next tile's stages land in it
+      if (nk > 0) issue(src, 0);
+      if (NSTG == 3 && nk > 1) issue(src, 1);
+    }
+  }
 
+  STAMP(1);
+  auto epilogue = [&]() {
   // ---- epilogue: lane owns rows m = m0 + wr*64 + i*16 + (lane&15) and, per row, NG groups of VPL consecutive columns:
   // group q starts at n0 + wc*64 + q*4*VPL + fq*VPL; register e = j*4 + r of the row is element e % VPL of group e / VPL.
   constexpr int VPL = EpiTraits<EPI>::VPL, NG = 16 / VPL;
@@ -398,6 +451,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
       }
     }
   }
+  };
+  epilogue();
+#ifdef LAFS_ABLATE
+  STAMP(2);
+  if (p.stamps && !PERSIST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+  STAMP(3);
+#endif
+  if (!PERSIST) break;
+  if (primed) locate(vb + gridDim.x, src);          // recomputed rather than kept live across the epilogue
+  }                                                  // virtual blocks
 }
 
 // ------------------------------------------------------------------------------------------------ TN
@@ -607,9 +670,32 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   if (g_debug_flags & 4) wm = 4;
   if (g_debug_flags & 8) bk64 = (a.klen % 64 == 0);
   if (g_debug_flags & 2) bk64 = bk64 && (g_debug_flags & 8);
+#ifdef LAFS_ABLATE
+  // Lab build only (debug flag 8388608): problems that need more than one residency wave of workgroups run persistently -- one
+  // wave of workgroups walking the tiles, the next tile's first ring stages in flight during the epilogue.  Measured on the C2
+  // shapes: within +-2 % of the one-tile-per-workgroup launch in isolation (fc1 135 vs 133 us) and 0.2 ms SLOWER per step
+  // (18.45 vs 18.23 ms): resident workgroups keep the side streams' kernels off the CUs.  Not built into the product library.
+  const long tiles = (wm == 4 ? t4 : t2);
+  const int resident = 256 * ((wm == 4 || bk64) ? 2 : 3);
+  if (splits == 1 && tiles > resident && (g_debug_flags & 8388608)) {
+    NTArgs b = a;
+    b.n_tiles = (int)tiles;
+    const dim3 grid((unsigned)resident, 1, 1);
+    if (wm == 4) {
+      if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 64, 2, true>), grid, dim3(512), 0, s, b);
+      else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32, 2, true>), grid, dim3(512), 0, s, b);
+    } else {
+      if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 2, true>), grid, dim3(256), 0, s, b);
+      else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 32, 2, true>), grid, dim3(256), 0, s, b);
+    }
+    LAFS_LAUNCH_CHECK();
+    return LAFS_OK;
+  }
+#endif
   if (wm == 4) {
     if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 64>), dim3((unsigned)t4 / splits, 1, splits), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32>), dim3((unsigned)t4 / splits, 1, splits), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32>), dim3((unsigned)t4 / splits, 1, splits), dim3(512),
+                            (g_debug_flags & 4194304) ? 24576 : 0 /* lab: extra LDS -> one workgroup per CU */, s, a);
   } else {
     if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64>), dim3((unsigned)t2 / splits, 1, splits), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 32>), dim3((unsigned)t2 / splits, 1, splits), dim3(256), 0, s, a);
@@ -632,7 +718,10 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   a.C = g->C; a.ldc = g->ldc; a.C2 = g->C2; a.ldc2 = g->ldc2;
   a.bias = g->bias; a.resid = g->resid; a.ldr = g->ldr;
   a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
-  a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux; a.pos = g->pos; a.npatch = g->npatch; a.dbg = g_debug_flags;
+  a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux; a.pos = g->pos; a.npatch = g->npatch; a.dbg = g_debug_flags; a.n_tiles = 0;
+#ifdef LAFS_ABLATE
+  a.stamps = g_stamps;
+#endif
   a.drop = make_drop(g->drop_p, g->drop_seed);
   a.act = g->act;
   LAFS_CHECK_ARG(g->drop_p >= 0.f && g->drop_p < 1.f, "drop_p must be in [0, 1)");
@@ -763,6 +852,9 @@ extern "C" int lafs_reduce_partials(float* part, int64_t part_stride, int n_part
 // the product path.
 extern "C" int lafs_debug_set(int flags) { g_debug_flags = flags; return LAFS_OK; }
 extern "C" int lafs_debug_get(void) { return g_debug_flags; }
+#ifdef LAFS_ABLATE
+extern "C" void lafs_lab_set_stamps(void* buf) { g_stamps = (unsigned long long*)buf; }
+#endif
 extern "C" int lafs_ablation_build(void) {
 #ifdef LAFS_ABLATE
   return 1;

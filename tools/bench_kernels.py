@@ -127,10 +127,17 @@ if "stagger" in which:
     _lib.lib().lafs_debug_set(0)
 if "gelucost" in which:
     print("--- fc1 forward (LAFS_USE_ABLATE_LIB=1): 0 product | 128 second tensor stored without the GELU math | 64 no second store")
-    for flag in (0, 1 << 24, 2 << 24, 4 << 24, 6 << 24, 8 << 24, 12 << 24):
+    for flag in (0, 4194304, 16, 16 + 4194304, 524288 + 32, 524288 + 32 + 4194304):
         _lib.lib().lafs_debug_set(flag)
         nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd f{flag}")
         nt(25216, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd teacher-size f{flag}")
+    _lib.lib().lafs_debug_set(0)
+if "nttile" in which:
+    print("--- NT GEMMs (LAFS_USE_ABLATE_LIB=1): 0 library choice | 2 128x128 tiles | 4 256x128 tiles | 8 64-deep stages")
+    for flag in (0, 2, 4, 2 + 8, 4 + 8):
+        _lib.lib().lafs_debug_set(flag)
+        for M, N, K, e, n in SHAPES[:8]:
+            nt(M, N, K, e, f"{n} f{flag}")
     _lib.lib().lafs_debug_set(0)
 if "ntstore" in which:
     print("--- NT epilogue stores: normal (default) vs non-temporal (flag 256)")
