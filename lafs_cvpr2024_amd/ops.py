@@ -52,8 +52,9 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     f32_out = epilogue in (_lib.EPI_RESID_F32, _lib.EPI_F32, _lib.EPI_ATOMIC_F32, _lib.EPI_EMBED_F32)
     if out is None:
         rows = M if out_rows is None else out_rows
-        out = (torch.zeros if epilogue == _lib.EPI_ATOMIC_F32 else torch.empty)(
-            rows, N, device=A.device, dtype=torch.float32 if f32_out else bf16)
+        out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if f32_out else bf16)
+        if epilogue == _lib.EPI_ATOMIC_F32:
+            zero_(out)
     _chk(out, torch.float32 if f32_out else bf16, "out")
     if epilogue == _lib.EPI_BF16_GELU and out2 is None:
         out2 = torch.empty(M, N, device=A.device, dtype=bf16)

@@ -9,7 +9,8 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
     if "attn_" not in k: continue
-    key = (k.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", ""), r["Grid_Size"])
+    import re
+    key = (re.sub(r"\(anonymous namespace\)::|void |\(.*", "", k), r["Grid_Size"])
     acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVE_CYCLES": cnt[key] += 1
 for key, c in sorted(acc.items()):

@@ -1,13 +1,13 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/gemm; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d $O/p -o g --output-format csv -- python3 $R/tools/bench_kernels.py nt tn > $O/out.txt 2> $O/err.txt
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d $O/p -o g --output-format csv -- python3 $R/tools/bench_kernels.py nt wg wgg > $O/out.txt 2> $O/err.txt
 python3 - <<PY
 import csv, glob, collections, re
 f = glob.glob("$O/p/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(int); dur = collections.defaultdict(float)
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    if "gemm_" not in k: continue
+    if "gemm_" not in k and "wgrad_" not in k: continue
     key = re.sub(r"\(anonymous namespace\)::|void |\(.*", "", k) + " grid " + r["Grid_Size"]
     acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
     if r["Counter_Name"] == "SQ_WAVE_CYCLES":
