@@ -55,15 +55,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // Each wave walks rows (grid-stride) and keeps the gamma/beta partial sums for its columns in registers;
 // they are combined across the 4 waves through LDS and leave the workgroup as one atomicAdd per column.
-template <int NI>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ dyf,
+// NW waves per workgroup: the gamma/beta sums cost one atomic per column and WORKGROUP, and 1024 workgroups x 768 same-address
+// atomics were ~15 us of the 75 us call at the ViT-S shape; 16-wave workgroups keep the 4096 waves in flight with a quarter of
+// the atomics.
+template <int NI, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ dyf,
                                                     int lddyf, const float* __restrict__ x, int ldx,
                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                                     float* __restrict__ g_io, int ldg, int accumulate,
                                                     bf16_t* __restrict__ gb, int ldgb, const float* __restrict__ seq_scale,
                                                     const int* __restrict__ row2seq, float* __restrict__ dgamma,
                                                     float* __restrict__ dbeta, int rows, int D, DropCfg drop) {
-  __shared__ float red[2][4][NI * 256];
+  __shared__ float red[NW][NI * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 gam[NI], ag[NI], ab[NI];
 #pragma unroll
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     float4 xh[NI], d[NI];
     float s1 = 0.f, s2 = 0.f;
@@ -124,16 +127,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     }
   }
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    *reinterpret_cast<float4*>(&red[0][wave][lane * 4 + 256 * i]) = ag[i];
-    *reinterpret_cast<float4*>(&red[1][wave][lane * 4 + 256 * i]) = ab[i];
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 256) {
-    const float sg = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-    atomicAdd(dgamma + c, sg);
-    atomicAdd(dbeta + c, sb);
+  for (int pass = 0; pass < 2; ++pass) {               // gamma sums, then beta sums, through the same LDS image
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(&red[wave][lane * 4 + 256 * i]) = pass ? ab[i] : ag[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += NW * 64) {
+      float sg = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sg += red[w][c];
+      atomicAdd((pass ? dbeta : dgamma) + c, sg);
+    }
   }
 }
 
@@ -195,6 +199,15 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     default: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), 0, stream, __VA_ARGS__); break;       \
   }
 
+#define LN_BWD_DISPATCH(NI_, ...)                                                                             \
+  switch (NI_) {                                                                                              \
+    case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 16>), grid, dim3(1024), 0, stream, __VA_ARGS__); break;      \
+    case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 16>), grid, dim3(1024), 0, stream, __VA_ARGS__); break;      \
+    case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 8>), grid, dim3(512), 0, stream, __VA_ARGS__); break;        \
+    case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, 8>), grid, dim3(512), 0, stream, __VA_ARGS__); break;        \
+    default: hipLaunchKernelGGL((ln_bwd_kernel<8, 4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;       \
+  }
+
 extern "C" int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps,
                                   void* y_bf16, int ldy, float* y_f32, int ldyf, float* stats, int rows, int D,
                                   hipStream_t stream) {
@@ -218,11 +231,12 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
   LAFS_CHECK_ARG((dy_bf16 || dy_f32) && x && stats && gamma && g_io && dgamma && dbeta, "null operand");
   LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
   LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
-  int blocks = ceil_div(rows, 4);
-  if (blocks > 1024) blocks = 1024;
-  const dim3 grid(blocks);
   const int ni = ceil_div(D, 256);
-  LN_DISPATCH(ni, ln_bwd_kernel, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
+  const int nw = ni <= 2 ? 16 : (ni <= 4 ? 8 : 4);          // 32 KB of LDS per workgroup in every case
+  int blocks = ceil_div(rows, nw);
+  if (blocks > 4096 / nw) blocks = 4096 / nw;
+  const dim3 grid(blocks);
+  LN_BWD_DISPATCH(ni, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
               (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D, make_drop(drop_p, drop_seed));
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;

@@ -127,7 +127,7 @@ if "stagger" in which:
     _lib.lib().lafs_debug_set(0)
 if "gelucost" in which:
     print("--- fc1 forward (LAFS_USE_ABLATE_LIB=1): 0 product | 128 second tensor stored without the GELU math | 64 no second store")
-    for flag in (0, 4194304, 16, 16 + 4194304, 524288 + 32, 524288 + 32 + 4194304):
+    for flag in (16, 16 + 2, 16 + 2 + 8, 16 + 4 + 8, 48, 48 + 2, 48 + 2 + 8, 48 + 4 + 8):
         _lib.lib().lafs_debug_set(flag)
         nt(T, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd f{flag}")
         nt(25216, 1536, 384, _lib.EPI_BF16_GELU, f"fc1 fwd teacher-size f{flag}")
@@ -236,6 +236,16 @@ if "ablate" in which:
     print("--- TN with plain stores instead of atomics (flag 1)")
     tn(T, 384, 1536, "fc2 wgrad")
     _lib.lib().lafs_debug_set(0)
+if "ln" in which:
+    print("--- LayerNorm forward / backward at the student shape (44160 x 384); distinct buffers per call (no cache residency)")
+    L = 6
+    xs = [torch.randn(T, 384, device=dev) for _ in range(L)]; dys = [torch.randn(T, 384, device=dev).to(bf) for _ in range(L)]
+    gs = [torch.randn(T, 384, device=dev) for _ in range(L)]; gbs = [torch.empty(T, 384, device=dev, dtype=bf) for _ in range(L)]
+    gam = torch.ones(384, device=dev); bet = torch.zeros(384, device=dev); dgam = torch.zeros(384, device=dev); dbet = torch.zeros(384, device=dev)
+    outs = [ops.layernorm_fwd(x, gam, bet, 1e-6) for x in xs]
+    tf = timeit(lambda: [ops.layernorm_fwd(x, gam, bet, 1e-6) for x in xs]) / L
+    tb = timeit(lambda: [ops.layernorm_bwd(dys[i], xs[i], outs[i][2], gam, gs[i], dgam, dbet, accumulate=True, gb_out=gbs[i]) for i in range(L)]) / L
+    print(f"   fwd {tf*1e6:6.1f} us ({T*384*6/tf/1e9:6.0f} GB/s)   bwd {tb*1e6:6.1f} us ({T*384*16/tb/1e9:6.0f} GB/s)")
 if "attn" in which:
     print("--- attention (student shapes: 128 seqs x 197 and 512 x 37, 6 heads)")
     for nseq, n in ((128, 197), (512, 37)):
