@@ -58,6 +58,8 @@ enum {
   LAFS_EPI_F32 = 3,        /* C(f32) = acc + bias                                                    */
   LAFS_EPI_DGELU_BF16 = 4, /* C(bf16) = acc * GELU'(aux[m][n])                                       */
   LAFS_EPI_ATOMIC_F32 = 5, /* C(f32) += acc, K split into `splits` slices (C must be pre-zeroed)     */
+                           /* (LAFS_EPI_F32 with splits > 1: C is [splits][M][ldc], one plain-store image per K slice, no bias;
+                            *  lafs_sum_slices adds them -- no atomics, deterministic) */
   LAFS_EPI_EMBED_F32 = 6,  /* C(f32)[m + m/npatch + 1] = acc + bias + pos[1 + m%npatch]  (tokens)    */
   LAFS_EPI_BF16_ACT = 7    /* C(bf16) = act(acc + bias + aux[m][n])   (aux bf16 residual or NULL)    */
 };
@@ -77,7 +79,7 @@ typedef struct lafs_gemm_nt_args {
   const int32_t* row2seq;          /* i32 [M]  row -> sequence index               */
   const void* aux; int ldaux;      /* bf16 [M, N] pre-activation (DGELU_BF16)      */
   const float* pos; int npatch;    /* f32 [npatch+1, N] (EMBED_F32)                */
-  int splits;                      /* ATOMIC_F32: number of K slices (>=1)         */
+  int splits;                      /* ATOMIC_F32 / F32: number of K slices (>=1)   */
   float drop_p; uint32_t drop_seed; /* element dropout (0 = off): on the linear's output before the residual add
                                       (RESID_F32), on GELU(u) (BF16_GELU: C2 only), and its backward (DGELU_BF16).
                                       Counter-based mask of (drop_seed, row, col): see lafs_debug_dropout_mask.       */
@@ -85,6 +87,9 @@ typedef struct lafs_gemm_nt_args {
 } lafs_gemm_nt_args;
 
 /* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue. */
+/* Number of K slices a request for `splits` actually produces (slices are whole pipeline stages): the image count of a
+ * K-split LAFS_EPI_F32 GEMM. */
+int lafs_gemm_nt_slices(int K, int splits);
 int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
 
 /* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
@@ -99,6 +104,8 @@ int lafs_gemm_tn_part(const void* A, int lda, const void* B, int ldb, float* par
                       int M, int N1, int N2, int splits, float* colsum_a, hipStream_t stream);
 /* out(f32)[i] += sum_x part[x*part_stride + i], then part[...] = 0;  n, part_stride multiples of 4. */
 int lafs_reduce_partials(float* part, int64_t part_stride, int n_part, int64_t n, float* out, hipStream_t stream);
+/* out(f32)[n] = sum over x < n_part of part[x * part_stride + i]: folds the slice images of a K-split LAFS_EPI_F32 GEMM. */
+int lafs_sum_slices(const float* part, int64_t part_stride, int n_part, int64_t n, float* out, hipStream_t stream);
 
 /* Second-generation weight gradient (csrc/wgrad.hip): C[N1,N2] = (accumulate ? C : 0) + A[M,N1]^T * B[M,N2].
  * One 4-wave workgroup per CU (one wave per SIMD, 512 registers) owns a (64 FA) x (64 FB) tile of v_mfma_f32_32x32x16_bf16

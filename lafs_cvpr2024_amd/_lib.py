@@ -64,6 +64,7 @@ _PROTOS = {
     "lafs_gemm_tn_acc": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "lafs_gemm_tn_part": [vp, i32, vp, i32, vp, i32, i64, i32, i32, i32, i32, vp],
     "lafs_reduce_partials": [vp, i64, i32, i64, vp],
+    "lafs_sum_slices": [vp, i64, i32, i64, vp],
     "lafs_wgrad": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i64],
     "lafs_wgrad_group": [C.POINTER(WgradItem), i32, i32, i32, vp, i64],
     "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
@@ -119,6 +120,7 @@ _PROTOS = {
 }
 _NO_STREAM = {
     "lafs_version": ([], i32),
+    "lafs_gemm_nt_slices": ([i32, i32], i32),
     "lafs_debug_set": ([i32], i32),
     "lafs_debug_get": ([], i32),
     "lafs_ablation_build": ([], i32),

@@ -441,7 +441,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
 #pragma unroll
           for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) w[e] += ps[e];
         }
-        float* c = reinterpret_cast<float*>(p.C) + orow * p.ldc + n;
+        // F32 with the K axis split over blockIdx.z: every slice stores its own [M][ldc] image (lafs_sum_slices folds them)
+        float* c = reinterpret_cast<float*>(p.C) + (EPI == EPI_F32 ? (size_t)blockIdx.z * p.M * p.ldc : 0) + orow * p.ldc + n;
         if (full) {
           st16f(c, w[0], w[1], w[2], w[3], ntst);
         } else {
@@ -644,6 +645,19 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(float* __restrict_
   reinterpret_cast<float4*>(out)[i] = acc;
 }
 
+// out[i] = sum_x part[x][i]   (slice images of a K-split F32 GEMM)
+__global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict__ part, long stride, int n_part, long n4,
+                                                        float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int x = 0; x < n_part; ++x) {
+    const float4 v = reinterpret_cast<const float4*>(part + x * stride)[i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = acc;
+}
+
 int g_debug_flags = 0;
 
 template <int EPI>
@@ -664,7 +678,7 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
     LAFS_LAUNCH_CHECK();
     return LAFS_OK;
   }
-  bool bk64 = (a.klen % 64 == 0) && a.klen >= 640 && splits == 1;    // K = 704 / 768 (ViT-B) included: 5-15 % over 32-deep stages
+  bool bk64 = (a.klen % 64 == 0) && a.klen >= 640 && (splits == 1 || a.K % 64 == 0);    // K = 704 / 768 (ViT-B) included: 5-15 % over 32-deep stages
   int wm = (!bk64 && a.N >= 1024 && a.M >= 4096) ? 4 : 2;
   if (g_debug_flags & 2) wm = 2;
   if (g_debug_flags & 4) wm = 4;
@@ -704,7 +718,18 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   return LAFS_OK;
 }
 
+// length of one K slice when K is split `splits` ways (a multiple of the stage depth; the last slice takes the remainder)
+int ksplit_len(int K, int splits) {
+  const int ksteps = K / 32;
+  splits = splits < 1 ? 1 : (splits > ksteps ? ksteps : splits);
+  int klen = ceil_div(ksteps, splits) * 32;
+  if (K % 64 == 0 && klen >= 640) klen = (klen + 63) / 64 * 64;     // long slices: 64-deep stages (full-line DMA requests)
+  return klen;
+}
+
 }  // namespace
+
+extern "C" int lafs_gemm_nt_slices(int K, int splits) { return K >= 32 ? ceil_div(K, ksplit_len(K, splits)) : 1; }
 
 extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
@@ -728,11 +753,9 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   LAFS_CHECK_ARG(!(g->drop_p > 0.f) || (long)g->M * g->N < 4294967296L, "dropout needs M*N < 2^32");
   int splits = 1;
   a.klen = g->K;
-  if (g->epilogue == LAFS_EPI_ATOMIC_F32) {
-    splits = g->splits > 0 ? g->splits : 1;
-    const int ksteps = g->K / 32;
-    splits = splits > ksteps ? ksteps : splits;
-    a.klen = ceil_div(ksteps, splits) * 32;
+  if (g->epilogue == LAFS_EPI_ATOMIC_F32 || (g->epilogue == LAFS_EPI_F32 && g->splits > 1)) {
+    LAFS_CHECK_ARG(g->epilogue == LAFS_EPI_ATOMIC_F32 || g->bias == nullptr, "a K-split F32 GEMM takes no bias (it would be added per slice)");
+    a.klen = ksplit_len(g->K, g->splits);
     splits = ceil_div(g->K, a.klen);
   }
   const bool vec_ok = (g->ldc % 8 == 0) || g->C == nullptr;
@@ -746,7 +769,7 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
       LAFS_CHECK_ARG(g->resid != nullptr && g->ldr % 4 == 0, "residual epilogue needs resid");
       LAFS_CHECK_ARG(g->seq_scale == nullptr || g->row2seq != nullptr, "seq_scale needs row2seq");
       return launch_nt<EPI_RESID_F32>(a, 1, stream);
-    case LAFS_EPI_F32: return launch_nt<EPI_F32>(a, 1, stream);
+    case LAFS_EPI_F32: return launch_nt<EPI_F32>(a, splits, stream);
     case LAFS_EPI_DGELU_BF16:
       LAFS_CHECK_ARG(g->aux != nullptr, "dGELU epilogue needs aux (pre-activation)");
       return launch_nt<EPI_DGELU_BF16>(a, 1, stream);
@@ -844,6 +867,15 @@ extern "C" int lafs_reduce_partials(float* part, int64_t part_stride, int n_part
   const long n4 = n / 4;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, part, (long)part_stride,
                      n_part, n4, out);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_sum_slices(const float* part, int64_t part_stride, int n_part, int64_t n, float* out, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(part && out && n_part > 0 && n > 0 && n % 4 == 0 && part_stride % 4 == 0, "n and part_stride must be multiples of 4");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, part, (long)part_stride, n_part, n4, out);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

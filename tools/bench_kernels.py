@@ -246,6 +246,20 @@ if "ln" in which:
     tf = timeit(lambda: [ops.layernorm_fwd(x, gam, bet, 1e-6) for x in xs]) / L
     tb = timeit(lambda: [ops.layernorm_bwd(dys[i], xs[i], outs[i][2], gam, gs[i], dgam, dbet, accumulate=True, gb_out=gbs[i]) for i in range(L)]) / L
     print(f"   fwd {tf*1e6:6.1f} us ({T*384*6/tf/1e9:6.0f} GB/s)   bwd {tb*1e6:6.1f} us ({T*384*16/tb/1e9:6.0f} GB/s)")
+if "dzn" in which:
+    print("--- head backward dzn = dlogits Wn (M=640, N=256, K=100096): split-K atomics vs slice images + fold")
+    from lafs_cvpr2024_amd.ops import _p, call
+    A = torch.randn(640, 100096, device=dev).to(bf); B = torch.randn(256, 100096, device=dev).to(bf)
+    for sp in (16, 32, 64, 96):
+        ta = timeit(lambda: ops.gemm_nt(A, B, _lib.EPI_ATOMIC_F32, splits=sp))
+        ns = _lib.lib().lafs_gemm_nt_slices(100096, sp)
+        part = torch.empty(ns, 640, 256, device=dev); out = torch.empty(640, 256, device=dev)
+        def f():
+            ops.gemm_nt(A, B, _lib.EPI_F32, splits=sp, out=part.view(-1, 256), out_rows=ns * 640)
+            call("lafs_sum_slices", _p(part), 640 * 256, ns, 640 * 256, _p(out))
+        tb = timeit(f)
+        ref = ops.gemm_nt(A, B, _lib.EPI_ATOMIC_F32, splits=sp)
+        print(f"   splits {sp:3d}: atomics {ta*1e6:6.1f} us | images + fold {tb*1e6:6.1f} us   max diff {float((ref - out).abs().max()):.2e} (|ref| {float(ref.abs().max()):.1f})")
 if "attn" in which:
     print("--- attention (student shapes: 128 seqs x 197 and 512 x 37, 6 heads)")
     for nseq, n in ((128, 197), (512, 37)):
