@@ -200,7 +200,7 @@ class LafsPretrainEngine:
         dd_s = vit._next_dropout() if self.partfvit else None
         feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s, self.pos_s), drop,
                                          save=True, dropout=dd_s, wgrad_overwrite=True,
-                                         wgrad_workgroups=160 if self.side_stream is not None else 0)
+                                         wgrad_workgroups=int(os.environ.get("LAFS_WGRAD_WG", 200)) if self.side_stream is not None else 0)
         _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self.logits_s)
         cur.wait_stream(side)
         # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
