@@ -671,10 +671,11 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   //    fc1 forward / GELU' dgrad (141 -> 128 us, 138 -> 129 us) but LOSE in the real step (21.3 -> 21.5 ms: a 16-wave
   //    workgroup owns the CU while the weight-gradient stream wants to share it); kept behind debug flag 65536.
   const bool wide256 = (g_debug_flags & 65536) != 0;
-  if (wide256 && splits == 1 &&
+  if (wide256 && splits == 1 && a.N >= 1024 && a.N % 256 == 0 && a.M >= 4096 &&
       (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_DGELU_BF16)) {
     const unsigned t44 = (unsigned)(ceil_div(a.M, 256) * ceil_div(a.N, 256));
-    hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32, 4>), dim3(t44, 1, 1), dim3(1024), 0, s, a);
+    if ((g_debug_flags & 8) && a.klen % 64 == 0) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 64, 4>), dim3(t44, 1, 1), dim3(1024), 0, s, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32, 4>), dim3(t44, 1, 1), dim3(1024), 0, s, a);
     LAFS_LAUNCH_CHECK();
     return LAFS_OK;
   }

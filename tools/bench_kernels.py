@@ -134,7 +134,7 @@ if "gelucost" in which:
     _lib.lib().lafs_debug_set(0)
 if "nttile" in which:
     print("--- NT GEMMs (LAFS_USE_ABLATE_LIB=1): 0 library choice | 2 128x128 tiles | 4 256x128 tiles | 8 64-deep stages")
-    for flag in (0, 2, 4, 2 + 8, 4 + 8):
+    for flag in (0, 65536, 65536 + 8):
         _lib.lib().lafs_debug_set(flag)
         for M, N, K, e, n in SHAPES[:8]:
             nt(M, N, K, e, f"{n} f{flag}")
