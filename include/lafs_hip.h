@@ -91,6 +91,9 @@ typedef struct lafs_gemm_nt_args {
  * K-split LAFS_EPI_F32 GEMM. */
 int lafs_gemm_nt_slices(int K, int splits);
 int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
+/* Which kernel lafs_gemm_nt runs for this request: 0 = the tiled LDS-DMA kernel (gemm.hip), 1 = the K-resident streaming kernel
+ * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout). */
+int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
 
 /* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
  * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0.

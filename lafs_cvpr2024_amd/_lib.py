@@ -121,6 +121,7 @@ _PROTOS = {
 _NO_STREAM = {
     "lafs_version": ([], i32),
     "lafs_gemm_nt_slices": ([i32, i32], i32),
+    "lafs_gemm_nt_route": ([C.POINTER(GemmNTArgs)], i32),
     "lafs_debug_set": ([i32], i32),
     "lafs_debug_get": ([], i32),
     "lafs_ablation_build": ([], i32),

@@ -16,6 +16,7 @@
 // 32-64 B per lane (bias, residual, GELU, fp32/bf16 stores) with no LDS transpose.
 #include "common.hpp"
 #include "lafs_hip.h"
+#include "gemm_kres.hpp"
 
 // Timing ablations that change RESULTS (no stores / no MFMA / ...) exist only in the -DLAFS_ABLATE build (make ablate ->
 // liblafs_hip_ablate.so, used by tools/bench_kernels.py): in the product library the branches below are compiled out, so no
@@ -732,6 +733,8 @@ int ksplit_len(int K, int splits) {
 
 extern "C" int lafs_gemm_nt_slices(int K, int splits) { return K >= 32 ? ceil_div(K, ksplit_len(K, splits)) : 1; }
 
+extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) { return (g != nullptr && lafs_kres_eligible(g)) ? 1 : 0; }
+
 extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g != nullptr && g->A && g->B && (g->C || (g->epilogue == LAFS_EPI_BF16_GELU && g->C2)), "null operand");
@@ -752,6 +755,7 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   a.act = g->act;
   LAFS_CHECK_ARG(g->drop_p >= 0.f && g->drop_p < 1.f, "drop_p must be in [0, 1)");
   LAFS_CHECK_ARG(!(g->drop_p > 0.f) || (long)g->M * g->N < 4294967296L, "dropout needs M*N < 2^32");
+  if (lafs_kres_eligible(g)) return lafs_kres_launch(g, stream);   // K = 384 streaming shapes of the ViT-S trunk (gemm_kres.hip)
   int splits = 1;
   a.klen = g->K;
   if (g->epilogue == LAFS_EPI_ATOMIC_F32 || (g->epilogue == LAFS_EPI_F32 && g->splits > 1)) {

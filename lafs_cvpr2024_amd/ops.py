@@ -44,8 +44,10 @@ def zeros(*shape, device, dtype=torch.float32):
 
 
 def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=None, seq_scale=None, row2seq=None,
-            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0, act=0):
-    """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*)."""
+            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0, act=0, skip_pre=False,
+            route_only=False):
+    """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*).  skip_pre (BF16_GELU): write only
+    GELU(u), as the forward-only teacher pass does; route_only: return lafs_gemm_nt_route for this request instead of running it."""
     _chk(A, bf16, "A"); _chk(B, bf16, "B")
     M, K = A.shape
     N = B.shape[0] if n_cols is None else n_cols
@@ -78,6 +80,10 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     if pos is not None:
         _chk(pos, torch.float32, "pos"); a.pos, a.npatch = pos.data_ptr(), npatch
     a.splits = splits
+    if skip_pre and epilogue == _lib.EPI_BF16_GELU:
+        a.C = None
+    if route_only:
+        return int(_lib.lib().lafs_gemm_nt_route(C.byref(a)))
     call("lafs_gemm_nt", C.byref(a))
     return (out, out2) if epilogue == _lib.EPI_BF16_GELU else out
 

@@ -64,6 +64,77 @@ def test_gemm_nt_epilogues(M, N, K):
     assert relerr(out, A.float() @ B.float().t()) < 2e-5 * math.sqrt(K)
 
 
+@pytest.mark.parametrize("M,N", [(2048 + 77, 384), (4096 + 5, 1152), (2560, 1536), (128 * 41 + 1, 1536), (128 * 70 + 33, 384)])
+def test_gemm_nt_k_resident_kernel(M, N):
+    """The K = 384 streaming shapes of the ViT-S trunk run on the K-resident kernel (gemm_kres.hip): every epilogue it covers
+    against fp32 torch, ragged row counts (last 128-row unit partly / wholly beyond M for some waves), in-place residual."""
+    K = 384
+    A, B = rnd_bf(M, K, seed=11), rnd_bf(N, K, scale=0.1, seed=12)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(13))
+    ref = A.float() @ B.float().t() + bias
+    Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 1, "expected the K-resident route"
+    assert ops.gemm_nt(Ad[:1024], Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 0
+    guard = 7.0
+    out = torch.full((M + 64, N), guard, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, out=out[:M])
+    assert relerr(out[:M].float(), ref) < 1e-2
+    assert torch.all(out[M:] == guard), "rows beyond M were written"
+    u, a = ops.gemm_nt(Ad, Bd, _lib.EPI_BF16_GELU, bias=bd)
+    assert relerr(u.float(), ref) < 1e-2 and relerr(a.float(), F.gelu(ref)) < 1e-2
+    u2 = torch.full((M, N), guard, device=DEV, dtype=torch.bfloat16)
+    _, a2 = ops.gemm_nt(Ad, Bd, _lib.EPI_BF16_GELU, bias=bd, out=u2, skip_pre=True)
+    assert torch.equal(a2, a) and torch.all(u2 == guard), "forward-only pass: same GELU(u), no pre-activation store"
+    nseq = 7
+    row2seq = (torch.arange(M) * nseq // M).int()
+    sc = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9, 0.0, 1.0 / 0.9, 1.0 / 0.9, 1.0 / 0.9])
+    resid = torch.randn(M, N, generator=torch.Generator().manual_seed(14))
+    exp = resid + sc[row2seq.long()].unsqueeze(1) * ref
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=resid.to(DEV), route_only=True) == 1
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=resid.to(DEV), seq_scale=sc.to(DEV), row2seq=row2seq.to(DEV))
+    assert relerr(out, exp) < 2e-4
+    inplace = resid.to(DEV)
+    ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=inplace, seq_scale=sc.to(DEV), row2seq=row2seq.to(DEV), out=inplace)
+    assert torch.equal(inplace, out), "in-place residual"
+    aux = rnd_bf(M, N, seed=15)
+    x = aux.float().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV))              # (whichever kernel the library routes GELU' to)
+    assert relerr(out.float(), (A.float() @ B.float().t()) * x.grad) < 1e-2
+    # a K split in two slices keeps a request off the K-resident route
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_F32, splits=2, route_only=True) == 0
+
+
+_KRES_DGELU_SNIPPET = """
+import torch, torch.nn.functional as F
+from lafs_cvpr2024_amd import _lib, ops
+M, N, K = 128 * 41 + 1, 1536, 384
+g = torch.Generator().manual_seed(21)
+A = torch.randn(M, K, generator=g).to(torch.bfloat16); B = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16)
+aux = torch.randn(M, N, generator=g).to(torch.bfloat16)
+x = aux.float().requires_grad_(True); F.gelu(x).sum().backward()
+Ad, Bd, ad = A.cuda(), B.cuda(), aux.cuda()
+assert ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=ad, route_only=True) == 1
+out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=ad).float().cpu()
+ref = (A.float() @ B.float().t()) * x.grad
+err = ((out - ref).abs().max() / ref.abs().max()).item()
+assert err < 1e-2, err
+print("KRES_DGELU_OK", err)
+"""
+
+
+def test_gemm_nt_k_resident_gelu_grad_variant():
+    """The library routes the GELU' input gradient to the tiled kernel by default (LAFS_KRES mask 7); the K-resident variant of
+    that epilogue (operand fetched a step ahead) is kept correct behind LAFS_KRES=15: checked in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LAFS_KRES="15", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", _KRES_DGELU_SNIPPET], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "KRES_DGELU_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_gemm_nt_embed_epilogue():
     nseq, npatch, D = 3, 36, 128
     A, B = rnd_bf(nseq * npatch, 192, seed=1), rnd_bf(D, 192, scale=0.1, seed=2)
