@@ -122,11 +122,27 @@ def roofline_fc1(device, iters=30):
     u = torch.empty(M, N, device=device, dtype=torch.bfloat16)
     a = torch.empty(M, N, device=device, dtype=torch.bfloat16)
     dur = _time_on_stream(lambda: ops.gemm_nt(A, W, _lib.EPI_BF16_GELU, bias=b, out=u, out2=a), iters)
-    return _roof("gemm_nt_kernel<BF16_GELU,4,32> M=44160 N=1536 K=384 (student MLP fc1 + GELU)", dur, 2.0 * M * N * K,
-                 (M * K + N * K + 2 * M * N) * 2.0, _pmc_traffic("fc1"))
+    return _roof("gemm_kres_kernel<BF16_GELU> M=44160 N=1536 K=384 (student MLP fc1 + GELU, K-resident streaming kernel)", dur,
+                 2.0 * M * N * K, (M * K + N * K + 2 * M * N) * 2.0, _pmc_traffic("fc1"))
 
 
-ROOFLINE_KERNELS = {"wgrad_kernel": roofline_wgrad_group, "gemm_nt_kernel": roofline_fc1}
+def roofline_fc2(device, iters=30):
+    """Heaviest launch left on the tiled NT kernel: student MLP fc2 forward (M = 44160, N = 384, K = 1536, residual epilogue:
+    x = x1 + DropPath(fc2(a) + b)).  Algorithmic bytes: A and W (bf16) read once, the fp32 residual read once, the fp32 output
+    written once."""
+    from lafs_cvpr2024_amd import _lib, ops
+    M, N, K = 44160, 384, 1536
+    A = torch.randn(M, K, device=device).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=device) * 0.02).to(torch.bfloat16)
+    b = torch.zeros(N, device=device)
+    x1 = torch.randn(M, N, device=device)
+    out = torch.empty(M, N, device=device)
+    dur = _time_on_stream(lambda: ops.gemm_nt(A, W, _lib.EPI_RESID_F32, bias=b, resid=x1, out=out), iters)
+    return _roof("gemm_nt_kernel<RESID_F32,2,64> M=44160 N=384 K=1536 (student MLP fc2 + residual, tiled LDS-DMA kernel)", dur,
+                 2.0 * M * N * K, (M * K + N * K) * 2.0 + 2.0 * M * N * 4.0, _pmc_traffic("fc2"))
+
+
+ROOFLINE_KERNELS = {"wgrad_kernel": roofline_wgrad_group, "gemm_nt_kernel": roofline_fc2, "gemm_kres_kernel": roofline_fc1}
 
 
 def dominant_kernel_name():

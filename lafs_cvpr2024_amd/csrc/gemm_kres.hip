@@ -16,11 +16,12 @@
 //     interleaved so that two MFMAs give it 8 consecutive bf16 columns: every store instruction writes 16 rows x 64 contiguous
 //     bytes (the pattern the HBM write path sustains at full rate; 16-byte pieces scattered over 32 rows -- what a 32x32 MFMA
 //     layout produces -- measured 1.8-2.6 TB/s, tools/lab/lab_kres.cpp);
-//   * work = (128-row unit, 32-column block) steps in unit-major order, cut into equal contiguous runs, one per workgroup
-//     (4 waves, 2 workgroups per CU): no tail round; every stage a wave emits the 2-4 stores of its 32x32 block, so the memory
-//     pipeline sees a steady trickle of stores between the LDS-DMA requests instead of per-tile bursts;
-//   * the LDS-DMA ring runs across steps with counted s_waitcnt vmcnt (loads and stores retire in issue order on gfx950, the
-//     epilogue's memory operations are a compile-time count per step).
+//   * work = (128-row unit, 64-column block) items in unit-major order, cut into equal contiguous runs, one per workgroup
+//     (4 waves, 2 workgroups per CU): no tail round.  An item is two ring stages (32 columns each) and one epilogue: the two
+//     stages' 64-byte pieces of a row are stored back to back and complete 128-byte lines; a wave emits 4-8 stores per item, so
+//     the memory pipeline sees a steady trickle of stores between the LDS-DMA requests instead of per-tile bursts;
+//   * the LDS-DMA ring runs across items with counted s_waitcnt vmcnt (loads and stores retire in issue order on gfx950, the
+//     epilogue's memory operations are a compile-time count per item).
 #include <stdlib.h>
 #include "common.hpp"
 #include "gemm_kres.hpp"
@@ -40,7 +41,7 @@ constexpr int NTH = 256;
 constexpr int NDMA = STAGE / 16 / NTH;     // LDS-DMA instructions per thread and stage (6)
 constexpr int NKK = KK / 32;               // k steps of a 16x16x32 MFMA (12)
 constexpr int MAXN = 1536;                 // bias vector staged in LDS
-constexpr int FD_MAX = 8;                  // fragment reads in flight ahead of their MFMAs (6 where the epilogue operands need the registers)
+constexpr int FD = 8;                      // fragment reads in flight ahead of their MFMAs
 static_assert(CPR % 16 == 0 && STAGE % (16 * NTH) == 0, "stage layout");
 
 struct KArgs {
@@ -50,8 +51,8 @@ struct KArgs {
   const float* bias; const float* resid; int ldr;
   const float* seq_scale; const int* row2seq;
   const bf16_t* aux; int ldaux;
-  int cbn, steps;                          // 32-column blocks per row unit; row units x column blocks
-  unsigned long long* stamps;              // lab (ABL & 32): per workgroup {wait + barrier, issue, MFMA loop, epilogue, whole run, steps} cycles of wave 0
+  int cbn, items;                          // 64-column blocks per row unit; row units x column blocks
+  unsigned long long* stamps;              // lab (ABL & 32): per workgroup {wait + barrier, issue, MFMA loop, epilogue, whole run, stages, reload wait, reloads} cycles of wave 0
 };
 // ABL (template argument, 0 in the library; tools/lab/lab_kres.cpp instantiates others): timing ablations
 //   1 stores only from lane 0 (dead-code-proof "no stores"), 2 no MFMA, 4 no LDS-DMA after the prologue, 8 no epilogue math,
@@ -73,27 +74,28 @@ __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float 
 // memory operations of one step besides its LDS-DMA: S stores (active waves only) + P epilogue-operand loads
 template <int EPI, bool HAS_U> struct EpiOps {
   static constexpr bool F32 = (EPI == LAFS_EPI_RESID_F32);
-  static constexpr int S = F32 ? 4 : ((EPI == LAFS_EPI_BF16_GELU && HAS_U) ? 4 : 2);
-  static constexpr int P = F32 ? 4 : ((EPI == LAFS_EPI_DGELU_BF16) ? 2 : 0);
+  static constexpr int S = F32 ? 8 : ((EPI == LAFS_EPI_BF16_GELU && HAS_U) ? 8 : 4);
+  static constexpr int P = F32 ? 8 : ((EPI == LAFS_EPI_DGELU_BF16) ? 4 : 0);
 };
 
 template <int EPI, bool HAS_U, int ABL>
 __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
   constexpr int S = EpiOps<EPI, HAS_U>::S, P = EpiOps<EPI, HAS_U>::P;
   constexpr bool F32 = EpiOps<EPI, HAS_U>::F32;
-  // epilogue operand fetched one step ahead (GELU': its load latency no longer sits in front of the epilogue math); the
-  // residual epilogue fetches within the step -- a second 16-register buffer does not fit beside its other state
+  // epilogue operand fetched one item ahead (GELU': its load latency no longer sits in front of the epilogue math); the
+  // residual epilogue fetches within the item -- a second 32-register buffer does not fit beside its other state
   constexpr bool AHEAD = (EPI == LAFS_EPI_DGELU_BF16);
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
   __shared__ __attribute__((aligned(16))) float sbias[MAXN];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15, q = lane >> 4;
-  // blocks b, b+8, ... share an XCD: give each XCD a contiguous run of step ranges (the ranges of one row unit read the same A rows)
+  // blocks b, b+8, ... share an XCD: give each XCD a contiguous run of item ranges (the ranges of one row unit read the same A rows)
   const int G = (int)gridDim.x, per = G >> 3;
   const int id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int sb = (int)((long)p.steps * id / G), se = (int)((long)p.steps * (id + 1) / G);
-  if (se <= sb) return;
+  const int ib = (int)((long)p.items * id / G), ie = (int)((long)p.items * (id + 1) / G);
+  if (ie <= ib) return;
+  const int kb = 2 * ib, ke = 2 * ie;                 // stages of this run (two per item)
 
   for (int i = tid; i < p.N; i += NTH) sbias[i] = p.bias ? p.bias[i] : 0.f;
   __syncthreads();                                    // (also keeps the bias loads out of the counted waits below)
@@ -115,12 +117,12 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
   // LDS-DMA from inline asm (common.hpp): with the builtin, hipcc's wait-count pass drains the whole DMA queue (vmcnt(0)) in
   // front of the first fragment read of every stage; the ring is counted by hand instead (wait_vm below)
   const unsigned lds0 = lds_addr_of(smem);
-  auto issue = [&](int step) {                        // stage of step `step` (absolute step index)
-    const int cb = step % cbn;
-    const bf16_t* base = p.B + (size_t)(cb * 32) * p.ldb;
-    const unsigned st = lds0 + ((step - sb) % NSTG) * STAGE + wave * 1024;
+  auto issue = [&](int k) {                           // stage k (absolute: item k >> 1, half k & 1)
+    const int cb = (k >> 1) % cbn;
+    const bf16_t* base = p.B + (size_t)(cb * 64 + 32 * (k & 1)) * p.ldb;
+    const unsigned st = lds0 + ((k - kb) % NSTG) * STAGE + wave * 1024;
     fence();
-    if (!(KABL(4) && step >= sb + 2)) {
+    if (!(KABL(4) && k >= kb + 2)) {
 #pragma unroll
       for (int i = 0; i < NDMA; ++i) lds_dma16_m0(base + doff[i], st + i * (NTH * 16));
     }
@@ -135,14 +137,14 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     asm volatile("" : "+v"(foff[i]));
   }
   bf16x8_t areg[2][NKK];                              // two 16-token blocks x 12 k steps: lane (t, q) holds k = 32 kk + 8 q .. + 7
-  f32x4_t acc[2][2];                                  // [weight row group][token block]
-  uint4 pre[P > 0 ? P : 1], nxt[P > 0 ? P : 1];       // epilogue operand of this step / of the next one (fetched a step ahead)
+  f32x4_t acc[2][2][2];                               // [stage of the item][weight row group][token block]
+  uint4 pre[P > 0 ? P : 1], nxt[P > 0 ? P : 1];       // epilogue operand of this item / of the next one (fetched an item ahead)
   float sc[2] = {1.0f, 1.0f};
   int cur_mu = -1;
   bool active = false;
   int m0 = 0;
 
-  unsigned long long tacc[4] = {0, 0, 0, 0}, t_begin = 0, t_last = 0;
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, t_begin = 0, t_last = 0;   // [4]: wait + barrier of the reload stages, [5]: how many
   auto lap = [&](int slot) {
     if constexpr (KABL(32)) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -151,24 +153,61 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     }
   };
   if constexpr (KABL(32)) t_begin = t_last = __builtin_amdgcn_s_memtime();
-  auto fetch = [&](int step, uint4 (&dst)[P > 0 ? P : 1]) {        // exactly P loads: the epilogue operand of `step`
+  auto fetch = [&](int item, uint4 (&dst)[P > 0 ? P : 1]) {        // exactly P loads: the epilogue operand of `item`
     if (P == 0) return;
-    const int st = min(step, p.steps - 1);
-    const int mu = st / cbn, n0 = (st - mu * cbn) * 32;
+    const int it = min(item, p.items - 1);
+    const int mu = it / cbn, n0 = (it - mu * cbn) * 64;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-      const int b = i & 1, gi = i >> 1;
+      const int b = i & 1, x = i >> 1;                // bf16: x = stage; fp32: x = stage * 2 + row group
       const int mr = min(mu * 128 + wave * 32 + t + 16 * b, p.M - 1);
-      if (F32) dst[i] = *reinterpret_cast<const uint4*>(p.resid + (size_t)mr * p.ldr + n0 + 16 * gi + 4 * q);
-      else dst[i] = *reinterpret_cast<const uint4*>(p.aux + (size_t)mr * p.ldaux + n0 + 8 * q);
+      if (F32) dst[i] = *reinterpret_cast<const uint4*>(p.resid + (size_t)mr * p.ldr + n0 + 16 * x + 4 * q);
+      else dst[i] = *reinterpret_cast<const uint4*>(p.aux + (size_t)mr * p.ldaux + n0 + 32 * x + 8 * q);
     }
     fence();
   };
-  issue(sb);
-  if (sb + 1 < se) issue(sb + 1);
+  auto mfma_stage = [&](int stage, f32x4_t (&a)[2][2]) {            // 48 MFMAs on one ring stage
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) a[gi][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        bf16x8_t w = areg[gi][(kk + 1) % NKK];
+        if constexpr (!KABL(16)) w = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256 + gi * (16 * ROWB));
+        if constexpr (!KABL(2)) {
+          a[gi][0] = mfma16(w, areg[0][kk], a[gi][0]);
+          a[gi][1] = mfma16(w, areg[1][kk], a[gi][1]);
+        } else {
+          asm volatile("" :: "v"(w));
+        }
+      }
+    // fragment reads run FD ahead of the MFMA pairs that consume them (hipcc on its own keeps one read in flight and exposes
+    // the LDS latency 24 times per stage: 1440 instead of ~1000 cycles, tools/lab/lab_kres.cpp)
+    if constexpr (!KABL(16) && !KABL(2)) {
+      __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);
+#pragma unroll
+      for (int i = 0; i < 2 * NKK - FD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * FD, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  issue(kb);
+  issue(kb + 1);
   int stage = 0;
-  for (int s = sb; s < se; ++s) {
-    const int mu = s / cbn, cb = s - mu * cbn;
+  for (int it = ib; it < ie; ++it) {
+    const int mu = it / cbn, cb = it - mu * cbn;
+    const int k0 = 2 * it;
+    const bool reloaded_lab = (mu != cur_mu);
+    // ---------------- first stage of the item
     if (mu != cur_mu) {                               // new row unit: (re)load the resident operand, then drain everything
       cur_mu = mu;
       m0 = mu * 128 + wave * 32 + t;
@@ -181,102 +220,106 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
         for (int kk = 0; kk < NKK; ++kk) areg[b][kk] = *reinterpret_cast<const bf16x8_t*>(arow + (4 * kk + q) * 8);
         if (EPI == LAFS_EPI_RESID_F32 && p.seq_scale != nullptr) sc[b] = p.seq_scale[p.row2seq[mr]];
       }
-      if (AHEAD && s == sb) fetch(s, pre);            // first step of the run: nobody fetched its epilogue operand ahead
+      if (AHEAD && it == ib) fetch(it, pre);          // first item of the run: nobody fetched its epilogue operand ahead
       wait_vm<0>();
       __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0) again, in a form hipcc's wait-count pass sees: no waits on areg inside the MFMA loop
-    } else if (s + 1 < se) {                          // younger than this stage's DMA: two steps of epilogue operations + one stage
-      if (active) wait_vm<NDMA + 2 * (S + P)>(); else wait_vm<NDMA + 2 * P>();
-    } else {                                          // last step of the run: no younger stage
-      if (active) wait_vm<2 * (S + P)>(); else wait_vm<2 * P>();
+    } else {                                          // younger than this stage's DMA: the other stage of the previous item + its epilogue operations
+      if (active) wait_vm<NDMA + S + P>(); else wait_vm<NDMA + P>();
+    }
+    if constexpr (!KABL(64)) __builtin_amdgcn_s_barrier();
+    if constexpr (KABL(32)) {
+      if (reloaded_lab) { lap(4); tacc[5] += 1; } else lap(0);
+    }
+    if (k0 + 2 < ke) issue(k0 + 2);
+    if (AHEAD) fetch(it + 1, nxt);                    // P loads, consumed by the NEXT item's epilogue
+    lap(1);
+    mfma_stage(stage, acc[0]);
+    stage = (stage + 1 == NSTG) ? 0 : stage + 1;
+    lap(2);
+    // ---------------- second stage
+    if (k0 + 2 < ke) {
+      if (active) wait_vm<NDMA + S + P>(); else wait_vm<NDMA + P>();
+    } else {                                          // last stage of the run: nothing younger than it but the previous epilogue's operations
+      if (active) wait_vm<S + P>(); else wait_vm<P>();
     }
     if constexpr (!KABL(64)) __builtin_amdgcn_s_barrier();
     lap(0);
-    if (s + 2 < se) issue(s + 2);
-    const int n0 = cb * 32;
-    if (AHEAD) fetch(s + 1, nxt);                     // P loads, consumed by the NEXT step's epilogue
-    else fetch(s, pre);
+    if (k0 + 3 < ke) issue(k0 + 3);
+    if (!AHEAD) fetch(it, pre);                       // P loads, consumed a stage of MFMAs later
     lap(1);
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc[gi][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    {
-      __builtin_amdgcn_sched_barrier(0);
-      const unsigned char* st = smem + stage * STAGE;
-#pragma unroll
-      for (int kk = 0; kk < NKK; ++kk)
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-          bf16x8_t w = areg[gi][(kk + 1) % NKK];
-          if constexpr (!KABL(16)) w = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256 + gi * (16 * ROWB));
-          if constexpr (!KABL(2)) {
-            acc[gi][0] = mfma16(w, areg[0][kk], acc[gi][0]);
-            acc[gi][1] = mfma16(w, areg[1][kk], acc[gi][1]);
-          } else {
-            asm volatile("" :: "v"(w));
-          }
-        }
-      // fragment reads run FD ahead of the MFMA pairs that consume them (hipcc on its own keeps one read in flight and exposes
-      // the LDS latency 24 times per stage: 1440 instead of ~800 cycles, tools/lab/lab_kres.cpp)
-      constexpr int FD = FD_MAX;
-      if constexpr (!KABL(16) && !KABL(2)) {
-        __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);
-#pragma unroll
-        for (int i = 0; i < 2 * NKK - FD; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 2 * FD, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    mfma_stage(stage, acc[1]);
     stage = (stage + 1 == NSTG) ? 0 : stage + 1;
     lap(2);
 
-    // ---------------- epilogue: lane (t, q) owns rows m0 and m0 + 16 and, per row, 8 consecutive columns (bf16 outputs: both
-    // row groups) or 2 x 4 consecutive columns (fp32 outputs: one piece per row group)
+    // ---------------- epilogue: lane (t, q) owns rows m0 and m0 + 16 and, per row and stage, 8 consecutive columns (bf16 outputs:
+    // both row groups) or 2 x 4 consecutive columns (fp32 outputs: one piece per row group).  The two stages' pieces of a row
+    // are stored back to back: each pair completes 128-byte lines (one step apart they reached the HBM as separate half-line
+    // writes: 1.28x write traffic, profiles/round2_kernel_pmc.json history).
     fence();
+    const int n0 = cb * 64;
+    // lab (ABL & 256): every store instruction writes one contiguous KiB (values land in the wrong places)
+    auto lin = [&](int k) { return (size_t)((((it * 4 + wave) * 8 + k) & 32767) * 1024 + lane * 16); };
     if (active) {
       const bool lab_lane0 = !KABL(1) || lane == 0;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int m = m0 + 16 * b;
         const bool rowok = (m < p.M) && lab_lane0 && !KABL(128);
-        if constexpr (KABL(128)) asm volatile("" :: "v"(acc[0][b]), "v"(acc[1][b]));
+        if constexpr (KABL(128)) asm volatile("" :: "v"(acc[0][0][b]), "v"(acc[0][1][b]), "v"(acc[1][0][b]), "v"(acc[1][1][b]));
         if (F32) {
 #pragma unroll
-          for (int gi = 0; gi < 2; ++gi) {
-            const int n = n0 + 16 * gi + 4 * q;
+          for (int x = 0; x < 4; ++x) {                // x = stage * 2 + row group: 16 columns each
+            const int g = x >> 1, gi = x & 1;
+            const int n = n0 + 16 * x + 4 * q;
             const float4 b4 = *reinterpret_cast<const float4*>(sbias + n);
-            const uint4 r4 = pre[gi * 2 + b];
-            float v0 = acc[gi][b][0] + b4.x, v1 = acc[gi][b][1] + b4.y, v2 = acc[gi][b][2] + b4.z, v3 = acc[gi][b][3] + b4.w;
+            const uint4 r4 = pre[x * 2 + b];
+            float v0 = acc[g][gi][b][0] + b4.x, v1 = acc[g][gi][b][1] + b4.y, v2 = acc[g][gi][b][2] + b4.z, v3 = acc[g][gi][b][3] + b4.w;
             if (!KABL(8)) {
               v0 = __uint_as_float(r4.x) + sc[b] * v0; v1 = __uint_as_float(r4.y) + sc[b] * v1;
               v2 = __uint_as_float(r4.z) + sc[b] * v2; v3 = __uint_as_float(r4.w) + sc[b] * v3;
             }
-            if (rowok) st16f(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v0, v1, v2, v3);
+            if (KABL(256)) st16f(reinterpret_cast<unsigned char*>(p.C) + lin(b * 4 + x), v0, v1, v2, v3);
+            else if (rowok) st16f(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, v0, v1, v2, v3);
           }
         } else {
-          const int n = n0 + 8 * q;
-          const float4 b0 = *reinterpret_cast<const float4*>(sbias + n), b1 = *reinterpret_cast<const float4*>(sbias + n + 4);
-          float v[8] = {acc[0][b][0] + b0.x, acc[0][b][1] + b0.y, acc[0][b][2] + b0.z, acc[0][b][3] + b0.w,
-                        acc[1][b][0] + b1.x, acc[1][b][1] + b1.y, acc[1][b][2] + b1.z, acc[1][b][3] + b1.w};
-          if (EPI == LAFS_EPI_DGELU_BF16 && !KABL(8)) {
-            const uint4 a4 = pre[b];
-            v[0] *= gelu_grad_f(bf_lo(a4.x)); v[1] *= gelu_grad_f(bf_hi(a4.x)); v[2] *= gelu_grad_f(bf_lo(a4.y)); v[3] *= gelu_grad_f(bf_hi(a4.y));
-            v[4] *= gelu_grad_f(bf_lo(a4.z)); v[5] *= gelu_grad_f(bf_hi(a4.z)); v[6] *= gelu_grad_f(bf_lo(a4.w)); v[7] *= gelu_grad_f(bf_hi(a4.w));
+          float v[2][8];
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const int n = n0 + 32 * g + 8 * q;
+            const float4 b0 = *reinterpret_cast<const float4*>(sbias + n), b1 = *reinterpret_cast<const float4*>(sbias + n + 4);
+            v[g][0] = acc[g][0][b][0] + b0.x; v[g][1] = acc[g][0][b][1] + b0.y; v[g][2] = acc[g][0][b][2] + b0.z; v[g][3] = acc[g][0][b][3] + b0.w;
+            v[g][4] = acc[g][1][b][0] + b1.x; v[g][5] = acc[g][1][b][1] + b1.y; v[g][6] = acc[g][1][b][2] + b1.z; v[g][7] = acc[g][1][b][3] + b1.w;
+            if (EPI == LAFS_EPI_DGELU_BF16 && !KABL(8)) {
+              const uint4 a4 = pre[g * 2 + b];
+              v[g][0] *= gelu_grad_f(bf_lo(a4.x)); v[g][1] *= gelu_grad_f(bf_hi(a4.x)); v[g][2] *= gelu_grad_f(bf_lo(a4.y)); v[g][3] *= gelu_grad_f(bf_hi(a4.y));
+              v[g][4] *= gelu_grad_f(bf_lo(a4.z)); v[g][5] *= gelu_grad_f(bf_hi(a4.z)); v[g][6] *= gelu_grad_f(bf_lo(a4.w)); v[g][7] *= gelu_grad_f(bf_hi(a4.w));
+            }
           }
           if (EPI != LAFS_EPI_BF16_GELU || HAS_U) {
-            if (rowok) st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n, pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]),
-                            pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int n = n0 + 32 * g + 8 * q;
+              if (KABL(256)) st16(reinterpret_cast<unsigned char*>(p.C) + lin(b * 2 + g), pack_bf2(v[g][0], v[g][1]), pack_bf2(v[g][2], v[g][3]),
+                                  pack_bf2(v[g][4], v[g][5]), pack_bf2(v[g][6], v[g][7]));
+              else if (rowok) st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n, pack_bf2(v[g][0], v[g][1]), pack_bf2(v[g][2], v[g][3]),
+                                   pack_bf2(v[g][4], v[g][5]), pack_bf2(v[g][6], v[g][7]));
+            }
           }
           if (EPI == LAFS_EPI_BF16_GELU) {
             if (!KABL(8)) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+              for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[g][e] = gelu_f(v[g][e]);
             }
-            if (rowok) st16(reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n, pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]),
-                            pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int n = n0 + 32 * g + 8 * q;
+              if (KABL(256)) st16(reinterpret_cast<unsigned char*>(p.C2) + lin(b * 2 + g), pack_bf2(v[g][0], v[g][1]), pack_bf2(v[g][2], v[g][3]),
+                                  pack_bf2(v[g][4], v[g][5]), pack_bf2(v[g][6], v[g][7]));
+              else if (rowok) st16(reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n, pack_bf2(v[g][0], v[g][1]), pack_bf2(v[g][2], v[g][3]),
+                                   pack_bf2(v[g][4], v[g][5]), pack_bf2(v[g][6], v[g][7]));
+            }
           }
         }
       }
@@ -292,7 +335,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     if (tid == 0 && p.stamps != nullptr) {
       unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
       o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3];
-      o[4] = __builtin_amdgcn_s_memtime() - t_begin; o[5] = (unsigned long long)(se - sb);
+      o[4] = __builtin_amdgcn_s_memtime() - t_begin; o[5] = (unsigned long long)(ke - kb); o[6] = tacc[4]; o[7] = tacc[5];
     }
   }
 }
@@ -308,13 +351,13 @@ int launch(const KArgs& a, int grid, hipStream_t s) {
 
 bool lafs_kres_eligible(const lafs_gemm_nt_args* g) {
   // LAFS_KRES = bit mask of the epilogues routed here (1 plain, 2 GELU, 4 residual, 8 GELU'); 0 = tiled kernel everywhere.
-  // Default 7: the GELU' input gradient stays on the tiled kernel (134 vs 120 us in the step: its epilogue is VALU-bound)
-  static const int mask = [] { const char* v = getenv("LAFS_KRES"); return v != nullptr ? atoi(v) : 7; }();
+  // Default 15 (whole step, one box, tools/lab/ab_env.sh: 16.95 ms against 17.22 with mask 7 and 17.57 with 0).
+  static const int mask = [] { const char* v = getenv("LAFS_KRES"); return v != nullptr ? atoi(v) : 15; }();
   const int e = g->epilogue;
   const int bit = e == LAFS_EPI_BF16 ? 1 : (e == LAFS_EPI_BF16_GELU ? 2 : (e == LAFS_EPI_RESID_F32 ? 4 : (e == LAFS_EPI_DGELU_BF16 ? 8 : 0)));
   if (!(mask & bit)) return false;
   if (g->splits > 1) return false;
-  if (g->K != KK || g->N % 32 != 0 || g->N > MAXN || g->N < 32 || g->M < 2048) return false;
+  if (g->K != KK || g->N % 64 != 0 || g->N > MAXN || g->N < 64 || g->M < 2048) return false;
   if (!(e == LAFS_EPI_BF16 || e == LAFS_EPI_BF16_GELU || e == LAFS_EPI_RESID_F32 || e == LAFS_EPI_DGELU_BF16)) return false;
   if (g->drop_p > 0.f) return false;
   if (g->lda % 8 != 0 || g->ldb % 8 != 0 || g->ldc % 8 != 0) return false;
@@ -335,15 +378,15 @@ int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_overrid
   a.bias = (e == LAFS_EPI_DGELU_BF16) ? nullptr : g->bias;
   a.resid = g->resid; a.ldr = g->ldr; a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
   a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux;
-  a.cbn = g->N / 32;
+  a.cbn = g->N / 64;
   a.stamps = stamps;
 
   const int mus = (g->M + 127) / 128;
-  a.steps = mus * a.cbn;
-  // two 4-wave workgroups per CU: one residency wave of equal step runs (at least ~8 steps each, or the reload of the
+  a.items = mus * a.cbn;
+  // two 4-wave workgroups per CU: one residency wave of equal item runs (at least ~4 items each, or the reload of the
   // resident operand per run stops being amortised)
   int grid = 512;
-  while (grid > 8 && a.steps / grid < 8) grid >>= 1;
+  while (grid > 8 && a.items / grid < 4) grid >>= 1;
   if (grid_override > 0) grid = grid_override;
   switch (e) {
     case LAFS_EPI_BF16: return launch<LAFS_EPI_BF16, true, ABL>(a, grid, stream);

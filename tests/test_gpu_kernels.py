@@ -99,40 +99,45 @@ def test_gemm_nt_k_resident_kernel(M, N):
     aux = rnd_bf(M, N, seed=15)
     x = aux.float().requires_grad_(True)
     F.gelu(x).sum().backward()
-    out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV))              # (whichever kernel the library routes GELU' to)
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV), route_only=True) == 1
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV))
     assert relerr(out.float(), (A.float() @ B.float().t()) * x.grad) < 1e-2
     # a K split in two slices keeps a request off the K-resident route
     assert ops.gemm_nt(Ad, Bd, _lib.EPI_F32, splits=2, route_only=True) == 0
 
 
-_KRES_DGELU_SNIPPET = """
+_TILED_SNIPPET = """
 import torch, torch.nn.functional as F
 from lafs_cvpr2024_amd import _lib, ops
 M, N, K = 128 * 41 + 1, 1536, 384
 g = torch.Generator().manual_seed(21)
 A = torch.randn(M, K, generator=g).to(torch.bfloat16); B = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16)
-aux = torch.randn(M, N, generator=g).to(torch.bfloat16)
+aux = torch.randn(M, N, generator=g).to(torch.bfloat16); bias = torch.randn(N, generator=g); resid = torch.randn(M, N, generator=g)
 x = aux.float().requires_grad_(True); F.gelu(x).sum().backward()
-Ad, Bd, ad = A.cuda(), B.cuda(), aux.cuda()
-assert ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=ad, route_only=True) == 1
-out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=ad).float().cpu()
-ref = (A.float() @ B.float().t()) * x.grad
-err = ((out - ref).abs().max() / ref.abs().max()).item()
-assert err < 1e-2, err
-print("KRES_DGELU_OK", err)
+Ad, Bd, ad, bd = A.cuda(), B.cuda(), aux.cuda(), bias.cuda()
+rel = lambda o, r: ((o.float().cpu() - r).abs().max() / r.abs().max()).item()
+ref = A.float() @ B.float().t()
+for epi, kw in ((_lib.EPI_BF16, {}), (_lib.EPI_BF16_GELU, {}), (_lib.EPI_RESID_F32, dict(resid=resid.cuda())), (_lib.EPI_DGELU_BF16, dict(aux=ad))):
+    assert ops.gemm_nt(Ad, Bd, epi, bias=None if epi == _lib.EPI_DGELU_BF16 else bd, route_only=True, **kw) == 0, "LAFS_KRES=0 must route to the tiled kernel"
+assert rel(ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd), ref + bias) < 1e-2
+u, a = ops.gemm_nt(Ad, Bd, _lib.EPI_BF16_GELU, bias=bd)
+assert rel(u, ref + bias) < 1e-2 and rel(a, F.gelu(ref + bias)) < 1e-2
+assert rel(ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=resid.cuda()), resid + ref + bias) < 2e-4
+assert rel(ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=ad), ref * x.grad) < 1e-2
+print("TILED_OK")
 """
 
 
-def test_gemm_nt_k_resident_gelu_grad_variant():
-    """The library routes the GELU' input gradient to the tiled kernel by default (LAFS_KRES mask 7); the K-resident variant of
-    that epilogue (operand fetched a step ahead) is kept correct behind LAFS_KRES=15: checked in a fresh process."""
+def test_gemm_nt_tiled_kernel_at_the_streaming_shapes():
+    """LAFS_KRES=0 (the A/B switch of tools/lab/ab_env.sh) sends the K = 384 streaming shapes back to the tiled kernel: same
+    four epilogues, same tolerances, in a fresh process (the mask is read once per process)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LAFS_KRES="15", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, "-c", _KRES_DGELU_SNIPPET], env=env, capture_output=True, text=True, timeout=300, cwd=root)
-    assert r.returncode == 0 and "KRES_DGELU_OK" in r.stdout, r.stdout + r.stderr
+    env = dict(os.environ, LAFS_KRES="0", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", _TILED_SNIPPET], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "TILED_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_gemm_nt_embed_epilogue():

@@ -2,6 +2,7 @@
 // 256 MB Infinity Cache, as a function of workgroups per CU and 16-byte requests in flight per lane?
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // MODE 0: read (sum), 1: write, 2: copy, 3: read two streams + write one (residual epilogue shape), 4: copy with non-temporal stores
@@ -41,6 +42,23 @@ void run(const char* name, u32x4* a, u32x4* b, u32x4* c, size_t n16, unsigned* s
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-28s U=%d wg/CU=%d  %7.1f us  %6.2f TB/s\n", name, U, per_cu, ms / 3 * 1e3, bytes / (ms / 3 * 1e-3) / 1e12);
+  }
+}
+
+// Per-CU rates: the same streams from only `grid` workgroups (one or two per CU on grid <= 512): is a store stream bound by the
+// CU's own memory pipeline or by the memory side?
+template <int MODE, int U>
+void run_cus(const char* name, u32x4* a, u32x4* b, u32x4* c, size_t n16, unsigned* sink) {
+  const double bytes = (double)n16 * 16 * (MODE == 0 || MODE == 1 ? 1 : (MODE == 3 ? 3 : 2));
+  for (int grid : {16, 32, 64, 128, 256, 512}) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((stream_kernel<MODE, U>), dim3(grid), dim3(256), 0, 0, a, b, c, n16, sink);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((stream_kernel<MODE, U>), dim3(grid), dim3(256), 0, 0, a, b, c, n16, sink);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double tbs = bytes / (ms * 1e-3) / 1e12;
+    printf("%-28s U=%d workgroups=%3d  %8.1f us  %6.2f TB/s  = %6.1f GB/s per workgroup\n", name, U, grid, ms * 1e3, tbs, tbs * 1e3 / grid);
   }
 }
 
@@ -84,6 +102,12 @@ int main() {
   run<2, 1>("copy", a, b, c, n16, sink); run<2, 4>("copy", a, b, c, n16, sink); run<2, 8>("copy", a, b, c, n16, sink);
   run<4, 4>("copy, non-temporal stores", a, b, c, n16, sink);
   run<3, 4>("read 2 + write 1", a, b, c, n16, sink);
+  if (getenv("LAB_PER_CU")) {
+    const size_t n = (size_t)1 << 24;                  // 256 MiB
+    run_cus<1, 4>("write", a, b, c, n, sink); run_cus<0, 4>("read", a, b, c, n, sink); run_cus<2, 4>("copy", a, b, c, n, sink);
+    run_cus<0, 4>("read 32 MiB (cache-resident)", a, b, c, (size_t)1 << 21, sink);
+    return 0;
+  }
   // working sets that fit the Infinity Cache: 64 MiB read after write
   const size_t small = (size_t)1 << 22;
   run<2, 4>("copy 64 MiB (cache-resident)", a, b, c, small, sink);

@@ -39,10 +39,10 @@ void phases(const char* name, int epi, int M, int N, const Bufs& b, unsigned lon
   hipDeviceSynchronize();
   std::vector<unsigned long long> h(4096 * 8);
   hipMemcpy(h.data(), dst, 4096 * 64, hipMemcpyDeviceToHost);
-  double sum[6] = {0, 0, 0, 0, 0, 0}; int n = 0;
-  for (int w = 0; w < 4096; ++w) if (h[w * 8 + 5]) { for (int k = 0; k < 6; ++k) sum[k] += (double)h[w * 8 + k]; ++n; }
-  printf("%-12s abl%-2d workgroups %4d, steps/wg %.1f: per step [ticks of s_memtime] wait+barrier %.0f  issue %.0f  mfma %.0f  epilogue %.0f | whole run %.0f ticks\n",
-         name, ABL, n, sum[5] / n, sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / n);
+  double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int n = 0;
+  for (int w = 0; w < 4096; ++w) if (h[w * 8 + 5]) { for (int k = 0; k < 8; ++k) sum[k] += (double)h[w * 8 + k]; ++n; }
+  printf("%-12s abl%-2d workgroups %4d, steps/wg %.1f: per step [ticks of s_memtime] wait+barrier %.0f  issue %.0f  mfma %.0f  epilogue %.0f | whole run %.0f ticks, of which %.2f reloads of %.0f ticks each\n",
+         name, ABL, n, sum[5] / n, sum[0] / (sum[5] - sum[7]), sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5], sum[4] / n, sum[7] / n, sum[6] / sum[7]);
 }
 
 int main() {

@@ -11,7 +11,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "profiles"), os.path.join(ROOT, "profiles")
 R = sys.argv[1] if len(sys.argv) > 1 else "round2"
-DOM = "gemm_nt_kernel<1, 4, 32"           # BF16_GELU epilogue, 256x128 tile, 32-deep stages (prefix: further template arguments follow)
+DOM = "gemm_kres_kernel<1, true"          # student fc1: BF16_GELU epilogue (pre-activation stored) on the K-resident kernel
+FC2 = "gemm_nt_kernel<2, 2, 64"           # student fc2: RESID_F32 epilogue, 128x128 tile, 64-deep stages (prefix: further template arguments follow)
 
 
 def pmc_per_launch(path, name_parts, counters, launches_per_group=1):
@@ -61,8 +62,10 @@ def main():
         "wgrad_group": kernel_entry("wgrad_kernel<2,2,3,3,5> + wgrad_fold_kernel: four weight gradients of one ViT-S block, M=44160",
                                     ["wgrad_kernel", "wgrad_fold_kernel"],
                                     sum(2.0 * M * (a + b) + 4.0 * a * b for a, b in pairs), sum(2.0 * M * a * b for a, b in pairs)),
-        "fc1": kernel_entry("gemm_nt_kernel<BF16_GELU, WM=4, BK=32>  M=44160 N=1536 K=384 (student fc1 forward)", [DOM],
+        "fc1": kernel_entry("gemm_kres_kernel<BF16_GELU>  M=44160 N=1536 K=384 (student fc1 forward, K-resident kernel)", [DOM],
                             (M * 384 + 1536 * 384 + 2 * M * 1536) * 2.0, 2.0 * M * 1536 * 384),
+        "fc2": kernel_entry("gemm_nt_kernel<RESID_F32, WM=2, BK=64>  M=44160 N=384 K=1536 (student fc2 forward, tiled kernel)", [FC2],
+                            (M * 1536 + 384 * 1536) * 2.0 + 2.0 * M * 384 * 4.0, 2.0 * M * 384 * 1536),
     }
     json.dump(out, open(os.path.join(DST, f"{R}_kernel_pmc.json"), "w"), indent=1)
     for name, sub in (("serial", "serial"), ("landmark_cnn", "cnn")):
@@ -95,7 +98,7 @@ def main():
             for k, v in cnt.most_common():
                 fo.write(f"{v:5d}  {k}\n")
     print(json.dumps({k: {kk: out[k][kk] for kk in ("launches_averaged", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch")}
-                      for k in ("wgrad_group", "fc1")}))
+                      for k in ("wgrad_group", "fc1", "fc2")}))
 
 
 if __name__ == "__main__":
