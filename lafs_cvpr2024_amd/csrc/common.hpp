@@ -59,10 +59,16 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(y, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// d/dx gelu(x) = Phi(x) + x phi(x).  The A&S 7.1.26 form of erf(x / sqrt 2) already evaluates exp(-x^2 / 2) -- the same
+// exponential the density needs -- so one v_exp and one v_rcp serve both terms (the GELU' epilogues are VALU-bound).
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
-  return cdf + x * pdf;
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);               // exp(-x^2 / 2)
+  const float erf_abs = 1.0f - poly * e;
+  const float cdf = 0.5f + 0.5f * copysignf(erf_abs, x);
+  return cdf + x * (0.39894228040143268f * e);
 }
 
 // ---- element dropout (nn.Dropout of Part-fViT, face_pre_pro/ViT_face.py:131-133,150-153,614): counter-based mask, so
