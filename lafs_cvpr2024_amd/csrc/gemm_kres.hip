@@ -17,7 +17,7 @@
 //     bytes (the pattern the HBM write path sustains at full rate; 16-byte pieces scattered over 32 rows -- what a 32x32 MFMA
 //     layout produces -- measured 1.8-2.6 TB/s, tools/lab/lab_kres.cpp);
 //   * work = (128-row unit, 64-column block) items in unit-major order, cut into equal contiguous runs, one per workgroup
-//     (4 waves, 2 workgroups per CU): no tail round.  An item is two ring stages (32 columns each) and one epilogue: the two
+//     (4 waves, 2 workgroups per CU, all resident at once).  An item is two ring stages (32 columns each) and one epilogue: the two
 //     stages' 64-byte pieces of a row are stored back to back and complete 128-byte lines; a wave emits 4-8 stores per item, so
 //     the memory pipeline sees a steady trickle of stores between the LDS-DMA requests instead of per-tile bursts;
 //   * the LDS-DMA ring runs across items with counted s_waitcnt vmcnt (loads and stores retire in issue order on gfx950, the
