@@ -37,8 +37,8 @@ constexpr int ROWB = KK * 2;               // bytes per weight row
 constexpr int GROWS = 32;                  // weight rows per stage = output columns per step
 constexpr int STAGE = GROWS * ROWB;        // 24 KiB
 constexpr int NSTG = 3;
-constexpr int NTH = 256;
-constexpr int NDMA = STAGE / 16 / NTH;     // LDS-DMA instructions per thread and stage (6)
+constexpr int NTH = 256;                   // product: 4 waves per workgroup (lab, ABL & 1024: 8 waves on one ring, 256-row units)
+constexpr int NDMA4 = STAGE / 16 / NTH;    // LDS-DMA instructions per thread and stage (6)
 constexpr int NKK = KK / 32;               // k steps of a 16x16x32 MFMA (12)
 constexpr int MAXN = 1536;                 // bias vector staged in LDS
 constexpr int FD = 8;                      // fragment reads in flight ahead of their MFMAs
@@ -79,7 +79,8 @@ template <int EPI, bool HAS_U> struct EpiOps {
 };
 
 template <int EPI, bool HAS_U, int ABL>
-__global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
+__global__ __launch_bounds__((ABL & 1024) ? 512 : 256, 2) void gemm_kres_kernel(KArgs p) {
+  constexpr int NTH = (ABL & 1024) ? 512 : 256, UROWS = NTH / 2, NDMA = STAGE / 16 / NTH;
   constexpr int S = EpiOps<EPI, HAS_U>::S, P = EpiOps<EPI, HAS_U>::P;
   constexpr bool F32 = EpiOps<EPI, HAS_U>::F32;
   // epilogue operand fetched one item ahead (GELU': its load latency no longer sits in front of the epilogue math); the
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const int b = i & 1, x = i >> 1;                // bf16: x = stage; fp32: x = stage * 2 + row group
-      const int mr = min(mu * 128 + wave * 32 + t + 16 * b, p.M - 1);
+      const int mr = min(mu * UROWS + wave * 32 + t + 16 * b, p.M - 1);
       if (F32) dst[i] = *reinterpret_cast<const uint4*>(p.resid + (size_t)mr * p.ldr + n0 + 16 * x + 4 * q);
       else dst[i] = *reinterpret_cast<const uint4*>(p.aux + (size_t)mr * p.ldaux + n0 + 32 * x + 8 * q);
     }
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     // ---------------- first stage of the item
     if (mu != cur_mu) {                               // new row unit: (re)load the resident operand, then drain everything
       cur_mu = mu;
-      m0 = mu * 128 + wave * 32 + t;
-      active = (mu * 128 + wave * 32) < p.M;
+      m0 = mu * UROWS + wave * 32 + t;
+      active = (mu * UROWS + wave * 32) < p.M;
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int mr = min(m0 + 16 * b, p.M - 1);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
 
 template <int EPI, bool HAS_U, int ABL>
 int launch(const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_kres_kernel<EPI, HAS_U, ABL>), dim3(grid), dim3(NTH), 0, s, a);
+  hipLaunchKernelGGL((gemm_kres_kernel<EPI, HAS_U, ABL>), dim3(grid), dim3((ABL & 1024) ? 512 : 256), 0, s, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -381,11 +382,12 @@ int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_overrid
   a.cbn = g->N / 64;
   a.stamps = stamps;
 
-  const int mus = (g->M + 127) / 128;
+  constexpr int UR = (ABL & 1024) ? 256 : 128;
+  const int mus = (g->M + UR - 1) / UR;
   a.items = mus * a.cbn;
   // two 4-wave workgroups per CU: one residency wave of equal item runs (at least ~4 items each, or the reload of the
   // resident operand per run stops being amortised)
-  int grid = 512;
+  int grid = (ABL & 1024) ? 256 : 512;
   while (grid > 8 && a.items / grid < 4) grid >>= 1;
   if (grid_override > 0) grid = grid_override;
   switch (e) {
