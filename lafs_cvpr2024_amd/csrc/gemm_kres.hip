@@ -9,7 +9,7 @@
 // epilogue by the HBM write rate, and the two phases add up (fc1: 52 + 58 us alone, 131-138 together) because a tile's stores
 // leave as one burst per workgroup.  Here the token operand never touches the LDS and the stores never burst:
 //   * a wave keeps its 32 token rows x all 384 k RESIDENT IN REGISTERS (two 16-row MFMA blocks, 96 VGPRs, loaded once per
-//     128-row unit) and walks along N; only the weights stream through the LDS -- as whole contiguous rows (768 B: full cache
+//     128-row unit -- through the ring buffers, as four 32-row stages, while no weight stage is in flight) and walks along N; only the weights stream through the LDS -- as whole contiguous rows (768 B: full cache
 //     lines), 32 rows = 24 KiB per ring stage, 3 stages;  L2 -> LDS traffic per fc1 GEMM 407 MB, none for A;
 //   * v_mfma_f32_16x16x32_bf16 computes C^T blocks (first operand = 16 weight rows, second = 16 tokens): 48 MFMAs per stage and
 //     barrier.  A lane (token t, quarter q) ends up with 4 consecutive output columns per MFMA; the weight rows of a stage are
@@ -37,7 +37,7 @@ constexpr int ROWB = KK * 2;               // bytes per weight row
 constexpr int GROWS = 32;                  // weight rows per stage = output columns per step
 constexpr int STAGE = GROWS * ROWB;        // 24 KiB
 constexpr int NSTG = 3;
-constexpr int NTH = 256;                   // product: 4 waves per workgroup (lab, ABL & 1024: 8 waves on one ring, 256-row units)
+constexpr int NTH = 256;
 constexpr int NDMA4 = STAGE / 16 / NTH;    // LDS-DMA instructions per thread and stage (6)
 constexpr int NKK = KK / 32;               // k steps of a 16x16x32 MFMA (12)
 constexpr int MAXN = 1536;                 // bias vector staged in LDS
@@ -79,13 +79,16 @@ template <int EPI, bool HAS_U> struct EpiOps {
 };
 
 template <int EPI, bool HAS_U, int ABL>
-__global__ __launch_bounds__((ABL & 1024) ? 512 : 256, 2) void gemm_kres_kernel(KArgs p) {
-  constexpr int NTH = (ABL & 1024) ? 512 : 256, UROWS = NTH / 2, NDMA = STAGE / 16 / NTH;
+__global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
+  constexpr int UROWS = 128, NDMA = NDMA4;
   constexpr int S = EpiOps<EPI, HAS_U>::S, P = EpiOps<EPI, HAS_U>::P;
   constexpr bool F32 = EpiOps<EPI, HAS_U>::F32;
   // epilogue operand fetched one item ahead (GELU': its load latency no longer sits in front of the epilogue math); the
   // residual epilogue fetches within the item -- a second 32-register buffer does not fit beside its other state
-  constexpr bool AHEAD = (EPI == LAFS_EPI_DGELU_BF16);
+  constexpr bool AHEAD = (EPI == LAFS_EPI_DGELU_BF16) && KABL(2048);   // (lab: with the staged reload the second operand buffer no longer fits)
+  // resident rows (re)loaded through the ring buffers (the GELU' variant has no registers to spare for that code path: it keeps
+  // the per-lane loads)
+  constexpr bool STAGED = !KABL(512) && !AHEAD;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
   __shared__ __attribute__((aligned(16))) float sbias[MAXN];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,14 +121,30 @@ __global__ __launch_bounds__((ABL & 1024) ? 512 : 256, 2) void gemm_kres_kernel(
   // LDS-DMA from inline asm (common.hpp): with the builtin, hipcc's wait-count pass drains the whole DMA queue (vmcnt(0)) in
   // front of the first fragment read of every stage; the ring is counted by hand instead (wait_vm below)
   const unsigned lds0 = lds_addr_of(smem);
+  int pstage = 0;                                     // ring buffer the next issued stage goes to
   auto issue = [&](int k) {                           // stage k (absolute: item k >> 1, half k & 1)
     const int cb = (k >> 1) % cbn;
     const bf16_t* base = p.B + (size_t)(cb * 64 + 32 * (k & 1)) * p.ldb;
-    const unsigned st = lds0 + ((k - kb) % NSTG) * STAGE + wave * 1024;
+    const unsigned st = lds0 + pstage * STAGE + wave * 1024;
+    pstage = (pstage + 1 == NSTG) ? 0 : pstage + 1;
     fence();
     if (!(KABL(4) && k >= kb + 2)) {
 #pragma unroll
       for (int i = 0; i < NDMA; ++i) lds_dma16_m0(base + doff[i], st + i * (NTH * 16));
+    }
+    fence();
+  };
+  // The 32 token rows of wave `w` of unit `mu` as ONE ring stage (same 768-byte rows, same chunk swizzle as a weight stage):
+  // LDS-DMA fetches whole rows (the per-lane gather of 16 rows x 64 bytes per instruction it replaces took ~7 us per reload,
+  // bound by the CU's outstanding misses); the owning wave then reads its fragments with the weight-fragment addressing.
+  auto issue_rows = [&](int mu, int w, int buf) {
+    const unsigned st = lds0 + buf * STAGE + wave * 1024;
+    fence();
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int x = i * NTH + tid, rho = x / CPR, cp = x % CPR, c = cp ^ (rho & 15);
+      const int row = min(mu * UROWS + w * 32 + rho, p.M - 1);
+      lds_dma16_m0(p.A + (size_t)row * p.lda + c * 8, st + i * (NTH * 16));
     }
     fence();
   };
@@ -190,40 +209,76 @@ __global__ __launch_bounds__((ABL & 1024) ? 512 : 256, 2) void gemm_kres_kernel(
     // fragment reads run FD ahead of the MFMA pairs that consume them (hipcc on its own keeps one read in flight and exposes
     // the LDS latency 24 times per stage: 1440 instead of ~1000 cycles, tools/lab/lab_kres.cpp)
     if constexpr (!KABL(16) && !KABL(2)) {
-      __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);
+      constexpr int FDV = AHEAD ? 6 : FD;                // (the two operand buffers of the GELU' variant need the registers)
+      __builtin_amdgcn_sched_group_barrier(0x100, FDV, 0);
 #pragma unroll
-      for (int i = 0; i < 2 * NKK - FD; ++i) {
+      for (int i = 0; i < 2 * NKK - FDV; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * FD, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * FDV, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  issue(kb);
-  issue(kb + 1);
-  int stage = 0;
+  auto read_rows = [&](int buf) {                     // this wave's 32 rows out of ring buffer `buf` into areg
+    const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk)
+        areg[b][kk] = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256 + b * (16 * ROWB));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the reads have returned before the buffer is handed back at the barrier
+  };
+  int stage = 0;                                      // ring buffer the next consumed stage sits in
+  bool fresh = false;                                 // first item after a (re)load: no epilogue operations in flight yet
   for (int it = ib; it < ie; ++it) {
     const int mu = it / cbn, cb = it - mu * cbn;
     const int k0 = 2 * it;
     const bool reloaded_lab = (mu != cur_mu);
+    // the stages of the NEXT item are issued from this one unless it starts a new row unit (its rows go through the ring first)
+    const bool feed_next = (it + 1 < ie) && ((it + 1) / cbn == mu);
     // ---------------- first stage of the item
-    if (mu != cur_mu) {                               // new row unit: (re)load the resident operand, then drain everything
+    if (mu != cur_mu) {                               // new row unit: (re)load the resident operand
       cur_mu = mu;
       m0 = mu * UROWS + wave * 32 + t;
       active = (mu * UROWS + wave * 32) < p.M;
+      if (EPI == LAFS_EPI_RESID_F32 && p.seq_scale != nullptr) {
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int mr = min(m0 + 16 * b, p.M - 1);
-        const bf16_t* arow = p.A + (size_t)mr * p.lda;
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) areg[b][kk] = *reinterpret_cast<const bf16x8_t*>(arow + (4 * kk + q) * 8);
-        if (EPI == LAFS_EPI_RESID_F32 && p.seq_scale != nullptr) sc[b] = p.seq_scale[p.row2seq[mr]];
+        for (int b = 0; b < 2; ++b) sc[b] = p.seq_scale[p.row2seq[min(m0 + 16 * b, p.M - 1)]];
       }
       if (AHEAD && it == ib) fetch(it, pre);          // first item of the run: nobody fetched its epilogue operand ahead
-      wait_vm<0>();
-      __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0) again, in a form hipcc's wait-count pass sees: no waits on areg inside the MFMA loop
+      if constexpr (STAGED) {
+        // No stage of this item is in flight (feed_next above), every ring buffer is free once all waves are here.
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        issue_rows(mu, 0, 0); issue_rows(mu, 1, 1); issue_rows(mu, 2, 2);
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (wave < 3) read_rows(wave);
+        __builtin_amdgcn_s_barrier();                 // buffers free again
+        issue_rows(mu, 3, 0);
+        pstage = 1;
+        issue(k0);                                    // -> buffer 1
+        issue(k0 + 1);                                // -> buffer 2; the stage after them goes to buffer 0
+        wait_vm<2 * NDMA>();                          // wave 3's rows have landed (the two weight stages are younger)
+        __builtin_amdgcn_s_barrier();
+        if (wave == 3) read_rows(0);
+        stage = 1;
+        wait_vm<NDMA>();                              // stage k0 has landed; the barrier below also hands buffer 0 back
+      } else {                                        // lab: per-lane global loads, then drain
+        if (it == ib) { pstage = 0; issue(k0); issue(k0 + 1); stage = 0; }
+        else { pstage = stage; issue(k0); issue(k0 + 1); }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const bf16_t* arow = p.A + (size_t)min(m0 + 16 * b, p.M - 1) * p.lda;
+#pragma unroll
+          for (int kk = 0; kk < NKK; ++kk) areg[b][kk] = *reinterpret_cast<const bf16x8_t*>(arow + (4 * kk + q) * 8);
+        }
+        wait_vm<0>();
+        __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) again, in a form hipcc's wait-count pass sees
+      }
+      fresh = true;
     } else {                                          // younger than this stage's DMA: the other stage of the previous item + its epilogue operations
       if (active) wait_vm<NDMA + S + P>(); else wait_vm<NDMA + P>();
     }
@@ -231,21 +286,25 @@ __global__ __launch_bounds__((ABL & 1024) ? 512 : 256, 2) void gemm_kres_kernel(
     if constexpr (KABL(32)) {
       if (reloaded_lab) { lap(4); tacc[5] += 1; } else lap(0);
     }
-    if (k0 + 2 < ke) issue(k0 + 2);
+    if (feed_next) issue(k0 + 2);
     if (AHEAD) fetch(it + 1, nxt);                    // P loads, consumed by the NEXT item's epilogue
     lap(1);
     mfma_stage(stage, acc[0]);
     stage = (stage + 1 == NSTG) ? 0 : stage + 1;
     lap(2);
-    // ---------------- second stage
-    if (k0 + 2 < ke) {
+    // ---------------- second stage: younger than its DMA are the previous item's epilogue operations (none right after a
+    // reload), the stage issued above (if any) and, with AHEAD, the fetch above
+    if (fresh) {
+      if (feed_next) wait_vm<NDMA + (AHEAD ? P : 0)>(); else wait_vm<(AHEAD ? P : 0)>();
+    } else if (feed_next) {
       if (active) wait_vm<NDMA + S + P>(); else wait_vm<NDMA + P>();
-    } else {                                          // last stage of the run: nothing younger than it but the previous epilogue's operations
+    } else {
       if (active) wait_vm<S + P>(); else wait_vm<P>();
     }
+    fresh = false;
     if constexpr (!KABL(64)) __builtin_amdgcn_s_barrier();
     lap(0);
-    if (k0 + 3 < ke) issue(k0 + 3);
+    if (feed_next) issue(k0 + 3);
     if (!AHEAD) fetch(it, pre);                       // P loads, consumed a stage of MFMAs later
     lap(1);
     mfma_stage(stage, acc[1]);
@@ -343,7 +402,7 @@ __global__ __launch_bounds__((ABL & 1024) ? 512 : 256, 2) void gemm_kres_kernel(
 
 template <int EPI, bool HAS_U, int ABL>
 int launch(const KArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_kres_kernel<EPI, HAS_U, ABL>), dim3(grid), dim3((ABL & 1024) ? 512 : 256), 0, s, a);
+  hipLaunchKernelGGL((gemm_kres_kernel<EPI, HAS_U, ABL>), dim3(grid), dim3(NTH), 0, s, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -382,12 +441,11 @@ int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_overrid
   a.cbn = g->N / 64;
   a.stamps = stamps;
 
-  constexpr int UR = (ABL & 1024) ? 256 : 128;
-  const int mus = (g->M + UR - 1) / UR;
+  const int mus = (g->M + 127) / 128;
   a.items = mus * a.cbn;
   // two 4-wave workgroups per CU: one residency wave of equal item runs (at least ~4 items each, or the reload of the
   // resident operand per run stops being amortised)
-  int grid = (ABL & 1024) ? 256 : 512;
+  int grid = 512;
   while (grid > 8 && a.items / grid < 4) grid >>= 1;
   if (grid_override > 0) grid = grid_override;
   switch (e) {

@@ -71,12 +71,12 @@ int main() {
   phases<32 + 4>("qkv nodma", LAFS_EPI_BF16, T, 1152, b, stamps);
   phases<32 + 16>("qkv nofrag", LAFS_EPI_BF16, T, 1152, b, stamps);
   phases<32 + 4 + 128>("qkv nodma nost", LAFS_EPI_BF16, T, 1152, b, stamps);
-  phases<32 + 1024>("qkv 8 waves", LAFS_EPI_BF16, T, 1152, b, stamps);
-  phases<32 + 1024>("fc1 8 waves", LAFS_EPI_BF16_GELU, T, 1536, b, stamps);
-  run<1024>("qkv 8 waves", LAFS_EPI_BF16, T, 1152, b); run<0>("qkv", LAFS_EPI_BF16, T, 1152, b);
-  run<1024>("fc1 8 waves", LAFS_EPI_BF16_GELU, T, 1536, b); run<0>("fc1", LAFS_EPI_BF16_GELU, T, 1536, b);
-  run<1024>("dgelu 8 waves", LAFS_EPI_DGELU_BF16, T, 1536, b); run<0>("dgelu", LAFS_EPI_DGELU_BF16, T, 1536, b);
-  run<1024>("proj 8 waves", LAFS_EPI_RESID_F32, T, 384, b); run<0>("proj", LAFS_EPI_RESID_F32, T, 384, b);
+  phases<32 + 512>("qkv lane reload", LAFS_EPI_BF16, T, 1152, b, stamps);
+  run<512>("qkv lane reload", LAFS_EPI_BF16, T, 1152, b); run<0>("qkv", LAFS_EPI_BF16, T, 1152, b);
+  run<512>("fc1 lane reload", LAFS_EPI_BF16_GELU, T, 1536, b); run<0>("fc1", LAFS_EPI_BF16_GELU, T, 1536, b);
+  run<512>("dgelu lane reload", LAFS_EPI_DGELU_BF16, T, 1536, b); run<0>("dgelu", LAFS_EPI_DGELU_BF16, T, 1536, b);
+  run<512 + 2048>("dgelu lane+ahead", LAFS_EPI_DGELU_BF16, T, 1536, b);
+  run<512>("proj lane reload", LAFS_EPI_RESID_F32, T, 384, b); run<0>("proj", LAFS_EPI_RESID_F32, T, 384, b);
   phases<32>("fc1", LAFS_EPI_BF16_GELU, T, 1536, b, stamps);
   phases<32>("dgelu", LAFS_EPI_DGELU_BF16, T, 1536, b, stamps);
   phases<32>("proj", LAFS_EPI_RESID_F32, T, 384, b, stamps);
