@@ -9,8 +9,9 @@
 // epilogue by the HBM write rate, and the two phases add up (fc1: 52 + 58 us alone, 131-138 together) because a tile's stores
 // leave as one burst per workgroup.  Here the token operand never touches the LDS and the stores never burst:
 //   * a wave keeps its 32 token rows x all 384 k RESIDENT IN REGISTERS (two 16-row MFMA blocks, 96 VGPRs, loaded once per
-//     128-row unit -- through the ring buffers, as four 32-row stages, while no weight stage is in flight) and walks along N; only the weights stream through the LDS -- as whole contiguous rows (768 B: full cache
-//     lines), 32 rows = 24 KiB per ring stage, 3 stages;  L2 -> LDS traffic per fc1 GEMM 407 MB, none for A;
+//     128-row unit -- through the ring buffers, as four 32-row stages, while no weight stage is in flight) and walks along N;
+//     only the weights stream through the LDS -- as whole contiguous rows (768 B: full cache lines), 32 rows = 24 KiB per ring
+//     stage, 3 stages;  L2 -> LDS traffic per fc1 GEMM 407 MB for the weights, 34-55 MB for the rows;
 //   * v_mfma_f32_16x16x32_bf16 computes C^T blocks (first operand = 16 weight rows, second = 16 tokens): 48 MFMAs per stage and
 //     barrier.  A lane (token t, quarter q) ends up with 4 consecutive output columns per MFMA; the weight rows of a stage are
 //     interleaved so that two MFMAs give it 8 consecutive bf16 columns: every store instruction writes 16 rows x 64 contiguous
