@@ -446,8 +446,9 @@ int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_overrid
   a.items = mus * a.cbn;
   // two 4-wave workgroups per CU: one residency wave of equal item runs (at least ~4 items each, or the reload of the
   // resident operand per run stops being amortised)
+  static const int min_items = [] { const char* v = getenv("LAFS_KRES_MIN_ITEMS"); return v != nullptr ? atoi(v) : 4; }();   // lab knob
   int grid = 512;
-  while (grid > 8 && a.items / grid < 4) grid >>= 1;
+  while (grid > 8 && a.items / grid < min_items) grid >>= 1;
   if (grid_override > 0) grid = grid_override;
   switch (e) {
     case LAFS_EPI_BF16: return launch<LAFS_EPI_BF16, true, ABL>(a, grid, stream);
