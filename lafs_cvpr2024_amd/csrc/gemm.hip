@@ -126,6 +126,7 @@ template <int BK> __device__ __forceinline__ int nt_swzk(int row) { return BK ==
 template <int EPI, int WM, int BK, int WN = 2, bool PERSIST = false>
 __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2))) void gemm_nt_kernel(NTArgs p) {
   constexpr int THREADS = WM * WN * 64, BMT = WM * 64, BN = WN * 64;
+  constexpr bool PIN32 = (WM == 2);                   // (the 8-wave variants run at the 128-register cap: pinning spills there)
   constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
   constexpr int ROWB = BK * 2;                        // bytes per LDS row
   constexpr int STAGE = (BMT + BN) * ROWB;
@@ -195,6 +196,30 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = mfma16(fb[j], fa[i], acc[j][i]);
+    }
+    // 64-deep stages at two waves per SIMD (the long-K GEMMs of the trunk): pin the 16 fragment reads ahead of the 32 MFMAs that
+    // consume them -- left alone, hipcc issues them in batches of 2-6 behind s_waitcnt lgkmcnt(0) and exposes the LDS latency four or
+    // five times per stage (the same finding as in gemm_kres.hip)
+    if constexpr (BK == 64 && WM == 2 && WN == 2) {
+      if (!DBG(p, 32)) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+      }
+    } else if constexpr (BK == 32 && WN == 2 && PIN32) {
+      if (!DBG(p, 32)) {                               // 32-deep stages: 8 reads, 16 MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      }
     }
   };
 
