@@ -141,6 +141,11 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_base) {
 __device__ __forceinline__ void lds_dma16_m0(const void* gsrc, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "memory");
 }
+// Same with a scalar base address and a 32-bit per-lane byte offset (global_load_lds ... v_off, s[base]): one VGPR of address per
+// lane instead of a 64-bit pair, no 64-bit add per piece.
+__device__ __forceinline__ void lds_dma16_m0_s(const void* sbase, unsigned voff_bytes, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff_bytes), "s"(sbase), "s"(lds_base) : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }

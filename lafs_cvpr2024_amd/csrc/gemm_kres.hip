@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
   constexpr bool F32 = EpiOps<EPI, HAS_U>::F32;
   // epilogue operand fetched one item ahead (GELU': its load latency no longer sits in front of the epilogue math); the
   // residual epilogue fetches within the item -- a second 32-register buffer does not fit beside its other state
-  constexpr bool AHEAD = (EPI == LAFS_EPI_DGELU_BF16) && KABL(2048);   // (lab: with the staged reload the second operand buffer no longer fits)
+  constexpr bool AHEAD = (EPI == LAFS_EPI_DGELU_BF16) && KABL(2048);   // (lab only: beside the staged reload the second operand buffer spills)
   // resident rows (re)loaded through the ring buffers (the GELU' variant has no registers to spare for that code path: it keeps
   // the per-lane loads)
   constexpr bool STAGED = !KABL(512) && !AHEAD;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     const int x = i * NTH + tid, rho = x / CPR, cp = x % CPR, c = cp ^ (rho & 15);
     const int s16 = rho & 15, gi = rho >> 4;
     const int rowrel = F32 ? rho : (8 * (s16 >> 2) + 4 * gi + (s16 & 3));
-    doff[i] = rowrel * p.ldb + c * 8;
+    doff[i] = (rowrel * p.ldb + c * 8) * 2;           // bytes
   }
   const int cbn = p.cbn;
   // LDS-DMA from inline asm (common.hpp): with the builtin, hipcc's wait-count pass drains the whole DMA queue (vmcnt(0)) in
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     fence();
     if (!(KABL(4) && k >= kb + 2)) {
 #pragma unroll
-      for (int i = 0; i < NDMA; ++i) lds_dma16_m0(base + doff[i], st + i * (NTH * 16));
+      for (int i = 0; i < NDMA; ++i) lds_dma16_m0_s(base, (unsigned)doff[i], st + i * (NTH * 16));
     }
     fence();
   };
