@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     // fragment reads run FD ahead of the MFMA pairs that consume them (hipcc on its own keeps one read in flight and exposes
     // the LDS latency 24 times per stage: 1440 instead of ~1000 cycles, tools/lab/lab_kres.cpp)
     if constexpr (!KABL(16) && !KABL(2)) {
-      constexpr int FDV = AHEAD ? 6 : FD;                // (the two operand buffers of the GELU' variant need the registers)
+      constexpr int FDV = FD;                            // (12 in flight measured no better: the phase is not latency-bound any more)
       __builtin_amdgcn_sched_group_barrier(0x100, FDV, 0);
 #pragma unroll
       for (int i = 0; i < 2 * NKK - FDV; ++i) {
