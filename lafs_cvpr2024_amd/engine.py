@@ -185,6 +185,8 @@ class LafsPretrainEngine:
         # teacher (two global views, no activations kept) runs on the side stream, concurrently with the student
         cur = torch.cuda.current_stream()
         side = self.side_stream if self.side_stream is not None else cur
+        if os.environ.get("LAFS_TEACHER_SERIAL") == "1":       # lab knob: teacher forward in front of the student on the main stream
+            side = cur
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             pos_t = self._pos_tokens(ta, self.spec_t, self.pos_t)[:1]
@@ -255,6 +257,15 @@ class LafsPretrainEngine:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graphs, pool = [], None
+        # a single rank has no collective to place between the segments: the whole step is ONE graph (five replay boundaries less)
+        self._one_graph = (self.world == 1) and os.environ.get("LAFS_ONE_GRAPH", "1") != "0"
+        if self._one_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for f in segs:
+                    f()
+            self._graphs = [g]
+            return
         for f in segs:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool):
@@ -293,6 +304,10 @@ class LafsPretrainEngine:
             self._capture()
             self._restore(saved)
             self.hyper_ring.upload(self.hyper, fill_hyper)
+        if self.use_graph and getattr(self, "_one_graph", False):
+            self._graphs[0].replay()
+            self.step_count += 1
+            return self.loss
         segs = self._segments()
         run = (lambda i: self._graphs[i].replay()) if self.use_graph else (lambda i: segs[i]())
         run(0)
