@@ -55,10 +55,12 @@ struct KArgs {
   int cbn, items;                          // 64-column blocks per row unit; row units x column blocks
   unsigned long long* stamps;              // lab (ABL & 32): per workgroup {wait + barrier, issue, MFMA loop, epilogue, whole run, stages, reload wait, reloads} cycles of wave 0
 };
-// ABL (template argument, 0 in the library; tools/lab/lab_kres.cpp instantiates others): timing ablations
-//   1 stores only from lane 0 (dead-code-proof "no stores"), 2 no MFMA, 4 no LDS-DMA after the prologue, 8 no epilogue math,
-//   16 no fragment reads, 32 phase time stamps of wave 0 (s_memtime) into KArgs::stamps,
-//   64 no workgroup barrier (racy), 128 no store instructions at all (accumulators kept alive by an empty asm)
+// ABL (template argument, 0 in the library; tools/lab/lab_kres.cpp instantiates others): timing ablations and variants
+//   1 stores only from lane 0 (dead-code-proof "no stores"), 2 no MFMA, 4 no weight stages after the first two, 8 no epilogue math,
+//   16 no fragment reads, 32 phase time stamps of wave 0 (s_memtime) into KArgs::stamps, 64 no workgroup barrier (racy),
+//   128 no store instructions at all (accumulators kept alive by an empty asm), 256 every store writes one contiguous KiB,
+//   512 resident rows (re)loaded by per-lane global loads instead of through the ring buffers, 2048 GELU' operand fetched an item
+//   ahead (needs 512: both together spill)
 #define KABL(bit) ((ABL & (bit)) != 0)
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -72,7 +74,7 @@ __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float 
   *reinterpret_cast<f32x4v_t*>(p) = v;
 }
 
-// memory operations of one step besides its LDS-DMA: S stores (active waves only) + P epilogue-operand loads
+// memory operations of one item besides its LDS-DMA: S stores (active waves only) + P epilogue-operand loads
 template <int EPI, bool HAS_U> struct EpiOps {
   static constexpr bool F32 = (EPI == LAFS_EPI_RESID_F32);
   static constexpr int S = F32 ? 8 : ((EPI == LAFS_EPI_BF16_GELU && HAS_U) ? 8 : 4);
