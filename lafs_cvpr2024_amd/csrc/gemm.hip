@@ -14,6 +14,7 @@
 // The NT kernel computes C^T tiles (MFMA A-operand = weight rows) and permutes which weight row feeds which
 // MFMA row so that every lane ends up with 16 CONTIGUOUS output columns of one row: epilogues read/write
 // 32-64 B per lane (bias, residual, GELU, fp32/bf16 stores) with no LDS transpose.
+#include <stdlib.h>
 #include "common.hpp"
 #include "lafs_hip.h"
 #include "gemm_kres.hpp"
@@ -124,15 +125,18 @@ template <int BK> __device__ __forceinline__ int nt_swzk(int row) { return BK ==
 // PERSIST (lab build only, see launch_nt): the grid is one residency wave of workgroups and each walks virtual blocks b,
 // b + grid, b + 2 grid, ...; while a workgroup stores tile j it already has the first ring stages of tile j+1 in flight.
 template <int EPI, int WM, int BK, int WN = 2, bool PERSIST = false>
-__global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2))) void gemm_nt_kernel(NTArgs p) {
+__global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2)))) void gemm_nt_kernel(NTArgs p) {
   constexpr int THREADS = WM * WN * 64, BMT = WM * 64, BN = WN * 64;
   constexpr bool PIN32 = (WM == 2);                   // (the 8-wave variants run at the 128-register cap: pinning spills there)
   constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
   constexpr int ROWB = BK * 2;                        // bytes per LDS row
   constexpr int STAGE = (BMT + BN) * ROWB;
   constexpr int NSTG = (BK == 32) ? 3 : 2;
-  constexpr int NA = (BMT * CPR) / THREADS;           // 16-byte A chunks per thread per stage
+  constexpr int NA = (BMT * CPR + THREADS - 1) / THREADS;   // 16-byte A chunks per thread per stage (the last round may be partial:
+  constexpr bool RAGGED_A = (BMT * CPR) % THREADS != 0;     // 128x384 tiles, 12 waves: 1024 chunks on 768 threads)
   constexpr int NB = (BN * CPR) / THREADS;            // 16-byte B chunks per thread per stage
+  static_assert((BN * CPR) % THREADS == 0, "B chunks must divide evenly");
+  static_assert(!RAGGED_A || NSTG == 2, "a partial A round is only counted right by the draining 2-stage ring");
   constexpr int NMAX = NA > NB ? NA : NB;
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
       const int q = i * THREADS + tid, row = q / CPR, ch = (q % CPR) ^ nt_swzk<BK>(row);
-      if (i < NA) o.a[i] = p.A + (size_t)min(o.m0 + row, p.M - 1) * p.lda + kbeg + ch * 8;
+      if (i < NA) o.a[i] = p.A + (size_t)min(o.m0 + min(row, BMT - 1), p.M - 1) * p.lda + kbeg + ch * 8;
       if (i < NB) o.b[i] = p.B + (size_t)min(o.n0 + nt_perm<EpiTraits<EPI>::VPL>(row), p.N - 1) * p.ldb + kbeg + ch * 8;
     }
   };
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 4) ? 4 : ((WM == 2) ? (BK == 3
     unsigned char* st = smem + (t % NSTG) * STAGE;
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) {
-      if (i < NA) glds16(o.a[i] + t * BK, st + ldsoff[i]);
+      if (i < NA && (!RAGGED_A || i * THREADS + (int)(threadIdx.x & ~63u) < BMT * CPR)) glds16(o.a[i] + t * BK, st + ldsoff[i]);   // (wave-uniform)
       if (i < NB) glds16(o.b[i] + t * BK, st + BMT * ROWB + ldsoff[i]);
     }
   };
@@ -733,6 +737,21 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
     return LAFS_OK;
   }
 #endif
+  // Long reductions onto N = 384 (fc2 forward, fc1 / qkv input gradients of ViT-S): 128x384 tiles, 12 waves -- the whole N per
+  // workgroup, so the A rows are staged once instead of three times and a wave issues 5.3 instead of 8 LDS-DMA instructions per
+  // 32 MFMAs (the staging cost is issue time in the wave)
+  // ... when its tiles fit ONE round of one workgroup per CU: 197 tiles (teacher, M = 25216) run 12-17 % faster than on the
+  // 128x128 kernel; 345 tiles (student: a second round of 89) are slower, and so is a split into whole rounds here + the rest on
+  // the 128x128 kernel (fc2 forward 92-98 against 83-86 us; tools/lab/nt_variants.py).  LAFS_NT_WIDE=0 switches it off (A/B).
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID_F32) {
+    static const bool wide_on = [] { const char* v = getenv("LAFS_NT_WIDE"); return v == nullptr || v[0] != '0'; }();
+    const int mt = ceil_div(a.M, 128);
+    if (wide_on && bk64 && splits == 1 && a.N % 384 == 0 && mt >= 160 && mt <= 256) {
+      hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 6>), dim3((unsigned)(mt * (a.N / 384)), 1, 1), dim3(768), 0, s, a);
+      LAFS_LAUNCH_CHECK();
+      return LAFS_OK;
+    }
+  }
   if (wm == 4) {
     if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 64>), dim3((unsigned)t4 / splits, 1, splits), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32>), dim3((unsigned)t4 / splits, 1, splits), dim3(512),

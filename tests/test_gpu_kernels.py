@@ -34,7 +34,8 @@ def test_lds_transpose_read_model():
     assert torch.equal(got, exp), f"transpose-read model mismatch:\n{got[:20]}"
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (197 * 3, 1152, 384), (640, 1000, 256)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (197 * 3, 1152, 384), (640, 1000, 256),
+                                   (128 * 196 + 7, 384, 1536)])      # the last one: 128x384 / 12-wave tiles for the plain and residual epilogues
 def test_gemm_nt_epilogues(M, N, K):
     A, B = rnd_bf(M, K, seed=1), rnd_bf(N, K, scale=0.1, seed=2)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
