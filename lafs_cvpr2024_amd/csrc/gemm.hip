@@ -746,7 +746,7 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID_F32) {
     static const bool wide_on = [] { const char* v = getenv("LAFS_NT_WIDE"); return v == nullptr || v[0] != '0'; }();
     const int mt = ceil_div(a.M, 128);
-    if (wide_on && bk64 && splits == 1 && a.N % 384 == 0 && mt >= 160 && mt <= 256) {
+    if (wide_on && bk64 && splits == 1 && a.N % 384 == 0 && mt * (a.N / 384) >= 160 && mt * (a.N / 384) <= 256) {
       hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 6>), dim3((unsigned)(mt * (a.N / 384)), 1, 1), dim3(768), 0, s, a);
       LAFS_LAUNCH_CHECK();
       return LAFS_OK;
