@@ -354,6 +354,9 @@ def main():
             "step_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
             "step_mfma_frac": round(fl / (ms * 1e-3) / 2.5e15, 4),
             "final_loss": round(loss_v, 4), "debug_flags": dbg,
+            # routing / scheduling knobs of the library and the engine that were set in the environment (none of them changes results;
+            # an empty object = the shipped configuration)
+            "lafs_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LAFS_") and k != "LAFS_BENCH_SHARE_GPU"},
         }
         hb = step_hbm_bytes()
         if hb is not None:                           # measured HBM bytes of one step (committed PMC profile) over this run's time
