@@ -83,9 +83,14 @@ typedef struct lafs_gemm_nt_args {
   float drop_p; uint32_t drop_seed; /* element dropout (0 = off): on the linear's output before the residual add
                                       (RESID_F32), on GELU(u) (BF16_GELU: C2 only), and its backward (DGELU_BF16).
                                       Counter-based mask of (drop_seed, row, col): see lafs_debug_dropout_mask.       */
-  int act;                         /* BF16_ACT: LAFS_ACT_*                         */
+  int act;                         /* BF16_ACT: LAFS_ACT_*.  BF16_GELU / DGELU_BF16: LAFS_GELU_SAVE_GRAD (see below) */
 } lafs_gemm_nt_args;
 
+/* act = LAFS_GELU_SAVE_GRAD with LAFS_EPI_BF16_GELU: C receives gelu'(u) (bf16) instead of the pre-activation u; with
+ * LAFS_EPI_DGELU_BF16: aux holds that gelu'(u) and is multiplied in as it is.  The backward of Mlp (vision_transformer.py:59-65)
+ * needs u only through gelu'(u): saved this way, the derivative's exponential / reciprocal are the forward's (shared with
+ * gelu(u)) and the GELU' epilogue of the input gradient is one multiply per value. */
+#define LAFS_GELU_SAVE_GRAD 1
 /* C[M,N] = A[M,K] * B[N,K]^T with a fused epilogue. */
 /* Number of K slices a request for `splits` actually produces (slices are whole pipeline stages): the image count of a
  * K-split LAFS_EPI_F32 GEMM. */

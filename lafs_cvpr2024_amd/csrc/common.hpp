@@ -71,6 +71,17 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * (0.39894228040143268f * e);
 }
 
+// gelu(x) and gelu'(x) together (one v_exp, one v_rcp): the fc1 epilogue that saves gelu'(u) for the backward instead of u
+__device__ __forceinline__ void gelu_both_f(float x, float& g, float& dg) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);               // exp(-x^2 / 2)
+  const float cdf = 0.5f + 0.5f * copysignf(1.0f - poly * e, x);
+  g = x * cdf;
+  dg = cdf + x * (0.39894228040143268f * e);
+}
+
 // ---- element dropout (nn.Dropout of Part-fViT, face_pre_pro/ViT_face.py:131-133,150-153,614): counter-based mask, so
 // the backward kernels regenerate exactly the forward's mask from (seed, row, col) instead of storing it.
 // keep <=> mix32(row * n_cols + col, seed) >= thresh, thresh = p * 2^32; kept values are scaled by 1/(1-p).

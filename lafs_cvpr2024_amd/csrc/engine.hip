@@ -113,9 +113,9 @@ int check_desc(const lafs_trunk_desc* d) {
 int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
          hipStream_t s, void* C2 = nullptr, int ldc2 = 0, const float* resid = nullptr, int ldr = 0,
          const float* seq_scale = nullptr, const int32_t* row2seq = nullptr, const void* aux = nullptr, int ldaux = 0,
-         float drop_p = 0.f, uint32_t drop_seed = 0) {
+         float drop_p = 0.f, uint32_t drop_seed = 0, int act = 0) {
   lafs_gemm_nt_args g = {};
-  g.drop_p = drop_p; g.drop_seed = drop_seed;
+  g.drop_p = drop_p; g.drop_seed = drop_seed; g.act = act;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.epilogue = epi;
   g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.seq_scale = seq_scale; g.row2seq = row2seq; g.aux = aux; g.ldaux = ldaux; g.splits = 1;
@@ -164,9 +164,11 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
     RUN(gemm(b.o, I, sh + o.w_proj, I, T, D, I, LAFS_EPI_RESID_F32, b.x1, D, d->master + o.b_proj, stream, nullptr, 0, cur, D, sa,
              d->row2seq, nullptr, 0, dp, ds + 0));
     RUN(lafs_layernorm_fwd(b.x1, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2, D, nullptr, 0, b.st2, T, D, stream));
-    // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2)
+    // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
+    // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
+    // becomes one multiply per value
     RUN(gemm(b.h2, D, sh + o.w_fc1, D, T, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u : nullptr, M, d->master + o.b_fc1, stream,
-             b.a, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1));
+             b.a, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD));
     RUN(gemm(b.a, M, sh + o.w_fc2, M, T, D, M, LAFS_EPI_RESID_F32, nxt, D, d->master + o.b_fc2, stream, nullptr, 0, b.x1, D, sm,
              d->row2seq, nullptr, 0, dp, ds + 2));
     cur = nxt;
@@ -223,7 +225,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     if (two && l + 2 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 2], 0);     // parity buffers free again
     // ---- MLP branch ----
     RUN(gemm(s.gbm[p], D, sht + o.w_fc2_t, D, T, M, D, LAFS_EPI_DGELU_BF16, s.du[p], M, nullptr, stream, nullptr, 0, nullptr, 0, nullptr,
-             nullptr, b.u, M, dp, dseed(l, 1)));
+             nullptr, b.u, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD));
     RUN(gemm(s.du[p], M, sht + o.w_fc1_t, M, T, D, M, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, b.x1, D, b.st2, d->master + o.ln2_g, g, D, 1, s.gba[p], D, scale(l, 0), d->row2seq,
                            gr + o.ln2_g, gr + o.ln2_b, T, D, dp, dseed(l, 0), stream));

@@ -397,11 +397,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
           const bf16_t* ax = p.aux + (size_t)m * p.ldaux + n;
           if (full) {
             const uint4 a4 = cur[q];
-            w[0] *= gelu_grad_f(bf_lo(a4.x)); w[1] *= gelu_grad_f(bf_hi(a4.x)); w[2] *= gelu_grad_f(bf_lo(a4.y)); w[3] *= gelu_grad_f(bf_hi(a4.y));
-            w[4] *= gelu_grad_f(bf_lo(a4.z)); w[5] *= gelu_grad_f(bf_hi(a4.z)); w[6] *= gelu_grad_f(bf_lo(a4.w)); w[7] *= gelu_grad_f(bf_hi(a4.w));
+            if (p.act == LAFS_GELU_SAVE_GRAD) {                  // aux already holds gelu'(u)
+              w[0] *= bf_lo(a4.x); w[1] *= bf_hi(a4.x); w[2] *= bf_lo(a4.y); w[3] *= bf_hi(a4.y);
+              w[4] *= bf_lo(a4.z); w[5] *= bf_hi(a4.z); w[6] *= bf_lo(a4.w); w[7] *= bf_hi(a4.w);
+            } else {
+              w[0] *= gelu_grad_f(bf_lo(a4.x)); w[1] *= gelu_grad_f(bf_hi(a4.x)); w[2] *= gelu_grad_f(bf_lo(a4.y)); w[3] *= gelu_grad_f(bf_hi(a4.y));
+              w[4] *= gelu_grad_f(bf_lo(a4.z)); w[5] *= gelu_grad_f(bf_hi(a4.z)); w[6] *= gelu_grad_f(bf_lo(a4.w)); w[7] *= gelu_grad_f(bf_hi(a4.w));
+            }
           } else {
 #pragma unroll
-            for (int e = 0; e < VPL; ++e) if (n + e < p.N) w[e] *= gelu_grad_f(bf2f(ax[e]));
+            for (int e = 0; e < VPL; ++e) if (n + e < p.N) w[e] *= (p.act == LAFS_GELU_SAVE_GRAD) ? bf2f(ax[e]) : gelu_grad_f(bf2f(ax[e]));
           }
           if (p.drop.thresh) {                                     // d(dropout(gelu(u))): the forward's mask, regenerated
 #pragma unroll
@@ -421,6 +426,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
         if (EPI == EPI_BF16_GELU && DBG(p, 16384)) c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc * 2 + (n >> 5) * 64 + (n & 31);
         if (EPI == EPI_BF16_GELU && (p.C == nullptr || !do_first)) {
           // forward-only pass (teacher): the pre-activation is not needed, only GELU(u) is written; second pass: already stored
+        } else if (EPI == EPI_BF16_GELU && p.act == LAFS_GELU_SAVE_GRAD) {        // the first tensor is gelu'(u), not u
+#pragma unroll
+          for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) c[e] = f2bf(gelu_grad_f(w[e]));
         } else if (full) {
           st16(c, pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]), ntst);
         } else {

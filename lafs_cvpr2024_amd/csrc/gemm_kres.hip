@@ -53,6 +53,7 @@ struct KArgs {
   const float* seq_scale; const int* row2seq;
   const bf16_t* aux; int ldaux;
   int cbn, items;                          // 64-column blocks per row unit; row units x column blocks
+  int save_grad;                           // LAFS_GELU_SAVE_GRAD: GELU epilogue stores gelu'(u) for u / GELU' epilogue multiplies aux in as it is
   unsigned long long* stamps;              // lab (ABL & 32): per workgroup {wait + barrier, issue, MFMA loop, epilogue, whole run, stages, reload wait, reloads} cycles of wave 0
 };
 // ABL (template argument, 0 in the library; tools/lab/lab_kres.cpp instantiates others): timing ablations and variants
@@ -354,11 +355,30 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
             v[g][4] = acc[g][1][b][0] + b1.x; v[g][5] = acc[g][1][b][1] + b1.y; v[g][6] = acc[g][1][b][2] + b1.z; v[g][7] = acc[g][1][b][3] + b1.w;
             if (EPI == LAFS_EPI_DGELU_BF16 && !KABL(8)) {
               const uint4 a4 = pre[g * 2 + b];
-              v[g][0] *= gelu_grad_f(bf_lo(a4.x)); v[g][1] *= gelu_grad_f(bf_hi(a4.x)); v[g][2] *= gelu_grad_f(bf_lo(a4.y)); v[g][3] *= gelu_grad_f(bf_hi(a4.y));
-              v[g][4] *= gelu_grad_f(bf_lo(a4.z)); v[g][5] *= gelu_grad_f(bf_hi(a4.z)); v[g][6] *= gelu_grad_f(bf_lo(a4.w)); v[g][7] *= gelu_grad_f(bf_hi(a4.w));
+              if (p.save_grad) {                         // aux already holds gelu'(u)
+                v[g][0] *= bf_lo(a4.x); v[g][1] *= bf_hi(a4.x); v[g][2] *= bf_lo(a4.y); v[g][3] *= bf_hi(a4.y);
+                v[g][4] *= bf_lo(a4.z); v[g][5] *= bf_hi(a4.z); v[g][6] *= bf_lo(a4.w); v[g][7] *= bf_hi(a4.w);
+              } else {
+                v[g][0] *= gelu_grad_f(bf_lo(a4.x)); v[g][1] *= gelu_grad_f(bf_hi(a4.x)); v[g][2] *= gelu_grad_f(bf_lo(a4.y)); v[g][3] *= gelu_grad_f(bf_hi(a4.y));
+                v[g][4] *= gelu_grad_f(bf_lo(a4.z)); v[g][5] *= gelu_grad_f(bf_hi(a4.z)); v[g][6] *= gelu_grad_f(bf_lo(a4.w)); v[g][7] *= gelu_grad_f(bf_hi(a4.w));
+              }
             }
           }
-          if (EPI != LAFS_EPI_BF16_GELU || HAS_U) {
+          float dv[2][8];                                // GELU epilogue saving gelu'(u): value and derivative from one exp / rcp
+          const bool both = (EPI == LAFS_EPI_BF16_GELU) && HAS_U && p.save_grad && !KABL(8);
+          if (both) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { float gv; gelu_both_f(v[g][e], gv, dv[g][e]); v[g][e] = gv; }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int n = n0 + 32 * g + 8 * q;
+              if (rowok) st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n, pack_bf2(dv[g][0], dv[g][1]), pack_bf2(dv[g][2], dv[g][3]),
+                              pack_bf2(dv[g][4], dv[g][5]), pack_bf2(dv[g][6], dv[g][7]));
+            }
+          }
+          if ((EPI != LAFS_EPI_BF16_GELU || HAS_U) && !both) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
               const int n = n0 + 32 * g + 8 * q;
@@ -369,7 +389,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
             }
           }
           if (EPI == LAFS_EPI_BF16_GELU) {
-            if (!KABL(8)) {
+            if (!KABL(8) && !both) {
 #pragma unroll
               for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -442,6 +462,7 @@ int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_overrid
   a.resid = g->resid; a.ldr = g->ldr; a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
   a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux;
   a.cbn = g->N / 64;
+  a.save_grad = (g->act == LAFS_GELU_SAVE_GRAD && (e == LAFS_EPI_BF16_GELU || e == LAFS_EPI_DGELU_BF16)) ? 1 : 0;
   a.stamps = stamps;
 
   const int mus = (g->M + 127) / 128;

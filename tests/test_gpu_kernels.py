@@ -60,6 +60,13 @@ def test_gemm_nt_epilogues(M, N, K):
     F.gelu(x).sum().backward()
     out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV))
     assert relerr(out.float(), (A.float() @ B.float().t()) * x.grad) < 1e-2
+    # LAFS_GELU_SAVE_GRAD: the forward stores gelu'(u) in place of u, the backward multiplies it in as it is
+    xr = ref.clone().requires_grad_(True)
+    F.gelu(xr).sum().backward()
+    ug, a2 = ops.gemm_nt(Ad, Bd, _lib.EPI_BF16_GELU, bias=bd, act=1)
+    assert relerr(ug.float(), xr.grad) < 1e-2 and torch.equal(a2, a)
+    out2 = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=ug, act=1)
+    assert relerr(out2.float(), (A.float() @ B.float().t()) * ug.float().cpu()) < 1e-2
     # split-K atomics
     out = ops.gemm_nt(Ad, Bd, _lib.EPI_ATOMIC_F32, splits=2)
     assert relerr(out, A.float() @ B.float().t()) < 2e-5 * math.sqrt(K)
@@ -103,6 +110,13 @@ def test_gemm_nt_k_resident_kernel(M, N):
     assert ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV), route_only=True) == 1
     out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV))
     assert relerr(out.float(), (A.float() @ B.float().t()) * x.grad) < 1e-2
+    # LAFS_GELU_SAVE_GRAD (what the trunk uses): gelu'(u) saved by the forward, multiplied in by the backward
+    xr = ref.clone().requires_grad_(True)
+    F.gelu(xr).sum().backward()
+    ug, a3 = ops.gemm_nt(Ad, Bd, _lib.EPI_BF16_GELU, bias=bd, act=1)
+    assert relerr(ug.float(), xr.grad) < 1e-2 and relerr(a3.float(), F.gelu(ref)) < 1e-2
+    out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=ug, act=1)
+    assert relerr(out.float(), (A.float() @ B.float().t()) * ug.float().cpu()) < 1e-2
     # a K split in two slices keeps a request off the K-resident route
     assert ops.gemm_nt(Ad, Bd, _lib.EPI_F32, splits=2, route_only=True) == 0
 
