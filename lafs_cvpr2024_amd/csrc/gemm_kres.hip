@@ -78,7 +78,7 @@ __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float 
 // memory operations of one item besides its LDS-DMA: S stores (active waves only) + P epilogue-operand loads
 template <int EPI, bool HAS_U> struct EpiOps {
   static constexpr bool F32 = (EPI == LAFS_EPI_RESID_F32);
-  static constexpr int S = F32 ? 8 : ((EPI == LAFS_EPI_BF16_GELU && HAS_U) ? 8 : 4);
+  static constexpr int S = F32 ? 8 : ((EPI == LAFS_EPI_BF16_GELU && HAS_U) ? 8 : 4);      // (HAS_U of the GELU' variants: see AUX_IS_GRAD)
   static constexpr int P = F32 ? 8 : ((EPI == LAFS_EPI_DGELU_BF16) ? 4 : 0);
 };
 
@@ -89,6 +89,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
   constexpr bool F32 = EpiOps<EPI, HAS_U>::F32;
   // epilogue operand fetched one item ahead (GELU': its load latency no longer sits in front of the epilogue math); the
   // residual epilogue fetches within the item -- a second 32-register buffer does not fit beside its other state
+  // GELU' variants: HAS_U = false means that aux already holds gelu'(u) (LAFS_GELU_SAVE_GRAD): no derivative math in the epilogue
+  constexpr bool AUX_IS_GRAD = (EPI == LAFS_EPI_DGELU_BF16) && !HAS_U;
   constexpr bool AHEAD = (EPI == LAFS_EPI_DGELU_BF16) && KABL(2048);   // (lab only: beside the staged reload the second operand buffer spills)
   // resident rows (re)loaded through the ring buffers (the GELU' variant has no registers to spare for that code path: it keeps
   // the per-lane loads)
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
             v[g][4] = acc[g][1][b][0] + b1.x; v[g][5] = acc[g][1][b][1] + b1.y; v[g][6] = acc[g][1][b][2] + b1.z; v[g][7] = acc[g][1][b][3] + b1.w;
             if (EPI == LAFS_EPI_DGELU_BF16 && !KABL(8)) {
               const uint4 a4 = pre[g * 2 + b];
-              if (p.save_grad) {                         // aux already holds gelu'(u)
+              if constexpr (AUX_IS_GRAD) {               // aux already holds gelu'(u)
                 v[g][0] *= bf_lo(a4.x); v[g][1] *= bf_hi(a4.x); v[g][2] *= bf_lo(a4.y); v[g][3] *= bf_hi(a4.y);
                 v[g][4] *= bf_lo(a4.z); v[g][5] *= bf_hi(a4.z); v[g][6] *= bf_lo(a4.w); v[g][7] *= bf_hi(a4.w);
               } else {
@@ -478,7 +480,8 @@ int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_overrid
     case LAFS_EPI_BF16_GELU:
       return g->C != nullptr ? launch<LAFS_EPI_BF16_GELU, true, ABL>(a, grid, stream) : launch<LAFS_EPI_BF16_GELU, false, ABL>(a, grid, stream);
     case LAFS_EPI_RESID_F32: return launch<LAFS_EPI_RESID_F32, true, ABL>(a, grid, stream);
-    default: return launch<LAFS_EPI_DGELU_BF16, true, ABL>(a, grid, stream);
+    default:
+      return a.save_grad ? launch<LAFS_EPI_DGELU_BF16, false, ABL>(a, grid, stream) : launch<LAFS_EPI_DGELU_BF16, true, ABL>(a, grid, stream);
   }
 }
 }  // namespace
