@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // NW waves per workgroup: the gamma/beta sums cost one atomic per column and WORKGROUP, and 1024 workgroups x 768 same-address
 // atomics were ~15 us of the 75 us call at the ViT-S shape; 16-wave workgroups keep the 4096 waves in flight with a quarter of
 // the atomics.
-template <int NI, int NW>
+template <int NI, int NW, bool DYF>
 __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ dyf,
                                                     int lddyf, const float* __restrict__ x, int ldx,
                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -76,21 +76,42 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int row = blockIdx.x * NW + wave; row < rows; row += gridDim.x * NW) {
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  // One row per wave and trip; the NEXT row's operands (x, dy, the gradient stream it accumulates into, statistics) are requested
+  // before this row's reductions, so a wave keeps two rows of loads in flight instead of one (the kernel is latency-bound on
+  // its 16 waves per CU otherwise).
+  struct RowIn { float4 xv[NI], df[DYF ? NI : 1], old[NI]; uint2 dw[DYF ? 1 : NI]; float mean, rstd, sc; };  // (dy stays packed until used)
+  auto load_row = [&](int row, RowIn& r) {
+    r.mean = stats[2 * row]; r.rstd = stats[2 * row + 1];
+    r.sc = (seq_scale != nullptr) ? seq_scale[row2seq[row]] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane * 4 + 256 * i;
+      if (c < D) {
+        r.xv[i] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
+        if constexpr (DYF) r.df[i] = *reinterpret_cast<const float4*>(dyf + (size_t)row * lddyf + c);
+        else r.dw[i] = *reinterpret_cast<const uint2*>(dy + (size_t)row * lddy + c);
+        r.old[i] = accumulate ? *reinterpret_cast<const float4*>(g_io + (size_t)row * ldg + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  const int stride = gridDim.x * NW;
+  int row = blockIdx.x * NW + wave;
+  RowIn cur;
+  if (row < rows) load_row(row, cur);
+  for (; row < rows; row += stride) {
+    RowIn nxt;
+    const bool more = row + stride < rows;              // (wave-uniform)
+    if (more) load_row(row + stride, nxt);
+    const float mean = cur.mean, rstd = cur.rstd;
     float4 xh[NI], d[NI];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = lane * 4 + 256 * i;
       if (c < D) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
-        if (dyf != nullptr) {
-          d[i] = *reinterpret_cast<const float4*>(dyf + (size_t)row * lddyf + c);
-        } else {
-          const uint2 w = *reinterpret_cast<const uint2*>(dy + (size_t)row * lddy + c);
-          d[i] = make_float4(bf_lo(w.x), bf_hi(w.x), bf_lo(w.y), bf_hi(w.y));
-        }
+        const float4 xv = cur.xv[i];
+        if constexpr (DYF) d[i] = cur.df[i];
+        else d[i] = make_float4(bf_lo(cur.dw[i].x), bf_hi(cur.dw[i].x), bf_lo(cur.dw[i].y), bf_hi(cur.dw[i].y));
         xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
         ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
         ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
@@ -102,7 +123,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
       }
     }
     const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
-    const float sc = (seq_scale != nullptr) ? seq_scale[row2seq[row]] : 1.0f;
+    const float sc = cur.sc;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = lane * 4 + 256 * i;
@@ -110,10 +131,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
         float4 o = make_float4(rstd * (d[i].x - m1 - xh[i].x * m2), rstd * (d[i].y - m1 - xh[i].y * m2),
                                rstd * (d[i].z - m1 - xh[i].z * m2), rstd * (d[i].w - m1 - xh[i].w * m2));
         float* gp = g_io + (size_t)row * ldg + c;
-        if (accumulate) {
-          const float4 old = *reinterpret_cast<const float4*>(gp);
-          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
-        }
+        o.x += cur.old[i].x; o.y += cur.old[i].y; o.z += cur.old[i].z; o.w += cur.old[i].w;
         *reinterpret_cast<float4*>(gp) = o;
         if (gb != nullptr) {
           float4 q = make_float4(sc * o.x, sc * o.y, sc * o.z, sc * o.w);
@@ -125,6 +143,7 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
         }
       }
     }
+    if (more) cur = nxt;
   }
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {               // gamma sums, then beta sums, through the same LDS image
@@ -199,13 +218,13 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     default: hipLaunchKernelGGL(KERNEL<8>, grid, dim3(256), 0, stream, __VA_ARGS__); break;       \
   }
 
-#define LN_BWD_DISPATCH(NI_, ...)                                                                             \
+#define LN_BWD_DISPATCH(NI_, DYF_, ...)                                                                       \
   switch (NI_) {                                                                                              \
-    case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 16>), grid, dim3(1024), 0, stream, __VA_ARGS__); break;      \
-    case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 16>), grid, dim3(1024), 0, stream, __VA_ARGS__); break;      \
-    case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 8>), grid, dim3(512), 0, stream, __VA_ARGS__); break;        \
-    case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, 8>), grid, dim3(512), 0, stream, __VA_ARGS__); break;        \
-    default: hipLaunchKernelGGL((ln_bwd_kernel<8, 4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;       \
+    case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 16, DYF_>), grid, dim3(1024), 0, stream, __VA_ARGS__); break; \
+    case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 16, DYF_>), grid, dim3(1024), 0, stream, __VA_ARGS__); break; \
+    case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 8, DYF_>), grid, dim3(512), 0, stream, __VA_ARGS__); break;  \
+    case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, 8, DYF_>), grid, dim3(512), 0, stream, __VA_ARGS__); break;  \
+    default: hipLaunchKernelGGL((ln_bwd_kernel<8, 4, DYF_>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
   }
 
 extern "C" int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, const float* beta, float eps,
@@ -236,8 +255,13 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
   int blocks = ceil_div(rows, nw);
   if (blocks > 4096 / nw) blocks = 4096 / nw;
   const dim3 grid(blocks);
-  LN_BWD_DISPATCH(ni, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
-              (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D, make_drop(drop_p, drop_seed));
+  if (dy_f32 != nullptr) {
+    LN_BWD_DISPATCH(ni, true, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
+                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D, make_drop(drop_p, drop_seed));
+  } else {
+    LN_BWD_DISPATCH(ni, false, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
+                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D, make_drop(drop_p, drop_seed));
+  }
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
