@@ -192,11 +192,18 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     }
     fence();
   };
+  // The accumulators of a stage start from the bias of their four columns (LDS reads issued a phase ahead -- before the wait and
+  // barrier in front of the item's first stage, before the first stage's MFMAs for the second -- straight into the registers the
+  // MFMAs accumulate in): no zero fill, no bias add, and no LDS latency exposed at the head of the epilogue.
+  auto bias_init = [&](f32x4_t (&a)[2][2], int n0, int g) {
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int n = F32 ? n0 + 16 * (2 * g + gi) + 4 * q : n0 + 32 * g + 8 * q + 4 * gi;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) a[gi][b] = *reinterpret_cast<const f32x4_t*>(sbias + n);
+    }
+  };
   auto mfma_stage = [&](int stage, f32x4_t (&a)[2][2]) {            // 48 MFMAs on one ring stage
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) a[gi][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* st = smem + stage * STAGE;
 #pragma unroll
@@ -244,6 +251,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     const bool reloaded_lab = (mu != cur_mu);
     // the stages of the NEXT item are issued from this one unless it starts a new row unit (its rows go through the ring first)
     const bool feed_next = (it + 1 < ie) && ((it + 1) / cbn == mu);
+    bias_init(acc[0], cb * 64, 0);
     // ---------------- first stage of the item
     if (mu != cur_mu) {                               // new row unit: (re)load the resident operand
       cur_mu = mu;
@@ -294,6 +302,7 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
     }
     if (feed_next) issue(k0 + 2);
     if (AHEAD) fetch(it + 1, nxt);                    // P loads, consumed by the NEXT item's epilogue
+    bias_init(acc[1], cb * 64, 1);
     lap(1);
     mfma_stage(stage, acc[0]);
     stage = (stage + 1 == NSTG) ? 0 : stage + 1;
@@ -337,9 +346,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
           for (int x = 0; x < 4; ++x) {                // x = stage * 2 + row group: 16 columns each
             const int g = x >> 1, gi = x & 1;
             const int n = n0 + 16 * x + 4 * q;
-            const float4 b4 = *reinterpret_cast<const float4*>(sbias + n);
             const uint4 r4 = pre[x * 2 + b];
-            float v0 = acc[g][gi][b][0] + b4.x, v1 = acc[g][gi][b][1] + b4.y, v2 = acc[g][gi][b][2] + b4.z, v3 = acc[g][gi][b][3] + b4.w;
+            float v0 = acc[g][gi][b][0], v1 = acc[g][gi][b][1], v2 = acc[g][gi][b][2], v3 = acc[g][gi][b][3];
             if (!KABL(8)) {
               v0 = __uint_as_float(r4.x) + sc[b] * v0; v1 = __uint_as_float(r4.y) + sc[b] * v1;
               v2 = __uint_as_float(r4.z) + sc[b] * v2; v3 = __uint_as_float(r4.w) + sc[b] * v3;
@@ -351,10 +359,8 @@ __global__ __launch_bounds__(NTH, 2) void gemm_kres_kernel(KArgs p) {
           float v[2][8];
 #pragma unroll
           for (int g = 0; g < 2; ++g) {
-            const int n = n0 + 32 * g + 8 * q;
-            const float4 b0 = *reinterpret_cast<const float4*>(sbias + n), b1 = *reinterpret_cast<const float4*>(sbias + n + 4);
-            v[g][0] = acc[g][0][b][0] + b0.x; v[g][1] = acc[g][0][b][1] + b0.y; v[g][2] = acc[g][0][b][2] + b0.z; v[g][3] = acc[g][0][b][3] + b0.w;
-            v[g][4] = acc[g][1][b][0] + b1.x; v[g][5] = acc[g][1][b][1] + b1.y; v[g][6] = acc[g][1][b][2] + b1.z; v[g][7] = acc[g][1][b][3] + b1.w;
+            v[g][0] = acc[g][0][b][0]; v[g][1] = acc[g][0][b][1]; v[g][2] = acc[g][0][b][2]; v[g][3] = acc[g][0][b][3];
+            v[g][4] = acc[g][1][b][0]; v[g][5] = acc[g][1][b][1]; v[g][6] = acc[g][1][b][2]; v[g][7] = acc[g][1][b][3];
             if (EPI == LAFS_EPI_DGELU_BF16 && !KABL(8)) {
               const uint4 a4 = pre[g * 2 + b];
               if constexpr (AUX_IS_GRAD) {               // aux already holds gelu'(u)
