@@ -19,34 +19,60 @@ __device__ __forceinline__ void online(float& m, float& s, float v) {
 }
 
 // stats[row] = {max, lse} of (x[row,:] - center) * inv_temp   (center may be NULL)
+// Four float4 per thread and trip (independent loads), one running (max, sum) update per 16 values in the log2 domain: one
+// v_exp per value plus one per trip (the per-value online update it replaces took a compare and up to two exponentials).
 __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int ld, const float* __restrict__ center,
                                                        float inv_temp, const float* __restrict__ dtemp, int K,
                                                        float* __restrict__ stats) {
   __shared__ float sm[4], ss[4];
   if (dtemp != nullptr) inv_temp = 1.0f / dtemp[0];
+  const float sc = inv_temp * 1.4426950408889634f;    // natural -> log2 domain
   const int row = blockIdx.x;
   const float* xr = x + (size_t)row * ld;
   float m = -INFINITY, s = 0.f;
   const int K4 = K >> 2;
-  for (int i = threadIdx.x; i < K4; i += 256) {
-    float4 v = reinterpret_cast<const float4*>(xr)[i];
-    if (center != nullptr) {
-      const float4 c = reinterpret_cast<const float4*>(center)[i];
-      v.x -= c.x; v.y -= c.y; v.z -= c.z; v.w -= c.w;
+  for (int i = threadIdx.x; i < K4; i += 1024) {
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ii = i + 256 * j;
+      if (ii < K4) {
+        v[j] = reinterpret_cast<const float4*>(xr)[ii];
+        if (center != nullptr) {
+          const float4 c = reinterpret_cast<const float4*>(center)[ii];
+          v[j].x -= c.x; v[j].y -= c.y; v[j].z -= c.z; v[j].w -= c.w;
+        }
+        v[j].x *= sc; v[j].y *= sc; v[j].z *= sc; v[j].w *= sc;
+      } else {
+        v[j] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
     }
-    online(m, s, v.x * inv_temp); online(m, s, v.y * inv_temp); online(m, s, v.z * inv_temp); online(m, s, v.w * inv_temp);
+    float bm = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));        // (j = 0 is always in range: bm is finite)
+#pragma unroll
+    for (int j = 1; j < 4; ++j) bm = fmaxf(bm, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+    const float mn = fmaxf(m, bm);
+    float add = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      add += __builtin_amdgcn_exp2f(v[j].x - mn) + __builtin_amdgcn_exp2f(v[j].y - mn) + __builtin_amdgcn_exp2f(v[j].z - mn) +
+             __builtin_amdgcn_exp2f(v[j].w - mn);
+    s = s * __builtin_amdgcn_exp2f(m - mn) + add;
+    m = mn;
   }
   for (int k = (K4 << 2) + threadIdx.x; k < K; k += 256) {
     float v = xr[k];
     if (center != nullptr) v -= center[k];
-    online(m, s, v * inv_temp);
+    v *= sc;
+    const float mn = fmaxf(m, v);
+    s = s * __builtin_amdgcn_exp2f(m - mn) + __builtin_amdgcn_exp2f(v - mn);
+    m = mn;
   }
   // combine (m, s) pairs: wave, then block
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float mo = __shfl_xor(m, o, 64), so = __shfl_xor(s, o, 64);
     const float mn = fmaxf(m, mo);
-    s = (mn == -INFINITY) ? 0.f : s * __expf(m - mn) + so * __expf(mo - mn);
+    s = (mn == -INFINITY) ? 0.f : s * __builtin_amdgcn_exp2f(m - mn) + so * __builtin_amdgcn_exp2f(mo - mn);
     m = mn;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -55,9 +81,9 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict_
   if (threadIdx.x == 0) {
     float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
     float S = 0.f;
-    for (int w = 0; w < 4; ++w) if (sm[w] != -INFINITY) S += ss[w] * __expf(sm[w] - M);
-    stats[2 * row] = M;
-    stats[2 * row + 1] = M + __logf(S);
+    for (int w = 0; w < 4; ++w) if (sm[w] != -INFINITY) S += ss[w] * __builtin_amdgcn_exp2f(sm[w] - M);
+    stats[2 * row] = M * 0.6931471805599453f;
+    stats[2 * row + 1] = (M + __log2f(S)) * 0.6931471805599453f;
   }
 }
 
@@ -123,40 +149,54 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
         part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
 }
 
-__global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ s_stats, const float* __restrict__ dots, int ncrops,
-                                                        int B, int nchunks, float* __restrict__ loss) {
-  __shared__ float red[4];
+// One workgroup of 1024 threads; thread j owns one (sample b, crop v) in the order the partial dot products are stored
+// ([chunk][b][v]: coalesced), fourteen chunks in flight per trip (the former one-(v, b)-per-thread loop over strided
+// addresses was a chain of ~100 dependent-latency loads: 52 us on the step's critical path).
+__global__ __launch_bounds__(1024) void loss_final_kernel(const float* __restrict__ s_stats, const float* __restrict__ dots, int ncrops,
+                                                         int B, int nchunks, float* __restrict__ loss) {
+  __shared__ float red[16];
   float acc = 0.f;
-  for (int i = threadIdx.x; i < ncrops * B; i += 256) {
-    const int v = i / B, b = i % B;
+  const int n = ncrops * B;
+  for (int j = threadIdx.x; j < n; j += 1024) {
+    const int b = j / ncrops, v = j - b * ncrops;
     float d = 0.f;
-    for (int c = 0; c < nchunks; ++c) d += dots[((size_t)c * B + b) * ncrops + v];
-    acc += ((v < 2) ? 1.f : 2.f) * s_stats[2 * i + 1] - d;
+    int c = 0;
+    for (; c + 14 <= nchunks; c += 14) {
+      float t[14];
+#pragma unroll
+      for (int u = 0; u < 14; ++u) t[u] = dots[(size_t)(c + u) * n + j];
+#pragma unroll
+      for (int u = 0; u < 14; ++u) d += t[u];
+    }
+    for (; c < nchunks; ++c) d += dots[(size_t)c * n + j];
+    acc += ((v < 2) ? 1.f : 2.f) * s_stats[2 * (v * B + b) + 1] - d;
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)((2 * ncrops - 2) * B);
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    loss[0] = t / (float)((2 * ncrops - 2) * B);
+  }
 }
 
-// out[k] = sum_r x[r, k]; thread owns 4 classes
+// out[k] = sum_r x[r, k]; thread owns one class (a wave reads 256 contiguous bytes of a row), eight rows in flight
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ x, int ld, int rows, int K, float* __restrict__ out) {
-  const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+  const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= K) return;
-  if (k + 4 <= K) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < rows; ++r) {
-      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ld + k);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    *reinterpret_cast<float4*>(out + k) = a;
-  } else {
-    for (int e = 0; k + e < K; ++e) {
-      float a = 0.f;
-      for (int r = 0; r < rows; ++r) a += x[(size_t)r * ld + k + e];
-      out[k + e] = a;
-    }
+  const float* xc = x + k;
+  float a = 0.f;
+  int r = 0;
+  for (; r + 8 <= rows; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = xc[(size_t)(r + j) * ld];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a += v[j];
   }
+  for (; r < rows; ++r) a += xc[(size_t)r * ld];
+  out[k] = a;
 }
 
 __global__ __launch_bounds__(256) void center_ema_kernel(float* __restrict__ center, const float* __restrict__ colsum, int K,
@@ -196,7 +236,7 @@ extern "C" int lafs_dino_loss_fwd_bwd(const float* student, const float* teacher
   else
     hipLaunchKernelGGL(loss_grad_kernel<false>, dim3(nchunks, B), dim3(256), 0, stream, student, teacher, ld, center, ncrops, B, K, its,
                        itt, s_stats, t_stats, grad, ldg, coef, dots, dev_temps);
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, stream, s_stats, dots, ncrops, B, nchunks, loss_out);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, stream, s_stats, dots, ncrops, B, nchunks, loss_out);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -204,7 +244,7 @@ extern "C" int lafs_dino_loss_fwd_bwd(const float* student, const float* teacher
 extern "C" int lafs_colsum_f32(const float* x, int ld, int rows, int K, float* out, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && out && rows > 0 && K > 0 && ld % 4 == 0, "bad operand");
-  hipLaunchKernelGGL(colsum_f32_kernel, dim3(ceil_div(ceil_div(K, 4), 256)), dim3(256), 0, stream, x, ld, rows, K, out);
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, stream, x, ld, rows, K, out);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -44,7 +44,16 @@ __global__ __launch_bounds__(256) void seg_sumsq_kernel(const float* __restrict_
   const int seg = blockIdx.x;
   const long c0 = first_chunk_of(chunk_seg, n_chunks, seg), c1 = first_chunk_of(chunk_seg, n_chunks, seg + 1);
   float s = 0.f;
-  for (long c = c0 + threadIdx.x; c < c1; c += 256) s += chunk_sumsq[c];
+  // (the head's last layer is one segment of ~25 k chunks: eight independent loads per trip instead of a chain of 100)
+  long c = c0 + threadIdx.x;
+  for (; c + 7 * 256 < c1; c += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = chunk_sumsq[c + j * 256];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  for (; c < c1; c += 256) s += chunk_sumsq[c];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
