@@ -284,7 +284,7 @@ int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
 /* dst(bf16)[c, r] = src(f32)[r, c]   (W^T shadows used by the dgrad GEMMs) */
 int lafs_transpose_cast_bf16(const float* src, int rows, int cols, void* dst, int ld_dst, hipStream_t stream);
 /* All W^T shadows of an arena in ONE launch.  table(i64, device)[4*i..] = {src offset into master, rows, cols, dst offset
- * into shadow_t}; tile_start(i32, device)[n_mat+1] = prefix sum of each matrix's 32x32-tile count; n_tiles = tile_start[n_mat]. */
+ * into shadow_t}; tile_start(i32, device)[n_mat+1] = prefix sum of each matrix's 64x64-tile count; n_tiles = tile_start[n_mat]. */
 int lafs_transpose_cast_table(const float* master, void* shadow_t, const int64_t* table, const int32_t* tile_start,
                               int n_mat, int n_tiles, hipStream_t stream);
 

@@ -128,7 +128,7 @@ class ParamArena:
                 p = self.params[self.names.index(name)]
                 r, c = p.shape[0], p.numel() // p.shape[0]
                 rows_ += [self.offsets[name], r, c, toff]
-                n += ((r + 31) // 32) * ((c + 31) // 32)
+                n += ((r + 63) // 64) * ((c + 63) // 64)            # 64x64 tiles (lafs_transpose_cast_table)
                 starts.append(n)
             self._t_table = torch.tensor(rows_, dtype=torch.int64, device=self.device)
             self._t_starts = torch.tensor(starts, dtype=torch.int32, device=self.device)

@@ -194,27 +194,40 @@ extern "C" int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_
 
 // table[4*i + {0,1,2,3}] = {src offset (elements into master), rows, cols, dst offset (elements into shadow_t)};
 // tile_start[i] = first 32x32-tile index of matrix i (prefix sum), tile_start[n] = total tiles.
+// 64x64 tiles: a wave reads 256 contiguous bytes of four source rows and writes whole 128-byte lines of the transposed bf16
+// image (thread = one destination row piece of 8 consecutive source rows); the 32x32 form wrote 64-byte pieces (2 TB/s).
 __global__ __launch_bounds__(256) void transpose_cast_table_kernel(const float* __restrict__ master, bf16_t* __restrict__ shadow_t,
                                                                   const long* __restrict__ table, const int* __restrict__ tile_start,
                                                                   int n_mat) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[64][65];
   int lo = 0, hi = n_mat;                                  // binary search: which matrix owns this tile
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (tile_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
   const long* e = table + 4 * lo;
   const int rows = (int)e[1], cols = (int)e[2];
   const float* src = master + e[0];
   bf16_t* dst = shadow_t + e[3];
-  const int local = blockIdx.x - tile_start[lo], tcols = (cols + 31) >> 5;
-  const int c0 = (local % tcols) * 32, r0 = (local / tcols) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int j = ty; j < 32; j += 8) {
+  const int local = blockIdx.x - tile_start[lo], tcols = (cols + 63) >> 6;
+  const int c0 = (local % tcols) * 64, r0 = (local / tcols) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+  for (int j = ty; j < 64; j += 4) {
     const int r = r0 + j, c = c0 + tx;
     tile[j][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
   }
   __syncthreads();
-  for (int j = ty; j < 32; j += 8) {
-    const int c = c0 + j, r = r0 + tx;
-    if (c < cols && r < rows) dst[(size_t)c * rows + r] = f2bf(tile[tx][j]);
+  const int r8 = (threadIdx.x & 7) * 8;
+  const bool vec = ((rows & 7) == 0) && ((e[3] & 7) == 0);       // 16-byte destination pieces
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int cl = (threadIdx.x >> 3) + 32 * pass, c = c0 + cl, r = r0 + r8;
+    if (c >= cols || r >= rows) continue;
+    if (vec) {
+      *reinterpret_cast<uint4*>(dst + (size_t)c * rows + r) =
+          make_uint4(pack_bf2(tile[r8][cl], tile[r8 + 1][cl]), pack_bf2(tile[r8 + 2][cl], tile[r8 + 3][cl]),
+                     pack_bf2(tile[r8 + 4][cl], tile[r8 + 5][cl]), pack_bf2(tile[r8 + 6][cl], tile[r8 + 7][cl]));
+    } else {
+      for (int u = 0; u < 8 && r + u < rows; ++u) dst[(size_t)c * rows + r + u] = f2bf(tile[r8 + u][cl]);
+    }
   }
 }
 
