@@ -21,6 +21,8 @@
 //     (4 waves, 2 workgroups per CU, all resident at once).  An item is two ring stages (32 columns each) and one epilogue: the two
 //     stages' 64-byte pieces of a row are stored back to back and complete 128-byte lines; a wave emits 4-8 stores per item, so
 //     the memory pipeline sees a steady trickle of stores between the LDS-DMA requests instead of per-tile bursts;
+//   * the accumulators of a stage start from the bias of their columns (LDS reads issued a phase ahead, straight into the
+//     accumulator registers): the epilogue neither zero-fills nor adds a bias;
 //   * the LDS-DMA ring runs across items with counted s_waitcnt vmcnt (loads and stores retire in issue order on gfx950, the
 //     epilogue's memory operations are a compile-time count per item).
 #include <stdlib.h>
