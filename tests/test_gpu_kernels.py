@@ -378,3 +378,36 @@ def test_fused_batchnorm_activation_matches_torch(training, act_name, H, monkeyp
     assert float((x.grad - xr.grad).abs().max()) < 2e-4 * max(scale, 1.0)
     torch.testing.assert_close(bn.weight.grad, ref_bn.weight.grad, rtol=1e-3, atol=2e-3)
     torch.testing.assert_close(bn.bias.grad, ref_bn.bias.grad, rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("K,ld,ncrops,B", [(1003, 1004, 10, 6), (4096, 4096, 4, 5), (2, 4, 2, 3), (100000, 100096, 3, 2)])
+@pytest.mark.parametrize("grad_bf16", [True, False])
+def test_dino_loss_kernels_against_torch(K, ld, ncrops, B, grad_bf16):
+    """Fused sharpen / center / softmax / cross-entropy (reference lafs_train.py:643-667) on padded logits with a ragged class
+    count: loss, dL/dstudent (autograd of the plain formula) and the column sums / center EMA of update_center (:669-679)."""
+    g = torch.Generator().manual_seed(K + ncrops)
+    s = torch.zeros(ncrops * B, ld); t = torch.zeros(2 * B, ld)
+    s[:, :K] = torch.randn(ncrops * B, K, generator=g) * 3; t[:, :K] = torch.randn(2 * B, K, generator=g) * 2
+    center = torch.randn(K, generator=g) * 0.1
+    ts, tt = 0.1, 0.04
+    sr = s[:, :K].clone().double().requires_grad_(True)
+    q = F.softmax((t[:, :K].double() - center.double()) / tt, dim=-1).chunk(2)
+    lp = F.log_softmax(sr / ts, dim=-1).chunk(ncrops)
+    total, n = 0.0, 0
+    for iq, qq in enumerate(q):
+        for v in range(ncrops):
+            if v == iq:
+                continue
+            total = total + torch.sum(-qq * lp[v], dim=-1).mean(); n += 1
+    ref = total / n
+    ref.backward()
+    cpad = torch.zeros(ld); cpad[:K] = center
+    loss, grad = ops.dino_loss_fwd_bwd(s.to(DEV), t.to(DEV), cpad.to(DEV), ncrops, ts, tt, K=K, grad_bf16=grad_bf16)
+    assert abs(float(loss) - float(ref.detach())) < 2e-5 * abs(float(ref.detach())) + 1e-6
+    gr = grad[:, :K].float().cpu()
+    tol = (8e-3 if grad_bf16 else 2e-5) * float(sr.grad.abs().max())
+    assert float((gr - sr.grad.float()).abs().max()) < tol
+    assert float(grad[:, K:].float().abs().max()) == 0.0 if ld > K else True
+    colsum = torch.zeros(ld, device=DEV)
+    ops.call("lafs_colsum_f32", ops._p(t.to(DEV)), ld, 2 * B, K, ops._p(colsum))
+    assert torch.allclose(colsum[:K].cpu(), t[:, :K].sum(0), rtol=1e-5, atol=1e-5)
