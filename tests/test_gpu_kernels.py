@@ -411,3 +411,43 @@ def test_dino_loss_kernels_against_torch(K, ld, ncrops, B, grad_bf16):
     colsum = torch.zeros(ld, device=DEV)
     ops.call("lafs_colsum_f32", ops._p(t.to(DEV)), ld, 2 * B, K, ops._p(colsum))
     assert torch.allclose(colsum[:K].cpu(), t[:, :K].sum(0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("K,Kpad,D,with_t", [(1000, 1024, 256, True), (77, 128, 256, True), (130, 192, 64, False), (65, 128, 512, False)])
+def test_weightnorm_forward_rows_and_transposed_copy(K, Kpad, D, with_t):
+    """nn.utils.weight_norm(dim=0) of DINOHead.last_layer (reference vision_transformer.py:282-285): w = g v / ||v|| per class row,
+    the zero-filled pad rows, 1/||v|| and the transposed bf16 copy the head backward reads."""
+    g_ = torch.Generator().manual_seed(K)
+    v = torch.randn(K, D, generator=g_).to(DEV); g = (torch.rand(K, generator=g_) + 0.5).to(DEV)
+    w = torch.full((Kpad, D), 7.0, device=DEV, dtype=bf16)
+    wt = torch.full((D, Kpad), 7.0, device=DEV, dtype=bf16) if with_t else None
+    inv = torch.empty(K, device=DEV)
+    ops.call("lafs_weightnorm_fwd", ops._p(v), ops._p(g), K, Kpad, D, ops._p(w), ops._p(wt), Kpad, ops._p(inv))
+    ref = (g[:, None] * v / v.norm(dim=1, keepdim=True))
+    assert torch.allclose(inv, 1.0 / v.norm(dim=1), rtol=1e-5)
+    assert float((w[:K].float() - ref).abs().max()) < 8e-3 * float(ref.abs().max())
+    assert float(w[K:].float().abs().max()) == 0.0
+    if with_t:
+        assert torch.equal(wt, w.t().contiguous())
+
+
+def test_transposed_weight_shadows_table_kernel():
+    """All W^T bf16 shadows in one launch (lafs_transpose_cast_table): matrices whose sides are / are not multiples of the 64x64
+    tile and of the 8-row store pieces, destination offsets aligned and not."""
+    shapes = [(1152, 384), (384, 192), (100, 37), (8, 2048), (257, 65), (64, 64)]
+    g_ = torch.Generator().manual_seed(3)
+    mats = [torch.randn(r, c, generator=g_) for r, c in shapes]
+    master = torch.cat([torch.zeros(5)] + [m.reshape(-1) for m in mats]).to(DEV)       # (matrix offsets not 16-byte aligned)
+    rows_, starts, n, off, toff = [], [0], 0, 5, 3
+    toffs = []
+    for r, c in shapes:
+        rows_ += [off, r, c, toff]; toffs.append(toff)
+        off += r * c; toff += r * c + (5 if r == 100 else 0)
+        n += ((r + 63) // 64) * ((c + 63) // 64); starts.append(n)
+    shadow = torch.full((toff + 8,), 9.0, device=DEV, dtype=bf16)
+    table = torch.tensor(rows_, dtype=torch.int64, device=DEV); st = torch.tensor(starts, dtype=torch.int32, device=DEV)
+    ops.call("lafs_transpose_cast_table", ops._p(master), ops._p(shadow), ops._p(table), ops._p(st), len(shapes), n)
+    for m, (r, c), to in zip(mats, shapes, toffs):
+        got = shadow[to:to + r * c].view(c, r).float().cpu()
+        assert torch.equal(got, m.t().to(bf16).float())
+    assert float(shadow[:3].float().min()) == 9.0 and float(shadow[toff:].float().min()) == 9.0      # nothing written outside
