@@ -219,7 +219,9 @@ def test_wgrad_group(M, dims):
         assert relerr(cs, csr) < 2e-5 * math.sqrt(M)
 
 
-@pytest.mark.parametrize("rows,D", [(50, 64), (1000, 384), (333, 192), (64, 768), (7, 2048)])
+# (rows beyond 4096: a backward wave walks several rows, the next one's operands in flight while it reduces the current one)
+@pytest.mark.parametrize("rows,D", [(50, 64), (1000, 384), (333, 192), (64, 768), (7, 2048), (9001, 384), (5003, 768), (8200, 192),
+                                    (4100, 1024)])
 def test_layernorm_fwd_bwd(rows, D):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(rows, D, generator=g) * 2 + 0.5
@@ -242,6 +244,12 @@ def test_layernorm_fwd_bwd(rows, D):
     assert relerr(g_io, g0 + xr.grad) < 1e-5
     assert relerr(dgam, gr.grad) < 1e-4 and relerr(dbet, br.grad) < 1e-4
     assert relerr(gb.float(), sc[row2seq.long()].unsqueeze(1) * (g0 + xr.grad)) < 1e-2
+    # fp32 upstream gradient (the final norm's), written instead of accumulated
+    g2 = torch.full((rows, D), 5.0, device=DEV)
+    dgam.zero_(); dbet.zero_()
+    ops.layernorm_bwd(dy.float().to(DEV), x.to(DEV), stats, gamma.to(DEV), g2, dgam, dbet, accumulate=False)
+    assert relerr(g2, xr.grad) < 1e-5
+    assert relerr(dgam, gr.grad) < 1e-4 and relerr(dbet, br.grad) < 1e-4
 
 
 def _attn_ref(qkv, cu, heads, scale):
