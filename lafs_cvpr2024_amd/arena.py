@@ -119,7 +119,7 @@ class ParamArena:
         self._versions = self._version_key()
 
     def refresh_transposed(self):
-        """All W^T shadows in one launch (table-driven 32x32 tile transpose)."""
+        """All W^T shadows in one launch (table-driven 64x64 tile transpose)."""
         if not self.t_offsets:
             return
         if getattr(self, "_t_table", None) is None:
