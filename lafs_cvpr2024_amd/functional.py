@@ -309,9 +309,12 @@ def head_backward(arena, prefix, st: HeadState, dlogits_bf, train_g=False, overw
     dz = torch.empty(n, Db, device=dev, dtype=f32)
     call("lafs_l2norm_bwd", _p(st.z), Db, _p(dzn), Db, _p(st.inv_z), _p(dz), Db, n, Db)
     dz_bf = ops.scale_cast_bf16(dz)
-    ops.gemm_tn_acc(dz_bf, st.a2, gv("mlp.4.weight").view(p2("mlp.4.weight")), colsum=gv("mlp.4.bias"))
     du2 = ops.gemm_nt(dz_bf, arena.tview(prefix + "mlp.4.weight"), _lib.EPI_DGELU_BF16, aux=st.u2)
-    ops.gemm_tn_acc(du2, st.a1, gv("mlp.2.weight").view(p2("mlp.2.weight")), colsum=gv("mlp.2.bias"))
     du1 = ops.gemm_nt(du2, arena.tview(prefix + "mlp.2.weight"), _lib.EPI_DGELU_BF16, aux=st.u1)
-    ops.gemm_tn_acc(du1, st.x_bf, gv("mlp.0.weight").view(p2("mlp.0.weight")), colsum=gv("mlp.0.bias"))
-    return ops.gemm_nt(du1, arena.tview(prefix + "mlp.0.weight"), _lib.EPI_F32)
+    dx = ops.gemm_nt(du1, arena.tview(prefix + "mlp.0.weight"), _lib.EPI_F32)
+    # the three MLP weight (+ bias) gradients as ONE grouped launch of the wide-tile kernel once all their operands exist
+    # (three 128x128-tile launches of ~39 us each before: 640 token rows leave each of them a fraction of the chip)
+    ops.wgrad_group([(dz_bf, st.a2, gv("mlp.4.weight").view(p2("mlp.4.weight")), True, gv("mlp.4.bias")),
+                     (du2, st.a1, gv("mlp.2.weight").view(p2("mlp.2.weight")), True, gv("mlp.2.bias")),
+                     (du1, st.x_bf, gv("mlp.0.weight").view(p2("mlp.0.weight")), True, gv("mlp.0.bias"))])
+    return dx
