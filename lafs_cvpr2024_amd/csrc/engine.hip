@@ -8,6 +8,7 @@
 // The residual stream is fp32; GEMM operands are bf16 (fp32 accumulate).
 #include <algorithm>
 #include <vector>
+#include <stdlib.h>
 #include "common.hpp"
 #include "lafs_hip.h"
 
@@ -124,6 +125,44 @@ int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, in
 
 }  // namespace
 
+// Side stream for the attention launches of the second and later crop-resolution groups: the 197-token and the 37-token launch
+// of a layer are independent (both read the qkv GEMM's output, both feed the projection) and latency-bound on their own
+// (profiles/round2_attention_pmc.txt: waves waiting 53-67 % of the time), so they run beside each other.  Created on first use
+// (the engines warm up eagerly before they capture); LAFS_ATTN_STREAM=0 or LAFS_SINGLE_STREAM=1 keeps everything on `stream`.
+struct AttnSide {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool on = false;
+};
+static AttnSide& attn_side() {
+  static AttnSide a = [] {
+    AttnSide x;
+    const char* v = getenv("LAFS_ATTN_STREAM");
+    const char* ss = getenv("LAFS_SINGLE_STREAM");
+    if ((v != nullptr && v[0] == '0') || (ss != nullptr && ss[0] == '1')) return x;
+    if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return x;
+    if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess) return x;
+    if (hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return x;
+    x.on = true;
+    return x;
+  }();
+  return a;
+}
+// stream of group gi's attention launch; call attn_fork before the first launch and attn_join after the last one
+static hipStream_t attn_stream_of(int gi, hipStream_t stream) { return (gi > 0 && attn_side().on) ? attn_side().s : stream; }
+static void attn_fork(hipStream_t stream) {
+  AttnSide& a = attn_side();
+  if (!a.on) return;
+  (void)hipEventRecord(a.fork, stream);
+  (void)hipStreamWaitEvent(a.s, a.fork, 0);
+}
+static void attn_join(hipStream_t stream) {
+  AttnSide& a = attn_side();
+  if (!a.on) return;
+  (void)hipEventRecord(a.join, a.s);
+  (void)hipStreamWaitEvent(stream, a.join, 0);
+}
+
 extern "C" int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward) {
   if (check_desc(d) != LAFS_OK) return -1;
   return (int64_t)carve(d, nullptr, save_for_backward).bytes;
@@ -151,11 +190,13 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
     RUN(gemm(b.h1, D, sh + o.w_qkv, D, T, 3 * I, D, LAFS_EPI_BF16, b.qkv, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, stream));
     if (d->n_groups > 1) {                                  // one launch per crop resolution, each with its own tile shape
       int s0 = 0;
+      attn_fork(stream);
       for (int gi = 0; gi < d->n_groups; ++gi) {
         RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads, d->attn_scale,
-                               b.o, I, b.lse, stream));
+                               b.o, I, b.lse, attn_stream_of(gi, stream)));
         s0 += d->group_n_seq[gi];
       }
+      attn_join(stream);
     } else {
       RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, stream));
     }
@@ -233,11 +274,13 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     RUN(gemm(s.gba[p], D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
     if (d->n_groups > 1) {
       int s0 = 0;
+      attn_fork(stream);
       for (int gi = 0; gi < d->n_groups; ++gi) {
         RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi],
-                               d->heads, d->attn_scale, s.dqkv[p], 3 * I, stream));
+                               d->heads, d->attn_scale, s.dqkv[p], 3 * I, attn_stream_of(gi, stream)));
         s0 += d->group_n_seq[gi];
       }
+      attn_join(stream);
     } else {
       RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale,
                              s.dqkv[p], 3 * I, stream));
