@@ -176,43 +176,70 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   const Carve c = carve(d, workspace, save_for_backward);
   const int T = d->n_tok, D = d->dim, I = d->inner, M = d->mlp;
   const bf16_t* sh = reinterpret_cast<const bf16_t*>(d->shadow);
-  const float* cur = x_in;
-  for (int l = 0; l < d->depth; ++l) {
-    const lafs_block_offsets& o = d->blocks[l];
-    const LayerBuf& b = c.layers[save_for_backward ? l : 0];
-    const float* sa = d->drop_scales ? d->drop_scales + ((size_t)l * 2 + 0) * d->n_seq : nullptr;
-    const float* sm = d->drop_scales ? d->drop_scales + ((size_t)l * 2 + 1) * d->n_seq : nullptr;
-    float* nxt;
-    if (l == d->depth - 1) nxt = x_out;
-    else if (save_for_backward) nxt = c.layers[l + 1].x0;
-    else nxt = (cur == c.xalt) ? x_out : c.xalt;            // ping-pong; never aliases x_in
-    RUN(lafs_layernorm_fwd(cur, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1, D, nullptr, 0, b.st1, T, D, stream));
-    RUN(gemm(b.h1, D, sh + o.w_qkv, D, T, 3 * I, D, LAFS_EPI_BF16, b.qkv, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, stream));
-    if (d->n_groups > 1) {                                  // one launch per crop resolution, each with its own tile shape
-      int s0 = 0;
-      attn_fork(stream);
-      for (int gi = 0; gi < d->n_groups; ++gi) {
-        RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads, d->attn_scale,
-                               b.o, I, b.lse, attn_stream_of(gi, stream)));
-        s0 += d->group_n_seq[gi];
+  // Nothing in the forward mixes token rows of different sequences: with two crop-resolution groups of full-length sequences
+  // (and no element dropout, whose masks are indexed by launch-relative rows) the groups' rows run as two independent chains of
+  // launches over row sub-ranges of the same buffers, the second on the attention side stream -- every kernel of the chain is
+  // latency-bound to some degree, and two chains side by side fill each other's gaps.  LAFS_ROW_CHAINS=0: one chain.
+  static const bool chains_on = [] { const char* v = getenv("LAFS_ROW_CHAINS"); return !(v != nullptr && v[0] == '0'); }();
+  int T0 = 0;
+  bool split = chains_on && attn_side().on && d->n_groups == 2 && !(d->dropout_p > 0.f);
+  if (split) {
+    T0 = d->group_n_seq[0] * d->group_max_len[0];
+    split = (T0 + d->group_n_seq[1] * d->group_max_len[1] == T) && T0 >= 2048 && T - T0 >= 2048;
+  }
+  // rows [r0, r0 + R) = the sequences of groups [g_lo, g_hi) (seq_lo = index of their first sequence) on stream st
+  auto chain = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, hipStream_t st, bool attn_two_streams) -> int {
+    const float* cur = x_in;
+    for (int l = 0; l < d->depth; ++l) {
+      const lafs_block_offsets& o = d->blocks[l];
+      const LayerBuf& b = c.layers[save_for_backward ? l : 0];
+      const float* sa = d->drop_scales ? d->drop_scales + ((size_t)l * 2 + 0) * d->n_seq : nullptr;
+      const float* sm = d->drop_scales ? d->drop_scales + ((size_t)l * 2 + 1) * d->n_seq : nullptr;
+      const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
+      float* nxt;
+      if (l == d->depth - 1) nxt = x_out;
+      else if (save_for_backward) nxt = c.layers[l + 1].x0;
+      else nxt = (cur == c.xalt) ? x_out : c.xalt;            // ping-pong; never aliases x_in
+      const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
+      RUN(lafs_layernorm_fwd(cur + rD, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1 + rD, D, nullptr, 0, b.st1 + 2 * (size_t)r0,
+                             R, D, st));
+      RUN(gemm(b.h1 + rD, D, sh + o.w_qkv, D, R, 3 * I, D, LAFS_EPI_BF16, b.qkv + 3 * rI, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, st));
+      if (g_hi - g_lo > 1 || d->n_groups > 1) {               // one launch per crop resolution, each with its own tile shape
+        int s0 = seq_lo;                                      // (the attention kernels address tokens through cu_seqlens: base pointers)
+        if (attn_two_streams) attn_fork(st);
+        for (int gi = g_lo; gi < g_hi; ++gi) {
+          RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads, d->attn_scale,
+                                 b.o, I, b.lse, attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
+          s0 += d->group_n_seq[gi];
+        }
+        if (attn_two_streams) attn_join(st);
+      } else {
+        RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, st));
       }
-      attn_join(stream);
-    } else {
-      RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, stream));
+      const float dp = d->dropout_p;
+      const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
+      RUN(gemm(b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
+               r2s, nullptr, 0, dp, ds + 0));
+      RUN(lafs_layernorm_fwd(b.x1 + rD, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D, nullptr, 0, b.st2 + 2 * (size_t)r0,
+                             R, D, st));
+      // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
+      // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
+      // becomes one multiply per value
+      RUN(gemm(b.h2 + rD, D, sh + o.w_fc1, D, R, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u + rM : nullptr, M, d->master + o.b_fc1, st,
+               b.a + rM, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD));
+      RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
+               r2s, nullptr, 0, dp, ds + 2));
+      cur = nxt;
     }
-    const float dp = d->dropout_p;
-    const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
-    RUN(gemm(b.o, I, sh + o.w_proj, I, T, D, I, LAFS_EPI_RESID_F32, b.x1, D, d->master + o.b_proj, stream, nullptr, 0, cur, D, sa,
-             d->row2seq, nullptr, 0, dp, ds + 0));
-    RUN(lafs_layernorm_fwd(b.x1, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2, D, nullptr, 0, b.st2, T, D, stream));
-    // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
-    // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
-    // becomes one multiply per value
-    RUN(gemm(b.h2, D, sh + o.w_fc1, D, T, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u : nullptr, M, d->master + o.b_fc1, stream,
-             b.a, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD));
-    RUN(gemm(b.a, M, sh + o.w_fc2, M, T, D, M, LAFS_EPI_RESID_F32, nxt, D, d->master + o.b_fc2, stream, nullptr, 0, b.x1, D, sm,
-             d->row2seq, nullptr, 0, dp, ds + 2));
-    cur = nxt;
+    return LAFS_OK;
+  };
+  if (split) {
+    attn_fork(stream);                                      // the side stream joins behind everything `stream` has enqueued so far
+    RUN(chain(0, T0, 0, 1, 0, stream, false));
+    RUN(chain(T0, T - T0, 1, 2, d->group_n_seq[0], attn_side().s, false));
+    attn_join(stream);
+  } else {
+    RUN(chain(0, T, 0, d->n_groups, 0, stream, d->n_groups > 1));
   }
   return LAFS_OK;
 }
