@@ -270,6 +270,13 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   const bool two = (wgrad_stream != nullptr) && (wgrad_stream != stream);
   hipStream_t s2 = two ? wgrad_stream : stream;
   const int nl = layer_hi - layer_lo;
+  static const bool chains_on = [] { const char* v = getenv("LAFS_ROW_CHAINS"); return !(v != nullptr && v[0] == '0'); }();
+  int T0 = T;
+  bool split = chains_on && attn_side().on && d->n_groups == 2 && !(d->dropout_p > 0.f);
+  if (split) {
+    T0 = d->group_n_seq[0] * d->group_max_len[0];
+    split = (T0 + d->group_n_seq[1] * d->group_max_len[1] == T) && T0 >= 2048 && T - T0 >= 2048;
+  }
   std::vector<hipEvent_t>& ev = event_pool(two ? (size_t)2 * nl + 1 : 0);
   LAFS_CHECK_ARG(!two || ev.size() >= (size_t)2 * nl + 1, "could not create HIP events");
   int evi = 0;
@@ -291,26 +298,43 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const float* x0 = (l == 0) ? x_in : b.x0;
     const int p = l & 1;
     if (two && l + 2 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 2], 0);     // parity buffers free again
-    // ---- MLP branch ----
-    RUN(gemm(s.gbm[p], D, sht + o.w_fc2_t, D, T, M, D, LAFS_EPI_DGELU_BF16, s.du[p], M, nullptr, stream, nullptr, 0, nullptr, 0, nullptr,
-             nullptr, b.u, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD));
-    RUN(gemm(s.du[p], M, sht + o.w_fc1_t, M, T, D, M, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
-    RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, b.x1, D, b.st2, d->master + o.ln2_g, g, D, 1, s.gba[p], D, scale(l, 0), d->row2seq,
-                           gr + o.ln2_g, gr + o.ln2_b, T, D, dp, dseed(l, 0), stream));
-    // ---- attention branch ----
-    RUN(gemm(s.gba[p], D, sht + o.w_proj_t, D, T, I, D, LAFS_EPI_BF16, s.d_o, I, nullptr, stream));
-    if (d->n_groups > 1) {
-      int s0 = 0;
-      attn_fork(stream);
-      for (int gi = 0; gi < d->n_groups; ++gi) {
-        RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi],
-                               d->heads, d->attn_scale, s.dqkv[p], 3 * I, attn_stream_of(gi, stream)));
-        s0 += d->group_n_seq[gi];
+    // rows [r0, r0 + R) of this layer from the GELU' input gradient to the attention backward (groups [g_lo, g_hi), first
+    // sequence seq_lo) on stream st.  With two crop-resolution groups of full-length sequences the two row ranges run beside
+    // each other (second on the attention side stream, forked and joined inside the layer like the attention launches: the
+    // pattern hipGraph captures; a chain that stays forked across layers and meets the weight-gradient stream's events does not)
+    auto part1 = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, hipStream_t st, bool attn_two_streams) -> int {
+      const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
+      const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
+      // ---- MLP branch ----
+      RUN(gemm(s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
+               nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD));
+      RUN(gemm(s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
+      RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, b.x1 + rD, D, b.st2 + 2 * (size_t)r0, d->master + o.ln2_g, g + rD, D, 1, s.gba[p] + rD, D,
+                             scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), st));
+      // ---- attention branch ----
+      RUN(gemm(s.gba[p] + rD, D, sht + o.w_proj_t, D, R, I, D, LAFS_EPI_BF16, s.d_o + rI, I, nullptr, st));
+      if (d->n_groups > 1) {
+        int s0 = seq_lo;
+        if (attn_two_streams) attn_fork(st);
+        for (int gi = g_lo; gi < g_hi; ++gi) {
+          RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi],
+                                 d->heads, d->attn_scale, s.dqkv[p], 3 * I, attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
+          s0 += d->group_n_seq[gi];
+        }
+        if (attn_two_streams) attn_join(st);
+      } else {
+        RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale,
+                               s.dqkv[p], 3 * I, st));
       }
+      return LAFS_OK;
+    };
+    if (split) {
+      attn_fork(stream);
+      RUN(part1(0, T0, 0, 1, 0, stream, false));
+      RUN(part1(T0, T - T0, 1, 2, d->group_n_seq[0], attn_side().s, false));
       attn_join(stream);
     } else {
-      RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale,
-                             s.dqkv[p], 3 * I, stream));
+      RUN(part1(0, T, 0, d->n_groups, 0, stream, d->n_groups > 1));
     }
     // ---- the block's four weight gradients: ONE grouped launch on the side stream, once all their operands exist.  Its
     // 48 (ViT-S) output tiles x 5 token slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four
@@ -327,14 +351,28 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
       RUN(lafs_wgrad_group(it, 4, T, two ? d->wgrad_workgroups : 0, c.wg_ws, (int64_t)c.wg_bytes, s2));
     }
     if (two) { done[l] = ev[evi++]; (void)hipEventRecord(done[l], s2); }
-    RUN(gemm(s.dqkv[p], 3 * I, sht + o.w_qkv_t, 3 * I, T, D, 3 * I, LAFS_EPI_BF16, s.dh, D, nullptr, stream));
     const bool more = l > 0;
     // the LayerNorm backward below writes gbm[(l-1)&1] == gbm[(l+1)&1], which layer l+1's fc2 weight-gradient GEMM reads on
-    // s2: gbm is produced one layer EARLY, so the two parity buffers only cover it if that GEMM has retired by now
+    // s2: gbm is produced one layer EARLY, so the two parity buffers only cover it if that GEMM has retired by now (waited for
+    // in front of the qkv input gradient: the second row range forks from `stream` behind this wait)
     if (two && more && l + 1 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 1], 0);
-    RUN(lafs_layernorm_bwd(s.dh, D, nullptr, 0, x0, D, b.st1, d->master + o.ln1_g, g, D, 1, more ? s.gbm[(l - 1) & 1] : nullptr, D,
-                           more ? scale(l - 1, 1) : nullptr, d->row2seq, gr + o.ln1_g, gr + o.ln1_b, T, D, more ? dp : 0.f,
-                           more ? dseed(l - 1, 2) : 0u, stream));
+    auto part2 = [&](int r0, int R, hipStream_t st) -> int {
+      const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I;
+      const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
+      RUN(gemm(s.dqkv[p] + 3 * rI, 3 * I, sht + o.w_qkv_t, 3 * I, R, D, 3 * I, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
+      RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, x0 + rD, D, b.st1 + 2 * (size_t)r0, d->master + o.ln1_g, g + rD, D, 1,
+                             more ? s.gbm[(l - 1) & 1] + rD : nullptr, D, more ? scale(l - 1, 1) : nullptr, r2s, gr + o.ln1_g, gr + o.ln1_b, R, D,
+                             more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, st));
+      return LAFS_OK;
+    };
+    if (split) {
+      attn_fork(stream);
+      RUN(part2(0, T0, stream));
+      RUN(part2(T0, T - T0, attn_side().s));
+      attn_join(stream);
+    } else {
+      RUN(part2(0, T, stream));
+    }
   }
   if (two) (void)hipStreamWaitEvent(stream, done[layer_lo], 0);                        // join (s2 is in-order)
   LAFS_LAUNCH_CHECK();
