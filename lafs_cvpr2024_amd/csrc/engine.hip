@@ -130,9 +130,10 @@ int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, in
 // (profiles/round2_attention_pmc.txt: waves waiting 53-67 % of the time), so they run beside each other.  Created on first use
 // (the engines warm up eagerly before they capture); LAFS_ATTN_STREAM=0 or LAFS_SINGLE_STREAM=1 keeps everything on `stream`.
 struct AttnSide {
-  hipStream_t s = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
+  hipStream_t s = nullptr, sx[2] = {nullptr, nullptr};      // s: second attention group / second row range; sx: third and fourth row ranges
+  hipEvent_t fork = nullptr, join = nullptr, joinx[2] = {nullptr, nullptr};
   bool on = false;
+  int chains = 2;                                            // row ranges of the trunk passes (LAFS_ROW_CHAINS: 0 / 1 = one chain, 2, 4)
 };
 static AttnSide& attn_side() {
   static AttnSide a = [] {
@@ -143,6 +144,12 @@ static AttnSide& attn_side() {
     if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return x;
     if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess) return x;
     if (hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return x;
+    for (int i = 0; i < 2; ++i) {
+      if (hipStreamCreateWithFlags(&x.sx[i], hipStreamNonBlocking) != hipSuccess) return x;
+      if (hipEventCreateWithFlags(&x.joinx[i], hipEventDisableTiming) != hipSuccess) return x;
+    }
+    const char* c = getenv("LAFS_ROW_CHAINS");
+    x.chains = (c == nullptr) ? 2 : ((c[0] == '4') ? 4 : ((c[0] == '0' || c[0] == '1') ? 1 : 2));
     x.on = true;
     return x;
   }();
@@ -150,17 +157,46 @@ static AttnSide& attn_side() {
 }
 // stream of group gi's attention launch; call attn_fork before the first launch and attn_join after the last one
 static hipStream_t attn_stream_of(int gi, hipStream_t stream) { return (gi > 0 && attn_side().on) ? attn_side().s : stream; }
-static void attn_fork(hipStream_t stream) {
+static void attn_fork(hipStream_t stream, int n = 2) {       // n streams in all: `stream`, s, sx[0], sx[1]
   AttnSide& a = attn_side();
   if (!a.on) return;
   (void)hipEventRecord(a.fork, stream);
   (void)hipStreamWaitEvent(a.s, a.fork, 0);
+  for (int i = 0; i + 2 < n; ++i) (void)hipStreamWaitEvent(a.sx[i], a.fork, 0);
 }
-static void attn_join(hipStream_t stream) {
+static void attn_join(hipStream_t stream, int n = 2) {
   AttnSide& a = attn_side();
   if (!a.on) return;
   (void)hipEventRecord(a.join, a.s);
   (void)hipStreamWaitEvent(stream, a.join, 0);
+  for (int i = 0; i + 2 < n; ++i) {
+    (void)hipEventRecord(a.joinx[i], a.sx[i]);
+    (void)hipStreamWaitEvent(stream, a.joinx[i], 0);
+  }
+}
+// Row ranges of a trunk pass: one per crop-resolution group (2) or per half group (4, cut at a sequence boundary) when there are
+// two groups of full-length sequences and no element dropout (its masks are indexed by launch-relative rows); else one range.
+struct RowRange { int r0, R, gi, seq_lo, nseq; hipStream_t st; };
+static int row_ranges(const lafs_trunk_desc* d, hipStream_t stream, RowRange (&rr)[4]) {
+  AttnSide& a = attn_side();
+  rr[0] = {0, d->n_tok, 0, 0, d->n_seq, stream};
+  if (!a.on || a.chains < 2 || d->n_groups != 2 || d->dropout_p > 0.f) return 1;
+  const int T0 = d->group_n_seq[0] * d->group_max_len[0], T1 = d->group_n_seq[1] * d->group_max_len[1];
+  if (T0 + T1 != d->n_tok || T0 < 4096 || T1 < 4096) return 1;
+  hipStream_t st[4] = {stream, a.s, a.sx[0], a.sx[1]};
+  int n = 0;
+  const int parts = (a.chains == 4 && d->group_n_seq[0] >= 2 && d->group_n_seq[1] >= 2) ? 2 : 1;
+  int row = 0, seq = 0;
+  for (int gi = 0; gi < 2; ++gi) {
+    const int ns = d->group_n_seq[gi], len = d->group_max_len[gi];
+    for (int h = 0; h < parts; ++h) {
+      const int q0 = ns * h / parts, q1 = ns * (h + 1) / parts;
+      rr[n] = {row + q0 * len, (q1 - q0) * len, gi, seq + q0, q1 - q0, st[n]};
+      ++n;
+    }
+    row += ns * len; seq += ns;
+  }
+  return n;
 }
 
 extern "C" int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward) {
@@ -179,16 +215,12 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   // Nothing in the forward mixes token rows of different sequences: with two crop-resolution groups of full-length sequences
   // (and no element dropout, whose masks are indexed by launch-relative rows) the groups' rows run as two independent chains of
   // launches over row sub-ranges of the same buffers, the second on the attention side stream -- every kernel of the chain is
-  // latency-bound to some degree, and two chains side by side fill each other's gaps.  LAFS_ROW_CHAINS=0: one chain.
-  static const bool chains_on = [] { const char* v = getenv("LAFS_ROW_CHAINS"); return !(v != nullptr && v[0] == '0'); }();
-  int T0 = 0;
-  bool split = chains_on && attn_side().on && d->n_groups == 2 && !(d->dropout_p > 0.f);
-  if (split) {
-    T0 = d->group_n_seq[0] * d->group_max_len[0];
-    split = (T0 + d->group_n_seq[1] * d->group_max_len[1] == T) && T0 >= 2048 && T - T0 >= 2048;
-  }
+  // latency-bound to some degree, and two chains side by side fill each other's gaps.  LAFS_ROW_CHAINS=0: one chain, 4: half groups.
+  RowRange rr[4];
+  const int n_rr = row_ranges(d, stream, rr);
   // rows [r0, r0 + R) = the sequences of groups [g_lo, g_hi) (seq_lo = index of their first sequence) on stream st
-  auto chain = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, hipStream_t st, bool attn_two_streams) -> int {
+  // (nseq >= 0: ONE attention launch over nseq sequences of group g_lo -- a row range of a split pass)
+  auto chain = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
     const float* cur = x_in;
     for (int l = 0; l < d->depth; ++l) {
       const lafs_block_offsets& o = d->blocks[l];
@@ -208,8 +240,8 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
         int s0 = seq_lo;                                      // (the attention kernels address tokens through cu_seqlens: base pointers)
         if (attn_two_streams) attn_fork(st);
         for (int gi = g_lo; gi < g_hi; ++gi) {
-          RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads, d->attn_scale,
-                                 b.o, I, b.lse, attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
+          RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, nseq >= 0 ? nseq : d->group_n_seq[gi], d->group_max_len[gi], d->heads,
+                                 d->attn_scale, b.o, I, b.lse, attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
           s0 += d->group_n_seq[gi];
         }
         if (attn_two_streams) attn_join(st);
@@ -233,13 +265,12 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
     }
     return LAFS_OK;
   };
-  if (split) {
-    attn_fork(stream);                                      // the side stream joins behind everything `stream` has enqueued so far
-    RUN(chain(0, T0, 0, 1, 0, stream, false));
-    RUN(chain(T0, T - T0, 1, 2, d->group_n_seq[0], attn_side().s, false));
-    attn_join(stream);
+  if (n_rr > 1) {
+    attn_fork(stream, n_rr);                                // the side streams join behind everything `stream` has enqueued so far
+    for (int i = 0; i < n_rr; ++i) RUN(chain(rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
+    attn_join(stream, n_rr);
   } else {
-    RUN(chain(0, T, 0, d->n_groups, 0, stream, d->n_groups > 1));
+    RUN(chain(0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
   }
   return LAFS_OK;
 }
@@ -270,13 +301,8 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   const bool two = (wgrad_stream != nullptr) && (wgrad_stream != stream);
   hipStream_t s2 = two ? wgrad_stream : stream;
   const int nl = layer_hi - layer_lo;
-  static const bool chains_on = [] { const char* v = getenv("LAFS_ROW_CHAINS"); return !(v != nullptr && v[0] == '0'); }();
-  int T0 = T;
-  bool split = chains_on && attn_side().on && d->n_groups == 2 && !(d->dropout_p > 0.f);
-  if (split) {
-    T0 = d->group_n_seq[0] * d->group_max_len[0];
-    split = (T0 + d->group_n_seq[1] * d->group_max_len[1] == T) && T0 >= 2048 && T - T0 >= 2048;
-  }
+  RowRange rr[4];
+  const int n_rr = row_ranges(d, stream, rr);
   std::vector<hipEvent_t>& ev = event_pool(two ? (size_t)2 * nl + 1 : 0);
   LAFS_CHECK_ARG(!two || ev.size() >= (size_t)2 * nl + 1, "could not create HIP events");
   int evi = 0;
@@ -302,7 +328,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     // sequence seq_lo) on stream st.  With two crop-resolution groups of full-length sequences the two row ranges run beside
     // each other (second on the attention side stream, forked and joined inside the layer like the attention launches: the
     // pattern hipGraph captures; a chain that stays forked across layers and meets the weight-gradient stream's events does not)
-    auto part1 = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, hipStream_t st, bool attn_two_streams) -> int {
+    auto part1 = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
       const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
       const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
       // ---- MLP branch ----
@@ -317,8 +343,9 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
         int s0 = seq_lo;
         if (attn_two_streams) attn_fork(st);
         for (int gi = g_lo; gi < g_hi; ++gi) {
-          RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi],
-                                 d->heads, d->attn_scale, s.dqkv[p], 3 * I, attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
+          RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, nseq >= 0 ? nseq : d->group_n_seq[gi],
+                                 d->group_max_len[gi], d->heads, d->attn_scale, s.dqkv[p], 3 * I,
+                                 attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
           s0 += d->group_n_seq[gi];
         }
         if (attn_two_streams) attn_join(st);
@@ -328,13 +355,12 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
       }
       return LAFS_OK;
     };
-    if (split) {
-      attn_fork(stream);
-      RUN(part1(0, T0, 0, 1, 0, stream, false));
-      RUN(part1(T0, T - T0, 1, 2, d->group_n_seq[0], attn_side().s, false));
-      attn_join(stream);
+    if (n_rr > 1) {
+      attn_fork(stream, n_rr);
+      for (int i = 0; i < n_rr; ++i) RUN(part1(rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
+      attn_join(stream, n_rr);
     } else {
-      RUN(part1(0, T, 0, d->n_groups, 0, stream, d->n_groups > 1));
+      RUN(part1(0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
     }
     // ---- the block's four weight gradients: ONE grouped launch on the side stream, once all their operands exist.  Its
     // 48 (ViT-S) output tiles x 5 token slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four
@@ -365,11 +391,10 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
                              more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, st));
       return LAFS_OK;
     };
-    if (split) {
-      attn_fork(stream);
-      RUN(part2(0, T0, stream));
-      RUN(part2(T0, T - T0, attn_side().s));
-      attn_join(stream);
+    if (n_rr > 1) {
+      attn_fork(stream, n_rr);
+      for (int i = 0; i < n_rr; ++i) RUN(part2(rr[i].r0, rr[i].R, rr[i].st));
+      attn_join(stream, n_rr);
     } else {
       RUN(part2(0, T, stream));
     }
