@@ -439,3 +439,56 @@ def test_checkpoint_resume_continues_the_uninterrupted_run(use_graph, tmp_path):
         # Adam turns a sign flip of a round-off-sized gradient into a step of up to 2 lr.  Everything else is bit-identical.
         assert float((d > 1e-6 * scale).float().mean()) < 0.02, (name, float((d > 1e-6 * scale).float().mean()))
         assert float(d.max()) <= 2.2 * lr4 + 1e-6 * scale, (name, float(d.max()))
+
+
+_CHAINS_SNIPPET = r'''
+import sys, torch
+from functools import partial
+import torch.nn as nn
+import lafs_cvpr2024_amd.vision_transformer as vits
+from lafs_cvpr2024_amd.utils import MultiCropWrapper
+from lafs_cvpr2024_amd.dino_loss import DINOLoss
+from lafs_cvpr2024_amd.engine import LafsPretrainEngine
+torch.manual_seed(11)
+B, K, nl = 14, 2048, 8                      # 2 x 14 x 197 = 5516 and 8 x 14 x 37 = 4144 token rows: both groups above the split threshold
+LN6 = partial(nn.LayerNorm, eps=1e-6)
+mk = lambda: vits.VisionTransformer(img_size=[224], patch_size=8, embed_dim=128, depth=3, num_heads=2, qkv_bias=True, norm_layer=LN6,
+                                    drop_path_rate=0.1)
+student = MultiCropWrapper(mk(), vits.DINOHead(128, K, hidden_dim=256, bottleneck_dim=64))
+teacher = MultiCropWrapper(mk(), vits.DINOHead(128, K, hidden_dim=256, bottleneck_dim=64))
+teacher.load_state_dict(student.state_dict())
+crops = [torch.randn(B, 3, 112, 112).clamp(-1, 1) for _ in range(2)] + [torch.randn(B, 3, 48, 48).clamp(-1, 1) for _ in range(nl)]
+eng = LafsPretrainEngine(student, teacher, DINOLoss(K, 2 + nl, 0.07, 0.04, 3, 10), B, n_local=nl, use_graph=True, device="cuda")
+losses = [float(eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item()) for _ in range(4)]
+torch.save({"losses": losses, "teacher": {k: v.cpu() for k, v in teacher.state_dict().items()},
+            "student": {k: v.cpu() for k, v in student.state_dict().items()}}, sys.argv[1])
+print("CHAINS_DONE")
+'''
+
+
+def test_row_chains_equal_the_single_chain(tmp_path):
+    """The trunk passes as two chains of launches over the row ranges of the two crop-resolution groups (csrc/engine.hip:
+    row_ranges; LAFS_ROW_CHAINS, read once per process) against ONE chain over all rows: four captured steps from the same
+    initialisation; the first loss is identical, the later ones and the weights agree up to the order of the fp32 atomics of the LayerNorm
+    parameter gradients as Adam's first steps amplify it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("2", "0"):
+        f = str(tmp_path / f"chains{mode}.pt")
+        env = dict(os.environ, LAFS_ROW_CHAINS=mode, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", _CHAINS_SNIPPET, f], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0 and "CHAINS_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        out[mode] = torch.load(f)
+    la, lb = out["2"]["losses"], out["0"]["losses"]
+    assert abs(la[0] - lb[0]) < 1e-6 * abs(lb[0]), (la, lb)            # same weights: the forward is the same arithmetic
+    assert abs(la[1] - lb[1]) < 2e-5 * abs(lb[1]), (la, lb)            # one update apart: atomics-order noise of the gradients
+    for a, b in zip(la[2:], lb[2:]):                                     # then Adam's first steps (lr * sign of a near-zero gradient)
+        assert abs(a - b) < 5e-3 * abs(b), (la, lb)                      # amplify that noise; a race would be orders above this
+    for name in ("teacher", "student"):
+        for k, v in out["0"][name].items():
+            dw = (out["2"][name][k].float() - v.float()).abs()
+            assert float(dw.max()) <= 4 * 2 * 1e-3 + 1e-6, (name, k)    # at most every step's update flipped: 4 steps x 2 lr
+            assert float(dw.median()) <= 2e-5 * (1.0 + float(v.float().abs().max())), (name, k)
