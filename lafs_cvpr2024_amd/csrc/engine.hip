@@ -318,86 +318,100 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   auto dseed = [&](int l, int site) { return d->dropout_seed + 3u * (uint32_t)l + (uint32_t)site; };
   RUN(lafs_scale_cast_bf16(g, D, s.gbm[(layer_hi - 1) & 1], D, scale(layer_hi - 1, 1), d->row2seq, T, D, dp, dseed(layer_hi - 1, 2),
                            stream));
-  for (int l = layer_hi - 1; l >= layer_lo; --l) {
+  // rows [r0, r0 + R) of layer l from the GELU' input gradient to the attention backward (groups [g_lo, g_hi), first sequence
+  // seq_lo; nseq >= 0: one attention launch over nseq sequences of group g_lo) on stream st
+  auto part1 = [&](int l, int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
+    const lafs_block_offsets& o = d->blocks[l];
+    const LayerBuf& b = c.layers[l];
+    const int p = l & 1;
+    const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
+    const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
+    // ---- MLP branch ----
+    RUN(gemm(s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
+             nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD));
+    RUN(gemm(s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
+    RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, b.x1 + rD, D, b.st2 + 2 * (size_t)r0, d->master + o.ln2_g, g + rD, D, 1, s.gba[p] + rD, D,
+                           scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), st));
+    // ---- attention branch ----
+    RUN(gemm(s.gba[p] + rD, D, sht + o.w_proj_t, D, R, I, D, LAFS_EPI_BF16, s.d_o + rI, I, nullptr, st));
+    if (d->n_groups > 1) {
+      int s0 = seq_lo;
+      if (attn_two_streams) attn_fork(st);
+      for (int gi = g_lo; gi < g_hi; ++gi) {
+        RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, nseq >= 0 ? nseq : d->group_n_seq[gi],
+                               d->group_max_len[gi], d->heads, d->attn_scale, s.dqkv[p], 3 * I,
+                               attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
+        s0 += d->group_n_seq[gi];
+      }
+      if (attn_two_streams) attn_join(st);
+    } else {
+      RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale,
+                             s.dqkv[p], 3 * I, st));
+    }
+    return LAFS_OK;
+  };
+  // ... and from the qkv input gradient to the LayerNorm backward that produces layer l-1's upstream gradient gbm[(l-1)&1]
+  auto part2 = [&](int l, int r0, int R, hipStream_t st) -> int {
     const lafs_block_offsets& o = d->blocks[l];
     const LayerBuf& b = c.layers[l];
     const float* x0 = (l == 0) ? x_in : b.x0;
     const int p = l & 1;
-    if (two && l + 2 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 2], 0);     // parity buffers free again
-    // rows [r0, r0 + R) of this layer from the GELU' input gradient to the attention backward (groups [g_lo, g_hi), first
-    // sequence seq_lo) on stream st.  With two crop-resolution groups of full-length sequences the two row ranges run beside
-    // each other (second on the attention side stream, forked and joined inside the layer like the attention launches: the
-    // pattern hipGraph captures; a chain that stays forked across layers and meets the weight-gradient stream's events does not)
-    auto part1 = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
-      const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
-      const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
-      // ---- MLP branch ----
-      RUN(gemm(s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
-               nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD));
-      RUN(gemm(s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
-      RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, b.x1 + rD, D, b.st2 + 2 * (size_t)r0, d->master + o.ln2_g, g + rD, D, 1, s.gba[p] + rD, D,
-                             scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), st));
-      // ---- attention branch ----
-      RUN(gemm(s.gba[p] + rD, D, sht + o.w_proj_t, D, R, I, D, LAFS_EPI_BF16, s.d_o + rI, I, nullptr, st));
-      if (d->n_groups > 1) {
-        int s0 = seq_lo;
-        if (attn_two_streams) attn_fork(st);
-        for (int gi = g_lo; gi < g_hi; ++gi) {
-          RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, nseq >= 0 ? nseq : d->group_n_seq[gi],
-                                 d->group_max_len[gi], d->heads, d->attn_scale, s.dqkv[p], 3 * I,
-                                 attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
-          s0 += d->group_n_seq[gi];
-        }
-        if (attn_two_streams) attn_join(st);
-      } else {
-        RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale,
-                               s.dqkv[p], 3 * I, st));
-      }
-      return LAFS_OK;
-    };
-    if (n_rr > 1) {
-      attn_fork(stream, n_rr);
-      for (int i = 0; i < n_rr; ++i) RUN(part1(rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
-      attn_join(stream, n_rr);
-    } else {
-      RUN(part1(0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
-    }
-    // ---- the block's four weight gradients: ONE grouped launch on the side stream, once all their operands exist.  Its
-    // 48 (ViT-S) output tiles x 5 token slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four
-    // separate launches (csrc/wgrad.hip)
-    fork();
-    {
-      lafs_wgrad_item it[4];
-      block_wgrad_shapes(d, it);
-      it[0].A = s.gbm[p]; it[0].B = b.a; it[0].C = gr + o.w_fc2; it[0].colsum_a = gr + o.b_fc2;
-      it[1].A = s.du[p]; it[1].B = b.h2; it[1].C = gr + o.w_fc1; it[1].colsum_a = gr + o.b_fc1;
-      it[2].A = s.gba[p]; it[2].B = b.o; it[2].C = gr + o.w_proj; it[2].colsum_a = gr + o.b_proj;
-      it[3].A = s.dqkv[p]; it[3].B = b.h1; it[3].C = gr + o.w_qkv; it[3].colsum_a = o.b_qkv >= 0 ? gr + o.b_qkv : nullptr;
-      for (auto& x : it) x.accumulate = d->wgrad_overwrite ? 0 : 1;
-      RUN(lafs_wgrad_group(it, 4, T, two ? d->wgrad_workgroups : 0, c.wg_ws, (int64_t)c.wg_bytes, s2));
-    }
-    if (two) { done[l] = ev[evi++]; (void)hipEventRecord(done[l], s2); }
     const bool more = l > 0;
-    // the LayerNorm backward below writes gbm[(l-1)&1] == gbm[(l+1)&1], which layer l+1's fc2 weight-gradient GEMM reads on
-    // s2: gbm is produced one layer EARLY, so the two parity buffers only cover it if that GEMM has retired by now (waited for
-    // in front of the qkv input gradient: the second row range forks from `stream` behind this wait)
-    if (two && more && l + 1 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 1], 0);
-    auto part2 = [&](int r0, int R, hipStream_t st) -> int {
-      const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I;
-      const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
-      RUN(gemm(s.dqkv[p] + 3 * rI, 3 * I, sht + o.w_qkv_t, 3 * I, R, D, 3 * I, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
-      RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, x0 + rD, D, b.st1 + 2 * (size_t)r0, d->master + o.ln1_g, g + rD, D, 1,
-                             more ? s.gbm[(l - 1) & 1] + rD : nullptr, D, more ? scale(l - 1, 1) : nullptr, r2s, gr + o.ln1_g, gr + o.ln1_b, R, D,
-                             more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, st));
-      return LAFS_OK;
-    };
+    const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I;
+    const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
+    RUN(gemm(s.dqkv[p] + 3 * rI, 3 * I, sht + o.w_qkv_t, 3 * I, R, D, 3 * I, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
+    RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, x0 + rD, D, b.st1 + 2 * (size_t)r0, d->master + o.ln1_g, g + rD, D, 1,
+                           more ? s.gbm[(l - 1) & 1] + rD : nullptr, D, more ? scale(l - 1, 1) : nullptr, r2s, gr + o.ln1_g, gr + o.ln1_b, R, D,
+                           more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, st));
+    return LAFS_OK;
+  };
+  // One forked section = the tail of layer l2 (part2) and the head of layer l1 = l2 - 1 (part1) for every row range: with two
+  // crop-resolution groups of full-length sequences the row ranges run beside each other (second on the side stream), forked and
+  // joined once per layer -- the pattern hipGraph captures; a chain that stays forked across layers and meets the weight-gradient
+  // stream's events does not.  -1 = no such part.
+  auto section = [&](int l2, int l1) -> int {
     if (n_rr > 1) {
       attn_fork(stream, n_rr);
-      for (int i = 0; i < n_rr; ++i) RUN(part2(rr[i].r0, rr[i].R, rr[i].st));
+      for (int i = 0; i < n_rr; ++i) {
+        if (l2 >= 0) RUN(part2(l2, rr[i].r0, rr[i].R, rr[i].st));
+        if (l1 >= 0) RUN(part1(l1, rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
+      }
       attn_join(stream, n_rr);
     } else {
-      RUN(part2(0, T, stream));
+      if (l2 >= 0) RUN(part2(l2, 0, T, stream));
+      if (l1 >= 0) RUN(part1(l1, 0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
     }
+    return LAFS_OK;
+  };
+  // the block's four weight gradients: ONE grouped launch on the side stream, once all their operands exist.  Its 48 (ViT-S)
+  // output tiles x 5 token slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four separate
+  // launches (csrc/wgrad.hip)
+  auto wgrad = [&](int l) -> int {
+    const lafs_block_offsets& o = d->blocks[l];
+    const LayerBuf& b = c.layers[l];
+    const int p = l & 1;
+    fork();
+    lafs_wgrad_item it[4];
+    block_wgrad_shapes(d, it);
+    it[0].A = s.gbm[p]; it[0].B = b.a; it[0].C = gr + o.w_fc2; it[0].colsum_a = gr + o.b_fc2;
+    it[1].A = s.du[p]; it[1].B = b.h2; it[1].C = gr + o.w_fc1; it[1].colsum_a = gr + o.b_fc1;
+    it[2].A = s.gba[p]; it[2].B = b.o; it[2].C = gr + o.w_proj; it[2].colsum_a = gr + o.b_proj;
+    it[3].A = s.dqkv[p]; it[3].B = b.h1; it[3].C = gr + o.w_qkv; it[3].colsum_a = o.b_qkv >= 0 ? gr + o.b_qkv : nullptr;
+    for (auto& x : it) x.accumulate = d->wgrad_overwrite ? 0 : 1;
+    RUN(lafs_wgrad_group(it, 4, T, two ? d->wgrad_workgroups : 0, c.wg_ws, (int64_t)c.wg_bytes, s2));
+    if (two) { done[l] = ev[evi++]; (void)hipEventRecord(done[l], s2); }
+    return LAFS_OK;
+  };
+  RUN(section(-1, layer_hi - 1));
+  RUN(wgrad(layer_hi - 1));
+  for (int l = layer_hi - 1; l >= layer_lo; --l) {
+    // The section below rewrites what layer l+1's weight gradient reads on s2 -- gbm[(l-1)&1] (by layer l's LayerNorm backward:
+    // gbm is produced one layer EARLY) and du / gba / dqkv of parity (l-1)&1 (by layer l-1's first part) -- so that launch has to
+    // have retired (the two parity buffers cover a lag of one layer, not two)
+    if (two && l + 1 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 1], 0);
+    const int l1 = (l - 1 >= layer_lo) ? l - 1 : -1;
+    RUN(section(l, l1));
+    if (l1 >= 0) RUN(wgrad(l1));
   }
   if (two) (void)hipStreamWaitEvent(stream, done[layer_lo], 0);                        // join (s2 is in-order)
   LAFS_LAUNCH_CHECK();
