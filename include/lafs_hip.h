@@ -323,6 +323,10 @@ typedef struct lafs_trunk_desc {
 
 /* Bytes of activation workspace for a forward with (1) / without (0) saving activations for backward. */
 int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward);
+/* Number of independent chains of launches (row ranges of the token batch, one stream each) the trunk passes of this descriptor
+ * run as: 2 when there are two crop-resolution groups of >= 4096 full-length rows each and no element dropout... (csrc/engine.hip:
+ * row_ranges), else 1.  Tests assert the route they mean to cover. */
+int lafs_trunk_row_ranges(const lafs_trunk_desc* d);
 /* x_in(f32) [n_tok, dim] -> x_out(f32) [n_tok, dim]: residual stream after the last block.  With
  * save_for_backward != 0 x_in must stay untouched until lafs_trunk_backward has run (it is layer 0's saved input)
  * and must not alias x_out. */

@@ -128,6 +128,7 @@ _NO_STREAM = {
     "lafs_last_error": ([], C.c_char_p),
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),
+    "lafs_trunk_row_ranges": ([C.POINTER(TrunkDesc)], i32),
     "lafs_wgrad_workspace_bytes": ([i32, i32, i32], i64),
     "lafs_wgrad_group_workspace_bytes": ([C.POINTER(WgradItem), i32, i32, i32], i64),
 }

@@ -204,6 +204,12 @@ extern "C" int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save
   return (int64_t)carve(d, nullptr, save_for_backward).bytes;
 }
 
+extern "C" int lafs_trunk_row_ranges(const lafs_trunk_desc* d) {
+  if (check_desc(d) != LAFS_OK) return -1;
+  RowRange rr[4];
+  return row_ranges(d, nullptr, rr);
+}
+
 extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, float* x_out, void* workspace,
                                   int save_for_backward, hipStream_t stream) {
   LAFS_CLEAR_ERROR();

@@ -172,7 +172,20 @@ class LafsPretrainEngine:
                 out.append(buf)
         return out
 
+    def set_droppath_scales(self, student=None, teacher=None):
+        """Parity hook: use the given stochastic-depth scales ([depth, 2, n_seq] of 0 or 1/keep, sequences in packed order: global
+        crops first) instead of drawing them on the device -- the tests hand the engine the masks the reference drew (F17).  None
+        restores the device draw.  Must be set before the step is captured."""
+        if self._graphs is not None:
+            raise _lib.LafsHipError("set_droppath_scales after the step has been captured")
+        dev = lambda t, like: None if t is None else t.to(self.device, f32).reshape(like.shape).contiguous()
+        self._drop_fixed = {0: dev(student, self.drop_s), 1: dev(teacher, self.drop_t)}
+
     def _drop_scales(self, keep, out, salt):
+        fixed = getattr(self, "_drop_fixed", {}).get(salt)
+        if fixed is not None:
+            out.copy_(fixed)
+            return out
         if keep is None:
             return None
         call("lafs_droppath_scales", _p(keep), out.shape[0], out.shape[2], (self.drop_seed + salt) & 0xFFFFFFFF,

@@ -159,6 +159,46 @@ def test_f16_lafs_step_on_partfvit_backbones():
         close(st.center, fx[f"s{s}.center"], 1e-4, 1e-7)
 
 
+def test_f17_lafs_step_k8192_with_the_reference_droppath_masks():
+    """One reference LAFS step at K = 8192 (loss ~ ln K, as at the benchmark's K = 100 000) with DropPath live in the student:
+    the oracle is fed the masks the reference itself drew (vision_transformer.py:27-35) and must reproduce loss, outputs, clipped
+    gradients, teacher EMA and center -- this pins the oracle's DropPath forward/backward scaling to the reference."""
+    fx = load_golden("f17_lafs_step_k8192_droppath")
+    cfg = vit.ViTConfig(patch_size=8, embed_dim=64, depth=3, num_heads=1, img_size=112)
+    st = step.LafsState(cfg, out_dim=8192, seed=0, hidden_dim=128, bottleneck_dim=32)
+    init = sub(fx, "init.")
+    assert set(init) == set(st.student)
+    st.student = {k: v.clone() for k, v in init.items()}
+    st.teacher = {k: v.clone() for k, v in init.items()}
+    st.exp_avg = {k: torch.zeros_like(v) for k, v in init.items()}
+    st.exp_avg_sq = {k: torch.zeros_like(v) for k, v in init.items()}
+    st.steps = {k: 0 for k in init}
+    st.center = fx["center0"].clone()
+    lr, wd, mom = fx["hyper"].tolist()
+    scales = [fx["scales_global"], fx["scales_local"]]
+    assert sum(int((s == 0).sum()) for s in scales) > 0                      # the fixture does drop paths
+    crops = [fx[f"crop{i}"] for i in range(5)]
+    tt = dino.teacher_temp_schedule(0.07, 0.04, 3, 10)
+    r = step.lafs_step(st, crops, epoch=1, lr=lr, wd=wd, momentum=mom, teacher_temp=tt[1], clip_grad=3.0, freeze_last_layer=1,
+                       drop_scales=scales)
+    close(r["loss"], fx["loss"], 1e-5, 1e-6)
+    close(r["teacher_out"], fx["t_out"], 1e-4, 1e-6)
+    close(r["student_out"], fx["s_out"], 1e-4, 1e-6)
+    names = [str(n) for n in fx["norm_names"]]
+    np.testing.assert_allclose([r["norms"][n] for n in names], fx["norms"].numpy(), rtol=2e-3, atol=1e-8)
+    for k, g in sub(fx, "grad_post.").items():
+        close(r["grads"][k], g, 2e-3, 1e-7)
+    for k, v in sub(fx, "teacher.").items():
+        close_adam(st.teacher[k], v, lr)
+    close(st.center, fx["center"], 1e-4, 1e-7)
+    # without the masks the result must differ (the test would be vacuous otherwise)
+    st2 = step.LafsState(cfg, out_dim=8192, seed=0, hidden_dim=128, bottleneck_dim=32)
+    st2.student = {k: v.clone() for k, v in init.items()}; st2.teacher = {k: v.clone() for k, v in init.items()}
+    st2.center = fx["center0"].clone()
+    r2 = step.lafs_step(st2, crops, epoch=1, lr=lr, wd=wd, momentum=mom, teacher_temp=tt[1])
+    assert abs(float(r2["loss"]) - float(fx["loss"])) > 1e-4 * float(fx["loss"])
+
+
 def test_f6_schedules():
     fx = load_golden("f6_schedules")
     np.testing.assert_allclose(optim.cosine_scheduler(5e-4 * 64 / 256, 1e-6, 6, 11, warmup_epochs=2), fx["lr"].numpy(), rtol=1e-12)

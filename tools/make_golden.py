@@ -259,6 +259,78 @@ def main():
     fx["teacher_backbone_keys"] = np.array([k[len("backbone."):] for k in teacher.state_dict() if k.startswith("backbone.")])
     save("f16_lafs_step_partfvit", **fx)
 
+    # ---------------------------------------------------------------- F17 one LAFS step at K = 8192 with DropPath LIVE in the
+    # student (rates linspace(0, 0.3, 3), vision_transformer.py:150): the reference's own masks are recorded by observing the
+    # torch.rand draws of drop_path (:30) during the student pass, so the HIP engine can be fed the same masks.  K >= 8192 puts
+    # the loss at ~ln K, the regime of the benchmark's K = 100 000, and holds the 1e-3 loss bar against reference output.
+    print("F17 lafs step, K = 8192, live DropPath")
+    torch.manual_seed(17)
+    K, B, ncrops, depth = 8192, 2, 5, 3
+    mk = lambda dpr: ref_vit.VisionTransformer(img_size=[112], patch_size=8, embed_dim=64, depth=depth, num_heads=1, qkv_bias=True,
+                                               drop_path_rate=dpr, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6))
+    student = ref_utils.MultiCropWrapper(mk(0.3), ref_vit.DINOHead(64, K, hidden_dim=128, bottleneck_dim=32, norm_last_layer=True))
+    teacher = ref_utils.MultiCropWrapper(mk(0.0), ref_vit.DINOHead(64, K, hidden_dim=128, bottleneck_dim=32))
+    teacher.load_state_dict(student.state_dict())
+    for p in teacher.parameters():
+        p.requires_grad = False
+    crit = ref_lafs.DINOLoss(K, ncrops, 0.07, 0.04, 3, 10)
+    crit.center.copy_(0.05 * torch.randn(1, K))                       # a non-trivial center, as in a run that is under way
+    opt = torch.optim.AdamW(ref_utils.get_params_groups(student))
+    fx = {"init." + k: v.clone() for k, v in student.state_dict().items()}
+    fx["center0"] = crit.center.clone()
+    lr, wd, mom, epoch = 5e-4, 0.04, 0.9, 1
+    imgs = [torch.randn(B, 3, 112, 112).clamp(-1, 1) for _ in range(2)] + [torch.randn(B, 3, 48, 48).clamp(-1, 1) for _ in range(ncrops - 2)]
+    for i, g in enumerate(opt.param_groups):
+        g["lr"] = lr
+        if i == 0:
+            g["weight_decay"] = wd
+    t_out = teacher(imgs[:2])
+    draws, real_rand = [], torch.rand
+    def observing_rand(*a, **k):
+        r = real_rand(*a, **k)
+        draws.append(r.clone())
+        return r
+    torch.rand = observing_rand
+    try:
+        s_out = student(imgs)
+    finally:
+        torch.rand = real_rand
+    # draws arrive per backbone pass (global group: 2B sequences, then local group: 3B), per block with rate > 0, attention branch
+    # then MLP branch (vision_transformer.py:107-113); block 0 has rate 0 and draws nothing
+    rates = [x.item() for x in torch.linspace(0, 0.3, depth)]
+    scales = []
+    it = iter(draws)
+    for n_seq in (2 * B, (ncrops - 2) * B):
+        sc = torch.ones(depth, 2, n_seq)
+        for l in range(depth):
+            if rates[l] == 0.0:
+                continue
+            for br in range(2):
+                r = next(it).view(-1)
+                assert r.numel() == n_seq
+                sc[l, br] = torch.floor(1 - rates[l] + r) / (1 - rates[l])
+        scales.append(sc)
+    assert next(it, None) is None
+    assert any(float((sc == 0).sum()) > 0 for sc in scales), "seed drew no dropped path"
+    loss = crit(s_out, t_out, epoch)
+    opt.zero_grad()
+    loss.backward()
+    norms = ref_utils.clip_gradients(student, 3.0)
+    post = {n: p.grad.clone() for n, p in student.named_parameters() if p.grad is not None}
+    ref_utils.cancel_gradients_last_layer(epoch, student, 1)
+    opt.step()
+    with torch.no_grad():
+        for pq, pk in zip(student.parameters(), teacher.parameters()):
+            pk.data.mul_(mom).add_((1 - mom) * pq.detach().data)
+    fx.update({f"crop{i}": im for i, im in enumerate(imgs)})
+    fx.update({"loss": loss, "center": crit.center, "t_out": t_out, "s_out": s_out, "norms": np.array(norms),
+               "scales_global": scales[0], "scales_local": scales[1], "rates": np.array(rates)})
+    fx.update({f"grad_post.{n}": g for n, g in post.items()})
+    fx.update({f"teacher.{k}": v.clone() for k, v in teacher.state_dict().items() if "last_layer" not in k})
+    fx["hyper"] = np.array([lr, wd, mom])
+    fx["norm_names"] = np.array([n for n, p in student.named_parameters() if p.requires_grad])
+    save("f17_lafs_step_k8192_droppath", **fx)
+
     # ---------------------------------------------------------------- F12 param_groups_lrd (train_largescale.py:122-196)
     # train_largescale.py is a script with top-level side effects (argparse, NCCL init) and cannot be imported; its two grouping
     # functions are pure, so their source lines are exec'ed straight out of the reference file here (nothing of it is stored).
