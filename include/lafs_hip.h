@@ -83,6 +83,9 @@ typedef struct lafs_gemm_nt_args {
   float drop_p; uint32_t drop_seed; /* element dropout (0 = off): on the linear's output before the residual add
                                       (RESID_F32), on GELU(u) (BF16_GELU: C2 only), and its backward (DGELU_BF16).
                                       Counter-based mask of (drop_seed, row, col): see lafs_debug_dropout_mask.       */
+  const float* drop_step;          /* NULL, or DEVICE pointer to the step counter: the mask's seed is drop_seed + 7919 * step, read
+                                      when the kernel runs -- a captured hipGraph then draws a new mask on every replay            */
+  int drop_row0;                   /* this launch's row 0 is row drop_row0 of the mask (a launch over a row sub-range of a batch) */
   int act;                         /* BF16_ACT: LAFS_ACT_*.  BF16_GELU / DGELU_BF16: LAFS_GELU_SAVE_GRAD (see below) */
 } lafs_gemm_nt_args;
 
@@ -162,19 +165,23 @@ int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int l
                        const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
                        void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
                        float* dgamma, float* dbeta, int rows, int D, float drop_p, uint32_t drop_seed,
-                       hipStream_t stream);
+                       const float* drop_step, int drop_row0, hipStream_t stream);
 
 /* gb(bf16)[r,:] = bf16(seq_scale[row2seq[r]] * g(f32)[r,:])  (seq_scale NULL -> plain cast). */
 int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb, const float* seq_scale,
                          const int32_t* row2seq, int rows, int D,
-                         float drop_p, uint32_t drop_seed, hipStream_t stream);
+                         float drop_p, uint32_t drop_seed, const float* drop_step, int drop_row0, hipStream_t stream);
 /* Element dropout (nn.Dropout of Part-fViT, face_pre_pro/ViT_face.py:131-133,150-153,614).  The mask is a pure function
  * of (drop_seed, row, col, n_cols): factor(r,c) = mix32(r*n_cols + c, seed) >= drop_p*2^32 ? 1/(1-drop_p) : 0, so a
  * backward kernel regenerates the forward's mask from the same seed; drop_p = 0 disables it.  In lafs_layernorm_bwd and
  * lafs_scale_cast_bf16 the factor multiplies gb_out (the gradient entering a dropped-out branch output).
  * lafs_dropout_f32: x(f32)[rows, D] *= factor in place (embedding dropout, forward and backward).
- * lafs_debug_dropout_mask: out(f32)[rows, cols] = factor (tests feed it to the oracle). */
-int lafs_dropout_f32(float* x, int ldx, int rows, int D, float drop_p, uint32_t drop_seed, hipStream_t stream);
+ * lafs_debug_dropout_mask: out(f32)[rows, cols] = factor (tests feed it to the oracle).
+ * drop_step (NULL or a DEVICE pointer to a float step counter): the seed used is drop_seed + 7919 * (uint32)step, read when the
+ * kernel runs, so a hipGraph-captured training step draws new masks on every replay (reference: nn.Dropout draws per call);
+ * drop_row0: the launch covers rows [drop_row0, drop_row0 + rows) of the mask (row chains of the trunk passes).  A host-side
+ * seed' = drop_seed + 7919 * step with drop_step = NULL produces the identical mask. */
+int lafs_dropout_f32(float* x, int ldx, int rows, int D, float drop_p, uint32_t drop_seed, const float* drop_step, hipStream_t stream);
 int lafs_debug_dropout_mask(int rows, int cols, float drop_p, uint32_t drop_seed, float* out, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -317,6 +324,7 @@ typedef struct lafs_trunk_desc {
    * n_groups = 0: a single launch over all sequences with max_len. */
   int n_groups; int group_n_seq[4]; int group_max_len[4];
   int wgrad_workgroups;               /* CUs the grouped weight-gradient launch may occupy (0 = all 256), see lafs_wgrad_group */
+  const float* dropout_step;          /* NULL or DEVICE pointer to the step counter added (x 7919) to dropout_seed inside the kernels */
   int wgrad_overwrite;                /* != 0: the block weight gradients are WRITTEN (not accumulated): the caller zeroes only the
                                          other tensors (lafs_zero_chunks, LAFS_SEG_OVERWRITTEN) and runs one backward per step */
 } lafs_trunk_desc;
@@ -324,7 +332,7 @@ typedef struct lafs_trunk_desc {
 /* Bytes of activation workspace for a forward with (1) / without (0) saving activations for backward. */
 int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward);
 /* Number of independent chains of launches (row ranges of the token batch, one stream each) the trunk passes of this descriptor
- * run as: 2 when there are two crop-resolution groups of >= 4096 full-length rows each and no element dropout... (csrc/engine.hip:
+ * run as: 2 when there are two crop-resolution groups of >= 4096 full-length rows each (csrc/engine.hip:
  * row_ranges), else 1.  Tests assert the route they mean to cover. */
 int lafs_trunk_row_ranges(const lafs_trunk_desc* d);
 /* x_in(f32) [n_tok, dim] -> x_out(f32) [n_tok, dim]: residual stream after the last block.  With

@@ -21,7 +21,8 @@ class GemmNTArgs(C.Structure):
                 ("bias", C.c_void_p), ("resid", C.c_void_p), ("ldr", C.c_int),
                 ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
                 ("aux", C.c_void_p), ("ldaux", C.c_int), ("pos", C.c_void_p), ("npatch", C.c_int),
-                ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32), ("act", C.c_int)]
+                ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
+                ("drop_step", C.c_void_p), ("drop_row0", C.c_int), ("act", C.c_int)]
 
 
 class WgradItem(C.Structure):
@@ -44,7 +45,7 @@ class TrunkDesc(C.Structure):
                 ("master", C.c_void_p), ("shadow", C.c_void_p), ("shadow_t", C.c_void_p), ("grad", C.c_void_p),
                 ("blocks", C.POINTER(BlockOffsets)),
                 ("n_groups", C.c_int), ("group_n_seq", C.c_int * 4), ("group_max_len", C.c_int * 4), ("wgrad_workgroups", C.c_int),
-                ("wgrad_overwrite", C.c_int)]
+                ("dropout_step", C.c_void_p), ("wgrad_overwrite", C.c_int)]
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32, EPI_BF16_ACT = range(8)
@@ -69,9 +70,9 @@ _PROTOS = {
     "lafs_wgrad_group": [C.POINTER(WgradItem), i32, i32, i32, vp, i64],
     "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
     "lafs_layernorm_fwd": [vp, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32],
-    "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, u32],
-    "lafs_scale_cast_bf16": [vp, i32, vp, i32, vp, vp, i32, i32, f32, u32],
-    "lafs_dropout_f32": [vp, i32, i32, i32, f32, u32],
+    "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, u32, vp, i32],
+    "lafs_scale_cast_bf16": [vp, i32, vp, i32, vp, vp, i32, i32, f32, u32, vp, i32],
+    "lafs_dropout_f32": [vp, i32, i32, i32, f32, u32, vp],
     "lafs_debug_dropout_mask": [i32, i32, f32, u32, vp],
     "lafs_attention_fwd": [vp, i32, vp, i32, i32, i32, f32, vp, i32, vp],
     "lafs_attention_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, vp, i32],

@@ -85,23 +85,38 @@ __device__ __forceinline__ void gelu_both_f(float x, float& g, float& dg) {
 // ---- element dropout (nn.Dropout of Part-fViT, face_pre_pro/ViT_face.py:131-133,150-153,614): counter-based mask, so
 // the backward kernels regenerate exactly the forward's mask from (seed, row, col) instead of storing it.
 // keep <=> mix32(row * n_cols + col, seed) >= thresh, thresh = p * 2^32; kept values are scaled by 1/(1-p).
-struct DropCfg { unsigned thresh; unsigned seed; float scale; };        // thresh == 0: disabled
+// A launch over rows [row0, row0 + R) of a larger batch numbers its elements from idx0 = row0 * n_cols, and a captured hipGraph
+// draws a new mask on every replay: the seed of a step is seed + 7919 * step with `step` read from DEVICE memory (hyper[HP_STEP],
+// the counter the DropPath scales use), so the same launch arguments give new masks step after step.  Passing step = nullptr and
+// seed' = seed + 7919 * step on the host gives the identical mask (lafs_debug_dropout_mask: tests).
+struct DropCfg { unsigned thresh; unsigned seed; float scale; unsigned idx0; const float* step; };        // thresh == 0: disabled
 __device__ __forceinline__ unsigned drop_mix32(unsigned idx, unsigned seed) {
   unsigned x = idx * 0x9E3779B1u ^ seed;
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ float drop_mult(const DropCfg& d, unsigned idx) {
-  return drop_mix32(idx, d.seed) >= d.thresh ? d.scale : 0.f;
+// once per kernel: raw seed (+ 7919 * device step) -> scrambled seed
+__device__ __forceinline__ DropCfg drop_resolve(DropCfg d) {
+  if (d.thresh) {
+    unsigned raw = d.seed;
+    if (d.step != nullptr) raw += 7919u * (unsigned)(*d.step);
+    d.seed = raw * 0x632BE5ABu + 0x7F4A7C15u;
+  }
+  return d;
 }
-inline DropCfg make_drop(float p, unsigned seed) {
+__device__ __forceinline__ float drop_mult(const DropCfg& d, unsigned idx) {
+  return drop_mix32(idx + d.idx0, d.seed) >= d.thresh ? d.scale : 0.f;
+}
+inline DropCfg make_drop(float p, unsigned seed, const float* step = nullptr, unsigned idx0 = 0) {
   DropCfg d;
+  d.idx0 = 0; d.step = nullptr;
   if (!(p > 0.f)) { d.thresh = 0; d.seed = 0; d.scale = 1.f; return d; }
   const double t = (double)p * 4294967296.0;
   d.thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
   if (d.thresh == 0) d.thresh = 1;
-  d.seed = seed * 0x632BE5ABu + 0x7F4A7C15u;
+  d.seed = seed;                                  // raw: drop_resolve scrambles it on the device
   d.scale = 1.0f / (1.0f - p);
+  d.idx0 = idx0; d.step = step;
   return d;
 }
 

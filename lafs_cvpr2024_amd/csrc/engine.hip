@@ -114,9 +114,9 @@ int check_desc(const lafs_trunk_desc* d) {
 int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
          hipStream_t s, void* C2 = nullptr, int ldc2 = 0, const float* resid = nullptr, int ldr = 0,
          const float* seq_scale = nullptr, const int32_t* row2seq = nullptr, const void* aux = nullptr, int ldaux = 0,
-         float drop_p = 0.f, uint32_t drop_seed = 0, int act = 0) {
+         float drop_p = 0.f, uint32_t drop_seed = 0, int act = 0, const float* drop_step = nullptr, int drop_row0 = 0) {
   lafs_gemm_nt_args g = {};
-  g.drop_p = drop_p; g.drop_seed = drop_seed; g.act = act;
+  g.drop_p = drop_p; g.drop_seed = drop_seed; g.act = act; g.drop_step = drop_step; g.drop_row0 = drop_row0;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.epilogue = epi;
   g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.resid = resid; g.ldr = ldr;
   g.seq_scale = seq_scale; g.row2seq = row2seq; g.aux = aux; g.ldaux = ldaux; g.splits = 1;
@@ -175,12 +175,12 @@ static void attn_join(hipStream_t stream, int n = 2) {
   }
 }
 // Row ranges of a trunk pass: one per crop-resolution group (2) or per half group (4, cut at a sequence boundary) when there are
-// two groups of full-length sequences and no element dropout (its masks are indexed by launch-relative rows); else one range.
+// two groups of full-length sequences (element-dropout masks are indexed by absolute rows: drop_row0); else one range.
 struct RowRange { int r0, R, gi, seq_lo, nseq; hipStream_t st; };
 static int row_ranges(const lafs_trunk_desc* d, hipStream_t stream, RowRange (&rr)[4]) {
   AttnSide& a = attn_side();
   rr[0] = {0, d->n_tok, 0, 0, d->n_seq, stream};
-  if (!a.on || a.chains < 2 || d->n_groups != 2 || d->dropout_p > 0.f) return 1;
+  if (!a.on || a.chains < 2 || d->n_groups != 2) return 1;
   const int T0 = d->group_n_seq[0] * d->group_max_len[0], T1 = d->group_n_seq[1] * d->group_max_len[1];
   if (T0 + T1 != d->n_tok || T0 < 4096 || T1 < 4096) return 1;
   hipStream_t st[4] = {stream, a.s, a.sx[0], a.sx[1]};
@@ -219,7 +219,7 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   const int T = d->n_tok, D = d->dim, I = d->inner, M = d->mlp;
   const bf16_t* sh = reinterpret_cast<const bf16_t*>(d->shadow);
   // Nothing in the forward mixes token rows of different sequences: with two crop-resolution groups of full-length sequences
-  // (and no element dropout, whose masks are indexed by launch-relative rows) the groups' rows run as two independent chains of
+  // (element-dropout masks are indexed by absolute rows) the groups' rows run as two independent chains of
   // launches over row sub-ranges of the same buffers, the second on the attention side stream -- every kernel of the chain is
   // latency-bound to some degree, and two chains side by side fill each other's gaps.  LAFS_ROW_CHAINS=0: one chain, 4: half groups.
   RowRange rr[4];
@@ -257,16 +257,16 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       const float dp = d->dropout_p;
       const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
       RUN(gemm(b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
-               r2s, nullptr, 0, dp, ds + 0));
+               r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0));
       RUN(lafs_layernorm_fwd(b.x1 + rD, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D, nullptr, 0, b.st2 + 2 * (size_t)r0,
                              R, D, st));
       // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
       // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
       // becomes one multiply per value
       RUN(gemm(b.h2 + rD, D, sh + o.w_fc1, D, R, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u + rM : nullptr, M, d->master + o.b_fc1, st,
-               b.a + rM, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD));
+               b.a + rM, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
       RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
-               r2s, nullptr, 0, dp, ds + 2));
+               r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
       cur = nxt;
     }
     return LAFS_OK;
@@ -323,7 +323,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   const float dp = d->dropout_p;
   auto dseed = [&](int l, int site) { return d->dropout_seed + 3u * (uint32_t)l + (uint32_t)site; };
   RUN(lafs_scale_cast_bf16(g, D, s.gbm[(layer_hi - 1) & 1], D, scale(layer_hi - 1, 1), d->row2seq, T, D, dp, dseed(layer_hi - 1, 2),
-                           stream));
+                           d->dropout_step, 0, stream));
   // rows [r0, r0 + R) of layer l from the GELU' input gradient to the attention backward (groups [g_lo, g_hi), first sequence
   // seq_lo; nseq >= 0: one attention launch over nseq sequences of group g_lo) on stream st
   auto part1 = [&](int l, int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
@@ -334,10 +334,10 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
     // ---- MLP branch ----
     RUN(gemm(s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
-             nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD));
+             nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
     RUN(gemm(s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
     RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, b.x1 + rD, D, b.st2 + 2 * (size_t)r0, d->master + o.ln2_g, g + rD, D, 1, s.gba[p] + rD, D,
-                           scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), st));
+                           scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), d->dropout_step, r0, st));
     // ---- attention branch ----
     RUN(gemm(s.gba[p] + rD, D, sht + o.w_proj_t, D, R, I, D, LAFS_EPI_BF16, s.d_o + rI, I, nullptr, st));
     if (d->n_groups > 1) {
@@ -368,7 +368,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     RUN(gemm(s.dqkv[p] + 3 * rI, 3 * I, sht + o.w_qkv_t, 3 * I, R, D, 3 * I, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
     RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, x0 + rD, D, b.st1 + 2 * (size_t)r0, d->master + o.ln1_g, g + rD, D, 1,
                            more ? s.gbm[(l - 1) & 1] + rD : nullptr, D, more ? scale(l - 1, 1) : nullptr, r2s, gr + o.ln1_g, gr + o.ln1_b, R, D,
-                           more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, st));
+                           more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, d->dropout_step, r0, st));
     return LAFS_OK;
   };
   // One forked section = the tail of layer l2 (part2) and the head of layer l1 = l2 - 1 (part1) for every row range: with two

@@ -126,6 +126,7 @@ template <int BK> __device__ __forceinline__ int nt_swzk(int row) { return BK ==
 // b + grid, b + 2 grid, ...; while a workgroup stores tile j it already has the first ring stages of tile j+1 in flight.
 template <int EPI, int WM, int BK, int WN = 2, bool PERSIST = false>
 __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2)))) void gemm_nt_kernel(NTArgs p) {
+  const DropCfg drop = drop_resolve(p.drop);
   constexpr int THREADS = WM * WN * 64, BMT = WM * 64, BN = WN * 64;
   constexpr bool PIN32 = (WM == 2);                   // (the 8-wave variants run at the 128-register cap: pinning spills there)
   constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
@@ -408,9 +409,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
             for (int e = 0; e < VPL; ++e) if (n + e < p.N) w[e] *= (p.act == LAFS_GELU_SAVE_GRAD) ? bf2f(ax[e]) : gelu_grad_f(bf2f(ax[e]));
           }
-          if (p.drop.thresh) {                                     // d(dropout(gelu(u))): the forward's mask, regenerated
+          if (drop.thresh) {                                     // d(dropout(gelu(u))): the forward's mask, regenerated
 #pragma unroll
-            for (int e = 0; e < VPL; ++e) w[e] *= drop_mult(p.drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
+            for (int e = 0; e < VPL; ++e) w[e] *= drop_mult(drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
           }
         }
         bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n;
@@ -443,10 +444,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
           if DBG(p, 16384) c2 = c + 32;
           if (full && DBG(p, 128)) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
-          } else if (p.drop.thresh) {
+          } else if (drop.thresh) {
 #pragma unroll
             for (int e = 0; e < VPL; ++e)
-              if (n + e < p.N) c2[e] = f2bf(gelu_f(w[e]) * drop_mult(p.drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e)));
+              if (n + e < p.N) c2[e] = f2bf(gelu_f(w[e]) * drop_mult(drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e)));
           } else if (full) {
             st16(c2, pack_bf2(gelu_f(w[0]), gelu_f(w[1])), pack_bf2(gelu_f(w[2]), gelu_f(w[3])),
                  pack_bf2(gelu_f(w[4]), gelu_f(w[5])), pack_bf2(gelu_f(w[6]), gelu_f(w[7])), ntst);
@@ -462,9 +463,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
       } else {                                                                        // VPL == 4: one float4
         if (EPI == EPI_RESID_F32) {
           const float* rs = p.resid + (size_t)m * p.ldr + n;
-          if (p.drop.thresh) {
+          if (drop.thresh) {
 #pragma unroll
-            for (int e = 0; e < VPL; ++e) w[e] *= drop_mult(p.drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
+            for (int e = 0; e < VPL; ++e) w[e] *= drop_mult(drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
           }
           if (full) {
             const float4 r4 = make_float4(__uint_as_float(cur[q].x), __uint_as_float(cur[q].y), __uint_as_float(cur[q].z),
@@ -803,10 +804,11 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
 #ifdef LAFS_ABLATE
   a.stamps = g_stamps;
 #endif
-  a.drop = make_drop(g->drop_p, g->drop_seed);
+  a.drop = make_drop(g->drop_p, g->drop_seed, g->drop_step, (unsigned)g->drop_row0 * (unsigned)g->N);
   a.act = g->act;
   LAFS_CHECK_ARG(g->drop_p >= 0.f && g->drop_p < 1.f, "drop_p must be in [0, 1)");
-  LAFS_CHECK_ARG(!(g->drop_p > 0.f) || (long)g->M * g->N < 4294967296L, "dropout needs M*N < 2^32");
+  LAFS_CHECK_ARG(!(g->drop_p > 0.f) || ((long)g->M + g->drop_row0) * g->N < 4294967296L, "dropout needs (row0 + M) * N < 2^32");
+  LAFS_CHECK_ARG(g->drop_row0 >= 0, "drop_row0 must be >= 0");
   if (lafs_kres_eligible(g)) return lafs_kres_launch(g, stream);   // K = 384 streaming shapes of the ViT-S trunk (gemm_kres.hip)
   int splits = 1;
   a.klen = g->K;

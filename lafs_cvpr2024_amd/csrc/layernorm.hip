@@ -65,7 +65,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
                                                     float* __restrict__ g_io, int ldg, int accumulate,
                                                     bf16_t* __restrict__ gb, int ldgb, const float* __restrict__ seq_scale,
                                                     const int* __restrict__ row2seq, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, int rows, int D, DropCfg drop) {
+                                                    float* __restrict__ dbeta, int rows, int D, DropCfg drop_in) {
+  const DropCfg drop = drop_resolve(drop_in);
   __shared__ float red[NW][NI * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4 gam[NI], ag[NI], ab[NI];
@@ -162,7 +163,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
 
 __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ g, int ldg, bf16_t* __restrict__ gb, int ldgb,
                                                         const float* __restrict__ seq_scale, const int* __restrict__ row2seq,
-                                                        int rows, int D, DropCfg drop) {
+                                                        int rows, int D, DropCfg drop_in) {
+  const DropCfg drop = drop_resolve(drop_in);
   const int per_row = D >> 2;
   const size_t total = (size_t)rows * per_row;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -179,8 +181,9 @@ __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict
 }
 
 // x(f32)[r, c] *= mask(r, c)/(1-p) in place (embedding dropout and its backward); out_mask (optional) receives the factors
-__global__ __launch_bounds__(256) void dropout_f32_kernel(float* __restrict__ x, int ldx, int rows, int D, DropCfg drop,
+__global__ __launch_bounds__(256) void dropout_f32_kernel(float* __restrict__ x, int ldx, int rows, int D, DropCfg drop_in,
                                                          float* __restrict__ out_mask) {
+  const DropCfg drop = drop_resolve(drop_in);
   const size_t total = (size_t)rows * D;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int row = (int)(i / D), c = (int)(i % D);
@@ -245,7 +248,7 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
                                   const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
                                   void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
                                   float* dgamma, float* dbeta, int rows, int D, float drop_p, uint32_t drop_seed,
-                                  hipStream_t stream) {
+                                  const float* drop_step, int drop_row0, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG((dy_bf16 || dy_f32) && x && stats && gamma && g_io && dgamma && dbeta, "null operand");
   LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
@@ -257,10 +260,12 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
   const dim3 grid(blocks);
   if (dy_f32 != nullptr) {
     LN_BWD_DISPATCH(ni, true, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
-                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D, make_drop(drop_p, drop_seed));
+                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D,
+                    make_drop(drop_p, drop_seed, drop_step, (unsigned)drop_row0 * (unsigned)D));
   } else {
     LN_BWD_DISPATCH(ni, false, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
-                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D, make_drop(drop_p, drop_seed));
+                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D,
+                    make_drop(drop_p, drop_seed, drop_step, (unsigned)drop_row0 * (unsigned)D));
   }
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
@@ -268,7 +273,7 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
 
 extern "C" int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb, const float* seq_scale,
                                     const int32_t* row2seq, int rows, int D, float drop_p, uint32_t drop_seed,
-                                    hipStream_t stream) {
+                                    const float* drop_step, int drop_row0, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g && gb && rows > 0 && D > 0 && D % 4 == 0, "bad operand");
   LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
@@ -276,19 +281,20 @@ extern "C" int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb,
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(scale_cast_kernel, dim3(blocks), dim3(256), 0, stream, g, ldg, (bf16_t*)gb, ldgb, seq_scale, row2seq, rows, D,
-                     make_drop(drop_p, drop_seed));
+                     make_drop(drop_p, drop_seed, drop_step, (unsigned)drop_row0 * (unsigned)D));
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
 
-extern "C" int lafs_dropout_f32(float* x, int ldx, int rows, int D, float drop_p, uint32_t drop_seed, hipStream_t stream) {
+extern "C" int lafs_dropout_f32(float* x, int ldx, int rows, int D, float drop_p, uint32_t drop_seed, const float* drop_step,
+                                hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && rows > 0 && D > 0 && drop_p >= 0.f && drop_p < 1.f && (long)rows * D < 4294967296L, "bad operand");
   if (!(drop_p > 0.f)) return LAFS_OK;
   const size_t total = (size_t)rows * D;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(dropout_f32_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, rows, D, make_drop(drop_p, drop_seed), nullptr);
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3(blocks), dim3(256), 0, stream, x, ldx, rows, D, make_drop(drop_p, drop_seed, drop_step), nullptr);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

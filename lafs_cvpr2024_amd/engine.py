@@ -94,13 +94,13 @@ class LafsPretrainEngine:
         else:
             g = int(math.isqrt(vit_s.pos_embed.shape[1] - 1))
             self.interp = [None if r == g else _interp_matrix(g, r, self.device) for r in self.grids]
-        # element dropout draws a new counter-based mask every step from a HOST-side seed (a kernel argument): a captured
-        # graph would replay one mask for ever, so such a model runs eagerly
+        # element dropout (Part-fViT: 0.1 live in student AND teacher, the reference never calls teacher.eval()): counter-based masks
+        # whose seed is (network seed + 7919 * hyper[HP_STEP]), the step read on the DEVICE inside the kernels exactly as the
+        # DropPath draw reads it -- a captured graph draws new masks on every replay, and the masks are indexed by absolute token
+        # rows, so the row chains stay legal
         self.has_dropout = self.partfvit and (vit_s.dropout_rate > 0 or vit_s.emb_dropout_rate > 0 or
                                               vit_t.dropout_rate > 0 or vit_t.emb_dropout_rate > 0)
-        if self.has_dropout and use_graph:
-            print("LafsPretrainEngine: element dropout is active -> eager launches (hipGraph capture would freeze the masks)")
-            use_graph = False
+        self.dropout_seed_s, self.dropout_seed_t = 0x5EED, 0x7EAC4E5       # independent masks in the two networks
         # static buffers
         dev = self.device
         self.hyper = torch.zeros(_lib.HP_COUNT, device=dev, dtype=f32)
@@ -135,7 +135,8 @@ class LafsPretrainEngine:
         over = {nm[k] for nm in self.spec_s.trunk.block_names for k in ("w_qkv", "w_proj", "w_fc1", "w_fc2")}
         over.add(self.head_prefix_s + "last_layer.weight_v")
         for i, name in enumerate(self.sa.names):
-            if name in over:
+            # (a frozen tensor's gradient is never written nor read: nothing to zero either)
+            if name in over or not self.sa.params[i].requires_grad:
                 flags[i] |= _lib.SEG_OVERWRITTEN
         self.sa.seg_flags.copy_(torch.tensor(flags, dtype=torch.int32))
         # gradient ranges for the two all-reduces: [trunk | head]
@@ -151,6 +152,10 @@ class LafsPretrainEngine:
         off = lambda blk: self.sa.offsets[self.spec_s.trunk.block_names[blk]["ln1_g"]] if blk > 0 else 0
         self.cut_offsets = [off(c) for c in self.cuts[1:]]                                   # arena offset where each run starts
         self.reducer = FlatReducer()
+        # large frozen tensors (Part-fViT's 30000 x 768 CosFace table: 92 MB of zeros per step on the wire otherwise) are cut out
+        # of the all-reduced ranges; small frozen ones (weight_g) ride along rather than splitting a collective
+        self._frozen_runs = [(self.sa.offsets[n], self.sa.offsets[n] + (p.numel() + _lib.CHUNK - 1) // _lib.CHUNK * _lib.CHUNK)
+                             for n, p in zip(self.sa.names, self.sa.params) if not p.requires_grad and p.numel() >= (1 << 20)]
         # teacher forward / weight-gradient GEMMs run on a second stream; LAFS_SINGLE_STREAM=1 serialises everything (profiling)
         self.side_stream = None if os.environ.get("LAFS_SINGLE_STREAM") == "1" else torch.cuda.Stream(device=self.device)
         self.use_graph = use_graph
@@ -192,6 +197,12 @@ class LafsPretrainEngine:
              _p(self.hyper[_lib.HP_STEP:]), _p(out))
         return out
 
+    def _dropout_cfg(self, vit, seed):
+        """(p_trunk, p_embedding, seed, device step counter) of a Part-fViT network in training mode, else None."""
+        if not self.partfvit or not vit.training or (vit.dropout_rate == 0.0 and vit.emb_dropout_rate == 0.0):
+            return None
+        return (vit.dropout_rate, vit.emb_dropout_rate, seed, self.hyper[_lib.HP_STEP:])
+
     def _seg_forward(self):
         sa, ta, B = self.sa, self.ta, self.B
         call("lafs_zero_chunks", _p(sa.grad), _p(sa.chunk_seg), _p(sa.seg_flags), sa.n_chunks, _lib.SEG_OVERWRITTEN)
@@ -205,14 +216,14 @@ class LafsPretrainEngine:
             pos_t = self._pos_tokens(ta, self.spec_t, self.pos_t)[:1]
             vit_t = self.teacher.backbone
             drop_t = self._drop_scales(self.keep_t, self.drop_t, 1) if vit_t.training else None   # rate 0 for the DINO ViT teacher
-            dd_t = vit_t._next_dropout() if self.partfvit else None
+            dd_t = self._dropout_cfg(vit_t, self.dropout_seed_t)
             feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, drop_t, save=False, dropout=dd_t)
             Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self.logits_t)
         # student: all views in one packed pass
         vit = self.student.backbone
         drop = self._drop_scales(self.keep_s, self.drop_s, 0) if vit.training else None
         imgs = [self.in_global_all] + ([self.in_local_all] if self.n_local else [])
-        dd_s = vit._next_dropout() if self.partfvit else None
+        dd_s = self._dropout_cfg(vit, self.dropout_seed_s)
         feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s, self.pos_s), drop,
                                          save=True, dropout=dd_s, wgrad_overwrite=True,
                                          wgrad_workgroups=int(os.environ.get("LAFS_WGRAD_WG", 200)) if self.side_stream is not None else 0)
@@ -326,18 +337,35 @@ class LafsPretrainEngine:
         run(0)
         # head gradients + center sums go out over RCCL while the trunk backward runs; each run of blocks follows as soon as
         # its graph segment has been enqueued (arena order: [embed | blocks 0..depth-1 | norm | head])
-        self.reducer.launch(self.sa.grad[self.head_start:])
+        self._reduce_range(self.head_start, self.sa.size)
         self.reducer.launch(self.colsum)
         hi = self.head_start
         for k, lo in enumerate(self.cut_offsets):
             run(1 + k)
             if hi > lo:
-                self.reducer.launch(self.sa.grad[lo:hi])
+                self._reduce_range(lo, hi)
             hi = lo
         self.reducer.wait_all()
         run(len(segs) - 1)
         self.step_count += 1
         return self.loss
+
+    def _reduce_range(self, lo, hi):
+        """Asynchronous SUM all-reduce of grad[lo:hi) minus the large frozen tensors inside it."""
+        for a, b in self._trainable_runs(lo, hi):
+            self.reducer.launch(self.sa.grad[a:b])
+
+    def _trainable_runs(self, lo, hi):
+        runs, cur = [], lo
+        for a, b in sorted(self._frozen_runs):
+            if b <= cur or a >= hi:
+                continue
+            if a > cur:
+                runs.append((cur, min(a, hi)))
+            cur = max(cur, b)
+        if cur < hi:
+            runs.append((cur, hi))
+        return runs
 
     # warm-up/capture executes real optimisation steps on whatever is in the buffers: snapshot and restore the state
     def _snapshot(self):
@@ -357,11 +385,14 @@ class LafsPretrainEngine:
     # ------------------------------------------------------------------ checkpoint helpers (reference layout)
     def _adamw_order(self):
         """Parameter names in torch.optim.AdamW(utils.get_params_groups(student)) index order: the regularised group first
-        (>= 2-D non-bias tensors), then the rest, each in named_parameters order, trainable tensors only (reference
-        lafs_train.py:385-392, utils.py:662-673)."""
+        (>= 2-D non-bias tensors), then the rest, each in named_parameters order (reference lafs_train.py:385-392,
+        utils.py:662-673).  The reference registers every tensor with requires_grad=True -- including Part-fViT's CosFace
+        `loss.weight`, which the SSL step never touches (gradient None: AdamW keeps no state for it, but it holds an index in the
+        regularised group).  Here such a tensor is frozen in the arena and marked `_lafs_optimizer_registered` by
+        build_backbones: it keeps its index and never gets a state entry."""
         reg, noreg = [], []
         for name, p in self.student.named_parameters():
-            if p.requires_grad:
+            if p.requires_grad or getattr(p, "_lafs_optimizer_registered", False):
                 (noreg if (name.endswith(".bias") or p.dim() == 1) else reg).append(name)
         return reg, noreg
 

@@ -80,7 +80,7 @@ class TrunkSpec:
 
 
 def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=None, with_grad=True, dropout_p=0.0, dropout_seed=0,
-                    wgrad_overwrite=False, wgrad_workgroups=0):
+                    wgrad_overwrite=False, wgrad_workgroups=0, dropout_step=None):
     """Build the C descriptor (keeps the ctypes block array alive on the returned object)."""
     blocks = (_lib.BlockOffsets * spec.depth)()
     for i, nm in enumerate(spec.block_names):
@@ -97,6 +97,7 @@ def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=No
     d.cu_seqlens, d.row2seq = geom.cu_seqlens.data_ptr(), geom.row2seq.data_ptr()
     d.drop_scales = drop_scales.data_ptr() if drop_scales is not None else None
     d.dropout_p, d.dropout_seed = float(dropout_p), int(dropout_seed) & 0xFFFFFFFF
+    d.dropout_step = dropout_step.data_ptr() if dropout_step is not None else None
     d.master, d.shadow, d.shadow_t = arena.master.data_ptr(), arena.shadow.data_ptr(), arena.shadow_t.data_ptr()
     d.grad = arena.grad.data_ptr() if (with_grad and arena.grad is not None) else None
     d.blocks = C.cast(blocks, C.POINTER(_lib.BlockOffsets))
@@ -106,7 +107,7 @@ def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=No
         d.n_groups = len(geom.groups)
         for gi, (n_img, side) in enumerate(geom.groups):
             d.group_n_seq[gi], d.group_max_len[gi] = n_img, (side // geom.patch) ** 2 + 1
-    d._keep = (blocks, drop_scales, geom, arena)
+    d._keep = (blocks, drop_scales, geom, arena, dropout_step)
     return d
 
 
@@ -142,17 +143,19 @@ EMB_DROP_SITE = 0x40000000          # seed offset of the embedding dropout (the 
 def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, drop_scales=None, save=True,
                 ws=None, x_in=None, x_out=None, dropout=None, wgrad_overwrite=False, wgrad_workgroups=0):
     """imgs: list of fp32 NCHW tensors (one per group); pos_tokens: list of fp32 [npatch+1, D] per group.
-    dropout: None or (p_trunk, p_embedding, seed): element dropout of Part-fViT (counter-based masks, see lafs_hip.h).
+    dropout: None or (p_trunk, p_embedding, seed[, step]): element dropout of Part-fViT (counter-based masks, see lafs_hip.h);
+    `step`: a DEVICE float tensor whose value x 7919 is added to the seed inside the kernels (graph-captured steps).
     Returns (feat f32 [n_seq, D], state)."""
     D = spec.trunk.dim
     dev = imgs[0].device
     pre = spec.prefix
     st = ViTState()
     st.geom = geom
-    p_trunk, p_emb, dseed = dropout if dropout is not None else (0.0, 0.0, 0)
-    st.dropout = (p_trunk, p_emb, dseed)
+    p_trunk, p_emb, dseed = dropout[:3] if dropout is not None else (0.0, 0.0, 0)
+    dstep = dropout[3] if (dropout is not None and len(dropout) > 3) else None
+    st.dropout = (p_trunk, p_emb, dseed, dstep)
     st.desc = make_trunk_desc(arena, spec.trunk, geom, drop_scales, with_grad=save, dropout_p=p_trunk, dropout_seed=dseed,
-                              wgrad_overwrite=wgrad_overwrite, wgrad_workgroups=wgrad_workgroups)
+                              wgrad_overwrite=wgrad_overwrite, wgrad_workgroups=wgrad_workgroups, dropout_step=dstep)
     st.ws = ws if ws is not None else trunk_workspace(st.desc, save, dev)
     st.x_in = x_in if x_in is not None else torch.empty(geom.n_tok, D, device=dev, dtype=f32)
     if x_out is None:
@@ -171,7 +174,7 @@ def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, dr
         call("lafs_embed_cls", _p(arena.view(arena.master, pre + spec.cls)), _p(pos_tokens[gi]), _p(rows), D, n_img, np_, D)
         st.patches.append(pt if save else None)
     if p_emb > 0:
-        call("lafs_dropout_f32", _p(st.x_in), D, geom.n_tok, D, float(p_emb), (dseed + EMB_DROP_SITE) & 0xFFFFFFFF)
+        call("lafs_dropout_f32", _p(st.x_in), D, geom.n_tok, D, float(p_emb), (dseed + EMB_DROP_SITE) & 0xFFFFFFFF, _p(dstep))
     call("lafs_trunk_forward", C.byref(st.desc), _p(st.x_in), _p(x_out), _p(st.ws), 1 if save else 0)
     st.cls_rows = torch.empty(geom.n_seq, D, device=dev, dtype=f32)
     call("lafs_gather_cls", _p(x_out), D, _p(geom.cu_seqlens), geom.n_seq, D, _p(st.cls_rows))
@@ -211,9 +214,9 @@ def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g, want_dx=False, dpos_
     dev = g.device
     gv = lambda n: arena.view(arena.grad, pre + n)
     dpos, dx = [], []
-    p_emb, dseed = st.dropout[1], st.dropout[2]
+    p_emb, dseed, dstep = st.dropout[1], st.dropout[2], st.dropout[3]
     if p_emb > 0:                                         # backward of the embedding dropout: the same mask on the gradient
-        call("lafs_dropout_f32", _p(g), D, geom.n_tok, D, float(p_emb), (dseed + EMB_DROP_SITE) & 0xFFFFFFFF)
+        call("lafs_dropout_f32", _p(g), D, geom.n_tok, D, float(p_emb), (dseed + EMB_DROP_SITE) & 0xFFFFFFFF, _p(dstep))
     wt = None
     if want_dx:                                           # W_patch^T bf16 [192, D]: B operand of dP = dTok @ W_patch
         wt = torch.empty(192, D, device=dev, dtype=bf16)

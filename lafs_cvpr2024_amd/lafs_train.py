@@ -213,8 +213,11 @@ def build_backbones(args):
                                           shuffle=False)
     sb, tb = mk(), mk()
     # `loss.weight` (CosFace, 30000 x dim) is part of the checkpoint layout but never used by the SSL step: the reference's
-    # AdamW skips it (its gradient is None); here it is simply not trainable, so the fused optimizer leaves it alone as well
+    # AdamW registers it (it holds an index in the regularised param group) but skips it (its gradient is None: no state entry).
+    # Here it is frozen in the arena, so the fused optimizer / zeroing / all-reduce leave it alone, and marked so that the
+    # checkpoint's optimizer state_dict keeps the reference's parameter indices (engine._adamw_order)
     sb.loss.weight.requires_grad_(False)
+    sb.loss.weight._lafs_optimizer_registered = True
     return sb, tb, dim
 
 

@@ -44,7 +44,7 @@ def zeros(*shape, device, dtype=torch.float32):
 
 
 def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=None, seq_scale=None, row2seq=None,
-            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0, act=0, skip_pre=False,
+            aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0, act=0, skip_pre=False, drop_step=None, drop_row0=0,
             route_only=False):
     """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*).  skip_pre (BF16_GELU): write only
     GELU(u), as the forward-only teacher pass does; route_only: return lafs_gemm_nt_route for this request instead of running it."""
@@ -64,6 +64,7 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     a.A, a.lda, a.B, a.ldb = A.data_ptr(), _ld(A), B.data_ptr(), _ld(B)
     a.M, a.N, a.K, a.epilogue = M, N, K, epilogue
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
+    a.drop_step, a.drop_row0 = (drop_step.data_ptr() if drop_step is not None else None), int(drop_row0)
     a.act = int(act)
     a.C, a.ldc = out.data_ptr(), _ld(out)
     if out2 is not None:
@@ -171,7 +172,7 @@ def layernorm_fwd(x, gamma, beta, eps, want_bf16=True, want_f32=False):
 
 
 def layernorm_bwd(dy, x, stats, gamma, g_io, dgamma, dbeta, accumulate=True, gb_out=None, seq_scale=None, row2seq=None,
-                  drop_p=0.0, drop_seed=0):
+                  drop_p=0.0, drop_seed=0, drop_step=None, drop_row0=0):
     """dy: bf16 or f32 [rows, D].  g_io (f32) receives (accumulates) dx; returns g_io."""
     rows, D = x.shape
     dy_b = dy if dy.dtype == bf16 else None
@@ -179,16 +180,16 @@ def layernorm_bwd(dy, x, stats, gamma, g_io, dgamma, dbeta, accumulate=True, gb_
     call("lafs_layernorm_bwd", _p(dy_b), D if dy_b is None else _ld(dy_b), _p(dy_f), D if dy_f is None else _ld(dy_f),
          _p(x), _ld(x), _p(stats), _p(gamma), _p(g_io), _ld(g_io), 1 if accumulate else 0,
          _p(gb_out), D if gb_out is None else _ld(gb_out), _p(seq_scale), _p(row2seq), _p(dgamma), _p(dbeta), rows, D,
-         float(drop_p), int(drop_seed) & 0xFFFFFFFF)
+         float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(drop_step), int(drop_row0))
     return g_io
 
 
-def scale_cast_bf16(g, seq_scale=None, row2seq=None, out=None, drop_p=0.0, drop_seed=0):
+def scale_cast_bf16(g, seq_scale=None, row2seq=None, out=None, drop_p=0.0, drop_seed=0, drop_step=None, drop_row0=0):
     rows, D = g.shape
     if out is None:
         out = torch.empty(rows, D, device=g.device, dtype=bf16)
     call("lafs_scale_cast_bf16", _p(g), _ld(g), _p(out), _ld(out), _p(seq_scale), _p(row2seq), rows, D,
-         float(drop_p), int(drop_seed) & 0xFFFFFFFF)
+         float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(drop_step), int(drop_row0))
     return out
 
 

@@ -459,3 +459,51 @@ def test_transposed_weight_shadows_table_kernel():
         got = shadow[to:to + r * c].view(c, r).float().cpu()
         assert torch.equal(got, m.t().to(bf16).float())
     assert float(shadow[:3].float().min()) == 9.0 and float(shadow[toff:].float().min()) == 9.0      # nothing written outside
+
+
+def test_dropout_seed_from_a_device_step_counter_and_row_offsets():
+    """Element dropout for graph-captured steps (lafs_hip.h: drop_step / drop_row0): the seed of a launch is drop_seed + 7919 * step
+    with `step` read from DEVICE memory when the kernel runs, and a launch over rows [r0, r0 + R) of a batch applies rows r0.. of the
+    batch's mask.  Every site -- residual epilogue, GELU epilogue, GELU' epilogue, LayerNorm-backward / cast gradients, in-place
+    embedding dropout -- must reproduce the mask lafs_debug_dropout_mask exports for the host-side seed' = seed + 7919 * step."""
+    from lafs_cvpr2024_amd import _lib
+    from lafs_cvpr2024_amd.ops import _p, call
+    torch.manual_seed(5)
+    M, N, K, p, seed, stepv, r0 = 320, 256, 128, 0.25, 0x1234, 37.0, 96
+    step = torch.tensor([stepv], device=DEV)
+    eff = (seed + 7919 * int(stepv)) & 0xFFFFFFFF
+    mask = ops.dropout_mask(M, N, p, eff, DEV)
+    assert abs(float((mask > 0).float().mean()) - (1 - p)) < 0.02
+    assert not torch.equal(mask, ops.dropout_mask(M, N, p, seed, DEV))            # the step changes the mask
+    A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV) * 0.1).to(torch.bfloat16)
+    resid = torch.randn(M, N, device=DEV)
+    plain = ops.gemm_nt(A, W, _lib.EPI_RESID_F32, resid=resid) - resid
+    # residual epilogue: the whole batch, then a row sub-range with its offset
+    full = ops.gemm_nt(A, W, _lib.EPI_RESID_F32, resid=resid, drop_p=p, drop_seed=seed, drop_step=step) - resid
+    torch.testing.assert_close(full, plain * mask, rtol=1e-5, atol=1e-5)
+    part = ops.gemm_nt(A[r0:], W, _lib.EPI_RESID_F32, resid=resid[r0:], drop_p=p, drop_seed=seed, drop_step=step, drop_row0=r0) - resid[r0:]
+    torch.testing.assert_close(part, full[r0:], rtol=0, atol=0)
+    wrong = ops.gemm_nt(A[r0:], W, _lib.EPI_RESID_F32, resid=resid[r0:], drop_p=p, drop_seed=seed, drop_step=step) - resid[r0:]
+    assert not torch.equal(wrong, full[r0:])                                      # without the offset: launch-relative rows
+    # the counter is read when the kernel runs: same arguments, new value -> new mask
+    step.fill_(stepv + 1)
+    full2 = ops.gemm_nt(A, W, _lib.EPI_RESID_F32, resid=resid, drop_p=p, drop_seed=seed, drop_step=step) - resid
+    torch.testing.assert_close(full2, plain * ops.dropout_mask(M, N, p, (seed + 7919 * int(stepv + 1)) & 0xFFFFFFFF, DEV), rtol=1e-5, atol=1e-5)
+    step.fill_(stepv)
+    # GELU epilogue (mask on GELU(u) only) and its backward
+    _, a_plain = ops.gemm_nt(A, W, _lib.EPI_BF16_GELU)
+    u, a_drop = ops.gemm_nt(A[r0:], W, _lib.EPI_BF16_GELU, drop_p=p, drop_seed=seed, drop_step=step, drop_row0=r0)
+    torch.testing.assert_close(a_drop.float(), (a_plain.float() * mask)[r0:].to(torch.bfloat16).float(), rtol=1e-2, atol=1e-3)
+    dy = torch.randn(M - r0, K, device=DEV).to(torch.bfloat16)
+    d_plain = ops.gemm_nt(dy, W, _lib.EPI_DGELU_BF16, aux=u)
+    d_drop = ops.gemm_nt(dy, W, _lib.EPI_DGELU_BF16, aux=u, drop_p=p, drop_seed=seed, drop_step=step, drop_row0=r0)
+    torch.testing.assert_close(d_drop.float(), (d_plain.float() * mask[r0:]).to(torch.bfloat16).float(), rtol=1e-2, atol=1e-3)
+    # gradient casts
+    g = torch.randn(M, N, device=DEV)
+    gb = ops.scale_cast_bf16(g[r0:], drop_p=p, drop_seed=seed, drop_step=step, drop_row0=r0)
+    torch.testing.assert_close(gb.float(), (g * mask)[r0:].to(torch.bfloat16).float(), rtol=0, atol=0)
+    x = torch.randn(M, N, device=DEV)
+    x2 = x.clone()
+    call("lafs_dropout_f32", _p(x2), N, M, N, p, seed, _p(step))
+    torch.testing.assert_close(x2, x * mask, rtol=0, atol=0)

@@ -320,19 +320,75 @@ def test_f16_partfvit_pair_two_steps_against_reference(use_graph, tmp_path):
         load_ssl_teacher(ft, str(ck))
 
 
-def test_partfvit_pair_runs_with_live_dropout_and_droppath():
-    """The reference never puts its Part-fViT teacher in eval mode: dropout 0.1 and DropPath 0.1 are live in BOTH networks.
-    Such a pair must run (eagerly: the masks come from a host-side seed), give finite, step-dependent losses, and the teacher
-    output must differ between two passes over the same input (stochastic teacher)."""
+def test_partfvit_pair_with_live_dropout_and_droppath_is_graph_captured():
+    """The reference never puts its Part-fViT teacher in eval mode: dropout 0.1 and DropPath 0.1 are live in BOTH networks
+    (lafs_train.py:300-335, ViT_face.py:126-153,614).  The element-dropout seed is derived on the device from hyper[HP_STEP], so
+    the pair runs as ONE captured graph: losses are finite and step-dependent, the teacher output differs between two replays on
+    the same input (stochastic teacher, new masks per replay), and the captured step equals the eager step launch for launch."""
     fx = load_golden("f16_lafs_step_partfvit")
-    student, teacher, crit, eng = _build_partfvit(fx, True, dropout=0.1, drop_path=0.1)
-    assert eng.use_graph is False and eng.has_dropout
     crops = [fx[f"s0.crop{i}"] for i in range(4)]
-    l0 = float(eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item())
-    t0 = eng.logits_t.clone()
-    l1 = float(eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item())
-    assert math.isfinite(l0) and math.isfinite(l1) and l0 != l1
-    assert not torch.equal(t0, eng.logits_t)
+    out = {}
+    for use_graph in (True, False):
+        student, teacher, crit, eng = _build_partfvit(fx, use_graph, dropout=0.1, drop_path=0.1)
+        assert eng.use_graph is use_graph and eng.has_dropout
+        l0 = float(eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item())
+        t0 = eng.logits_t.clone()
+        l1 = float(eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item())
+        assert math.isfinite(l0) and math.isfinite(l1) and l0 != l1
+        assert not torch.equal(t0, eng.logits_t)
+        out[use_graph] = (l0, l1, t0)
+        if use_graph:
+            assert eng._graphs is not None and len(eng._graphs) == 1
+    # same seeds, same step counters -> the same masks in the captured and the eager run
+    assert abs(out[True][0] - out[False][0]) < 1e-5 * abs(out[False][0]), (out[True][:2], out[False][:2])
+    assert abs(out[True][1] - out[False][1]) < 2e-3 * abs(out[False][1]), (out[True][:2], out[False][:2])
+    torch.testing.assert_close(out[True][2], out[False][2], rtol=1e-4, atol=1e-4)
+
+
+def test_partfvit_pair_dropout_masks_match_the_oracle_inside_the_engine():
+    """The LAFS engine's element dropout against the oracle: the masks of student and teacher are exported for the seeds the
+    engine derives (network seed + 7919 * step, sites seed + 3 l + {0, 1, 2}, embedding site) and fed to oracle.partfvit (whose
+    dropout sites are pinned to the reference by F14); DropPath off so that dropout is the only stochastic part; loss to 3e-3
+    (K = 256 toy head), logits rel-L2 2e-2."""
+    from lafs_cvpr2024_amd import functional as Fn, ops
+    from oracle import dino, partfvit, vit as ovit
+    fx = load_golden("f16_lafs_step_partfvit")
+    p = 0.1
+    student, teacher, crit, eng = _build_partfvit(fx, False, dropout=p, drop_path=0.0)
+    crops = [fx[f"s0.crop{i}"] for i in range(4)]
+    eng.step_count = 5                                                    # any step: the seed follows the device counter
+    loss = float(eng.step(crops, lr=0.0, wd=0.0, momentum=1.0, teacher_temp=0.05, epoch=1).item())
+    B, D, H = 2, 64, 128
+    cfg = partfvit.PartFViTConfig(dim=64, depth=2, heads=2, mlp_dim=128, num_patches=196)
+    init = sub(fx, "init.")
+    Pb = {k[len("backbone."):]: v for k, v in init.items() if k.startswith("backbone.")}
+    Ph = {k[len("head."):]: v for k, v in init.items() if k.startswith("head.")}
+
+    def masks_for(seed, rows0, n_img, n_tok, total_rows):
+        """oracle mask dict of one crop group: rows [rows0, rows0 + n_img * n_tok) of the packed batch's masks."""
+        eff = (seed + 7919 * 5) & 0xFFFFFFFF
+        cut = lambda m, C: m[rows0:rows0 + n_img * n_tok].view(n_img, n_tok, C).cpu()
+        out = {"emb": cut(ops.dropout_mask(total_rows, D, p, (eff + Fn.EMB_DROP_SITE) & 0xFFFFFFFF, DEV), D)}
+        for l in range(2):
+            out[(l, 0)] = cut(ops.dropout_mask(total_rows, D, p, eff + 3 * l + 0, DEV), D)
+            out[(l, 1)] = cut(ops.dropout_mask(total_rows, H, p, eff + 3 * l + 1, DEV), H)
+            out[(l, 2)] = cut(ops.dropout_mask(total_rows, D, p, eff + 3 * l + 2, DEV), D)
+        return out
+    Ts, Tt = eng.geom_s.n_tok, eng.geom_t.n_tok
+    with torch.no_grad():
+        t_feat = partfvit.forward_embedding(Pb, torch.cat(crops[:2]), cfg, masks=masks_for(eng.dropout_seed_t, 0, 2 * B, 197, Tt))
+        t_out = ovit.dino_head_forward(Ph, t_feat)
+        s_feat = torch.cat([partfvit.forward_embedding(Pb, torch.cat(crops[:2]), cfg, masks=masks_for(eng.dropout_seed_s, 0, 2 * B, 197, Ts)),
+                            partfvit.forward_embedding(Pb, torch.cat(crops[2:]), cfg,
+                                                       masks=masks_for(eng.dropout_seed_s, 2 * B * 197, 2 * B, 37, Ts))])
+        s_out = ovit.dino_head_forward(Ph, s_feat)
+        ref = float(dino.dino_loss(s_out, t_out, torch.zeros(1, 256), 4, 0.05, 0.1))
+    assert rel_l2(eng.logits_t[:, :256], t_out) < 2e-2 and rel_l2(eng.logits_s[:, :256], s_out) < 2e-2
+    assert abs(loss - ref) / ref < 3e-3, (loss, ref)
+    # and without the masks the oracle is visibly elsewhere (the comparison is not vacuous)
+    with torch.no_grad():
+        t_plain = ovit.dino_head_forward(Ph, partfvit.forward_embedding(Pb, torch.cat(crops[:2]), cfg))
+    assert rel_l2(eng.logits_t[:, :256], t_plain) > 3e-2
 
 
 # ------------------------------------------------------------------------------------------------ checkpoint layout / resume

@@ -141,3 +141,31 @@ def test_recordio_epoch_shards_are_equal_disjoint_and_reshuffled():
     flat = [i for s in e0 for i in s]
     assert len(set(flat)) == len(flat) == (n // world) * world
     assert e0[3] != e1[3] and sorted(i for s in e1 for i in s) != sorted(flat) or e0 != e1
+
+
+def test_mynet_optimizer_index_order_is_the_reference_adamw_order():
+    """checkpoint['optimizer'] of the reference's real configuration (--arch mynet): torch.optim.AdamW(get_params_groups(student))
+    registers Part-fViT's CosFace `loss.weight` (requires_grad stays True in the reference, lafs_train.py:316-335, 385-392) in the
+    regularised group although the SSL step never gives it a gradient (no state entry).  The engine freezes that tensor but must
+    keep its index, or every later index shifts and a reference checkpoint cannot be resumed (and vice versa)."""
+    import types
+    from lafs_cvpr2024_amd.engine import LafsPretrainEngine
+    from lafs_cvpr2024_amd.lafs_train import build_backbones
+    from lafs_cvpr2024_amd.utils import get_params_groups
+    from lafs_cvpr2024_amd.vision_transformer import DINOHead
+    args = types.SimpleNamespace(arch="mynet", mynet_dims="64,2,2,128", mynet_dropout=0.1)
+    sb, _, dim = build_backbones(args)
+    student = MultiCropWrapper(sb, DINOHead(dim, 256, hidden_dim=64, bottleneck_dim=32, norm_last_layer=True))
+    assert not sb.loss.weight.requires_grad                                  # frozen in the arena ...
+    reg, noreg = LafsPretrainEngine._adamw_order(types.SimpleNamespace(student=student))
+    assert "backbone.loss.weight" in reg                                      # ... but it keeps its index
+    # the reference's view of the same model: loss.weight trainable, weight_g frozen by norm_last_layer
+    sb.loss.weight.requires_grad_(True)
+    groups = get_params_groups(student)
+    by_id = {id(p): n for n, p in student.named_parameters()}
+    assert [by_id[id(p)] for p in groups[0]["params"]] == reg
+    assert [by_id[id(p)] for p in groups[1]["params"]] == noreg
+    # a reference-style state_dict (no state for loss.weight) round-trips through torch's own loader with these group sizes
+    opt = torch.optim.AdamW(groups)
+    sd = opt.state_dict()
+    assert [len(g["params"]) for g in sd["param_groups"]] == [len(reg), len(noreg)]
