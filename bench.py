@@ -41,8 +41,8 @@ def step_flops(arch_dims, B, n_local, K):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)           # >= 50 timed steps after >= 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--arch", default="vit_small")
     ap.add_argument("--out-dim", type=int, default=100000)
@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the roofline kernels' loops (for rocprofv3)")
     ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the non-headline workloads appended to the JSON line at 1 GPU (`extras`: the reference's real "
+                         "pre-training pair --arch mynet, and the C4 fine-tune step)")
+    ap.add_argument("--extras-only", default="", help="run only this extra workload (mynet | finetune | finetune_plain | partialfc) and print it")
     ap.add_argument("--augment", action="store_true",
                     help="with --frontend: also run the device-side DataAugmentation_LAFS (uint8 batch -> 20 views) every step")
     ap.add_argument("--frontend", action="store_true",
@@ -85,11 +89,56 @@ def _roof(kernel, dur, flops, alg_bytes, traffic=None):
             "mfma_tflops": round(tf, 1), "mfma_frac": round(tf / 2500.0, 4), "intensity_flop_per_byte": round(flops / alg_bytes, 1)}
 
 
-def _pmc_traffic(name):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/round2_kernel_pmc.json), or None."""
-    f = os.path.join(ROOT, "profiles", "round2_kernel_pmc.json")
+def csrc_fingerprint():
+    """sha256 (12 hex digits) over the kernel sources the library is built from: profiles/*_pmc.json record the fingerprint they
+    were measured on (tools/publish_profiles.py, tools/profile_step_hbm.sh), and numbers read from a profile are only printed while
+    it still matches -- a kernel edit without a profile refresh turns them into null instead of a stale figure."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lafs_cvpr2024_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def _latest_profile(suffix):
+    """(path, parsed json, file sha) of the newest committed profiles/round<N>_<suffix>, or (None, None, None)."""
+    import glob
+    import hashlib
+    import re
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_" + suffix)),
+                  key=lambda f: int(re.search(r"round(\d+)_", os.path.basename(f)).group(1)))
+    if not hits:
+        return None, None, None
     try:
-        return round(json.load(open(f))[name]["hbm_bytes_per_launch"])
+        raw = open(hits[-1], "rb").read()
+        return hits[-1], json.loads(raw), hashlib.sha256(raw).hexdigest()[:12]
+    except Exception:
+        return None, None, None
+
+
+PROFILE_NOTES = {}
+
+
+def _fresh(tag, path, data, sha):
+    """True when the profile was measured on the kernels this run uses; records provenance for the JSON line either way."""
+    ok = data is not None and data.get("csrc_sha") == csrc_fingerprint()
+    PROFILE_NOTES[tag] = {"file": os.path.relpath(path, ROOT) if path else None, "sha256": sha,
+                          "measured_on_csrc": None if data is None else data.get("csrc_sha"), "current_csrc": csrc_fingerprint(),
+                          "used": bool(ok)}
+    return ok
+
+
+def _pmc_traffic(name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/round<N>_kernel_pmc.json), or None when there is
+    no such profile or it was measured on other kernel sources than the ones built now."""
+    path, data, sha = _latest_profile("kernel_pmc.json")
+    if not _fresh("kernel_pmc", path, data, sha):
+        return None
+    try:
+        return round(data[name]["hbm_bytes_per_launch"])
     except Exception:
         return None
 
@@ -146,11 +195,14 @@ ROOFLINE_KERNELS = {"wgrad_kernel": roofline_wgrad_group, "gemm_nt_kernel": roof
 
 
 def dominant_kernel_name():
-    """The kernel with the largest per-step total in the committed serialised profile of the step
-    (profiles/round2_serial_kernel_stats.csv, rocprofv3 --kernel-trace --stats); falls back to the weight-gradient kernel."""
+    """The kernel with the largest per-step total in the newest committed serialised profile of the step
+    (profiles/round<N>_serial_kernel_stats.csv, rocprofv3 --kernel-trace --stats); falls back to the weight-gradient kernel."""
     import csv
-    f = os.path.join(ROOT, "profiles", "round2_serial_kernel_stats.csv")
+    import glob
+    import re
     try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_serial_kernel_stats.csv")),
+                   key=lambda x: int(re.search(r"round(\d+)_", os.path.basename(x)).group(1)))[-1]
         rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
         for r in rows:
             for key in ROOFLINE_KERNELS:
@@ -169,41 +221,132 @@ def dominant_kernel_roofline(device, iters=30):
 
 
 def step_hbm_bytes():
-    """HBM bytes of ONE whole step from profiles/round2_step_hbm_pmc.json (FETCH_SIZE x2 + WRITE_SIZE over all kernels)."""
+    """HBM bytes of ONE whole step from the newest profiles/round<N>_step_hbm_pmc.json (FETCH_SIZE x2 + WRITE_SIZE over all
+    kernels of a step), or None when that profile does not describe the kernels built now."""
+    path, data, sha = _latest_profile("step_hbm_pmc.json")
+    if not _fresh("step_hbm_pmc", path, data, sha):
+        return None
     try:
-        return int(json.load(open(os.path.join(ROOT, "profiles", "round2_step_hbm_pmc.json")))["hbm_bytes_per_step"])
+        return int(data["hbm_bytes_per_step"])
     except Exception:
         return None
 
 
-def cpu_baseline(arch_dims, n_local, K, batch):
-    """The oracle (fp32 torch-CPU restatement, parity-locked to the reference's golden vectors) timed on the host cores
-    on a bounded sample of the same workload: ONE step of the same model/crop geometry at a small batch."""
-    from oracle import dino, step as ostep, vit as ovit
+def cpu_baseline(arch_dims, n_local, K, batch, timed=2):
+    """The oracle (fp32 torch-CPU restatement, parity-locked to the reference's golden vectors) timed on the host cores on a
+    bounded sample of the same workload: steps of the same model / crop geometry at batch `batch` -- ONE untimed warm-up step
+    (thread pool start, allocator growth, first-touch of the 100 000-class head) and then `timed` timed steps, median reported."""
+    from oracle import step as ostep, vit as ovit
     D, depth, heads = arch_dims
     # torch's CPU GEMMs stop scaling (and collapse when oversubscribed) beyond a few dozen threads at these sizes:
     # measured on the GPU box host, 32 threads is the fastest setting (256 threads is 100x slower)
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+
+    def run(cfg, b, nl, n_timed):
+        st = ostep.LafsState(cfg, out_dim=K, seed=0)
+        g = torch.Generator().manual_seed(0)
+        crops = [torch.randn(b, 3, 112, 112, generator=g).clamp(-1, 1) for _ in range(2)] + \
+                [torch.randn(b, 3, 48, 48, generator=g).clamp(-1, 1) for _ in range(nl)]
+        ts, r = [], None
+        for i in range(1 + n_timed):
+            t0 = time.time()
+            r = ostep.lafs_step(st, crops, epoch=1, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04)
+            if i > 0:
+                ts.append(time.time() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])
+        return med, ts, float(r["loss"])
+
     cfg = ovit.ViTConfig(patch_size=8, embed_dim=D, depth=depth, num_heads=heads, img_size=224)
-    st = ostep.LafsState(cfg, out_dim=K, seed=0)
-    g = torch.Generator().manual_seed(0)
-    crops = [torch.randn(batch, 3, 112, 112, generator=g).clamp(-1, 1) for _ in range(2)] + \
-            [torch.randn(batch, 3, 48, 48, generator=g).clamp(-1, 1) for _ in range(n_local)]
-    t0 = time.time()
-    r = ostep.lafs_step(st, crops, epoch=1, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04)
-    dt = time.time() - t0
-    out = {"value": round(batch * (2 + n_local) / dt, 3), "unit": "face-crops/s", "cores": cores, "kind": "port",
-           "sample": f"1 step of the same model/crops at batch {batch} (fp32, torch CPU, {dt:.1f} s), loss {float(r['loss']):.4f}"}
+    med, ts, loss = run(cfg, batch, n_local, timed)
+    out = {"value": round(batch * (2 + n_local) / med, 3), "unit": "face-crops/s", "cores": cores, "kind": "port",
+           "sample": f"same model/crops at batch {batch}, fp32 torch CPU: 1 warm-up + {timed} timed steps, median {med:.2f} s "
+                     f"(all: {', '.join('%.2f' % t for t in ts)}), loss {loss:.4f}"}
     # config C1 of BASELINE.json (ViT-Tiny, 2 global + 2 local crops, batch 8): the always-run CPU case, for round-to-round comparison
     cfg1 = ovit.ViTConfig(patch_size=8, embed_dim=192, depth=12, num_heads=3, img_size=224)
-    st1 = ostep.LafsState(cfg1, out_dim=K, seed=0)
-    crops1 = [torch.randn(8, 3, 112, 112, generator=g).clamp(-1, 1) for _ in range(2)] + \
-             [torch.randn(8, 3, 48, 48, generator=g).clamp(-1, 1) for _ in range(2)]
-    t0 = time.time()
-    ostep.lafs_step(st1, crops1, epoch=1, lr=5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04)
-    dt1 = time.time() - t0
-    out["c1"] = {"value": round(8 * 4 / dt1, 3), "unit": "face-crops/s", "sample": f"C1: ViT-Tiny, 2g+2l, batch 8, out_dim {K}, 1 step ({dt1:.1f} s)"}
+    med1, ts1, _ = run(cfg1, 8, 2, 3)
+    out["c1"] = {"value": round(8 * 4 / med1, 3), "unit": "face-crops/s",
+                 "sample": f"C1: ViT-Tiny, 2g+2l, batch 8, out_dim {K}: 1 warm-up + 3 timed steps, median {med1:.2f} s"}
+    return out
+
+
+def extra_mynet_pretrain(device, B=64, nl=8, K=100000, steps=12, warmup=4):
+    """NON-headline: the pair the reference actually pre-trains (lafs_train.py:300-335, --arch mynet): Part-fViT dim 768 / depth 12 /
+    11 heads / mlp 2048 student AND teacher with dropout 0.1 + DropPath 0.1 live in both, [B, n, 192] landmark-patch tokens,
+    2 global + 8 local crops, batch 64, K = 100 000, one captured hipGraph (element-dropout seed read from the device counter)."""
+    import types
+    from lafs_cvpr2024_amd.dino_loss import DINOLoss
+    from lafs_cvpr2024_amd.engine import LafsPretrainEngine
+    from lafs_cvpr2024_amd.lafs_train import build_backbones
+    from lafs_cvpr2024_amd.utils import MultiCropWrapper
+    from lafs_cvpr2024_amd import vision_transformer as vits
+    torch.manual_seed(0)
+    sb, tb, dim = build_backbones(types.SimpleNamespace(arch="mynet", mynet_dims="768,12,11,2048", mynet_dropout=0.1))
+    student = MultiCropWrapper(sb, vits.DINOHead(dim, K, use_bn=False, norm_last_layer=True))
+    teacher = MultiCropWrapper(tb, vits.DINOHead(dim, K, use_bn=False))
+    teacher.load_state_dict(student.state_dict())
+    crit = DINOLoss(K, 2 + nl, 0.07, 0.04, 30, 41)
+    eng = LafsPretrainEngine(student, teacher, crit, B, n_local=nl, clip_grad=3.0, freeze_last_layer=1, use_graph=True, device=device)
+    g = torch.Generator(device=device).manual_seed(0)
+    eng.in_global_all.copy_(torch.randn(eng.in_global_all.shape, device=device, generator=g).clamp_(-1, 1))
+    eng.in_local_all.copy_(torch.randn(eng.in_local_all.shape, device=device, generator=g).clamp_(-1, 1))
+    one = lambda: eng.step(lr=2.5e-4, wd=0.04, momentum=0.996, teacher_temp=0.04, epoch=1)
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    return {"workload": f"Part-fViT (768/12/11/2048) LAFS pair, dropout 0.1 + DropPath 0.1 live in student and teacher, 2g+{nl}l crops, "
+                        f"batch {B}, out_dim {K}, hipGraph {bool(eng._graphs)}", "ms_per_step": round(dt * 1e3, 2),
+            "face_crops_per_s": round(B * (2 + nl) / dt, 1), "steps": steps, "warmup": warmup, "loss": round(float(loss.item()), 4)}
+
+
+def extra_finetune(device, head="CosFace", with_land=True, dropout=0.1, B=128, C=205990, steps=12, warmup=4):
+    """NON-headline: BASELINE.json configs[3] on ONE GPU as train_largescale.py builds it (:432, 542-561, 785-891): Part-fViT ViT-B +
+    CosFace over 205 990 classes, trainable landmark branch, dropout 0.1, mixup alpha 0.2 / prob 0.1, batch 128, acc_step 1 here
+    (every micro-step followed by AdamW: the upper bound of the per-step cost).  head = PartialFC: configs[4]'s sampled head."""
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    torch.manual_seed(0)
+    sharded = head == "PartialFC"
+    m = ViT_face_landmark_patch8(loss_type="None" if sharded else "CosFace", GPU_ID=None, num_class=C, image_size=112, patch_size=8,
+                                 dim=768, depth=12, heads=11, mlp_dim=2048, dropout=dropout, emb_dropout=dropout,
+                                 with_land=with_land, drop_path_rate=0.1)
+    sh = None
+    if sharded:
+        from lafs_cvpr2024_amd.partial_fc import PartialFC
+        sh = PartialFC(768, C, B, sample_rate=0.1, device=device)
+    eng = FinetuneEngine(m, B, acc_step=1, device=device, sharded_head=sh)
+    m.train()
+    x = torch.randint(0, 256, (B, 3, 112, 112), dtype=torch.uint8, device=device)
+    y = torch.randint(0, C, (B,), device=device)
+    for _ in range(warmup):
+        eng.step(x, y, lr=1e-4)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = eng.step(x, y, lr=1e-4)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    return {"workload": f"Part-fViT ViT-B + {head} fine-tune step, batch {B}, {C} classes, with_land={with_land}, dropout={dropout}"
+                        + (", sample_rate 0.1" if sharded else ""), "ms_per_step": round(dt * 1e3, 2),
+            "images_per_s": round(B / dt, 1), "steps": steps, "warmup": warmup, "loss": round(float(loss.item()), 4)}
+
+
+EXTRAS = {"mynet": lambda d: extra_mynet_pretrain(d),
+          "finetune": lambda d: extra_finetune(d),
+          "finetune_plain": lambda d: extra_finetune(d, with_land=False, dropout=0.0),
+          "partialfc": lambda d: extra_finetune(d, head="PartialFC", with_land=False, B=256, C=200000)}
+
+
+def run_extras(device, which=("mynet", "finetune")):
+    out = {}
+    for k in which:
+        torch.cuda.empty_cache()
+        try:
+            out[k] = EXTRAS[k](device)
+        except Exception as e:                       # an extra must never cost the headline line
+            out[k] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 
@@ -268,6 +411,13 @@ def main():
     if args.roofline_only:
         print(json.dumps({"roofline": dominant_kernel_roofline(device, iters=200)}))
         return
+    if args.extras_only:
+        print(json.dumps({"extras": run_extras(device, [k for k in args.extras_only.split(",") if k])}))
+        return
+    # the number of ranks the communication backend really sees must be the number of GPUs the line will claim
+    comm_ranks = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    if comm_ranks != args.gpus:
+        sys.exit(f"bench.py: the process group has {comm_ranks} rank(s) but --gpus is {args.gpus}")
 
     dims = {"vit_small": (384, 12, 6), "vit_tiny": (192, 12, 3), "vit_base": (768, 12, 12)}[args.arch]
     torch.manual_seed(0)
@@ -354,6 +504,7 @@ def main():
             "step_tflops_per_gpu": round(fl / (ms * 1e-3) / 1e12, 1),
             "step_mfma_frac": round(fl / (ms * 1e-3) / 2.5e15, 4),
             "final_loss": round(loss_v, 4), "debug_flags": dbg,
+            "comm": {"backend": (dist.get_backend() if world > 1 else None), "ranks_seen": comm_ranks},
             # routing / scheduling knobs of the library and the engine that were set in the environment (none of them changes results;
             # an empty object = the shipped configuration)
             "lafs_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("LAFS_") and k != "LAFS_BENCH_SHARE_GPU"},
@@ -363,8 +514,12 @@ def main():
             out["step_hbm_bytes"] = hb
             out["step_hbm_frac"] = round(hb / (ms * 1e-3) / 8e12, 4)
         out["roofline"] = dominant_kernel_roofline(device)
+        out["profile_provenance"] = PROFILE_NOTES       # which committed profile each read-back number came from (null = stale)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, nl, K, args.cpu_batch)
+        if world == 1 and not args.no_extras and args.arch == "vit_small" and not args.frontend:
+            del eng, student, teacher, crit
+            out["extras"] = run_extras(device)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

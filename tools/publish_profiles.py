@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "profiles"), os.path.join(ROOT, "profiles")
-R = sys.argv[1] if len(sys.argv) > 1 else "round2"
+R = sys.argv[1] if len(sys.argv) > 1 else "round3"
 DOM = "gemm_kres_kernel<1, true"          # student fc1: BF16_GELU epilogue (pre-activation stored) on the K-resident kernel
 FC2 = "gemm_nt_kernel<2, 2, 64"           # student fc2: RESID_F32 epilogue, 128x128 tile, 64-deep stages (prefix: further template arguments follow)
 
@@ -54,7 +54,9 @@ def main():
     shutil.copy(os.path.join(SRC, "dom_bench.json"), os.path.join(DST, f"{R}_roofline_kernels_bench.json"))
     M, D, I, H = 44160, 384, 384, 1536
     pairs = [(D, H), (H, D), (D, I), (3 * I, D)]
+    sha_file = os.path.join(SRC, "csrc_sha.txt")
     out = {
+        "csrc_sha": open(sha_file).read().strip() if os.path.isfile(sha_file) else None,
         "command": "rocprofv3 --kernel-trace --pmc <counter group> -- python3 bench.py --roofline-only   (one pass per group: FETCH_SIZE | "
                    "WRITE_SIZE | SQ_*)",
         "gfx950_correction": "FETCH_SIZE counts 128-B requests at 64 B for wide coalesced streams -> x2 (MI355X_MICROARCH.md, HBM "
