@@ -103,6 +103,29 @@ int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
  * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout). */
 int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
 
+/* Fused two-GEMM MLP (csrc/mlp_fused.hip; embedding width D = 384, H % 64 == 0, H <= 2048): the hidden activation stays on chip
+ * between the GEMMs.  Replaces Mlp.forward + DropPath + residual (vision_transformer.py:49-65, 107-113) and, in the backward,
+ * the input gradients of fc2 / GELU / fc1.
+ *   lafs_mlp_fwd:  out(f32)[M,D] = resid + seq_scale[row2seq[m]] * (gelu(x W1^T + b1) W2^T + b2);  x bf16 [M,D], w1 bf16 [H,D],
+ *                  w2 bf16 [D,H].  save_dgelu / save_act (both or neither; bf16 [M,H], row stride lds): gelu'(u) and gelu(u) for the
+ *                  backward -- the same tensors LAFS_EPI_BF16_GELU with LAFS_GELU_SAVE_GRAD writes.
+ *   lafs_mlp_bwd:  save_act(bf16)[M,H] = du = (x w1^T) .* save_dgelu;  out(bf16)[M,D] = du w2^T;  x = upstream gradient bf16 [M,D],
+ *                  w1 = fc2.weight^T shadow [H,D], w2 = fc1.weight^T shadow [D,H], save_dgelu = the forward's gelu'(u).
+ * lafs_mlp_fused_eligible: 1 when the trunk engine routes a block's MLP here (LAFS_MLP_FUSED=0 switches it off for A/B runs). */
+typedef struct lafs_mlp_args {
+  const void* x; int ldx;
+  const void* w1; int ldw1; const float* b1;
+  const void* w2; int ldw2; const float* b2;
+  void* save_dgelu; void* save_act; int lds;
+  const float* resid; int ldr;
+  const float* seq_scale; const int32_t* row2seq;
+  void* out; int ldo;
+  int M, D, H;
+} lafs_mlp_args;
+int lafs_mlp_fused_eligible(int M, int D, int H);
+int lafs_mlp_fwd(const lafs_mlp_args* args, hipStream_t stream);
+int lafs_mlp_bwd(const lafs_mlp_args* args, hipStream_t stream);
+
 /* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
  * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0.
  * colsum_a (optional f32 [N1]) += column sums of A: the bias gradient db = sum_m dY[m,:] rides along for free. */
