@@ -103,29 +103,6 @@ int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
  * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout). */
 int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
 
-/* Fused two-GEMM MLP (csrc/mlp_fused.hip; embedding width D = 384, H % 64 == 0, H <= 2048): the hidden activation stays on chip
- * between the GEMMs.  Replaces Mlp.forward + DropPath + residual (vision_transformer.py:49-65, 107-113) and, in the backward,
- * the input gradients of fc2 / GELU / fc1.
- *   lafs_mlp_fwd:  out(f32)[M,D] = resid + seq_scale[row2seq[m]] * (gelu(x W1^T + b1) W2^T + b2);  x bf16 [M,D], w1 bf16 [H,D],
- *                  w2 bf16 [D,H].  save_dgelu / save_act (both or neither; bf16 [M,H], row stride lds): gelu'(u) and gelu(u) for the
- *                  backward -- the same tensors LAFS_EPI_BF16_GELU with LAFS_GELU_SAVE_GRAD writes.
- *   lafs_mlp_bwd:  save_act(bf16)[M,H] = du = (x w1^T) .* save_dgelu;  out(bf16)[M,D] = du w2^T;  x = upstream gradient bf16 [M,D],
- *                  w1 = fc2.weight^T shadow [H,D], w2 = fc1.weight^T shadow [D,H], save_dgelu = the forward's gelu'(u).
- * lafs_mlp_fused_eligible: 1 when the trunk engine routes a block's MLP here (LAFS_MLP_FUSED=0 switches it off for A/B runs). */
-typedef struct lafs_mlp_args {
-  const void* x; int ldx;
-  const void* w1; int ldw1; const float* b1;
-  const void* w2; int ldw2; const float* b2;
-  void* save_dgelu; void* save_act; int lds;
-  const float* resid; int ldr;
-  const float* seq_scale; const int32_t* row2seq;
-  void* out; int ldo;
-  int M, D, H;
-} lafs_mlp_args;
-int lafs_mlp_fused_eligible(int M, int D, int H);
-int lafs_mlp_fwd(const lafs_mlp_args* args, hipStream_t stream);
-int lafs_mlp_bwd(const lafs_mlp_args* args, hipStream_t stream);
-
 /* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
  * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0.
  * colsum_a (optional f32 [N1]) += column sums of A: the bias gradient db = sum_m dY[m,:] rides along for free. */
@@ -309,8 +286,21 @@ int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_avg, float* 
                         void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t n_chunks,
                         const int32_t* seg_flags, int32_t* seg_step, int n_seg, const float* seg_sumsq,
                         const float* hyper, hipStream_t stream);
+/* The same two passes restricted to the tensors [seg_lo, seg_hi) = the chunks [chunk_lo, chunk_hi) (base pointers are those of the
+ * whole arena): the engine updates a range of the arena as soon as its gradients are final, beside the rest of the backward. */
+int lafs_grad_sumsq_range(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int64_t chunk_lo, int64_t chunk_hi,
+                          int seg_lo, int seg_hi, const float* hyper, float* chunk_sumsq, float* seg_sumsq, hipStream_t stream);
+int lafs_clip_adamw_ema_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* teacher,
+                              void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t chunk_lo, int64_t chunk_hi,
+                              const int32_t* seg_flags, int32_t* seg_step, int seg_lo, int seg_hi, const float* seg_sumsq,
+                              const float* hyper, hipStream_t stream);
 /* dst(bf16)[i] = src(f32)[i] */
 int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
+/* dst(f32)[i] = src(bf16)[i]   (gradients that travelled over the wire as bf16: LAFS_GRAD_WIRE=bf16, distributed.py) */
+int lafs_cast_f32(const void* src, float* dst, int64_t n, hipStream_t stream);
+/* Data-parallel runs: leave `cus` compute units to the collective library's kernels -- the K-resident GEMM (otherwise two resident
+ * workgroups on every CU) shrinks its grid to 2 * (256 - cus) workgroups.  0 (default) = the whole chip.  Returns the value set. */
+int lafs_set_comm_cus(int cus);
 /* dst(bf16)[c, r] = src(f32)[r, c]   (W^T shadows used by the dgrad GEMMs) */
 int lafs_transpose_cast_bf16(const float* src, int rows, int cols, void* dst, int ld_dst, hipStream_t stream);
 /* All W^T shadows of an arena in ONE launch.  table(i64, device)[4*i..] = {src offset into master, rows, cols, dst offset

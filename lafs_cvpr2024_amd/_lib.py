@@ -25,14 +25,6 @@ class GemmNTArgs(C.Structure):
                 ("drop_step", C.c_void_p), ("drop_row0", C.c_int), ("act", C.c_int)]
 
 
-class MlpArgs(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int), ("w1", C.c_void_p), ("ldw1", C.c_int), ("b1", C.c_void_p),
-                ("w2", C.c_void_p), ("ldw2", C.c_int), ("b2", C.c_void_p),
-                ("save_dgelu", C.c_void_p), ("save_act", C.c_void_p), ("lds", C.c_int),
-                ("resid", C.c_void_p), ("ldr", C.c_int), ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
-                ("out", C.c_void_p), ("ldo", C.c_int), ("M", C.c_int), ("D", C.c_int), ("H", C.c_int)]
-
-
 class WgradItem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
                 ("N1", C.c_int), ("N2", C.c_int), ("accumulate", C.c_int), ("colsum_a", C.c_void_p)]
@@ -70,8 +62,6 @@ vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 _PROTOS = {
     "lafs_debug_tr16": [vp, vp],
     "lafs_gemm_nt": [C.POINTER(GemmNTArgs)],
-    "lafs_mlp_fwd": [C.POINTER(MlpArgs)],
-    "lafs_mlp_bwd": [C.POINTER(MlpArgs)],
     "lafs_gemm_tn_acc": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "lafs_gemm_tn_part": [vp, i32, vp, i32, vp, i32, i64, i32, i32, i32, i32, vp],
     "lafs_reduce_partials": [vp, i64, i32, i64, vp],
@@ -100,7 +90,10 @@ _PROTOS = {
     "lafs_center_ema": [vp, vp, i32, f32, f32],
     "lafs_grad_sumsq": [vp, vp, i64, i32, vp, vp, vp],
     "lafs_clip_adamw_ema": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp],
+    "lafs_grad_sumsq_range": [vp, vp, i64, i64, i64, i32, i32, vp, vp, vp],
+    "lafs_clip_adamw_ema_range": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, i32, i32, vp, vp],
     "lafs_cast_bf16": [vp, vp, i64],
+    "lafs_cast_f32": [vp, vp, i64],
     "lafs_droppath_scales": [vp, i32, i32, u32, vp, vp],
     "lafs_pos_interp_fwd": [vp, vp, vp, i32, i32, i32],
     "lafs_pos_interp_bwd": [vp, vp, vp, i32, i32, i32],
@@ -133,7 +126,7 @@ _NO_STREAM = {
     "lafs_version": ([], i32),
     "lafs_gemm_nt_slices": ([i32, i32], i32),
     "lafs_gemm_nt_route": ([C.POINTER(GemmNTArgs)], i32),
-    "lafs_mlp_fused_eligible": ([i32, i32, i32], i32),
+    "lafs_set_comm_cus": ([i32], i32),
     "lafs_debug_set": ([i32], i32),
     "lafs_debug_get": ([], i32),
     "lafs_ablation_build": ([], i32),

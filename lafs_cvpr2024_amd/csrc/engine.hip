@@ -263,22 +263,10 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
       // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
       // becomes one multiply per value
-      if (!(dp > 0.f) && lafs_mlp_fused_eligible(R, D, M)) {
-        // fc1 -> GELU -> fc2 -> DropPath + residual as ONE launch (csrc/mlp_fused.hip): gelu(u) is consumed from registers; a saving
-        // pass still stores gelu'(u) and gelu(u) (the backward and the fc2 weight gradient read them), a forward-only pass nothing
-        lafs_mlp_args ma = {};
-        ma.x = b.h2 + rD; ma.ldx = D; ma.w1 = sh + o.w_fc1; ma.ldw1 = D; ma.b1 = d->master + o.b_fc1;
-        ma.w2 = sh + o.w_fc2; ma.ldw2 = M; ma.b2 = d->master + o.b_fc2;
-        ma.save_dgelu = save_for_backward ? b.u + rM : nullptr; ma.save_act = save_for_backward ? b.a + rM : nullptr; ma.lds = M;
-        ma.resid = b.x1 + rD; ma.ldr = D; ma.seq_scale = sm; ma.row2seq = r2s; ma.out = nxt + rD; ma.ldo = D;
-        ma.M = R; ma.D = D; ma.H = M;
-        RUN(lafs_mlp_fwd(&ma, st));
-      } else {
-        RUN(gemm(b.h2 + rD, D, sh + o.w_fc1, D, R, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u + rM : nullptr, M, d->master + o.b_fc1, st,
-                 b.a + rM, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
-        RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
-                 r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
-      }
+      RUN(gemm(b.h2 + rD, D, sh + o.w_fc1, D, R, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u + rM : nullptr, M, d->master + o.b_fc1, st,
+               b.a + rM, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
+      RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
+               r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
       cur = nxt;
     }
     return LAFS_OK;
@@ -345,18 +333,9 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
     const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
     // ---- MLP branch ----
-    if (!(dp > 0.f) && lafs_mlp_fused_eligible(R, D, M)) {
-      // du = (gbm W2) .* gelu'(u) and dh = du W1 as ONE launch: du is stored for the fc1 weight gradient but consumed from registers
-      lafs_mlp_args ma = {};
-      ma.x = s.gbm[p] + rD; ma.ldx = D; ma.w1 = sht + o.w_fc2_t; ma.ldw1 = D; ma.w2 = sht + o.w_fc1_t; ma.ldw2 = M;
-      ma.save_dgelu = b.u + rM; ma.save_act = s.du[p] + rM; ma.lds = M; ma.out = s.dh + rD; ma.ldo = D;
-      ma.M = R; ma.D = D; ma.H = M;
-      RUN(lafs_mlp_bwd(&ma, st));
-    } else {
-      RUN(gemm(s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
-               nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
-      RUN(gemm(s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
-    }
+    RUN(gemm(s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
+             nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
+    RUN(gemm(s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
     RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, b.x1 + rD, D, b.st2 + 2 * (size_t)r0, d->master + o.ln2_g, g + rD, D, 1, s.gba[p] + rD, D,
                            scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), d->dropout_step, r0, st));
     // ---- attention branch ----

@@ -461,6 +461,12 @@ bool lafs_kres_eligible(const lafs_gemm_nt_args* g) {
   return true;
 }
 
+static int g_comm_cus = 0;
+extern "C" int lafs_set_comm_cus(int cus) {
+  g_comm_cus = cus < 0 ? 0 : (cus > 192 ? 192 : cus);
+  return g_comm_cus;
+}
+
 namespace {
 template <int ABL>
 int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_override = 0, unsigned long long* stamps = nullptr) {
@@ -482,6 +488,7 @@ int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_overrid
   static const int min_items = [] { const char* v = getenv("LAFS_KRES_MIN_ITEMS"); return v != nullptr ? atoi(v) : 4; }();   // lab knob
   int grid = 512;
   while (grid > 8 && a.items / grid < min_items) grid >>= 1;
+  if (g_comm_cus > 0 && grid > 2 * (256 - g_comm_cus)) grid = (2 * (256 - g_comm_cus)) & ~7;     // CUs left to RCCL (lafs_set_comm_cus)
   if (grid_override > 0) grid = grid_override;
   switch (e) {
     case LAFS_EPI_BF16: return launch<LAFS_EPI_BF16, true, ABL>(a, grid, stream);

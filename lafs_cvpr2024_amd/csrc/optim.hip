@@ -39,9 +39,10 @@ __device__ __forceinline__ long first_chunk_of(const int* __restrict__ chunk_seg
 }
 
 __global__ __launch_bounds__(256) void seg_sumsq_kernel(const float* __restrict__ chunk_sumsq, const int* __restrict__ chunk_seg,
-                                                       long n_chunks, const float* __restrict__ hyper, float* __restrict__ seg_sumsq) {
+                                                       long n_chunks, const float* __restrict__ hyper, float* __restrict__ seg_sumsq,
+                                                       int seg0) {
   __shared__ float red[4];
-  const int seg = blockIdx.x;
+  const int seg = blockIdx.x + seg0;
   const long c0 = first_chunk_of(chunk_seg, n_chunks, seg), c1 = first_chunk_of(chunk_seg, n_chunks, seg + 1);
   float s = 0.f;
   // (the head's last layer is one segment of ~25 k chunks: eight independent loads per trip instead of a chain of 100)
@@ -63,9 +64,9 @@ __global__ __launch_bounds__(256) void seg_sumsq_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void seg_step_kernel(const int* __restrict__ seg_flags, int* __restrict__ seg_step, int n_seg,
+__global__ __launch_bounds__(256) void seg_step_kernel(const int* __restrict__ seg_flags, int* __restrict__ seg_step, int seg0, int n_seg,
                                                       const float* __restrict__ hyper) {
-  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int s = seg0 + blockIdx.x * 256 + threadIdx.x;
   if (s >= n_seg) return;
   const int f = seg_flags[s];
   const bool frozen = (f & LAFS_SEG_LAST_LAYER) && hyper[LAFS_HP_FREEZE_LAST] != 0.f;
@@ -77,9 +78,10 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(float* __restrict__
                                                             float* __restrict__ teacher, bf16_t* __restrict__ param_bf,
                                                             bf16_t* __restrict__ teacher_bf, const int* __restrict__ chunk_seg,
                                                             const int* __restrict__ seg_flags, const int* __restrict__ seg_step,
-                                                            const float* __restrict__ seg_sumsq, const float* __restrict__ hyper) {
-  const size_t i = (size_t)blockIdx.x * LAFS_CHUNK + threadIdx.x * 4;
-  const int seg = chunk_seg[blockIdx.x];
+                                                            const float* __restrict__ seg_sumsq, const float* __restrict__ hyper,
+                                                            long chunk0) {
+  const size_t i = ((size_t)blockIdx.x + chunk0) * LAFS_CHUNK + threadIdx.x * 4;
+  const int seg = chunk_seg[blockIdx.x + chunk0];
   const int flags = seg_flags[seg];
   const bool frozen = (flags & LAFS_SEG_LAST_LAYER) && hyper[LAFS_HP_FREEZE_LAST] != 0.f;
   const bool update = (flags & LAFS_SEG_TRAINABLE) && !frozen;
@@ -136,6 +138,17 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(256) void cast_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      const uint2 v = *reinterpret_cast<const uint2*>(src + i);
+      *reinterpret_cast<float4*>(dst + i) = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+    } else {
+      for (size_t e = i; e < n; ++e) dst[e] = bf2f(src[e]);
+    }
+  }
+}
+
 // dst[c, r] = bf16(src[r, c]); 32x32 tiles through LDS
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, int rows, int cols, bf16_t* __restrict__ dst,
                                                             int ld) {
@@ -155,15 +168,41 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 
 }  // namespace
 
+// Range forms: the tensors [seg_lo, seg_hi) = the chunks [chunk_lo, chunk_hi) of the arena (a tensor is a whole number of chunks).
+// The training engine updates a range as soon as its gradients are final -- the DINO head while the trunk backward still runs,
+// each run of blocks while the next one is computed -- so that these HBM-bound passes overlap GEMM-heavy work instead of
+// forming a serial tail of the step.  Base pointers are those of the WHOLE arena.
+extern "C" int lafs_grad_sumsq_range(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int64_t chunk_lo, int64_t chunk_hi,
+                                     int seg_lo, int seg_hi, const float* hyper, float* chunk_sumsq, float* seg_sumsq,
+                                     hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(grad && chunk_seg && hyper && chunk_sumsq && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31), "bad operand");
+  LAFS_CHECK_ARG(0 <= chunk_lo && chunk_lo < chunk_hi && chunk_hi <= n_chunks && 0 <= seg_lo && seg_lo < seg_hi, "bad range");
+  const long nc = (long)(chunk_hi - chunk_lo);
+  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, stream, grad + chunk_lo * LAFS_CHUNK, nc,
+                     chunk_sumsq + chunk_lo);
+  LAFS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(seg_sumsq_kernel, dim3((unsigned)(seg_hi - seg_lo)), dim3(256), 0, stream, chunk_sumsq, chunk_seg, (long)n_chunks, hyper,
+                     seg_sumsq, seg_lo);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
 extern "C" int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int n_seg, const float* hyper,
                                float* chunk_sumsq, float* seg_sumsq, hipStream_t stream) {
+  return lafs_grad_sumsq_range(grad, chunk_seg, n_chunks, 0, n_chunks, 0, n_seg, hyper, chunk_sumsq, seg_sumsq, stream);
+}
+
+extern "C" int lafs_clip_adamw_ema_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* teacher,
+                                         void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t chunk_lo, int64_t chunk_hi,
+                                         const int32_t* seg_flags, int32_t* seg_step, int seg_lo, int seg_hi, const float* seg_sumsq,
+                                         const float* hyper, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
-  LAFS_CHECK_ARG(grad && chunk_seg && hyper && chunk_sumsq && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31) && n_seg > 0,
-                 "bad operand");
-  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, grad, (long)n_chunks, chunk_sumsq);
-  LAFS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(seg_sumsq_kernel, dim3((unsigned)n_seg), dim3(256), 0, stream, chunk_sumsq, chunk_seg, (long)n_chunks, hyper,
-                     seg_sumsq);
+  LAFS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && chunk_seg && seg_flags && seg_step && seg_sumsq && hyper, "null operand");
+  LAFS_CHECK_ARG(0 <= chunk_lo && chunk_lo < chunk_hi && chunk_hi < (1ll << 31) && 0 <= seg_lo && seg_lo < seg_hi, "bad range");
+  hipLaunchKernelGGL(seg_step_kernel, dim3(ceil_div(seg_hi - seg_lo, 256)), dim3(256), 0, stream, seg_flags, seg_step, seg_lo, seg_hi, hyper);
+  hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3((unsigned)(chunk_hi - chunk_lo)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq,
+                     teacher, (bf16_t*)param_bf16, (bf16_t*)teacher_bf16, chunk_seg, seg_flags, seg_step, seg_sumsq, hyper, (long)chunk_lo);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -172,14 +211,9 @@ extern "C" int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_a
                                    void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t n_chunks,
                                    const int32_t* seg_flags, int32_t* seg_step, int n_seg, const float* seg_sumsq,
                                    const float* hyper, hipStream_t stream) {
-  LAFS_CLEAR_ERROR();
-  LAFS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && chunk_seg && seg_flags && seg_step && seg_sumsq && hyper, "null operand");
-  LAFS_CHECK_ARG(n_chunks > 0 && n_chunks < (1ll << 31) && n_seg > 0, "bad sizes");
-  hipLaunchKernelGGL(seg_step_kernel, dim3(ceil_div(n_seg, 256)), dim3(256), 0, stream, seg_flags, seg_step, n_seg, hyper);
-  hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3((unsigned)n_chunks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, teacher,
-                     (bf16_t*)param_bf16, (bf16_t*)teacher_bf16, chunk_seg, seg_flags, seg_step, seg_sumsq, hyper);
-  LAFS_LAUNCH_CHECK();
-  return LAFS_OK;
+  LAFS_CHECK_ARG(n_chunks > 0 && n_seg > 0, "bad sizes");
+  return lafs_clip_adamw_ema_range(param, grad, exp_avg, exp_avg_sq, teacher, param_bf16, teacher_bf16, chunk_seg, 0, n_chunks, seg_flags,
+                                   seg_step, 0, n_seg, seg_sumsq, hyper, stream);
 }
 
 extern "C" int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {
@@ -188,6 +222,16 @@ extern "C" int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_
   int64_t blocks = (n + 1023) / 1024;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, (bf16_t*)dst, (size_t)n);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cast_f32(const void* src, float* dst, int64_t n, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(src && dst && n > 0, "bad operand");
+  int64_t blocks = (n + 1023) / 1024;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)src, dst, (size_t)n);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -466,7 +466,10 @@ int group_impl(const lafs_wgrad_item* items, int n_items, int M, int max_workgro
   }
   a.n_items = n_items; a.M = M; a.mlen = pl.mlen; a.slices = pl.slices; a.tiles = pl.tiles;
   a.nblk = (pl.slices * pl.tiles + 7) & ~7;
-  static const bool map_on = [] { const char* v = getenv("LAFS_WGRAD_XCD_MAP"); return v == nullptr || v[0] != '0'; }();   // A/B knob
+  // LAFS_WGRAD_XCD_MAP=1 switches the map on.  Measured (tools/lab/NOTES.md, round 3): whole step 15.76-15.79 ms with the map against
+  // 15.64 without on one box -- the panels the XCDs re-fetch come out of the Infinity Cache, not the HBM, and packing groups whole
+  // loads the XCDs unevenly (32 / 32 / ... / 16 workgroups) beside the dgrad chain; the contiguous runs stay the default
+  static const bool map_on = [] { const char* v = getenv("LAFS_WGRAD_XCD_MAP"); return v != nullptr && v[0] == '1'; }();
   if (map_on && pl.slices * pl.tiles <= 256 && pl.slices * n_items <= MAXG * 64) {
     a.use_map = 1;
     a.nblk = xcd_map(pl, n_items, a.map);

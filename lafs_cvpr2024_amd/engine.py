@@ -152,6 +152,27 @@ class LafsPretrainEngine:
         off = lambda blk: self.sa.offsets[self.spec_s.trunk.block_names[blk]["ln1_g"]] if blk > 0 else 0
         self.cut_offsets = [off(c) for c in self.cuts[1:]]                                   # arena offset where each run starts
         self.reducer = FlatReducer()
+        if self.world > 1:
+            # the K-resident GEMM keeps two workgroups resident on every CU: leave some CUs to RCCL's kernels while gradients are on
+            # the wire (LAFS_COMM_CUS, default 16 of 256 in data-parallel runs; unmeasured on hardware: no multi-GPU box this round)
+            _lib.lib().lafs_set_comm_cus(int(os.environ.get("LAFS_COMM_CUS", "16")))
+        # Update pieces: ranges of the arena in the order their gradients become final -- the DINO head (31 of 53 M parameters at C2)
+        # after the head backward, then each run of blocks after its segment of the trunk backward.  A piece's per-tensor norms,
+        # clip + AdamW + teacher EMA + shadow refresh run on a stream of their own at the START of a later segment, beside that
+        # segment's GEMM-heavy work, instead of as a serial HBM-bound tail of the step (the reference's optimizer.step() /
+        # EMA loop, lafs_train.py:606-613, touches nothing the backward still reads: a block's weights are dead once its
+        # gradients exist).  Data-parallel runs give every piece one segment of slack for its all-reduce.
+        bounds = [self.sa.size, self.head_start] + list(self.cut_offsets)
+        self.pieces = [(bounds[i + 1], bounds[i]) for i in range(len(bounds) - 1) if bounds[i] > bounds[i + 1]]
+        seg_at = {self.sa.offsets[n]: i for i, n in enumerate(self.sa.names)}
+        seg_at[self.sa.size] = self.sa.n_seg
+        self.piece_segs = [(seg_at[lo], seg_at[hi]) for lo, hi in self.pieces]
+        n_segments = len(self.cuts) + 1                     # forward, the runs of the trunk backward, the final update
+        slack = 1 if self.world > 1 else 0
+        serial = os.environ.get("LAFS_OPT_OVERLAP", "1") == "0"          # A/B knob: every piece in the final segment
+        self.piece_runs_at = [n_segments - 1 if serial else min(p + 1 + slack, n_segments - 1) for p in range(len(self.pieces))]
+        self._piece_tokens = [[] for _ in self.pieces]
+        self.opt_stream = None if os.environ.get("LAFS_SINGLE_STREAM") == "1" else torch.cuda.Stream(device=self.device)
         # large frozen tensors (Part-fViT's 30000 x 768 CosFace table: 92 MB of zeros per step on the wire otherwise) are cut out
         # of the all-reduced ranges; small frozen ones (weight_g) ride along rather than splitting a collective
         self._frozen_runs = [(self.sa.offsets[n], self.sa.offsets[n] + (p.numel() + _lib.CHUNK - 1) // _lib.CHUNK * _lib.CHUNK)
@@ -255,21 +276,45 @@ class LafsPretrainEngine:
                 if dr is None:
                     call("lafs_pos_interp_bwd", _p(dp), _p(M), _p(gpe), M.shape[0], M.shape[1], self.spec_s.trunk.dim)
 
-    def _seg_update(self):
+    def _update_piece(self, p):
+        """Per-tensor gradient norms, clip + AdamW + teacher EMA + bf16 shadows for the tensors of update piece p."""
         sa, ta = self.sa, self.ta
+        (lo, hi), (s_lo, s_hi) = self.pieces[p], self.piece_segs[p]
+        c_lo, c_hi = lo // _lib.CHUNK, hi // _lib.CHUNK
+        call("lafs_grad_sumsq_range", _p(sa.grad), _p(sa.chunk_seg), sa.n_chunks, c_lo, c_hi, s_lo, s_hi, _p(self.hyper),
+             _p(sa.chunk_sumsq), _p(sa.seg_sumsq))
+        call("lafs_clip_adamw_ema_range", _p(sa.master), _p(sa.grad), _p(sa.exp_avg), _p(sa.exp_avg_sq), _p(ta.master),
+             _p(sa.shadow), _p(ta.shadow), _p(sa.chunk_seg), c_lo, c_hi, _p(sa.seg_flags), _p(sa.seg_step), s_lo, s_hi,
+             _p(sa.seg_sumsq), _p(self.hyper))
+
+    def _seg_update(self):
         call("lafs_center_ema", _p(self.dino_loss.center), _p(self.colsum), self.K, 1.0 / (2 * self.B * self.world),
              float(self.dino_loss.center_momentum))
-        call("lafs_grad_sumsq", _p(sa.grad), _p(sa.chunk_seg), sa.n_chunks, sa.n_seg, _p(self.hyper), _p(sa.chunk_sumsq),
-             _p(sa.seg_sumsq))
-        call("lafs_clip_adamw_ema", _p(sa.master), _p(sa.grad), _p(sa.exp_avg), _p(sa.exp_avg_sq), _p(ta.master),
-             _p(sa.shadow), _p(ta.shadow), _p(sa.chunk_seg), sa.n_chunks, _p(sa.seg_flags), _p(sa.seg_step), sa.n_seg,
-             _p(sa.seg_sumsq), _p(self.hyper))
-        sa.refresh_transposed()
+
+    def _with_pieces(self, k, body):
+        """Segment k = `body` with the update pieces scheduled at k: on their own stream beside the body (forked at the start, joined
+        at the end: the pattern hipGraph captures), or -- in the final segment -- in line, followed by the W^T shadow refresh."""
+        here = [p for p, at in enumerate(self.piece_runs_at) if at == k]
+        last = k == len(self.cuts)
+        cur = torch.cuda.current_stream()
+        if here and not last and self.opt_stream is not None:
+            self.opt_stream.wait_stream(cur)
+            with torch.cuda.stream(self.opt_stream):
+                for p in here:
+                    self._update_piece(p)
+            body()
+            cur.wait_stream(self.opt_stream)
+            return
+        body()
+        for p in here:
+            self._update_piece(p)
+        if last:
+            self.sa.refresh_transposed()
 
     # ------------------------------------------------------------------ step
     def _segments(self):
-        runs = [(lambda k=k: self._seg_trunk_backward(k)) for k in range(len(self.cuts) - 1)]
-        return [self._seg_forward] + runs + [self._seg_update]
+        bodies = [self._seg_forward] + [(lambda k=k: self._seg_trunk_backward(k)) for k in range(len(self.cuts) - 1)] + [self._seg_update]
+        return [(lambda k=k, b=b: self._with_pieces(k, b)) for k, b in enumerate(bodies)]
 
     def _capture(self):
         segs = self._segments()
@@ -333,27 +378,31 @@ class LafsPretrainEngine:
             self.step_count += 1
             return self.loss
         segs = self._segments()
-        run = (lambda i: self._graphs[i].replay()) if self.use_graph else (lambda i: segs[i]())
+        replay = (lambda i: self._graphs[i].replay()) if self.use_graph else (lambda i: segs[i]())
+
+        def run(i):                              # a segment's update pieces need their gradients reduced: wait (stream-side) first
+            for p, at in enumerate(self.piece_runs_at):
+                if at == i:
+                    self.reducer.wait(self._piece_tokens[p])
+            replay(i)
         run(0)
         # head gradients + center sums go out over RCCL while the trunk backward runs; each run of blocks follows as soon as
         # its graph segment has been enqueued (arena order: [embed | blocks 0..depth-1 | norm | head])
-        self._reduce_range(self.head_start, self.sa.size)
-        self.reducer.launch(self.colsum)
-        hi = self.head_start
-        for k, lo in enumerate(self.cut_offsets):
+        self._piece_tokens[0] = self._reduce_range(*self.pieces[0])
+        center_tok = self.reducer.launch(self.colsum)
+        for k in range(len(self.cuts) - 1):
             run(1 + k)
-            if hi > lo:
-                self._reduce_range(lo, hi)
-            hi = lo
-        self.reducer.wait_all()
+            if 1 + k < len(self.pieces):
+                self._piece_tokens[1 + k] = self._reduce_range(*self.pieces[1 + k])
+        self.reducer.wait([center_tok])
         run(len(segs) - 1)
+        self.reducer.wait_all()
         self.step_count += 1
         return self.loss
 
     def _reduce_range(self, lo, hi):
-        """Asynchronous SUM all-reduce of grad[lo:hi) minus the large frozen tensors inside it."""
-        for a, b in self._trainable_runs(lo, hi):
-            self.reducer.launch(self.sa.grad[a:b])
+        """Asynchronous SUM all-reduce of grad[lo:hi) minus the large frozen tensors inside it; returns the reducer's tokens."""
+        return [self.reducer.launch(self.sa.grad[a:b]) for a, b in self._trainable_runs(lo, hi)]
 
     def _trainable_runs(self, lo, hi):
         runs, cur = [], lo

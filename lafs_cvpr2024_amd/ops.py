@@ -98,48 +98,6 @@ def gemm_tn_acc(A, B, Cacc, splits=0, colsum=None):
     return Cacc
 
 
-def _mlp_args(x, w1, w2, H):
-    a = _lib.MlpArgs()
-    a.x, a.ldx, a.w1, a.ldw1, a.w2, a.ldw2 = x.data_ptr(), _ld(x), w1.data_ptr(), _ld(w1), w2.data_ptr(), _ld(w2)
-    a.M, a.D, a.H = x.shape[0], x.shape[1], H
-    return a
-
-
-def mlp_fwd(x, w1, b1, w2, b2, resid, seq_scale=None, row2seq=None, save=True):
-    """Fused Mlp.forward + DropPath + residual (csrc/mlp_fused.hip): x bf16 [M, 384], w1 bf16 [H, 384], w2 bf16 [384, H], resid f32
-    [M, 384] -> (out f32 [M, 384], gelu'(u) bf16 [M, H] or None, gelu(u) bf16 [M, H] or None)."""
-    for t_, n in ((x, "x"), (w1, "w1"), (w2, "w2")):
-        _chk(t_, bf16, n)
-    _chk(resid, torch.float32, "resid")
-    M, H = x.shape[0], w1.shape[0]
-    a = _mlp_args(x, w1, w2, H)
-    a.b1, a.b2 = (None if b1 is None else b1.data_ptr()), (None if b2 is None else b2.data_ptr())
-    dg = torch.empty(M, H, device=x.device, dtype=bf16) if save else None
-    act = torch.empty(M, H, device=x.device, dtype=bf16) if save else None
-    a.save_dgelu, a.save_act, a.lds = (dg.data_ptr() if save else None), (act.data_ptr() if save else None), H
-    out = torch.empty(M, x.shape[1], device=x.device, dtype=torch.float32)
-    a.resid, a.ldr, a.out, a.ldo = resid.data_ptr(), _ld(resid), out.data_ptr(), _ld(out)
-    a.seq_scale = None if seq_scale is None else seq_scale.data_ptr()
-    a.row2seq = None if row2seq is None else row2seq.data_ptr()
-    call("lafs_mlp_fwd", C.byref(a))
-    return out, dg, act
-
-
-def mlp_bwd(g, w2t, dgelu, w1t):
-    """Fused input gradients of fc2 / GELU / fc1: g bf16 [M, 384] (upstream), w2t bf16 [H, 384] (fc2.weight^T), dgelu bf16 [M, H]
-    (the forward's gelu'(u)), w1t bf16 [384, H] (fc1.weight^T) -> (du bf16 [M, H], dh bf16 [M, 384])."""
-    for t_, n in ((g, "g"), (w2t, "w2t"), (dgelu, "dgelu"), (w1t, "w1t")):
-        _chk(t_, bf16, n)
-    M, H = g.shape[0], w2t.shape[0]
-    a = _mlp_args(g, w2t, w1t, H)
-    du = torch.empty(M, H, device=g.device, dtype=bf16)
-    dh = torch.empty(M, g.shape[1], device=g.device, dtype=bf16)
-    a.save_dgelu, a.save_act, a.lds = dgelu.data_ptr(), du.data_ptr(), H
-    a.out, a.ldo = dh.data_ptr(), _ld(dh)
-    call("lafs_mlp_bwd", C.byref(a))
-    return du, dh
-
-
 def wgrad_workspace(M, N1, N2, device):
     n = int(_lib.lib().lafs_wgrad_workspace_bytes(M, N1, N2))
     if n < 0:

@@ -507,67 +507,3 @@ def test_dropout_seed_from_a_device_step_counter_and_row_offsets():
     x2 = x.clone()
     call("lafs_dropout_f32", _p(x2), N, M, N, p, seed, _p(step))
     torch.testing.assert_close(x2, x * mask, rtol=0, atol=0)
-
-
-@pytest.mark.parametrize("M,H", [(2048, 1536), (2200, 1536), (2064, 256), (4144, 1536)])
-def test_fused_mlp_forward_matches_torch_and_the_two_gemm_path(M, H):
-    """lafs_mlp_fwd (csrc/mlp_fused.hip): fc1 -> GELU -> fc2 -> DropPath + residual in one launch, the hidden tile on chip, against
-    (a) the fp32 torch formula on the same bf16 operands and (b) the two-launch path (LAFS_EPI_BF16_GELU saving gelu'(u), then
-    LAFS_EPI_RESID_F32) it replaces -- incl. row counts that end inside a 128-row unit / a 32-row wave / a 16-row block, the saved
-    gelu'(u) / gelu(u) tensors the backward reads, per-sequence DropPath scales, and the forward-only variant that saves nothing."""
-    from lafs_cvpr2024_amd import _lib
-    torch.manual_seed(M + H)
-    D = 384
-    x = torch.randn(M, D, device=DEV).to(torch.bfloat16)
-    w1 = (torch.randn(H, D, device=DEV) * 0.05).to(torch.bfloat16)
-    w2 = (torch.randn(D, H, device=DEV) * 0.05).to(torch.bfloat16)
-    b1, b2 = torch.randn(H, device=DEV) * 0.1, torch.randn(D, device=DEV) * 0.1
-    resid = torch.randn(M, D, device=DEV)
-    n_seq = 37
-    row2seq = (torch.arange(M, device=DEV) * n_seq // M).to(torch.int32)
-    scale = torch.where(torch.rand(n_seq, device=DEV) < 0.2, torch.zeros(n_seq, device=DEV), torch.full((n_seq,), 1 / 0.9, device=DEV))
-    out, dg, act = ops.mlp_fwd(x, w1, b1, w2, b2, resid, seq_scale=scale, row2seq=row2seq, save=True)
-    # (a) fp32 torch on the same operands (gelu(u) enters fc2 as bf16, exactly as the layer stores it)
-    u = x.float() @ w1.float().t() + b1
-    a_ref = torch.nn.functional.gelu(u)
-    ur = u.detach().clone().requires_grad_(True)
-    torch.nn.functional.gelu(ur).sum().backward()
-    y = a_ref.to(torch.bfloat16).float() @ w2.float().t() + b2
-    ref = resid + scale[row2seq.long()][:, None] * y
-    assert rel_l2(out, ref) < 3e-3, rel_l2(out, ref)
-    assert rel_l2(act, a_ref) < 5e-3 and rel_l2(dg, ur.grad) < 5e-3
-    dropped = scale[row2seq.long()] == 0
-    assert torch.equal(out[dropped], resid[dropped])                        # a dropped path leaves the residual untouched, bit for bit
-    # (b) the two launches it replaces: identical saved tensors, output equal up to the fp32 summation order of fc2
-    g2, a2 = ops.gemm_nt(x, w1, _lib.EPI_BF16_GELU, bias=b1, act=1)        # act = LAFS_GELU_SAVE_GRAD
-    out2 = ops.gemm_nt(a2, w2, _lib.EPI_RESID_F32, bias=b2, resid=resid, seq_scale=scale, row2seq=row2seq)
-    assert torch.equal(act, a2) and torch.equal(dg, g2)
-    torch.testing.assert_close(out, out2, rtol=1e-4, atol=2e-4)
-    # forward-only (teacher) variant
-    out3, n1, n2 = ops.mlp_fwd(x, w1, b1, w2, b2, resid, seq_scale=scale, row2seq=row2seq, save=False)
-    assert n1 is None and n2 is None and torch.equal(out3, out)
-    # no DropPath, no biases
-    out4, _, _ = ops.mlp_fwd(x, w1, None, w2, None, resid, save=False)
-    y4 = torch.nn.functional.gelu(x.float() @ w1.float().t()).to(torch.bfloat16).float() @ w2.float().t()
-    assert rel_l2(out4, resid + y4) < 3e-3
-
-
-@pytest.mark.parametrize("M,H", [(2048, 1536), (2200, 1536), (2064, 256), (4144, 1536)])
-def test_fused_mlp_backward_matches_torch_and_the_two_gemm_path(M, H):
-    """lafs_mlp_bwd: du = (g W2) .* gelu'(u) (stored: the fc1 weight gradient reads it) and dh = du W1 in one launch, against fp32
-    torch and against the two launches it replaces (LAFS_EPI_DGELU_BF16 with the saved derivative, then a plain bf16 GEMM)."""
-    from lafs_cvpr2024_amd import _lib
-    torch.manual_seed(M * 3 + H)
-    D = 384
-    g = torch.randn(M, D, device=DEV).to(torch.bfloat16)
-    w2t = (torch.randn(H, D, device=DEV) * 0.05).to(torch.bfloat16)        # fc2.weight^T: [H, D]
-    w1t = (torch.randn(D, H, device=DEV) * 0.05).to(torch.bfloat16)        # fc1.weight^T: [D, H]
-    dgelu = (torch.rand(M, H, device=DEV) * 1.2 - 0.1).to(torch.bfloat16)
-    du, dh = ops.mlp_bwd(g, w2t, dgelu, w1t)
-    du_ref = (g.float() @ w2t.float().t()) * dgelu.float()
-    dh_ref = du_ref.to(torch.bfloat16).float() @ w1t.float().t()
-    assert rel_l2(du, du_ref) < 5e-3 and rel_l2(dh, dh_ref) < 5e-3, (rel_l2(du, du_ref), rel_l2(dh, dh_ref))
-    du2 = ops.gemm_nt(g, w2t, _lib.EPI_DGELU_BF16, aux=dgelu, act=1)
-    dh2 = ops.gemm_nt(du2, w1t, _lib.EPI_BF16)
-    assert torch.equal(du, du2)
-    assert rel_l2(dh, dh2) < 4e-3                                           # bf16 outputs of two summation orders
