@@ -39,8 +39,6 @@ struct WgItem {
 struct WgArgs {
   WgItem it[MAXG];
   int n_items, M, mlen, slices, tiles, nblk;          // tiles: all GEMMs together
-  int use_map;                                        // nblk <= 256: block -> (slice, tile) through `map` (-1 = no work)
-  short map[256];
 };
 
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
@@ -68,18 +66,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  // blocks b, b+8, ... share an XCD (and its L2).  One-round launches carry a host-built map that puts all tiles of one
-  // (GEMM, token slice) -- the workgroups that read the same operand panels -- on ONE XCD (xcd_map below); larger launches give
-  // every XCD a contiguous run of (slice, tile) pairs
-  int id;
-  if (p.use_map) {
-    id = p.map[blockIdx.x];
-    if (id < 0) return;
-  } else {
-    const int per = p.nblk >> 3;
-    id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (id >= p.slices * p.tiles) return;
-  }
+  // blocks b, b+8, ... share an XCD (and its L2): give every XCD a contiguous run of (slice, tile) pairs, so that the tiles of
+  // one token slice -- which read the same rows of A and B -- run behind the same L2.  (Packing every (GEMM, slice) group whole
+  // onto ONE XCD was measured in round 3: fabric reads 847 -> 794 MB per ViT-S block, step +0.13 ms; tools/lab/NOTES.md.)
+  const int per = p.nblk >> 3;
+  const int id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (id >= p.slices * p.tiles) return;
   const int slice = id / p.tiles, gtile = id % p.tiles;
   int gi = 0;                                          // which GEMM of the group this tile belongs to (wave-uniform)
 #pragma unroll
@@ -383,45 +375,6 @@ int64_t plan_bytes(const Plan& pl, const lafs_wgrad_item* items, int n) {
   return b;
 }
 
-// Block -> work map of a one-round launch.  Tiles of one GEMM over one token slice share operand panels (a row of tiles its A
-// panel, a column its B panel); spread over several XCDs every XCD's L2 fetches those panels again (round 2: 915 MB of fabric
-// reads per ViT-S block against 550 MB of operands).  Groups (GEMM, slice) are packed whole into XCDs -- largest first, into the
-// least-loaded XCD that still has room among its 32 CUs -- and block x + 8 j is slot j of XCD x.  Returns the block count.
-int xcd_map(const Plan& pl, int n_items, short (&map)[256]) {
-  struct Grp { int id0, count; };
-  Grp grp[MAXG * 64];
-  int ng = 0;
-  for (int s = 0; s < pl.slices; ++s)
-    for (int g = 0; g < n_items; ++g) {
-      const int t0 = pl.tile0[g], t1 = (g + 1 < n_items) ? pl.tile0[g + 1] : pl.tiles;
-      grp[ng++] = Grp{s * pl.tiles + t0, t1 - t0};
-    }
-  for (int i = 1; i < ng; ++i)                          // insertion sort, largest first (stable: deterministic maps)
-    for (int j = i; j > 0 && grp[j].count > grp[j - 1].count; --j) { const Grp t = grp[j]; grp[j] = grp[j - 1]; grp[j - 1] = t; }
-  int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  short slot[8][32];
-  for (int i = 0; i < ng; ++i) {
-    int left = grp[i].count, id = grp[i].id0;
-    while (left > 0) {
-      int best = -1;
-      for (int x = 0; x < 8; ++x)                       // least-loaded XCD that takes the whole remainder
-        if (load[x] + left <= 32 && (best < 0 || load[x] < load[best])) best = x;
-      if (best < 0)                                     // none: the emptiest one takes what fits
-        for (int x = 0; x < 8; ++x)
-          if (load[x] < 32 && (best < 0 || load[x] < load[best])) best = x;
-      const int take = left < 32 - load[best] ? left : 32 - load[best];
-      for (int k = 0; k < take; ++k) slot[best][load[best]++] = (short)id++;
-      left -= take;
-    }
-  }
-  int deep = 0;
-  for (int x = 0; x < 8; ++x) deep = load[x] > deep ? load[x] : deep;
-  for (int b = 0; b < 256; ++b) map[b] = -1;
-  for (int x = 0; x < 8; ++x)
-    for (int j = 0; j < load[x]; ++j) map[j * 8 + x] = slot[x][j];
-  return deep * 8;
-}
-
 template <int FA, int FB, int ABL>
 int launch(const WgArgs& a, hipStream_t s) {
   constexpr int NS = 5;                              // 2-3 stages (28-32 KiB each) in flight per CU
@@ -466,14 +419,6 @@ int group_impl(const lafs_wgrad_item* items, int n_items, int M, int max_workgro
   }
   a.n_items = n_items; a.M = M; a.mlen = pl.mlen; a.slices = pl.slices; a.tiles = pl.tiles;
   a.nblk = (pl.slices * pl.tiles + 7) & ~7;
-  // LAFS_WGRAD_XCD_MAP=1 switches the map on.  Measured (tools/lab/NOTES.md, round 3): whole step 15.76-15.79 ms with the map against
-  // 15.64 without on one box -- the panels the XCDs re-fetch come out of the Infinity Cache, not the HBM, and packing groups whole
-  // loads the XCDs unevenly (32 / 32 / ... / 16 workgroups) beside the dgrad chain; the contiguous runs stay the default
-  static const bool map_on = [] { const char* v = getenv("LAFS_WGRAD_XCD_MAP"); return v != nullptr && v[0] == '1'; }();
-  if (map_on && pl.slices * pl.tiles <= 256 && pl.slices * n_items <= MAXG * 64) {
-    a.use_map = 1;
-    a.nblk = xcd_map(pl, n_items, a.map);
-  }
   int rc;
   if (pl.fa == 4 && pl.fb == 3) rc = launch<4, 3, ABL>(a, stream);
   else if (pl.fa == 3 && pl.fb == 4) rc = launch<3, 4, ABL>(a, stream);
