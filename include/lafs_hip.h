@@ -450,6 +450,53 @@ int lafs_bn_act_bwd_nchw(const float* x, const float* dy, const float* stat, con
 int lafs_augment_views(const uint8_t* images, const int32_t* params, const int32_t* table, int B, int K, float* views,
                        hipStream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * TRAINABLE landmark CNN of the fine-tune step (csrc/landmark_train.hip; reference face_pre_pro/mobilenet.py:224-313 trained through
+ * ViT_face.py:679-711 by train_largescale.py:785-891).  Activations are NHWC bf16 [N H W, ld] matrices, ld = channel count padded
+ * to a multiple of 32 with the pad channels exactly zero; 1x1 convolutions and their two gradients are lafs_gemm_nt / lafs_wgrad
+ * calls on those matrices; the rest is below.  `C` is the true channel count, `ld*` the padded row strides.
+ * ------------------------------------------------------------------------------------------------------------------------ */
+/* 3x3 stride-2 pad-1 stem as im2col rows: x f32 NCHW [N,3,S,S] -> P bf16 [N (S/2)^2, 32], column (c, ky, kx), columns 27..31 zero. */
+int lafs_cnn_im2col_stem(const float* x, int N, int S, void* P, hipStream_t stream);
+/* nn.BatchNorm2d in TRAINING mode over the rows of x bf16 [R, ldx]:
+ *   lafs_cnn_bn_stats : sums(f32)[0..C) += column sums, sums[C..2C) += column sums of squares (caller zeroes `sums`);
+ *   lafs_cnn_bn_apply : y = act((x - mean) rstd gamma + beta) (+ resid), biased batch variance; stat(f32)[2C] = {mean, rstd} for the
+ *                       backward; running_mean / running_var (NULL or both) get the momentum update with the unbiased variance;
+ *   lafs_cnn_bn_bwd   : dz = (dy + add_nc[n, c] / HW) act'(z) with z recomputed from x; dx(bf16) = gamma rstd (dz - mean(dz) -
+ *                       xhat mean(dz xhat)); dgamma += sum dz xhat, dbeta += sum dz (arena gradients, may be NULL);
+ *                       dsums(f32)[2C] = caller-zeroed scratch.  add_nc bf16 [N, ldadd] (the squeeze-excite pooling gradient) or NULL. */
+int lafs_cnn_bn_stats(const void* x, int ldx, int64_t R, int C, float* sums, hipStream_t stream);
+int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const float* sums, const float* gamma, const float* beta, float eps,
+                      float momentum, float* running_mean, float* running_var, int act, const void* resid, int ldr, void* y, int ldy,
+                      float* stat, hipStream_t stream);
+int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
+                    const float* beta, int act, const void* add_nc, int ldadd, int HW, float* dsums, void* dx, int lddx,
+                    float* dgamma, float* dbeta, hipStream_t stream);
+/* Depthwise k x k convolution (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) on NHWC bf16 with the weights in the module's own
+ * layout w f32 [C][k*k]: forward; backward = dx(bf16) and dw(f32 [C][k*k], +=). */
+int lafs_cnn_dwconv_train_fwd(const void* x, const float* w, int N, int H, int W, int ld, int C, int k, int stride, void* y,
+                              hipStream_t stream);
+int lafs_cnn_dwconv_train_bwd(const void* x, const void* dy, const float* w, int N, int H, int W, int ld, int C, int k, int stride,
+                              void* dx, float* dw, hipStream_t stream);
+/* Squeeze-excite: out = act(z gate[n, c]) (z kept); backward: ds = dout act'(z gate), dz = ds gate, dgate(f32)[n, c] = sum_p ds z. */
+int lafs_cnn_scale_act_out(const void* z, const void* s, int lds_, int N, int HW, int ld, int act, void* out, hipStream_t stream);
+int lafs_cnn_se_bwd(const void* dout, const void* z, const void* gate, int ldg, int N, int HW, int ld, int act, void* dz, float* dgate,
+                    int lddg, hipStream_t stream);
+/* out(bf16)[i] = dy[i] act'(.) from the POST-activation value y (relu, h-sigmoid: the squeeze-excite FCs); dy f32 or bf16. */
+int lafs_cnn_act_bwd_post(const float* dy_f32, const void* dy_bf16, const void* y, int64_t n, int act, void* out, hipStream_t stream);
+/* dx[n, p, c] = dfeat[n, c] / HW: backward of the final average pool. */
+int lafs_cnn_pool_bwd(const void* dfeat, int ldf, int N, int HW, int ld, void* dx, hipStream_t stream);
+/* Padded bf16 operand copies of fp32 arena tensors, ONE launch: table(i64, device)[8 e ..] = {src offset, rows, cols, dst offset,
+ * dst ld, transpose, padded rows, 0}; starts(i32)[e] = first workgroup of entry e (1024 destination elements per workgroup). */
+int lafs_cnn_pad_cast_table(const float* master, void* dst, const int64_t* table, const int32_t* starts, int n_entries, int n_blocks,
+                            hipStream_t stream);
+/* Padded fp32 weight gradients folded into the arena, ONE launch: table[8 e ..] = {src offset, rows, cols, src ld, grad offset, ...};
+ * 256 elements per workgroup. */
+int lafs_cnn_unpad_add_table(const float* padded, float* grad, const int64_t* table, const int32_t* starts, int n_entries, int n_blocks,
+                             hipStream_t stream);
+/* Backward of theta = (t - min) / (max - min) * 111 per image (ViT_face.py:698-706), incl. the paths through min and max. */
+int lafs_landmark_theta_bwd(const float* t, const float* dtheta, int B, int n, float* dt, hipStream_t stream);
+
 /* Landmark post-processing (face_pre_pro/ViT_face.py:1347-1378, 698-706): t f32 [B, 2*n_full] raw regressor output ->
  * theta f32 [B, n_out, 2] pixels:  theta = (t - min_b)/(max_b - min_b)*111  (+ noise_scale * noise[B, n_full, 2], the
  * N(0,1)*5 px jitter), landmark k of the output = landmark sel[b,k] of the input (random choice with replacement) or k

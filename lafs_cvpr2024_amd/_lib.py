@@ -116,6 +116,19 @@ _PROTOS = {
     "lafs_dwconv_nchw_bwd_weight": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "lafs_bn_act_fwd_nchw": [vp, vp, vp, vp, vp, f32, f32, i32, i32, i32, i32, i32, vp, vp, vp],
     "lafs_bn_act_bwd_nchw": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+    "lafs_cnn_im2col_stem": [vp, i32, i32, vp],
+    "lafs_cnn_bn_stats": [vp, i32, i64, i32, vp],
+    "lafs_cnn_bn_apply": [vp, i32, i64, i32, vp, vp, vp, f32, f32, vp, vp, i32, vp, i32, vp, i32, vp],
+    "lafs_cnn_bn_bwd": [vp, i32, vp, i32, i64, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, vp],
+    "lafs_cnn_dwconv_train_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "lafs_cnn_dwconv_train_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "lafs_cnn_scale_act_out": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "lafs_cnn_se_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32],
+    "lafs_cnn_act_bwd_post": [vp, vp, vp, i64, i32, vp],
+    "lafs_cnn_pool_bwd": [vp, i32, i32, i32, i32, vp],
+    "lafs_cnn_pad_cast_table": [vp, vp, vp, vp, i32, i32],
+    "lafs_cnn_unpad_add_table": [vp, vp, vp, vp, i32, i32],
+    "lafs_landmark_theta_bwd": [vp, vp, i32, i32, vp],
     "lafs_augment_views": [vp, vp, vp, i32, i32, vp],
     "lafs_landmark_theta": [vp, i32, i32, vp, f32, vp, i32, vp],
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32],

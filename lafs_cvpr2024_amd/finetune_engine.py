@@ -5,6 +5,7 @@
     <= 2 non-zeros per row) -> backward -> every `acc_step` micro-steps: AdamW over the flat arena.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -79,6 +80,14 @@ class FinetuneEngine:
         self.loss = torch.zeros(1, device=dev, dtype=f32)
         self.row_ws = torch.empty(batch_size, device=dev, dtype=f32)
         self.micro = 0
+        # trainable landmark branch: the HIP training plan (landmark_train.HipLandmarkTrainer) whenever the model is in training mode
+        # (BatchNorm batch statistics, Dropout(0.5)); an eval-mode model -- and LAFS_FT_CNN=torch, for A/B runs -- takes the nn.Module
+        # on torch autograd
+        self.cnn = None
+        if backbone.with_land and os.environ.get("LAFS_FT_CNN", "hip") == "hip":
+            from .landmark_train import HipLandmarkTrainer
+            self.cnn = HipLandmarkTrainer(backbone, self.arena, batch_size, image_size, device=dev)
+            backbone.register_state_dict_pre_hook(lambda *a, **k: self.cnn.flush_batches_tracked())
 
     def draw_lambda(self):
         if np.random.rand() < self.mixup_prob:
@@ -98,9 +107,10 @@ class FinetuneEngine:
         pos = a.view(a.master, m._spec.prefix + "pos_embedding").view(-1, D)[: self.geom.npatch(0) + 1]
         drop = m._sample_drop_scales(self.geom) if m.training else None
         img_in, theta = self.x, None
+        self._cnn_hip = m.with_land and self.cnn is not None and m.training
         if m.with_land:
-            # trainable landmark regressor (torch autograd over MIOpen) -> one-launch patch gather (ViT_face.py:679-711)
-            theta = m.landmarks(self.x)
+            # trainable landmark regressor -> one-launch patch gather (ViT_face.py:679-711)
+            theta = self.cnn.forward(self.x) if self._cnn_hip else m.landmarks(self.x)
             m.theta = theta
             th = theta.detach().contiguous()
             img_in = torch.empty_like(self.x)
@@ -174,7 +184,10 @@ class FinetuneEngine:
             dmosaic = Fn.unpatchify_grad(dx[0], m._spec.patch_order).contiguous()
             dth = torch.empty_like(th)
             call("lafs_patch_gather_bwd", _p(self.x), _p(th), _p(dmosaic), B, self.x.shape[-1], th.shape[1], _p(dth), None)
-            theta.backward(dth)                          # into stn.* / output_layer.* gradients (views of the arena)
+            if self._cnn_hip:
+                self.cnn.backward(dth)                   # into the arena's stn.* / output_layer.* gradients
+            else:
+                theta.backward(dth)                      # torch autograd: p.grad are views of the arena
         else:
             g = self._trunk_layers_backward(st, demb)
             dpos = Fn.vit_backward_end(a, m._spec, st, g)
@@ -207,6 +220,8 @@ class FinetuneEngine:
              _p(a.chunk_seg), a.n_chunks, _p(a.seg_flags), _p(a.seg_step), a.n_seg, _p(a.seg_sumsq), _p(self.hyper))
         a.refresh_transposed()
         a.zero_grad()
+        if self.cnn is not None:
+            self.cnn.mark_stale()                        # the master weights changed in place: new operand images next forward
 
     def step(self, inputs_u8, labels, lr, weight_decay=0.1):
         """micro_step + optimizer step every acc_step micro-steps (train_largescale.py:842-891)."""

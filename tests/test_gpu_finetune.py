@@ -616,3 +616,101 @@ def test_full_size_c5_whole_step_backbone_plus_partial_fc():
     assert int(moved.sum()) <= S and bool(moved[y].all())
     # a second micro-step on the updated weights still runs and gives a finite loss (fresh sample of centres)
     assert math.isfinite(float(eng.micro_step(u8, y).item()))
+
+
+def _train_cnn_pair(B, seed, fill):
+    """(model in TRAIN mode with its arena, HipLandmarkTrainer) for the landmark-branch tests."""
+    from lafs_cvpr2024_amd.landmark_train import HipLandmarkTrainer
+    torch.manual_seed(seed)
+    m = ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=64, depth=1, heads=1,
+                                 mlp_dim=64, dropout=0.0, emb_dropout=0.0, with_land=True)
+    fill(m)
+    arena = attach_arena(m, DEV)
+    m.train()
+    return m, arena, HipLandmarkTrainer(m, arena, B, 112, device=DEV)
+
+
+def test_f18_hip_training_plan_of_the_landmark_cnn_against_the_reference():
+    """The HIP training plan of the trainable landmark CNN (landmark_train.py: NHWC bf16, BatchNorm with batch statistics, Dropout(0.5),
+    min-max scaling; backward through all of it) against the REFERENCE's own train-mode run (F18: ViT_face.py:679-706 on det_fill
+    weights, dropout mask recorded): raw regressor output, landmarks, the gradients of every kind of tensor (stem, depthwise, 1x1,
+    squeeze-excite FCs, BatchNorm affine, regressor), gradient norms of ALL CNN tensors, and the BatchNorm running statistics."""
+    from conftest import det_fill
+    fx = load_golden("f18_landmark_train")
+
+    def fill(m):
+        det_fill(m.stn); det_fill(m.output_layer)
+    m, arena, tr = _train_cnn_pair(4, 0, fill)
+    tr.fixed_drop = fx["drop_keep"].float() / 0.5                           # the reference's mask, scaled as nn.Dropout does
+    theta = tr.forward(fx["x"].to(DEV))
+    torch.cuda.synchronize()
+    e_t = rel_l2(tr.B["t"], fx["t"])
+    d = (theta.cpu() - fx["theta"]).abs()
+    print(f"[F18] raw regressor rel-L2 {e_t:.3e}; landmarks mean {float(d.mean()):.3f} px, max {float(d.max()):.3f} px")
+    assert e_t < 3e-2 and float(d.mean()) < 1.0 and float(d.max()) < 4.0
+    tr.backward(fx["dtheta"].to(DEV))
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    errs = {k: rel_l2(named[k].grad, g) for k, g in sub(fx, "g.").items()}
+    gate_errors("F18 landmark CNN, train mode (HIP plan vs reference)", errs, 8e-2)
+    ref = dict(zip([str(k) for k in fx["gnorm_keys"]], fx["gnorms"].tolist()))
+    off = {k: (float(named[k].grad.norm()), v) for k, v in ref.items() if v > 1e-12 and abs(float(named[k].grad.norm()) - v) > 0.15 * v}
+    assert not off, off
+    sd = m.state_dict()                                                     # (flushes num_batches_tracked through the hook-less path below)
+    tr.flush_batches_tracked()
+    for k in ("stn.features.0.1", "stn.features.4.conv.4", "stn.features.15.conv.8"):
+        torch.testing.assert_close(m.state_dict()[k + ".running_mean"].cpu(), fx["rm." + k], rtol=2e-2, atol=2e-3)
+        torch.testing.assert_close(m.state_dict()[k + ".running_var"].cpu(), fx["rv." + k], rtol=3e-2, atol=2e-3)
+    assert int(m.state_dict()["stn.features.0.1.num_batches_tracked"]) == int(fx["nbt"]) == 1
+    del sd
+
+
+def test_hip_training_plan_of_the_landmark_cnn_matches_torch_autograd():
+    """Random (trained-looking) weights, batch 8: theta and EVERY parameter gradient of the trainable landmark branch from the HIP
+    plan against torch autograd over the same nn.Module in fp32 (train mode, the same dropout mask), plus a second forward/backward
+    accumulating into the same gradient arena (acc_step > 1) and the refresh of the operand images after a weight change."""
+    def fill(m):
+        with torch.no_grad():
+            for mod in m.stn.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.weight.uniform_(0.7, 1.3); mod.bias.normal_(0, 0.1)
+            m.output_layer[1].weight.normal_(0, 0.05); m.output_layer[1].bias.normal_(0, 0.1)
+    B = 8
+    m, arena, tr = _train_cnn_pair(B, 3, fill)
+    x = torch.randn(B, 3, 112, 112, device=DEV).clamp(-1, 1)
+    keep = (torch.rand(B, 160, device=DEV) >= 0.5).float() / 0.5
+    dth = torch.randn(B, 196, 2, device=DEV) * 0.05
+    # torch autograd over the module (fp32, MIOpen / HIP depthwise), dropout replaced by the same mask
+    import torch.nn.functional as F
+    rm0 = m.stn.features[0][1].running_mean.clone()
+    feat = m.stn(x).mean(dim=(-2, -1)) * keep
+    t_ref = F.linear(feat, m.output_layer[1].weight, m.output_layer[1].bias)
+    tmax, tmin = t_ref.max(1, keepdim=True)[0], t_ref.min(1, keepdim=True)[0]
+    th_ref = ((t_ref - tmin) / (tmax - tmin) * 111).view(B, 196, 2)
+    (th_ref * dth).sum().backward()
+    ref = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    arena.zero_grad()
+    with torch.no_grad():                                                    # undo the module pass's running-statistics update
+        for mod in m.stn.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.zero_(); mod.running_var.fill_(1.0)
+    tr.fixed_drop = keep
+    theta = tr.forward(x)
+    dpx = (theta - th_ref.detach()).abs()
+    assert rel_l2(tr.B["t"], t_ref) < 3e-2 and float(dpx.mean()) < 1.0 and float(dpx.max()) < 5.0, (float(dpx.mean()), float(dpx.max()))
+    tr.backward(dth)
+    named = dict(m.named_parameters())
+    errs = {k: rel_l2(named[k].grad, g) for k, g in ref.items() if float(g.abs().max()) > 1e-10}
+    assert len(errs) >= 170
+    gate_errors("landmark CNN training plan vs torch autograd (all tensors)", errs, 8e-2)
+    assert float((m.stn.features[0][1].running_mean - rm0).abs().max()) > 0          # running statistics were updated
+    # a second micro-step accumulates
+    g1 = arena.grad.clone()
+    tr.forward(x); tr.backward(dth)
+    torch.testing.assert_close(arena.grad, 2 * g1, rtol=2e-2, atol=1e-5 * float(g1.abs().max()))
+    # operand images follow the master weights
+    with torch.no_grad():
+        m.stn.features[1].conv[0].weight.mul_(0.5)
+    tr.mark_stale()
+    th2 = tr.forward(x)
+    assert float((th2 - theta).abs().max()) > 1e-3

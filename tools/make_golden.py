@@ -459,6 +459,49 @@ def main():
          gnorm_keys=np.array(sorted(g13.keys())), gnorms=np.array([float(g13[k].norm()) for k in sorted(g13.keys())]),
          **{"g." + k: g13[k] for k in keep},
          **{"p." + k: v for k, v in pl.state_dict().items() if not k.startswith(("stn.", "output_layer."))})
+    # ---------------------------------------------------------------- F18 the landmark branch in TRAIN mode (what train_largescale.py
+    # really runs, :432 + model.train()): MobileNetV3 trunk with BatchNorm batch statistics, Dropout(0.5) in front of the regressor
+    # (mask recorded), min-max scaling -- exactly the lines ViT_face.py:679-706 -- and the backward from a given d(loss)/d(theta).
+    # Pins nn.BatchNorm2d's training semantics (biased variance in the normalisation, momentum update of the running statistics
+    # with the unbiased one) and the gradient paths through min / max for the HIP training plan of the CNN.
+    print("F18 landmark branch, train mode")
+    torch.manual_seed(18)
+    pt = ref_face.ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8,
+                                           dim=64, depth=1, heads=1, mlp_dim=64, dropout=0.0, emb_dropout=0.0, with_land=True)
+    det_fill(pt.stn); det_fill(pt.output_layer)
+    pt.train()
+    x18 = torch.randn(4, 3, 112, 112).clamp(-1, 1)
+    rec18 = []
+    def recording_dropout18(inp, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return inp
+        keep = torch.rand_like(inp) >= p
+        rec18.append(keep)
+        return inp * keep / (1.0 - p)
+    orig_dropout18 = torch.nn.functional.dropout
+    torch.nn.functional.dropout = recording_dropout18
+    try:
+        t18 = pt.stn(x18).mean(dim=(-2, -1))
+        t18 = pt.output_layer(t18)
+    finally:
+        torch.nn.functional.dropout = orig_dropout18
+    assert len(rec18) == 1 and rec18[0].shape == (4, 160)
+    tmax = torch.max(t18, 1)[0].unsqueeze(1).repeat(1, 392)
+    tmin = torch.min(t18, 1)[0].unsqueeze(1).repeat(1, 392)
+    th18 = ((t18 - tmin) / (tmax - tmin) * 111).view(-1, 196, 2)
+    dth18 = torch.randn(4, 196, 2) * 0.05
+    (th18 * dth18).sum().backward()
+    g18 = {k: p.grad for k, p in pt.named_parameters() if p.grad is not None and k.startswith(("stn.", "output_layer."))}
+    keep18 = ["output_layer.1.weight", "output_layer.1.bias", "stn.features.0.0.weight", "stn.features.0.1.weight", "stn.features.1.conv.3.weight",
+              "stn.features.4.conv.5.fc.0.weight", "stn.features.4.conv.5.fc.2.weight", "stn.features.4.conv.4.bias", "stn.features.7.conv.0.weight",
+              "stn.features.13.conv.3.weight", "stn.features.15.conv.7.weight", "stn.features.15.conv.8.weight"]
+    bn18 = ["stn.features.0.1", "stn.features.4.conv.4", "stn.features.15.conv.8"]
+    sd18 = pt.state_dict()
+    save("f18_landmark_train", x=x18, drop_keep=rec18[0], t=t18, theta=th18, dtheta=dth18,
+         gnorm_keys=np.array(sorted(g18.keys())), gnorms=np.array([float(g18[k].norm()) for k in sorted(g18.keys())]),
+         **{"g." + k: g18[k] for k in keep18},
+         **{"rm." + k: sd18[k + ".running_mean"] for k in bn18}, **{"rv." + k: sd18[k + ".running_var"] for k in bn18},
+         nbt=sd18["stn.features.0.1.num_batches_tracked"])
     # ---------------------------------------------------------------- F14 Part-fViT element dropout (train mode)
     # nn.Dropout sites of the reference (emb :614,768; to_out :150-153; after GELU and after fc2 :126-133) with the masks
     # captured: F.dropout is replaced by a recording implementation for this one forward, DropPath forced to 0.
