@@ -132,6 +132,7 @@ class HipLandmarkTrainer:
         self.seed = 0x1A2D
         self.n_forward = 0                     # training forwards since the last flush of num_batches_tracked
         self.fixed_drop = None                 # parity hook: dropout factors f32 [N, 160] (0 or 1/(1-p)) instead of the counter-based mask
+        self.keep_trace, self.trace = False, []   # parity hook: clones of every block's incoming / intermediate / outgoing gradients
         self._alloc()
 
     # ------------------------------------------------------------------ helpers over the flat buffers
@@ -320,14 +321,18 @@ class HipLandmarkTrainer:
 
         def give(buf):
             spare.append(buf)
+        self.trace = []
         for L, D in zip(reversed(self.blocks), reversed(B["layers"])):
             R, Ro, H, Ho = D["R"], D["Ro"], D["H"], D["Ho"]
+            tr = {"dy": dy.clone()} if self.keep_trace else None
             # y = BN3(y_raw) (+ x_in): the residual branch carries dy unchanged into the block input gradient
             b1 = take(); dy_raw = view(b1, Ro, L["po"])
             self._bn_bwd(L["bn3"], dy, D["y_raw"], Ro, _lib.ACT_NONE, dy_raw)
             self._wgrad(dy_raw, D["d"], L["proj"])
             b2 = take(); dd = view(b2, Ro, L["pe"])
             ops.gemm_nt(dy_raw, self._w(L["proj"]["wt"], L["pe"], L["po"]), _lib.EPI_BF16, out=dd)
+            if tr is not None:
+                tr["dd"] = dd.clone()
             se = L["se"]
             dd_raw = view(b1, Ro, L["pe"])                               # b1 (dy_raw) is dead after the two GEMMs above
             if se:
@@ -346,15 +351,22 @@ class HipLandmarkTrainer:
                 self._bn_bwd(L["bn2"], dd, D["d_raw"], Ro, L["act"], dd_raw)
                 free_after_dw, keep = b1, b2
             # depthwise: dd_raw [Ro, pe] -> de [R, pe]  (into `keep`, whose content is dead), dw accumulated in the arena
+            if tr is not None:
+                tr["dd_raw"] = dd_raw.clone()
             de = view(keep, R, L["pe"])
             call("lafs_cnn_dwconv_train_bwd", _p(D["e"]), _p(dd_raw), self._m(L["dw"]), N, H, H, L["pe"], L["cexp"], L["k"], L["stride"], _p(de),
                  self._g(L["dw"]))
+            if tr is not None:
+                tr["de"] = de.clone()
             de_raw = view(free_after_dw, R, L["pe"])
             self._bn_bwd(L["bn1"], de, D["e_raw"], R, L["act"], de_raw)
             self._wgrad(de_raw, D["x_in"], L["exp"])
             dcur = view(keep, R, L["pi"])
             ops.gemm_nt(de_raw, self._w(L["exp"]["wt"], L["pi"], L["pe"]), _lib.EPI_BF16_ACT, out=dcur, aux=dy if L["residual"] else None,
                         act=_lib.ACT_NONE)
+            if tr is not None:
+                tr["dcur"] = dcur.clone()
+                self.trace.append(tr)
             give(dy_buf); give(free_after_dw)
             dy_buf, dy = keep, dcur
         # stem

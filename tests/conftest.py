@@ -64,6 +64,30 @@ def det_fill(module):
 
 
 
+def det_fill_random(module):
+    """Like det_fill, but pseudo-random: every floating tensor of the state_dict is drawn from a CPU generator seeded with the
+    crc32 of its key -- identical on the reference model (tools/make_golden.py) and on this build's model without storing 2.8 M
+    weights.  Convolution / linear weights ~ N(0, 2 / fan_out) (the trunk's own kaiming fan_out initialisation), BatchNorm weights
+    1 + 0.1 n, biases 0.1 n, running statistics untouched.  Unlike det_fill's sinusoids (whose convolutions cancel almost exactly:
+    a BatchNorm in TRAINING mode then renormalises rounding noise) these weights give the well-conditioned network bf16 kernels can
+    be held against."""
+    import zlib
+    with torch.no_grad():
+        for k, v in module.state_dict().items():
+            if not v.dtype.is_floating_point or k.endswith(("running_mean", "running_var")):
+                continue
+            g = torch.Generator().manual_seed(zlib.crc32(k.encode()))
+            t = torch.randn(v.shape, generator=g, dtype=torch.float64)
+            if v.dim() >= 2:
+                fan_out = v.shape[0] * (v[0][0].numel() if v.dim() > 2 else 1)
+                val = t * (2.0 / fan_out) ** 0.5
+            elif k.endswith("weight"):
+                val = 1.0 + 0.1 * t
+            else:
+                val = 0.1 * t
+            v.copy_(val.to(v.dtype))
+
+
 def gate_errors(name, errs, gate):
     """Assert every per-tensor relative-L2 error in `errs` (dict key -> error) is below `gate`, and always PRINT the worst
     observed value (pytest -s / the captured output of a failure): the gates are 2x the worst value seen on MI355X and the

@@ -630,87 +630,210 @@ def _train_cnn_pair(B, seed, fill):
     return m, arena, HipLandmarkTrainer(m, arena, B, 112, device=DEV)
 
 
-def test_f18_hip_training_plan_of_the_landmark_cnn_against_the_reference():
-    """The HIP training plan of the trainable landmark CNN (landmark_train.py: NHWC bf16, BatchNorm with batch statistics, Dropout(0.5),
-    min-max scaling; backward through all of it) against the REFERENCE's own train-mode run (F18: ViT_face.py:679-706 on det_fill
-    weights, dropout mask recorded): raw regressor output, landmarks, the gradients of every kind of tensor (stem, depthwise, 1x1,
-    squeeze-excite FCs, BatchNorm affine, regressor), gradient norms of ALL CNN tensors, and the BatchNorm running statistics."""
-    from conftest import det_fill
-    fx = load_golden("f18_landmark_train")
+def _bn_train(x, bn):
+    mu = x.mean(dim=(0, 2, 3), keepdim=True)
+    var = x.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    return (x - mu) / torch.sqrt(var + bn.eps) * bn.weight.view(1, -1, 1, 1) + bn.bias.view(1, -1, 1, 1)
+
+
+def _landmark_branch_torch(m, x, keep, rnd):
+    """The trainable landmark branch (ViT_face.py:679-706, train mode) in plain differentiable torch: `rnd` is applied wherever the HIP
+    plan stores a tensor as bf16 or feeds a bf16 GEMM operand (identity -> the fp32 formula of the nn.Module)."""
+    import torch.nn.functional as F
+    feats = m.stn.features
+    cur = rnd(feats[0][2](_bn_train(rnd(F.conv2d(rnd(x), rnd(feats[0][0].weight), None, 2, 1)), feats[0][1])))
+    for blk in feats[1:]:
+        c = blk.conv
+        e = rnd(c[2](_bn_train(rnd(F.conv2d(cur, rnd(c[0].weight))), c[1])))
+        d_raw = rnd(F.conv2d(e, c[3].weight, None, c[3].stride, c[3].padding, 1, c[3].groups))
+        if isinstance(c[5], torch.nn.Identity):
+            d = rnd(c[6](_bn_train(d_raw, c[4])))
+        else:
+            zb = rnd(_bn_train(d_raw, c[4]))
+            hid = rnd(F.relu(F.linear(rnd(zb.mean(dim=(2, 3))), rnd(c[5].fc[0].weight))))
+            gate = rnd(F.hardsigmoid(F.linear(hid, rnd(c[5].fc[2].weight))))
+            d = rnd(c[6](zb * gate[:, :, None, None]))
+        y = _bn_train(rnd(F.conv2d(d, rnd(c[7].weight))), c[8])
+        cur = rnd(y + cur if blk.residual else y)
+    feat = rnd(rnd(cur.mean(dim=(2, 3))) * keep)
+    t = F.linear(feat, rnd(m.output_layer[1].weight), m.output_layer[1].bias)
+    tmax, tmin = t.max(1, keepdim=True)[0], t.min(1, keepdim=True)[0]
+    return t, ((t - tmin) / (tmax - tmin) * 111).view(x.shape[0], -1, 2)
+
+
+def _ste_bf16(t):
+    return t + (t.to(torch.bfloat16).float() - t).detach()
+
+
+def test_landmark_cnn_training_plan_stage_by_stage():
+    """Kernel correctness of the trainable landmark branch's HIP plan (landmark_train.py), batch 8: EVERY stage of the forward and
+    of the backward against the same stage stated in torch (fp32 ops, a bf16 rounding wherever the plan stores bf16), each stage fed
+    the PLAN'S OWN inputs.  End-to-end comparisons of two 16-bit pipelines cannot be tight here: bf16 roundings that fall on the
+    other side of a boundary in 0.01 % of the elements decorrelate the two runs' rounding noise within a few blocks (measured:
+    1e-5 per stage in isolation, 4 % end to end; tools/lab/debug_cnn_train.py) -- the network-level distance to the reference is the
+    subject of the F18 test below.  Also: accumulation over two micro-steps, operand refresh after a weight change."""
+    import torch.nn.functional as F
+    from conftest import det_fill_random
 
     def fill(m):
-        det_fill(m.stn); det_fill(m.output_layer)
-    m, arena, tr = _train_cnn_pair(4, 0, fill)
-    tr.fixed_drop = fx["drop_keep"].float() / 0.5                           # the reference's mask, scaled as nn.Dropout does
-    theta = tr.forward(fx["x"].to(DEV))
-    torch.cuda.synchronize()
-    e_t = rel_l2(tr.B["t"], fx["t"])
-    d = (theta.cpu() - fx["theta"]).abs()
-    print(f"[F18] raw regressor rel-L2 {e_t:.3e}; landmarks mean {float(d.mean()):.3f} px, max {float(d.max()):.3f} px")
-    assert e_t < 3e-2 and float(d.mean()) < 1.0 and float(d.max()) < 4.0
-    tr.backward(fx["dtheta"].to(DEV))
-    torch.cuda.synchronize()
-    named = dict(m.named_parameters())
-    errs = {k: rel_l2(named[k].grad, g) for k, g in sub(fx, "g.").items()}
-    gate_errors("F18 landmark CNN, train mode (HIP plan vs reference)", errs, 8e-2)
-    ref = dict(zip([str(k) for k in fx["gnorm_keys"]], fx["gnorms"].tolist()))
-    off = {k: (float(named[k].grad.norm()), v) for k, v in ref.items() if v > 1e-12 and abs(float(named[k].grad.norm()) - v) > 0.15 * v}
-    assert not off, off
-    sd = m.state_dict()                                                     # (flushes num_batches_tracked through the hook-less path below)
-    tr.flush_batches_tracked()
-    for k in ("stn.features.0.1", "stn.features.4.conv.4", "stn.features.15.conv.8"):
-        torch.testing.assert_close(m.state_dict()[k + ".running_mean"].cpu(), fx["rm." + k], rtol=2e-2, atol=2e-3)
-        torch.testing.assert_close(m.state_dict()[k + ".running_var"].cpu(), fx["rv." + k], rtol=3e-2, atol=2e-3)
-    assert int(m.state_dict()["stn.features.0.1.num_batches_tracked"]) == int(fx["nbt"]) == 1
-    del sd
-
-
-def test_hip_training_plan_of_the_landmark_cnn_matches_torch_autograd():
-    """Random (trained-looking) weights, batch 8: theta and EVERY parameter gradient of the trainable landmark branch from the HIP
-    plan against torch autograd over the same nn.Module in fp32 (train mode, the same dropout mask), plus a second forward/backward
-    accumulating into the same gradient arena (acc_step > 1) and the refresh of the operand images after a weight change."""
-    def fill(m):
-        with torch.no_grad():
-            for mod in m.stn.modules():
-                if isinstance(mod, torch.nn.BatchNorm2d):
-                    mod.weight.uniform_(0.7, 1.3); mod.bias.normal_(0, 0.1)
-            m.output_layer[1].weight.normal_(0, 0.05); m.output_layer[1].bias.normal_(0, 0.1)
+        det_fill_random(m.stn); det_fill_random(m.output_layer)
     B = 8
     m, arena, tr = _train_cnn_pair(B, 3, fill)
     x = torch.randn(B, 3, 112, 112, device=DEV).clamp(-1, 1)
     keep = (torch.rand(B, 160, device=DEV) >= 0.5).float() / 0.5
     dth = torch.randn(B, 196, 2, device=DEV) * 0.05
-    # torch autograd over the module (fp32, MIOpen / HIP depthwise), dropout replaced by the same mask
-    import torch.nn.functional as F
     rm0 = m.stn.features[0][1].running_mean.clone()
-    feat = m.stn(x).mean(dim=(-2, -1)) * keep
-    t_ref = F.linear(feat, m.output_layer[1].weight, m.output_layer[1].bias)
-    tmax, tmin = t_ref.max(1, keepdim=True)[0], t_ref.min(1, keepdim=True)[0]
-    th_ref = ((t_ref - tmin) / (tmax - tmin) * 111).view(B, 196, 2)
-    (th_ref * dth).sum().backward()
-    ref = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
-    arena.zero_grad()
-    with torch.no_grad():                                                    # undo the module pass's running-statistics update
-        for mod in m.stn.modules():
-            if isinstance(mod, torch.nn.BatchNorm2d):
-                mod.running_mean.zero_(); mod.running_var.fill_(1.0)
-    tr.fixed_drop = keep
+    tr.fixed_drop, tr.keep_trace = keep, True
     theta = tr.forward(x)
-    dpx = (theta - th_ref.detach()).abs()
-    assert rel_l2(tr.B["t"], t_ref) < 3e-2 and float(dpx.mean()) < 1.0 and float(dpx.max()) < 5.0, (float(dpx.mean()), float(dpx.max()))
     tr.backward(dth)
+    torch.cuda.synchronize()
+    rnd = _ste_bf16
+    nchw = lambda buf, H, C: buf.view(B, H, H, -1)[..., :C].permute(0, 3, 1, 2).float().contiguous()
     named = dict(m.named_parameters())
-    errs = {k: rel_l2(named[k].grad, g) for k, g in ref.items() if float(g.abs().max()) > 1e-10}
-    assert len(errs) >= 170
-    gate_errors("landmark CNN training plan vs torch autograd (all tensors)", errs, 8e-2)
+    feats = m.stn.features
+    fwd, bwd, par = {}, {}, {}
+
+    def grads(out, ins, gout):
+        return torch.autograd.grad(out, ins, gout, allow_unused=True)
+
+    def pgrad(key, g):
+        par[key] = rel_l2(named[key].grad, g)
+    trace = list(reversed(tr.trace))                        # block order
+    for i, (blk, L, D, T) in enumerate(zip(feats[1:], tr.blocks, tr.B["layers"], trace), start=1):
+        c, H, Ho, pre = blk.conv, D["H"], D["Ho"], f"stn.features.{i}.conv."
+        cur = nchw(D["x_in"], H, L["cin"]).requires_grad_(True)
+        # expand + BN1 + activation
+        e_raw = rnd(F.conv2d(cur, rnd(c[0].weight)))
+        e = rnd(c[2](_bn_train(e_raw, c[1])))
+        fwd[f"b{i}.e_raw"] = rel_l2(nchw(D["e_raw"], H, L["cexp"]), e_raw)
+        fwd[f"b{i}.e"] = rel_l2(nchw(D["e"], H, L["cexp"]), e)
+        g_cur, g_w0, g_g1, g_b1 = grads(e, [cur, c[0].weight, c[1].weight, c[1].bias], nchw(T["de"], H, L["cexp"]))
+        if blk.residual:
+            g_cur = g_cur + nchw(T["dy"], Ho, L["cout"])
+        bwd[f"b{i}.dcur"] = rel_l2(nchw(T["dcur"], H, L["cin"]), g_cur)
+        pgrad(pre + "0.weight", g_w0); pgrad(pre + "1.weight", g_g1); pgrad(pre + "1.bias", g_b1)
+        # depthwise
+        e_in = nchw(D["e"], H, L["cexp"]).requires_grad_(True)
+        d_raw = rnd(F.conv2d(e_in, c[3].weight, None, c[3].stride, c[3].padding, 1, c[3].groups))
+        fwd[f"b{i}.d_raw"] = rel_l2(nchw(D["d_raw"], Ho, L["cexp"]), d_raw)
+        g_e, g_w3 = grads(d_raw, [e_in, c[3].weight], nchw(T["dd_raw"], Ho, L["cexp"]))
+        bwd[f"b{i}.de"] = rel_l2(nchw(T["de"], H, L["cexp"]), g_e)
+        pgrad(pre + "3.weight", g_w3)
+        # BN2 (+ squeeze-excite) + activation
+        dr = nchw(D["d_raw"], Ho, L["cexp"]).requires_grad_(True)
+        if L["se"] is None:
+            d = rnd(c[6](_bn_train(dr, c[4])))
+            ins = [dr, c[4].weight, c[4].bias]
+        else:
+            zb = rnd(_bn_train(dr, c[4]))
+            hid = rnd(F.relu(F.linear(rnd(zb.mean(dim=(2, 3))), rnd(c[5].fc[0].weight))))
+            gate = rnd(F.hardsigmoid(F.linear(hid, rnd(c[5].fc[2].weight))))
+            d = rnd(c[6](zb * gate[:, :, None, None]))
+            ins = [dr, c[4].weight, c[4].bias, c[5].fc[0].weight, c[5].fc[2].weight]
+            fwd[f"b{i}.gate"] = rel_l2(D["gate"][:, :L["cexp"]].float(), gate)
+        fwd[f"b{i}.d"] = rel_l2(nchw(D["d"], Ho, L["cexp"]), d)
+        gs = grads(d, ins, nchw(T["dd"], Ho, L["cexp"]))
+        bwd[f"b{i}.dd_raw"] = rel_l2(nchw(T["dd_raw"], Ho, L["cexp"]), gs[0])
+        pgrad(pre + "4.weight", gs[1]); pgrad(pre + "4.bias", gs[2])
+        if L["se"] is not None:
+            pgrad(pre + "5.fc.0.weight", gs[3]); pgrad(pre + "5.fc.2.weight", gs[4])
+        # project + BN3 (+ residual)
+        d_in = nchw(D["d"], Ho, L["cexp"]).requires_grad_(True)
+        y_raw = rnd(F.conv2d(d_in, rnd(c[7].weight)))
+        y = _bn_train(y_raw, c[8])
+        y = rnd(y + nchw(D["x_in"], H, L["cin"]) if blk.residual else y)
+        fwd[f"b{i}.y"] = rel_l2(nchw(D["y"], Ho, L["cout"]), y)
+        g_d, g_w7, g_g3, g_b3 = grads(y, [d_in, c[7].weight, c[8].weight, c[8].bias], nchw(T["dy"], Ho, L["cout"]))
+        bwd[f"b{i}.dd"] = rel_l2(nchw(T["dd"], Ho, L["cexp"]), g_d)
+        pgrad(pre + "7.weight", g_w7); pgrad(pre + "8.weight", g_g3); pgrad(pre + "8.bias", g_b3)
+    # stem (its input gradient is not needed) and regressor head + min-max scaling
+    s_raw = rnd(F.conv2d(rnd(x), rnd(feats[0][0].weight), None, 2, 1))
+    x0 = rnd(feats[0][2](_bn_train(s_raw, feats[0][1])))
+    fwd["x0"] = rel_l2(nchw(tr.B["x0"], 56, 16), x0)
+    gs = grads(x0, [feats[0][0].weight, feats[0][1].weight, feats[0][1].bias], nchw(trace[0]["dcur"], 56, 16))
+    pgrad("stn.features.0.0.weight", gs[0]); pgrad("stn.features.0.1.weight", gs[1]); pgrad("stn.features.0.1.bias", gs[2])
+    Hl = tr.H_last
+    y_last = nchw(tr.B["layers"][-1]["y"], Hl, 160).requires_grad_(True)
+    feat = rnd(rnd(y_last.mean(dim=(2, 3))) * keep)
+    t = F.linear(feat, rnd(m.output_layer[1].weight), m.output_layer[1].bias)
+    tmax, tmin = t.max(1, keepdim=True)[0], t.min(1, keepdim=True)[0]
+    th = ((t - tmin) / (tmax - tmin) * 111).view(B, 196, 2)
+    fwd["t"] = rel_l2(tr.B["t"], t); fwd["theta"] = rel_l2(theta, th)
+    g_y, g_wh, g_bh = grads(th, [y_last, m.output_layer[1].weight, m.output_layer[1].bias], dth)
+    bwd["d(y_last)"] = rel_l2(nchw(trace[-1]["dy"], Hl, 160), g_y)
+    pgrad("output_layer.1.weight", g_wh); pgrad("output_layer.1.bias", g_bh)
+    gate_errors("landmark CNN plan, forward stages", fwd, 2e-3)
+    gate_errors("landmark CNN plan, backward stages (activation gradients)", bwd, 1.5e-2)
+    gate_errors("landmark CNN plan, parameter gradients per stage", par, 1.5e-2)
+    assert len(par) == 156 and len(bwd) >= 60 and len(fwd) >= 75              # every CNN tensor, every stage
     assert float((m.stn.features[0][1].running_mean - rm0).abs().max()) > 0          # running statistics were updated
-    # a second micro-step accumulates
+    # a second micro-step accumulates into the same gradient arena
+    tr.keep_trace = False
     g1 = arena.grad.clone()
     tr.forward(x); tr.backward(dth)
-    torch.testing.assert_close(arena.grad, 2 * g1, rtol=2e-2, atol=1e-5 * float(g1.abs().max()))
+    torch.testing.assert_close(arena.grad, 2 * g1, rtol=2e-2, atol=1e-4 * float(g1.abs().max()))
     # operand images follow the master weights
     with torch.no_grad():
         m.stn.features[1].conv[0].weight.mul_(0.5)
     tr.mark_stale()
     th2 = tr.forward(x)
     assert float((th2 - theta).abs().max()) > 1e-3
+
+
+def test_f18_hip_training_plan_of_the_landmark_cnn_against_the_reference():
+    """The plan against the REFERENCE's own train-mode run of the landmark branch (F18: ViT_face.py:679-706 with BatchNorm batch
+    statistics, Dropout(0.5) mask recorded, backward from a given d(loss)/d(theta)): raw regressor, landmarks, gradients of every
+    kind of tensor (stem, depthwise, 1x1, squeeze-excite FCs, BatchNorm affine, regressor), gradient norms of ALL tensors, running
+    statistics.  The tolerances are those of ANY 16-bit evaluation of this algorithm, which the test measures itself: the same branch
+    stated in torch with straight-through bf16 roundings sits 9 % (regressor) / up to 0.45 rel-L2, cosine 0.91 (gradients) from the
+    fp32 reference, and with fp16 roundings -- what the reference's own GPU run does under autocast, train_largescale.py:803-804 --
+    1 % / 0.41 / 0.92: batch-statistics BatchNorm on a freshly initialised MobileNetV3 amplifies rounding noise, and the min-max
+    scaling routes gradient through arg-min / arg-max, which a 1 % change of the regressor re-selects.  The plan is gated at 1.5x
+    the bf16 statement's own distance (kernel correctness is the stage-by-stage test above)."""
+    from conftest import det_fill_random
+    fx = load_golden("f18_landmark_train")
+
+    def fill(m):
+        det_fill_random(m.stn); det_fill_random(m.output_layer)
+    m, arena, tr = _train_cnn_pair(4, 0, fill)
+    keep = fx["drop_keep"].float().to(DEV) / 0.5                             # the reference's mask, scaled as nn.Dropout does
+    x, dth = fx["x"].to(DEV), fx["dtheta"].to(DEV)
+    named = dict(m.named_parameters())
+    gref = sub(fx, "g.")
+    cosine = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten().cpu().double(), b.flatten().double(), dim=0))
+    # this build's fp32 statement == the reference; its bf16 statement = the yardstick
+    t32, th32 = _landmark_branch_torch(m, x, keep, lambda t: t)
+    assert rel_l2(t32, fx["t"]) < 1e-3 and float((th32.detach().cpu() - fx["theta"]).abs().max()) < 0.1
+    tb, thb = _landmark_branch_torch(m, x, keep, _ste_bf16)
+    (thb * dth).sum().backward()
+    yard_t = rel_l2(tb, fx["t"])
+    yard_g = {k: rel_l2(named[k].grad, g) for k, g in gref.items()}
+    yard_c = {k: cosine(named[k].grad, g) for k, g in gref.items()}
+    arena.zero_grad()
+    tr.fixed_drop = keep
+    theta = tr.forward(x)
+    tr.backward(dth)
+    torch.cuda.synchronize()
+    e_t = rel_l2(tr.B["t"], fx["t"])
+    d = (theta.cpu() - fx["theta"]).abs()
+    errs = {k: rel_l2(named[k].grad, g) for k, g in gref.items()}
+    cos = {k: cosine(named[k].grad, g) for k, g in gref.items()}
+    print(f"[F18] regressor rel-L2: plan {e_t:.3e}, bf16 torch statement {yard_t:.3e}; landmarks mean {float(d.mean()):.2f} px, max "
+          f"{float(d.max()):.2f} px; worst gradient rel-L2: plan {max(errs.values()):.3f}, statement {max(yard_g.values()):.3f}; "
+          f"min cosine: plan {min(cos.values()):.3f}, statement {min(yard_c.values()):.3f}")
+    assert e_t < 1.5 * yard_t + 0.02 and float(d.mean()) < 3.0 and float(d.max()) < 20.0, (e_t, yard_t)
+    assert max(errs.values()) < 1.5 * max(yard_g.values()) + 0.05, (errs, yard_g)
+    assert min(cos.values()) > min(yard_c.values()) - 0.08, (cos, yard_c)
+    # gradient norms of ALL tensors.  (A BatchNorm bias whose output only feeds a 1x1 convolution + batch-statistics BatchNorm has
+    # an exactly zero gradient -- the shift is removed again by the next mean subtraction -- which the reference reproduces down to
+    # fp32 round-off (1e-4) and any 16-bit evaluation only down to ITS round-off: those tensors are left out of the comparison.)
+    ref = dict(zip([str(k) for k in fx["gnorm_keys"]], fx["gnorms"].tolist()))
+    floor = 1e-2 * float(np.median(list(ref.values())))
+    off = {k: (float(named[k].grad.norm()), v) for k, v in ref.items() if v > floor and abs(float(named[k].grad.norm()) - v) > 0.5 * v}
+    assert not off, off
+    assert sum(v > floor for v in ref.values()) >= 130
+    tr.flush_batches_tracked()
+    for k in ("stn.features.0.1", "stn.features.4.conv.4", "stn.features.15.conv.8"):
+        torch.testing.assert_close(m.state_dict()[k + ".running_mean"].cpu(), fx["rm." + k], rtol=5e-2, atol=2e-2)
+        torch.testing.assert_close(m.state_dict()[k + ".running_var"].cpu(), fx["rv." + k], rtol=1e-1, atol=2e-2)
+    assert int(m.state_dict()["stn.features.0.1.num_batches_tracked"]) == int(fx["nbt"]) == 1

@@ -463,12 +463,14 @@ def main():
     # really runs, :432 + model.train()): MobileNetV3 trunk with BatchNorm batch statistics, Dropout(0.5) in front of the regressor
     # (mask recorded), min-max scaling -- exactly the lines ViT_face.py:679-706 -- and the backward from a given d(loss)/d(theta).
     # Pins nn.BatchNorm2d's training semantics (biased variance in the normalisation, momentum update of the running statistics
-    # with the unbiased one) and the gradient paths through min / max for the HIP training plan of the CNN.
+    # with the unbiased one) and the gradient paths through min / max for the HIP training plan of the CNN.  Weights: det_fill_random
+    # (pseudo-random by key: det_fill's sinusoids make the convolutions cancel, which batch-statistics BatchNorm turns into noise).
     print("F18 landmark branch, train mode")
     torch.manual_seed(18)
     pt = ref_face.ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8,
                                            dim=64, depth=1, heads=1, mlp_dim=64, dropout=0.0, emb_dropout=0.0, with_land=True)
-    det_fill(pt.stn); det_fill(pt.output_layer)
+    from conftest import det_fill_random
+    det_fill_random(pt.stn); det_fill_random(pt.output_layer)
     pt.train()
     x18 = torch.randn(4, 3, 112, 112).clamp(-1, 1)
     rec18 = []
