@@ -64,59 +64,74 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restric
                       pack_bf2(v[8 * k + 6], v[8 * k + 7]));
 }
 
-// BatchNorm statistics: sums[c] += sum_r x[r,c], sums[C + c] += sum_r x[r,c]^2.  Grid (row slabs, channel-group tiles of 32 groups).
-__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, int ldx, long R, int C, int rows_per_block,
-                                                       float* __restrict__ sums) {
-  // thread = (channel group g of 32 per tile, row lane rl of 8): 256 threads cover 32 groups x 8 row lanes
-  const int g = blockIdx.y * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
-  const int c = g * 8;
+// Column reductions over the rows of bf16 [R, ld] matrices.  Thread layout: GB channel groups (8 channels each) x 256 / GB row lanes,
+// GB = 4, 8, 16 or 32 (the smallest that covers ld / 8, or 32 with grid.y tiles for wider matrices): at 32 channels a wave reads
+// 16 whole rows = 1 KiB contiguous, and every thread of the workgroup has work (a fixed 32-group layout left 7 of 8 threads idle
+// on the early, largest layers of the trunk).  Two sums per channel, LDS tree over the row lanes, fp32 atomics into out[0..C), [C..2C).
+template <typename F>
+__device__ __forceinline__ void col_reduce2(int GB, int C, long R, int rows_per_block, float* __restrict__ out, F body) {
+  __shared__ float red[256][16];
+  const int RL = 256 / GB;
+  const int gl = threadIdx.x % GB, rl = threadIdx.x / GB;
+  const int c = (blockIdx.y * GB + gl) * 8;
   const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  if (c < C) {
-    for (long r = r0 + rl; r < r1; r += 8) {
+  if (c < C) body(c, r0 + rl, r1, RL, s1, s2);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < GB * 16; i += 256) {
+    const int gg = i >> 4, e = i & 15;
+    float s = 0.f;
+    for (int k = 0; k < RL; ++k) s += red[k * GB + gg][e];
+    const int cc = (blockIdx.y * GB + gg) * 8 + (e & 7);
+    if (cc < C) atomicAdd(out + (e < 8 ? 0 : C) + cc, s);
+  }
+}
+inline int group_block(int ld) { const int g = ld / 8; return g <= 4 ? 4 : (g <= 8 ? 8 : (g <= 16 ? 16 : 32)); }
+
+// BatchNorm statistics: sums[c] += sum_r x[r,c], sums[C + c] += sum_r x[r,c]^2
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, int ldx, long R, int C, int rows_per_block, int GB,
+                                                       float* __restrict__ sums) {
+  col_reduce2(GB, C, R, rows_per_block, sums, [&](int c, long ra, long rb, int step, float (&s1)[8], float (&s2)[8]) {
+    for (long r = ra; r < rb; r += step) {
       float v[8];
       unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * ldx + c), v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] = fmaf(v[e], v[e], s2[e]); }
     }
-  }
-  __shared__ float red[8][32][16];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { red[rl][threadIdx.x & 31][e] = s1[e]; red[rl][threadIdx.x & 31][8 + e] = s2[e]; }
-  __syncthreads();
-  // 32 groups x 16 values = 512 sums: two per thread
-  for (int i = threadIdx.x; i < 512; i += 256) {
-    const int gg = i >> 4, e = i & 15;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k][gg][e];
-    const int cc = (blockIdx.y * 32 + gg) * 8 + (e & 7);
-    if (cc < C) atomicAdd(sums + (e < 8 ? 0 : C) + cc, s);
-  }
+  });
 }
 
-// BatchNorm apply (training): y = act((x - mean) rstd gamma + beta) (+ resid); block 0 also writes stat = {mean[C], rstd[C]} and
-// updates the running statistics.  Pad channels (>= C) are written as zero.
+// BatchNorm apply (training): y = act(x scale + shift) (+ resid) with scale = rstd gamma, shift = beta - mean scale staged in LDS
+// once per workgroup; block 0 also writes stat = {mean[C], rstd[C]} and updates the running statistics.  Pad channels (>= C) -> 0.
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, int ldx, long R, int C, const float* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                        float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                        int act, const bf16_t* __restrict__ resid, int ldr, bf16_t* __restrict__ y, int ldy,
                                                        float* __restrict__ stat) {
+  extern __shared__ float sc[];                          // [2 ldy]: scale, shift
   const int C8 = ldy >> 3;
   const long total = R * C8;
   const float invR = 1.0f / (float)R;
-  if (blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < C; c += 256) {
-      const float m = sums[c] * invR, var = fmaxf(sums[C + c] * invR - m * m, 0.f);
-      stat[c] = m; stat[C + c] = rsqrtf(var + eps);
-      if (running_mean != nullptr) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)R / (float)(R > 1 ? R - 1 : 1));
+  for (int c = threadIdx.x; c < ldy; c += 256) {
+    float scale = 0.f, shift = 0.f;
+    if (c < C) {
+      const float m = sums[c] * invR, var = fmaxf(sums[C + c] * invR - m * m, 0.f), rs = rsqrtf(var + eps);
+      scale = rs * gamma[c]; shift = beta[c] - m * scale;
+      if (blockIdx.x == 0) {
+        stat[c] = m; stat[C + c] = rs;
+        if (running_mean != nullptr) {
+          running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+          running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * ((float)R / (float)(R > 1 ? R - 1 : 1));
+        }
       }
     }
+    sc[c] = scale; sc[ldy + c] = shift;
   }
+  __syncthreads();
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = (int)(idx % C8) * 8;
     const long r = idx / C8;
@@ -125,33 +140,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
     float rs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (resid != nullptr) unpack8(*reinterpret_cast<const uint4*>(resid + (size_t)r * ldr + c), rs);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int cc = c + e;
-      if (cc < C) {
-        const float m = sums[cc] * invR, var = fmaxf(sums[C + cc] * invR - m * m, 0.f);
-        const float z = (v[e] - m) * rsqrtf(var + eps) * gamma[cc] + beta[cc];
-        o[e] = act_f(z, act) + rs[e];
-      } else {
-        o[e] = 0.f;
-      }
-    }
+    for (int e = 0; e < 8; ++e) o[e] = (c + e < C) ? act_f(fmaf(v[e], sc[c + e], sc[ldy + c + e]), act) + rs[e] : 0.f;
     *reinterpret_cast<uint4*>(y + (size_t)r * ldy + c) = pack8(o);
   }
 }
 
 // BatchNorm backward, pass 1: dz = (dy + add[n, c] / HW) act'(z), z recomputed from the raw input;  dsums[c] += sum dz,
-// dsums[C + c] += sum dz xhat.  Same thread layout as bn_stats_kernel.
+// dsums[C + c] += sum dz xhat
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                             long R, int C, const float* __restrict__ stat, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int act, const bf16_t* __restrict__ add,
-                                                            int ldadd, int HW, int rows_per_block, float* __restrict__ dsums) {
-  const int g = blockIdx.y * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
-  const int c = g * 8;
-  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(R, r0 + rows_per_block);
-  float s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  if (c < C) {
+                                                            int ldadd, int HW, int rows_per_block, int GB, float* __restrict__ dsums) {
+  col_reduce2(GB, C, R, rows_per_block, dsums, [&](int c, long ra, long rb, int step, float (&s1)[8], float (&s2)[8]) {
     float m[8], rs[8], ga[8], be[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
       m[e] = stat[cc]; rs[e] = stat[C + cc]; ga[e] = gamma[cc]; be[e] = beta[cc];
     }
     const float invHW = 1.0f / (float)HW;
-    for (long r = r0 + rl; r < r1; r += 8) {
+    for (long r = ra; r < rb; r += step) {
       float v[8], d[8];
       unpack8(*reinterpret_cast<const uint4*>(x + (size_t)r * ldx + c), v);
       unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)r * lddy + c), d);
@@ -172,37 +172,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float xh = (v[e] - m[e]) * rs[e];
-        const float dz = d[e] * act_grad_f(fmaf(xh, ga[e], be[e]), act);
+        const float dz = (c + e < C) ? d[e] * act_grad_f(fmaf(xh, ga[e], be[e]), act) : 0.f;
         s1[e] += dz; s2[e] = fmaf(dz, xh, s2[e]);
       }
     }
-  }
-  __shared__ float red[8][32][16];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { red[rl][threadIdx.x & 31][e] = s1[e]; red[rl][threadIdx.x & 31][8 + e] = s2[e]; }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 512; i += 256) {
-    const int gg = i >> 4, e = i & 15;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) s += red[k][gg][e];
-    const int cc = (blockIdx.y * 32 + gg) * 8 + (e & 7);
-    if (cc < C) atomicAdd(dsums + (e < 8 ? 0 : C) + cc, s);
-  }
+  });
 }
 
-// BatchNorm backward, pass 2: dx = gamma rstd (dz - sum dz / R - xhat sum(dz xhat) / R); block 0 adds dgamma, dbeta into the arena
+// BatchNorm backward, pass 2: dx = gamma rstd (dz - sum dz / R - xhat sum(dz xhat) / R) with the per-channel constants staged in
+// LDS once per workgroup; block 0 adds dgamma, dbeta into the arena
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                            long R, int C, const float* __restrict__ stat, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int act, const bf16_t* __restrict__ add,
                                                            int ldadd, int HW, const float* __restrict__ dsums, bf16_t* __restrict__ dx,
                                                            int lddx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float sc[];                          // [6 lddx]: mean, rstd, gamma, beta, sum dz / R, sum dz xhat / R
   const int C8 = lddx >> 3;
   const long total = R * C8;
   const float invR = 1.0f / (float)R, invHW = 1.0f / (float)HW;
-  if (blockIdx.x == 0 && dgamma != nullptr) {
-    for (int c = threadIdx.x; c < C; c += 256) { dgamma[c] += dsums[C + c]; dbeta[c] += dsums[c]; }
+  for (int c = threadIdx.x; c < lddx; c += 256) {
+    const bool ok = c < C;
+    sc[c] = ok ? stat[c] : 0.f; sc[lddx + c] = ok ? stat[C + c] : 0.f; sc[2 * lddx + c] = ok ? gamma[c] : 0.f;
+    sc[3 * lddx + c] = ok ? beta[c] : 0.f; sc[4 * lddx + c] = ok ? dsums[c] * invR : 0.f; sc[5 * lddx + c] = ok ? dsums[C + c] * invR : 0.f;
+    if (ok && blockIdx.x == 0 && dgamma != nullptr) { dgamma[c] += dsums[C + c]; dbeta[c] += dsums[c]; }
   }
+  __syncthreads();
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = (int)(idx % C8) * 8;
     const long r = idx / C8;
@@ -218,14 +212,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int cc = c + e;
-      if (cc < C) {
-        const float m = stat[cc], rs = stat[C + cc], ga = gamma[cc];
-        const float xh = (v[e] - m) * rs;
-        const float dz = d[e] * act_grad_f(fmaf(xh, ga, beta[cc]), act);
-        o[e] = ga * rs * (dz - dsums[cc] * invR - xh * dsums[C + cc] * invR);
-      } else {
-        o[e] = 0.f;
-      }
+      const float rs = sc[lddx + cc], ga = sc[2 * lddx + cc];
+      const float xh = (v[e] - sc[cc]) * rs;
+      const float dz = d[e] * act_grad_f(fmaf(xh, ga, sc[3 * lddx + cc]), act);
+      o[e] = ga * rs * (dz - sc[4 * lddx + cc] - xh * sc[5 * lddx + cc]);        // pad channels: gamma = 0 -> 0
     }
     *reinterpret_cast<uint4*>(dx + (size_t)r * lddx + c) = pack8(o);
   }
@@ -501,10 +491,10 @@ __global__ __launch_bounds__(256) void theta_bwd_kernel(const float* __restrict_
     else hipLaunchKernelGGL((KERNEL<5>), __VA_ARGS__);             \
   } while (0)
 
-int rows_per_block_for(long R) {                       // ~2048 row slabs at most, at least 64 rows each
-  long rpb = (R + 2047) / 2048;
-  if (rpb < 64) rpb = 64;
-  return (int)((rpb + 7) / 8 * 8);
+int rows_per_block_for(long R) {                       // ~1024 row slabs at most, at least 256 rows each
+  long rpb = (R + 1023) / 1024;
+  if (rpb < 256) rpb = 256;
+  return (int)((rpb + 63) / 64 * 64);
 }
 
 }  // namespace
@@ -520,9 +510,9 @@ extern "C" int lafs_cnn_im2col_stem(const float* x, int N, int S, void* P, hipSt
 extern "C" int lafs_cnn_bn_stats(const void* x, int ldx, int64_t R, int C, float* sums, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && sums && R > 0 && C > 0 && ldx >= C && ldx % 8 == 0, "bad operand");
-  const int rpb = rows_per_block_for(R);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((R + rpb - 1) / rpb), (unsigned)((C + 255) / 256)), dim3(256), 0, stream,
-                     (const bf16_t*)x, ldx, (long)R, C, rpb, sums);
+  const int rpb = rows_per_block_for(R), GB = group_block(ldx);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)((R + rpb - 1) / rpb), (unsigned)((C + 8 * GB - 1) / (8 * GB))), dim3(256), 0, stream,
+                     (const bf16_t*)x, ldx, (long)R, C, rpb, GB, sums);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -536,7 +526,7 @@ extern "C" int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const
   LAFS_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "running statistics come in pairs");
   long blocks = (R * (ldy / 8) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)x, ldx, (long)R, C, sums, gamma, beta, eps,
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(256), 2 * ldy * sizeof(float), stream, (const bf16_t*)x, ldx, (long)R, C, sums, gamma, beta, eps,
                      momentum, running_mean, running_var, act, (const bf16_t*)resid, ldr, (bf16_t*)y, ldy, stat);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
@@ -549,14 +539,14 @@ extern "C" int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx,
   LAFS_CHECK_ARG(dy && x && stat && gamma && beta && dsums && dx && R > 0 && C > 0 && HW > 0, "null operand");
   LAFS_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && lddx >= C && lddy >= lddx && ldx >= lddx, "bad strides");
   LAFS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr) && (add_nc == nullptr || (ldadd >= lddx && ldadd % 8 == 0)), "bad operand");
-  const int rpb = rows_per_block_for(R);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)((R + rpb - 1) / rpb), (unsigned)((C + 255) / 256)), dim3(256), 0, stream,
+  const int rpb = rows_per_block_for(R), GB = group_block(lddx);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)((R + rpb - 1) / rpb), (unsigned)((C + 8 * GB - 1) / (8 * GB))), dim3(256), 0, stream,
                      (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (long)R, C, stat, gamma, beta, act, (const bf16_t*)add_nc, ldadd, HW,
-                     rpb, dsums);
+                     rpb, GB, dsums);
   LAFS_LAUNCH_CHECK();
   long blocks = (R * (lddx / 8) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (long)R,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 6 * lddx * sizeof(float), stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (long)R,
                      C, stat, gamma, beta, act, (const bf16_t*)add_nc, ldadd, HW, dsums, (bf16_t*)dx, lddx, dgamma, dbeta);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
