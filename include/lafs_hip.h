@@ -472,12 +472,18 @@ int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const float* sum
 int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
                     const float* beta, int act, const void* add_nc, int ldadd, int HW, float* dsums, void* dx, int lddx,
                     float* dgamma, float* dbeta, hipStream_t stream);
-/* Depthwise k x k convolution (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) on NHWC bf16 with the weights in the module's own
- * layout w f32 [C][k*k]: forward; backward = dx(bf16) and dw(f32 [C][k*k], +=). */
+/* Depthwise k x k convolution (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) on NHWC bf16.  w = tap-major fp32 image [k*k][ld] of
+ * the module's [C][1][k][k] tensor (lafs_cnn_dw_layout_table: table[8 e ..] = {src offset, C, k*k, dst offset, ld}, 256 elements per
+ * workgroup); forward; backward = dx(bf16) and dw(f32, += into a tap-major image [k*k][ld] that lafs_cnn_unpad_add_table folds,
+ * transposed, into the arena). */
+int lafs_cnn_dw_layout_table(const float* master, float* dst, const int64_t* table, const int32_t* starts, int n_entries, int n_blocks,
+                             hipStream_t stream);
 int lafs_cnn_dwconv_train_fwd(const void* x, const float* w, int N, int H, int W, int ld, int C, int k, int stride, void* y,
                               hipStream_t stream);
 int lafs_cnn_dwconv_train_bwd(const void* x, const void* dy, const float* w, int N, int H, int W, int ld, int C, int k, int stride,
                               void* dx, float* dw, hipStream_t stream);
+/* out(bf16)[n, c] = mean over the HW rows of image n (squeeze / final average pool), one workgroup per image. */
+int lafs_cnn_pool_train(const void* x, int N, int HW, int ld, void* out, int ldo, hipStream_t stream);
 /* Squeeze-excite: out = act(z gate[n, c]) (z kept); backward: ds = dout act'(z gate), dz = ds gate, dgate(f32)[n, c] = sum_p ds z. */
 int lafs_cnn_scale_act_out(const void* z, const void* s, int lds_, int N, int HW, int ld, int act, void* out, hipStream_t stream);
 int lafs_cnn_se_bwd(const void* dout, const void* z, const void* gate, int ldg, int N, int HW, int ld, int act, void* dz, float* dgate,
@@ -490,8 +496,8 @@ int lafs_cnn_pool_bwd(const void* dfeat, int ldf, int N, int HW, int ld, void* d
  * dst ld, transpose, padded rows, 0}; starts(i32)[e] = first workgroup of entry e (1024 destination elements per workgroup). */
 int lafs_cnn_pad_cast_table(const float* master, void* dst, const int64_t* table, const int32_t* starts, int n_entries, int n_blocks,
                             hipStream_t stream);
-/* Padded fp32 weight gradients folded into the arena, ONE launch: table[8 e ..] = {src offset, rows, cols, src ld, grad offset, ...};
- * 256 elements per workgroup. */
+/* Padded fp32 weight gradients folded into the arena, ONE launch: table[8 e ..] = {src offset, rows, cols, src ld, grad offset,
+ * transpose, ...}; 256 elements per workgroup.  transpose: the source image is [cols][ld] (tap-major depthwise gradients). */
 int lafs_cnn_unpad_add_table(const float* padded, float* grad, const int64_t* table, const int32_t* starts, int n_entries, int n_blocks,
                              hipStream_t stream);
 /* Backward of theta = (t - min) / (max - min) * 111 per image (ViT_face.py:698-706), incl. the paths through min and max. */

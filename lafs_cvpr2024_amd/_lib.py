@@ -127,6 +127,8 @@ _PROTOS = {
     "lafs_cnn_act_bwd_post": [vp, vp, vp, i64, i32, vp],
     "lafs_cnn_pool_bwd": [vp, i32, i32, i32, i32, vp],
     "lafs_cnn_pad_cast_table": [vp, vp, vp, vp, i32, i32],
+    "lafs_cnn_dw_layout_table": [vp, vp, vp, vp, i32, i32],
+    "lafs_cnn_pool_train": [vp, i32, i32, i32, vp, i32],
     "lafs_cnn_unpad_add_table": [vp, vp, vp, vp, i32, i32],
     "lafs_landmark_theta_bwd": [vp, vp, i32, i32, vp],
     "lafs_augment_views": [vp, vp, vp, i32, i32, vp],

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restric
 // on the early, largest layers of the trunk).  Two sums per channel, LDS tree over the row lanes, fp32 atomics into out[0..C), [C..2C).
 template <typename F>
 __device__ __forceinline__ void col_reduce2(int GB, int C, long R, int rows_per_block, float* __restrict__ out, F body) {
-  __shared__ float red[256][16];
+  __shared__ float red[256][17];                       // (+1: the tree below walks columns of 16 floats)
   const int RL = 256 / GB;
   const int gl = threadIdx.x % GB, rl = threadIdx.x / GB;
   const int c = (blockIdx.y * GB + gl) * 8;
@@ -82,12 +82,18 @@ __device__ __forceinline__ void col_reduce2(int GB, int C, long R, int rows_per_
 #pragma unroll
   for (int e = 0; e < 8; ++e) { red[threadIdx.x][e] = s1[e]; red[threadIdx.x][8 + e] = s2[e]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < GB * 16; i += 256) {
-    const int gg = i >> 4, e = i & 15;
-    float s = 0.f;
-    for (int k = 0; k < RL; ++k) s += red[k * GB + gg][e];
-    const int cc = (blockIdx.y * GB + gg) * 8 + (e & 7);
-    if (cc < C) atomicAdd(out + (e < 8 ? 0 : C) + cc, s);
+  for (int half = RL >> 1; half > 0; half >>= 1) {     // tree over the row lanes (thread = rl * GB + gl)
+    if (rl < half) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) red[threadIdx.x][e] += red[threadIdx.x + half * GB][e];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < GB && c < C) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (c + e < C) { atomicAdd(out + c + e, red[threadIdx.x][e]); atomicAdd(out + C + c + e, red[threadIdx.x][8 + e]); }
+    }
   }
 }
 inline int group_block(int ld) { const int g = ld / 8; return g <= 4 ? 4 : (g <= 8 ? 8 : (g <= 16 ? 16 : 32)); }
@@ -221,7 +227,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
-// ---- depthwise k x k convolution on NHWC bf16 with the weights in the module's own layout w f32 [C][k*k] (no bias, no activation)
+// ---- depthwise k x k convolution on NHWC bf16 (no bias, no activation).  Weights: tap-major fp32 image wt [k*k][ld] (pad channels
+// zero) built from the module's [C][1][k][k] tensor by lafs_cnn_dw_layout_table -- a thread's 8 channels of one tap are 32 contiguous
+// bytes (read straight from the [C][k*k] tensor they were 8 loads 100 bytes apart per tap: 95 us for a 6 MB layer)
 template <int K>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w, int N, int H, int W, int ld,
                                                      int C, int stride, bf16_t* __restrict__ y) {
@@ -245,8 +253,11 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const bf16_t* __restrict__ 
       if (ix < 0 || ix >= W) continue;
       float v[8];
       unpack8(*reinterpret_cast<const uint4*>(xn + ((size_t)iy * W + ix) * ld), v);
+      const float* wk = w + (size_t)(ky * K + kx) * ld + c;
+      const float4 w0 = *reinterpret_cast<const float4*>(wk), w1 = *reinterpret_cast<const float4*>(wk + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], (c + e < C) ? w[(size_t)(c + e) * K * K + ky * K + kx] : 0.f, acc[e]);
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], wv[e], acc[e]);
     }
   }
   *reinterpret_cast<uint4*>(y + (size_t)pix * ld + c) = pack8(acc);
@@ -280,15 +291,19 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const bf16_t* __restri
       if (ox >= Wo) continue;
       float v[8];
       unpack8(*reinterpret_cast<const uint4*>(dn + ((size_t)oy * Wo + ox) * ld), v);
+      const float* wk = w + (size_t)(ky * K + kx) * ld + c;
+      const float4 w0 = *reinterpret_cast<const float4*>(wk), w1 = *reinterpret_cast<const float4*>(wk + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], (c + e < C) ? w[(size_t)(c + e) * K * K + ky * K + kx] : 0.f, acc[e]);
+      for (int e = 0; e < 8; ++e) acc[e] = fmaf(v[e], wv[e], acc[e]);
     }
   }
   *reinterpret_cast<uint4*>(dx + (size_t)pix * ld + c) = pack8(acc);
 }
 
-// dw[c][ky,kx] += sum_{n,oy,ox} dy[n,oy,ox,c] x[n,iy,ix,c].  Grid (pixel slabs, channel groups of 8): a thread walks a strided
-// set of output pixels of its slab with K*K x 8 accumulators; wave reduction, then fp32 atomics into the arena gradient.
+// dwt[ky,kx][c] += sum_{n,oy,ox} dy[n,oy,ox,c] x[n,iy,ix,c] (tap-major image, folded into the arena's [C][k*k] gradient by
+// lafs_cnn_unpad_add_table).  Grid (pixel slabs, channel groups of 8): a thread walks a strided set of output pixels of its slab with
+// K*K x 8 accumulators; wave reduction, then fp32 atomics.
 template <int K>
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, int N, int H, int W,
                                                             int ld, int C, int stride, int pix_per_block, float* __restrict__ dw) {
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const bf16_t* __rest
   __syncthreads();
   for (int i = threadIdx.x; i < K * K * 8; i += 256) {
     const int t = i >> 3, e = i & 7;
-    if (c + e < C) atomicAdd(dw + (size_t)(c + e) * K * K + t, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+    if (c + e < C) atomicAdd(dw + (size_t)t * ld + c + e, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
   }
 }
 
@@ -354,32 +369,83 @@ __global__ __launch_bounds__(256) void scale_act_out_kernel(const bf16_t* __rest
   for (int e = 0; e < 8; ++e) o[e] = act_f(v[e] * g[e], act);
   *reinterpret_cast<uint4*>(out + (size_t)pix * ld + c) = pack8(o);
 }
-// backward: ds = dout act'(z gate); dz = ds gate (bf16, written); dgate[n, c] = sum_p ds z (fp32, one thread per (n, 8 channels))
+// backward: ds = dout act'(z gate); dz = ds gate (bf16, written); dgate[n, c] = sum_p ds z (fp32).  One workgroup per (image,
+// tile of GB channel groups): the pixels are spread over 256 / GB lanes and reduced through the LDS (one thread per (image, group)
+// walking all pixels left the early 14x14 layers with 2048 threads on the whole chip: 85 us each).
 __global__ __launch_bounds__(256) void se_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ z, const bf16_t* __restrict__ gate,
-                                                     int ldg, int N, int HW, int ld, int act, bf16_t* __restrict__ dz, float* __restrict__ dgate,
-                                                     int lddg) {
-  const int C8 = ld >> 3;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)N * C8) return;
-  const int c = (int)(idx % C8) * 8, n = (int)(idx / C8);
-  float g[8], acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  unpack8(*reinterpret_cast<const uint4*>(gate + (size_t)n * ldg + c), g);
-  for (int p = 0; p < HW; ++p) {
-    const size_t off = ((size_t)n * HW + p) * ld + c;
-    float d[8], v[8], o[8];
-    unpack8(*reinterpret_cast<const uint4*>(dout + off), d);
-    unpack8(*reinterpret_cast<const uint4*>(z + off), v);
+                                                     int ldg, int N, int HW, int ld, int act, int GB, bf16_t* __restrict__ dz,
+                                                     float* __restrict__ dgate, int lddg) {
+  __shared__ float red[256][9];
+  const int PL = 256 / GB;
+  const int gl = threadIdx.x % GB, pl = threadIdx.x / GB;
+  const int c = (blockIdx.y * GB + gl) * 8, n = blockIdx.x;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < ld) {
+    float g[8];
+    unpack8(*reinterpret_cast<const uint4*>(gate + (size_t)n * ldg + c), g);
+    for (int p = pl; p < HW; p += PL) {
+      const size_t off = ((size_t)n * HW + p) * ld + c;
+      float d[8], v[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(dout + off), d);
+      unpack8(*reinterpret_cast<const uint4*>(z + off), v);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float ds = d[e] * act_grad_f(v[e] * g[e], act);
-      o[e] = ds * g[e];
-      acc[e] = fmaf(ds, v[e], acc[e]);
+      for (int e = 0; e < 8; ++e) {
+        const float ds = d[e] * act_grad_f(v[e] * g[e], act);
+        o[e] = ds * g[e];
+        acc[e] = fmaf(ds, v[e], acc[e]);
+      }
+      *reinterpret_cast<uint4*>(dz + off) = pack8(o);
     }
-    *reinterpret_cast<uint4*>(dz + off) = pack8(o);
   }
-  float* dg = dgate + (size_t)n * lddg + c;
-  *reinterpret_cast<float4*>(dg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-  *reinterpret_cast<float4*>(dg + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  for (int half = PL >> 1; half > 0; half >>= 1) {
+    if (pl < half) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + half * GB][e];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < GB && c < ld) {
+    float* dg = dgate + (size_t)n * lddg + c;
+    *reinterpret_cast<float4*>(dg) = make_float4(red[threadIdx.x][0], red[threadIdx.x][1], red[threadIdx.x][2], red[threadIdx.x][3]);
+    *reinterpret_cast<float4*>(dg + 4) = make_float4(red[threadIdx.x][4], red[threadIdx.x][5], red[threadIdx.x][6], red[threadIdx.x][7]);
+  }
+}
+// out(bf16)[n, c] = mean_p x[n, p, c] with the same workgroup shape (the squeeze of squeeze-excite and the final average pool of the
+// TRAINING plan; the inference plan keeps lafs_cnn_pool)
+__global__ __launch_bounds__(256) void pool_wg_kernel(const bf16_t* __restrict__ x, int N, int HW, int ld, int GB, bf16_t* __restrict__ out, int ldo) {
+  __shared__ float red[256][9];
+  const int PL = 256 / GB;
+  const int gl = threadIdx.x % GB, pl = threadIdx.x / GB;
+  const int c = (blockIdx.y * GB + gl) * 8, n = blockIdx.x;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < ld) {
+    for (int p = pl; p < HW; p += PL) {
+      float v[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + ((size_t)n * HW + p) * ld + c), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += v[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = acc[e];
+  __syncthreads();
+  for (int half = PL >> 1; half > 0; half >>= 1) {
+    if (pl < half) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[threadIdx.x][e] += red[threadIdx.x + half * GB][e];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < GB && c < ld) {
+    const float inv = 1.0f / (float)HW;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = red[threadIdx.x][e] * inv;
+    *reinterpret_cast<uint4*>(out + (size_t)n * ldo + c) = pack8(o);
+  }
 }
 // out(bf16)[i] = dy[i] act'(.) with the derivative taken from the POST-activation value y (valid for relu and h-sigmoid: the
 // squeeze-excite FCs); dy fp32 (dy_f32 != null) or bf16
@@ -428,17 +494,30 @@ __global__ __launch_bounds__(256) void pad_cast_table_kernel(const float* __rest
     dst[doff + i] = (sr < rows && scol < cols) ? f2bf(master[src + sr * cols + scol]) : (bf16_t)0;
   }
 }
-// gradient fold: entry = {padded src offset (floats), rows, cols, src ld, arena grad offset}: grad[r][c] += src[r][c]
+// depthwise weight images: entry = {src offset (floats into master), C, k*k, dst offset (floats), ld}: dst[t][c] = src[c][t], pad 0
+__global__ __launch_bounds__(256) void dw_layout_table_kernel(const float* __restrict__ master, float* __restrict__ dst, const long* __restrict__ table,
+                                                              const int* __restrict__ starts, int n_ent) {
+  int lo = 0, hi = n_ent;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const long* e = table + 8 * lo;
+  const long src = e[0], C = e[1], kk = e[2], doff = e[3], ld = e[4];
+  const long i = (long)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
+  if (i >= kk * ld) return;
+  const long t = i / ld, c = i % ld;
+  dst[doff + i] = c < C ? master[src + c * kk + t] : 0.f;
+}
+// gradient fold: entry = {padded src offset (floats), rows, cols, src ld, arena grad offset, transpose}: grad[r][c] += src[r][c]
+// (transpose: the source image is [cols][ld] tap-major and grad[r][c] += src[c][r]: depthwise weight gradients)
 __global__ __launch_bounds__(256) void unpad_add_table_kernel(const float* __restrict__ padded, float* __restrict__ grad, const long* __restrict__ table,
                                                               const int* __restrict__ starts, int n_ent) {
   int lo = 0, hi = n_ent;
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
   const long* e = table + 8 * lo;
-  const long src = e[0], rows = e[1], cols = e[2], ld = e[3], goff = e[4];
+  const long src = e[0], rows = e[1], cols = e[2], ld = e[3], goff = e[4], tr = e[5];
   const long i = (long)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
   if (i >= rows * cols) return;
   const long r = i / cols, c = i % cols;
-  grad[goff + i] += padded[src + r * ld + c];
+  grad[goff + i] += tr ? padded[src + c * ld + r] : padded[src + r * ld + c];
 }
 
 // ---- backward of the per-image min-max scaling theta = (t - min) / (max - min) * 111 (ViT_face.py:698-706): the gradient also
@@ -491,8 +570,8 @@ __global__ __launch_bounds__(256) void theta_bwd_kernel(const float* __restrict_
     else hipLaunchKernelGGL((KERNEL<5>), __VA_ARGS__);             \
   } while (0)
 
-int rows_per_block_for(long R) {                       // ~1024 row slabs at most, at least 256 rows each
-  long rpb = (R + 1023) / 1024;
+int rows_per_block_for(long R) {                       // <= 256 row slabs (one per CU; 64 atomics each), at least 256 rows each
+  long rpb = (R + 255) / 256;
   if (rpb < 256) rpb = 256;
   return (int)((rpb + 63) / 64 * 64);
 }
@@ -601,8 +680,28 @@ extern "C" int lafs_cnn_se_bwd(const void* dout, const void* z, const void* gate
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(dout && z && gate && dz && dgate && N > 0 && HW > 0 && ld > 0 && ld % 8 == 0 && ldg >= ld && ldg % 8 == 0 && lddg >= ld && lddg % 4 == 0,
                  "bad operand");
-  hipLaunchKernelGGL(se_bwd_kernel, dim3(blocks_for((long)N * (ld / 8))), dim3(256), 0, stream, (const bf16_t*)dout, (const bf16_t*)z,
-                     (const bf16_t*)gate, ldg, N, HW, ld, act, (bf16_t*)dz, dgate, lddg);
+  const int GB = group_block(ld);
+  hipLaunchKernelGGL(se_bwd_kernel, dim3((unsigned)N, (unsigned)((ld / 8 + GB - 1) / GB)), dim3(256), 0, stream, (const bf16_t*)dout,
+                     (const bf16_t*)z, (const bf16_t*)gate, ldg, N, HW, ld, act, GB, (bf16_t*)dz, dgate, lddg);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_pool_train(const void* x, int N, int HW, int ld, void* out, int ldo, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(x && out && N > 0 && HW > 0 && ld > 0 && ld % 8 == 0 && ldo >= ld && ldo % 8 == 0, "bad operand");
+  const int GB = group_block(ld);
+  hipLaunchKernelGGL(pool_wg_kernel, dim3((unsigned)N, (unsigned)((ld / 8 + GB - 1) / GB)), dim3(256), 0, stream, (const bf16_t*)x, N, HW, ld, GB,
+                     (bf16_t*)out, ldo);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_dw_layout_table(const float* master, float* dst, const int64_t* table, const int32_t* starts, int n_entries, int n_blocks,
+                                        hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(master && dst && table && starts && n_entries > 0 && n_blocks > 0, "bad operand");
+  hipLaunchKernelGGL(dw_layout_table_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, master, dst, (const long*)table, starts, n_entries);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

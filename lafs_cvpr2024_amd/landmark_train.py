@@ -46,6 +46,7 @@ class _Tables:
     def __init__(self):
         self.cast, self.cast_blocks, self.cast_size = [], [0], 0          # entries of lafs_cnn_pad_cast_table
         self.fold, self.fold_blocks, self.grad_size = [], [0], 0          # entries of lafs_cnn_unpad_add_table
+        self.dwl, self.dwl_blocks, self.dw_size = [], [0], 0              # entries of lafs_cnn_dw_layout_table
 
     def operand(self, src_off, rows, cols, prow, pcol, transpose):
         """Image [prow, pcol] of src [rows, cols] (transpose: [pcol-padded cols as rows]); returns its offset (bf16 elements)."""
@@ -55,6 +56,19 @@ class _Tables:
         self.cast_blocks.append(self.cast_blocks[-1] + (r * c + 1023) // 1024)
         self.cast_size += (r * c + 63) // 64 * 64
         return off
+
+    def depthwise(self, src_off, C, kk, ld):
+        """Tap-major fp32 image [kk, ld] of a depthwise weight [C, 1, k, k] and the same-shaped gradient image (folded back transposed);
+        returns (weight image offset, gradient image offset)."""
+        off = self.dw_size
+        self.dwl.append([src_off, C, kk, off, ld, 0, 0, 0])
+        self.dwl_blocks.append(self.dwl_blocks[-1] + (kk * ld + 255) // 256)
+        self.dw_size += (kk * ld + 63) // 64 * 64
+        goff = self.grad_size
+        self.fold.append([goff, C, kk, ld, src_off, 1, 0, 0])                # grad[c][t] += image[t][c]
+        self.fold_blocks.append(self.fold_blocks[-1] + (C * kk + 255) // 256)
+        self.grad_size += (kk * ld + 63) // 64 * 64
+        return off, goff
 
     def gradient(self, rows, cols, prow, pcol, grad_off):
         """Padded fp32 image [prow, pcol] whose [rows, cols] corner is added to arena.grad[grad_off ...]; returns its offset."""
@@ -101,7 +115,7 @@ class HipLandmarkTrainer:
             pre = f"stn.features.{i}.conv."
             L = dict(cin=cin, cexp=cexp, cout=cout, pi=pi, pe=pe, po=po, k=k, stride=stride, residual=bool(blk.residual), act=_act_code(cv[2]),
                      exp=conv_spec(pre + "0.weight", cexp, cin, pe, pi), bn1=bn_spec(pre + "1", cv[1], cexp),
-                     dw=off(pre + "3.weight"), bn2=bn_spec(pre + "4", cv[4], cexp),
+                     dw=T.depthwise(off(pre + "3.weight"), cexp, k * k, pe), bn2=bn_spec(pre + "4", cv[4], cexp),
                      proj=conv_spec(pre + "7.weight", cout, cexp, po, pe), bn3=bn_spec(pre + "8", cv[8], cout), se=None)
             if not isinstance(cv[5], nn.Identity):
                 h = cv[5].fc[0].out_features
@@ -124,6 +138,12 @@ class HipLandmarkTrainer:
         self.fold_table = torch.tensor(T.fold, dtype=i64, device=dev).view(-1)
         self.fold_starts = torch.tensor(T.fold_blocks, dtype=torch.int32, device=dev)
         self.n_cast, self.cast_nblk, self.n_fold, self.fold_nblk = len(T.cast), T.cast_blocks[-1], len(T.fold), T.fold_blocks[-1]
+        self.dwl_table = torch.tensor(T.dwl, dtype=i64, device=dev).view(-1)
+        self.dwl_starts = torch.tensor(T.dwl_blocks, dtype=torch.int32, device=dev)
+        self.n_dwl, self.dwl_nblk = len(T.dwl), T.dwl_blocks[-1]
+        self.wdw = torch.zeros(T.dw_size, device=dev, dtype=f32)
+        self.dw_grad_lo = min(L["dw"][1] for L in self.blocks)             # the depthwise gradient images are zeroed every backward
+        self.dw_grad_hi = max(L["dw"][1] + ((L["k"] ** 2 * L["pe"] + 63) // 64 * 64) for L in self.blocks)
         self.wbf = torch.zeros(T.cast_size, device=dev, dtype=bf16)
         self.gpad = torch.zeros(T.grad_size, device=dev, dtype=f32)
         self.bn_ws = torch.zeros(sums[0], device=dev, dtype=f32)
@@ -151,9 +171,16 @@ class HipLandmarkTrainer:
     def _ws(self, offset):
         return C.c_void_p(self.bn_ws.data_ptr() + 4 * offset)
 
+    def _dww(self, L):                          # tap-major weight image / gradient image of a block's depthwise convolution
+        return C.c_void_p(self.wdw.data_ptr() + 4 * L["dw"][0])
+
+    def _dwg(self, L):
+        return C.c_void_p(self.gpad.data_ptr() + 4 * L["dw"][1])
+
     def refresh_operands(self):
         """Padded bf16 images (W and W^T) of every 1x1 / FC weight from the arena's fp32 master, one launch."""
         call("lafs_cnn_pad_cast_table", _p(self.arena.master), _p(self.wbf), _p(self.cast_table), _p(self.cast_starts), self.n_cast, self.cast_nblk)
+        call("lafs_cnn_dw_layout_table", _p(self.arena.master), _p(self.wdw), _p(self.dwl_table), _p(self.dwl_starts), self.n_dwl, self.dwl_nblk)
 
     def _alloc(self):
         N, dev = self.N, self.device
@@ -242,11 +269,11 @@ class HipLandmarkTrainer:
             R, Ro, H, Ho = D["R"], D["Ro"], D["H"], D["Ho"]
             ops.gemm_nt(cur, self._w(L["exp"]["w"], L["pe"], L["pi"]), _lib.EPI_BF16, out=D["e_raw"])
             self._bn_fwd(L["bn1"], D["e_raw"], R, L["act"], D["e"])
-            call("lafs_cnn_dwconv_train_fwd", _p(D["e"]), self._m(L["dw"]), N, H, H, L["pe"], L["cexp"], L["k"], L["stride"], _p(D["d_raw"]))
+            call("lafs_cnn_dwconv_train_fwd", _p(D["e"]), self._dww(L), N, H, H, L["pe"], L["cexp"], L["k"], L["stride"], _p(D["d_raw"]))
             se = L["se"]
             if se:
                 self._bn_fwd(L["bn2"], D["d_raw"], Ro, _lib.ACT_NONE, D["zb"])
-                call("lafs_cnn_pool", _p(D["zb"]), N, Ho * Ho, L["pe"], _p(D["pool"]), L["pe"])
+                call("lafs_cnn_pool_train", _p(D["zb"]), N, Ho * Ho, L["pe"], _p(D["pool"]), L["pe"])
                 ops.gemm_nt(D["pool"], self._w(se["fc1"]["w"], se["ph"], L["pe"]), _lib.EPI_BF16_ACT, out=D["hid"], act=se["act1"])
                 ops.gemm_nt(D["hid"], self._w(se["fc2"]["w"], L["pe"], se["ph"]), _lib.EPI_BF16_ACT, out=D["gate"], act=se["act2"])
                 call("lafs_cnn_scale_act_out", _p(D["zb"]), _p(D["gate"]), L["pe"], N, Ho * Ho, L["pe"], L["act"], _p(D["d"]))
@@ -257,7 +284,7 @@ class HipLandmarkTrainer:
             D["x_in"] = cur
             cur = D["y"]
         HW = self.H_last * self.H_last
-        call("lafs_cnn_pool", _p(cur), N, HW, self.p_last, _p(B["feat"]), self.p_last)
+        call("lafs_cnn_pool_train", _p(cur), N, HW, self.p_last, _p(B["feat"]), self.p_last)
         # Dropout(0.5) (training) + Linear(160, 2 r r): counter-based mask of (seed + 7919 step), regenerated in the backward
         call("lafs_cast_f32", _p(B["feat"]), _p(B["featf"]), B["feat"].numel())
         self.drop_seed = (self.seed + 7919 * self.step) & 0xFFFFFFFF
@@ -296,6 +323,7 @@ class HipLandmarkTrainer:
         a, B, N = self.arena, self.B, self.N
         n_full = self.n_out // 2
         call("lafs_landmark_theta_bwd", _p(B["t"]), _p(dtheta.contiguous()), N, self.n_out, _p(B["dt"]))
+        call("lafs_fill_zero", C.c_void_p(self.gpad.data_ptr() + 4 * self.dw_grad_lo), (self.dw_grad_hi - self.dw_grad_lo) * 4)
         ops.scale_cast_bf16(B["dt"], out=B["dt_bf"])                      # [N, n_out] -> bf16 image [N, p_out] (pad columns stay zero)
         # head: dW, db, d(feature)
         hd = self.head
@@ -354,8 +382,8 @@ class HipLandmarkTrainer:
             if tr is not None:
                 tr["dd_raw"] = dd_raw.clone()
             de = view(keep, R, L["pe"])
-            call("lafs_cnn_dwconv_train_bwd", _p(D["e"]), _p(dd_raw), self._m(L["dw"]), N, H, H, L["pe"], L["cexp"], L["k"], L["stride"], _p(de),
-                 self._g(L["dw"]))
+            call("lafs_cnn_dwconv_train_bwd", _p(D["e"]), _p(dd_raw), self._dww(L), N, H, H, L["pe"], L["cexp"], L["k"], L["stride"], _p(de),
+                 self._dwg(L))
             if tr is not None:
                 tr["de"] = de.clone()
             de_raw = view(free_after_dw, R, L["pe"])
