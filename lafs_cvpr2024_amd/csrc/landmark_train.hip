@@ -89,11 +89,12 @@ __device__ __forceinline__ void col_reduce2(int GB, int C, long R, int rows_per_
     }
     __syncthreads();
   }
-  if (threadIdx.x < GB && c < C) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if (c + e < C) { atomicAdd(out + c + e, red[threadIdx.x][e]); atomicAdd(out + C + c + e, red[threadIdx.x][8 + e]); }
-    }
+  // one atomic per thread, consecutive addresses per wave instruction (16 serial atomics from GB threads each made the kernel 2-5x
+  // slower: the atomic round trips, not the reads, were its critical path)
+  for (int i = threadIdx.x; i < GB * 16; i += 256) {
+    const int half = i / (GB * 8), j = i % (GB * 8);     // j = channel offset inside this block's GB * 8 channels
+    const int cc = blockIdx.y * GB * 8 + j;
+    if (cc < C) atomicAdd(out + half * C + cc, red[j >> 3][half * 8 + (j & 7)]);
   }
 }
 inline int group_block(int ld) { const int g = ld / 8; return g <= 4 ? 4 : (g <= 8 ? 8 : (g <= 16 ? 16 : 32)); }
@@ -589,9 +590,9 @@ __global__ __launch_bounds__(256) void theta_bwd_kernel(const float* __restrict_
     else hipLaunchKernelGGL((KERNEL<5>), __VA_ARGS__);             \
   } while (0)
 
-int rows_per_block_for(long R) {                       // ~2048 row slabs at most (8 workgroups per CU: these kernels live on memory
-  long rpb = (R + 2047) / 2048;                        // latency), at least 128 rows each; measured: one slab per CU is 2.3x slower
-  if (rpb < 128) rpb = 128;
+int rows_per_block_for(long R) {                       // ~1024 row slabs at most (4 workgroups per CU), at least 256 rows each
+  long rpb = (R + 1023) / 1024;
+  if (rpb < 256) rpb = 256;
   return (int)((rpb + 63) / 64 * 64);
 }
 

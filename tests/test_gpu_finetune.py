@@ -684,7 +684,7 @@ def test_landmark_cnn_training_plan_stage_by_stage():
     dth = torch.randn(B, 196, 2, device=DEV) * 0.05
     rm0 = m.stn.features[0][1].running_mean.clone()
     tr.fixed_drop, tr.keep_trace = keep, True
-    theta = tr.forward(x)
+    theta = tr.forward(x).clone()
     tr.backward(dth)
     torch.cuda.synchronize()
     rnd = _ste_bf16
