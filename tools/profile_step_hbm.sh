@@ -12,8 +12,8 @@ out = {}
 f = glob.glob("$O/m/**/*counter_collection.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"]
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-marks = [i for i, r in enumerate(rows) if "clip_adamw_ema" in r["Kernel_Name"]]
-step = rows[marks[-2] + 1:marks[-1] + 1]
+marks = [i for i, r in enumerate(rows) if "zero_chunks" in r["Kernel_Name"]]        # first kernel of a step
+step = rows[marks[-2]:marks[-1]]
 busy = sum(float(r["Counter_Value"]) for r in step)
 dur_ns = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step)
 out["mfma_busy_cycles_per_step"] = busy
@@ -24,9 +24,9 @@ for tag, ctr in (("f", "FETCH_SIZE"), ("w", "WRITE_SIZE")):
     f = glob.glob("$O/%s/**/*counter_collection.csv" % tag, recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    marks = [i for i, r in enumerate(rows) if "clip_adamw_ema" in r["Kernel_Name"]]
-    a, b = marks[-2], marks[-1]                       # one full step: after the previous optimizer kernel .. this one
-    step = rows[a + 1:b + 1]
+    marks = [i for i, r in enumerate(rows) if "zero_chunks" in r["Kernel_Name"]]
+    a, b = marks[-2], marks[-1]                       # one full step: from its first kernel (gradient zeroing) to the next step's
+    step = rows[a:b]
     out[ctr + "_KB_per_step"] = sum(float(r["Counter_Value"]) for r in step)
     out[ctr + "_kernels_per_step"] = len(step)
     by = {}

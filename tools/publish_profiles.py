@@ -89,8 +89,8 @@ def main():
     if tr:
         import collections, re
         rows = sorted(csv.DictReader(open(tr[0])), key=lambda r: int(r["Start_Timestamp"]))
-        marks = [i for i, r in enumerate(rows) if "clip_adamw_ema" in r["Kernel_Name"]]
-        step = rows[marks[-2] + 1:marks[-1] + 1]
+        marks = [i for i, r in enumerate(rows) if "zero_chunks" in r["Kernel_Name"]]      # first kernel of a step
+        step = rows[marks[-2]:marks[-1]]
         cnt = collections.Counter(re.sub(r"\(anonymous namespace\)::|void |\(.*", "", r["Kernel_Name"]) for r in step)
         span = (int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"])) / 1e6
         with open(os.path.join(DST, f"{R}_one_step_kernels.txt"), "w") as fo:
