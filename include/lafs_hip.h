@@ -344,6 +344,10 @@ typedef struct lafs_trunk_desc {
 
 /* Bytes of activation workspace for a forward with (1) / without (0) saving activations for backward. */
 int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward);
+/* Creates the library's side streams and events (row chains, attention groups, weight-gradient protocol) now instead of on first
+ * use: engines call it once at construction, so that nothing is created inside a hipGraph capture.  Returns 1 when the side streams
+ * are in use, 0 when LAFS_ATTN_STREAM=0 / LAFS_SINGLE_STREAM=1 keep everything on the caller's stream. */
+int lafs_trunk_streams_init(void);
 /* Number of independent chains of launches (row ranges of the token batch, one stream each) the trunk passes of this descriptor
  * run as: 2 when there are two crop-resolution groups of >= 4096 full-length rows each (csrc/engine.hip:
  * row_ranges), else 1.  Tests assert the route they mean to cover. */

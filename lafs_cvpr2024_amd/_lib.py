@@ -149,6 +149,7 @@ _NO_STREAM = {
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),
     "lafs_trunk_row_ranges": ([C.POINTER(TrunkDesc)], i32),
+    "lafs_trunk_streams_init": ([], i32),
     "lafs_wgrad_workspace_bytes": ([i32, i32, i32], i64),
     "lafs_wgrad_group_workspace_bytes": ([C.POINTER(WgradItem), i32, i32, i32], i64),
 }

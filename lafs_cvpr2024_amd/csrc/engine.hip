@@ -157,23 +157,50 @@ static AttnSide& attn_side() {
 }
 // stream of group gi's attention launch; call attn_fork before the first launch and attn_join after the last one
 static hipStream_t attn_stream_of(int gi, hipStream_t stream) { return (gi > 0 && attn_side().on) ? attn_side().s : stream; }
-static void attn_fork(hipStream_t stream, int n = 2) {       // n streams in all: `stream`, s, sx[0], sx[1]
+#define HIP_TRY(call)                                                                         \
+  do {                                                                                        \
+    const hipError_t e_ = (call);                                                             \
+    if (e_ != hipSuccess) {                                                                   \
+      lafs_set_error("%s:%d: %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));      \
+      return (int)e_;                                                                         \
+    }                                                                                         \
+  } while (0)
+static int attn_fork(hipStream_t stream, int n = 2) {        // n streams in all: `stream`, s, sx[0], sx[1]
   AttnSide& a = attn_side();
-  if (!a.on) return;
-  (void)hipEventRecord(a.fork, stream);
-  (void)hipStreamWaitEvent(a.s, a.fork, 0);
-  for (int i = 0; i + 2 < n; ++i) (void)hipStreamWaitEvent(a.sx[i], a.fork, 0);
+  if (!a.on) return LAFS_OK;
+  HIP_TRY(hipEventRecord(a.fork, stream));
+  HIP_TRY(hipStreamWaitEvent(a.s, a.fork, 0));
+  for (int i = 0; i + 2 < n; ++i) HIP_TRY(hipStreamWaitEvent(a.sx[i], a.fork, 0));
+  return LAFS_OK;
 }
-static void attn_join(hipStream_t stream, int n = 2) {
+// (always reached once a fork has been issued -- also on the error path of the forked work: side streams left forked inside a
+// hipGraph capture would make the capture fail later with an unrelated error)
+static int attn_join(hipStream_t stream, int n = 2) {
   AttnSide& a = attn_side();
-  if (!a.on) return;
-  (void)hipEventRecord(a.join, a.s);
-  (void)hipStreamWaitEvent(stream, a.join, 0);
+  if (!a.on) return LAFS_OK;
+  HIP_TRY(hipEventRecord(a.join, a.s));
+  HIP_TRY(hipStreamWaitEvent(stream, a.join, 0));
   for (int i = 0; i + 2 < n; ++i) {
-    (void)hipEventRecord(a.joinx[i], a.sx[i]);
-    (void)hipStreamWaitEvent(stream, a.joinx[i], 0);
+    HIP_TRY(hipEventRecord(a.joinx[i], a.sx[i]));
+    HIP_TRY(hipStreamWaitEvent(stream, a.joinx[i], 0));
   }
+  return LAFS_OK;
 }
+// forked region: run `body`, join in any case, report the first failure
+#define FORKED(stream, n, body)                 \
+  do {                                          \
+    RUN(attn_fork(stream, n));                  \
+    int rc_f = LAFS_OK;                         \
+    do { body } while (0);                      \
+    const int rc_j = attn_join(stream, n);      \
+    if (rc_f != LAFS_OK) return rc_f;           \
+    if (rc_j != LAFS_OK) return rc_j;           \
+  } while (0)
+#define TRY_F(call)                             \
+  {                                             \
+    rc_f = (call);                              \
+    if (rc_f != LAFS_OK) break;                 \
+  }
 // Row ranges of a trunk pass: one per crop-resolution group (2) or per half group (4, cut at a sequence boundary) when there are
 // two groups of full-length sequences (element-dropout masks are indexed by absolute rows: drop_row0); else one range.
 struct RowRange { int r0, R, gi, seq_lo, nseq; hipStream_t st; };
@@ -202,6 +229,24 @@ static int row_ranges(const lafs_trunk_desc* d, hipStream_t stream, RowRange (&r
 extern "C" int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward) {
   if (check_desc(d) != LAFS_OK) return -1;
   return (int64_t)carve(d, nullptr, save_for_backward).bytes;
+}
+
+// Events for the two-stream backward (weight gradients run on `wgrad_stream` concurrently with the dgrad / attention /
+// LayerNorm chain).  Lazily created, reused on every call; the only process-wide state of the library.
+static std::vector<hipEvent_t>& event_pool(size_t n) {
+  static std::vector<hipEvent_t> pool;
+  while (pool.size() < n) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
+    pool.push_back(e);
+  }
+  return pool;
+}
+
+extern "C" int lafs_trunk_streams_init(void) {
+  (void)attn_side();                      // creates the side streams / events now: never lazily inside a hipGraph capture
+  (void)event_pool(64);
+  return attn_side().on ? 1 : 0;
 }
 
 extern "C" int lafs_trunk_row_ranges(const lafs_trunk_desc* d) {
@@ -244,13 +289,19 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       RUN(gemm(b.h1 + rD, D, sh + o.w_qkv, D, R, 3 * I, D, LAFS_EPI_BF16, b.qkv + 3 * rI, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, st));
       if (g_hi - g_lo > 1 || d->n_groups > 1) {               // one launch per crop resolution, each with its own tile shape
         int s0 = seq_lo;                                      // (the attention kernels address tokens through cu_seqlens: base pointers)
-        if (attn_two_streams) attn_fork(st);
-        for (int gi = g_lo; gi < g_hi; ++gi) {
-          RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, nseq >= 0 ? nseq : d->group_n_seq[gi], d->group_max_len[gi], d->heads,
-                                 d->attn_scale, b.o, I, b.lse, attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
-          s0 += d->group_n_seq[gi];
+        if (attn_two_streams) {
+          FORKED(st, 2, for (int gi = g_lo; gi < g_hi; ++gi) {
+            TRY_F(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads, d->attn_scale, b.o, I,
+                                     b.lse, attn_stream_of(gi - g_lo, st)));
+            s0 += d->group_n_seq[gi];
+          });
+        } else {
+          for (int gi = g_lo; gi < g_hi; ++gi) {
+            RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, nseq >= 0 ? nseq : d->group_n_seq[gi], d->group_max_len[gi], d->heads,
+                                   d->attn_scale, b.o, I, b.lse, st));
+            s0 += d->group_n_seq[gi];
+          }
         }
-        if (attn_two_streams) attn_join(st);
       } else {
         RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, st));
       }
@@ -271,26 +322,13 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
     }
     return LAFS_OK;
   };
-  if (n_rr > 1) {
-    attn_fork(stream, n_rr);                                // the side streams join behind everything `stream` has enqueued so far
-    for (int i = 0; i < n_rr; ++i) RUN(chain(rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
-    attn_join(stream, n_rr);
+  if (n_rr > 1) {                                           // the side streams join behind everything `stream` has enqueued so far
+    FORKED(stream, n_rr, for (int i = 0; i < n_rr; ++i)
+      TRY_F(chain(rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false)););
   } else {
     RUN(chain(0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
   }
   return LAFS_OK;
-}
-
-// Events for the two-stream backward (weight gradients run on `wgrad_stream` concurrently with the dgrad / attention /
-// LayerNorm chain).  Lazily created, reused on every call; the only process-wide state of the library.
-static std::vector<hipEvent_t>& event_pool(size_t n) {
-  static std::vector<hipEvent_t> pool;
-  while (pool.size() < n) {
-    hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
-    pool.push_back(e);
-  }
-  return pool;
 }
 
 extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
@@ -312,11 +350,11 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   std::vector<hipEvent_t>& ev = event_pool(two ? (size_t)2 * nl + 1 : 0);
   LAFS_CHECK_ARG(!two || ev.size() >= (size_t)2 * nl + 1, "could not create HIP events");
   int evi = 0;
+  bool ev_failed = false;                  // a failed event call of the two-stream protocol (reported at the end of the call)
   auto fork = [&]() {                      // work enqueued on s2 after this sees everything enqueued on `stream` so far
     if (!two) return;
     hipEvent_t e = ev[evi++];
-    (void)hipEventRecord(e, stream);
-    (void)hipStreamWaitEvent(s2, e, 0);
+    if (hipEventRecord(e, stream) != hipSuccess || hipStreamWaitEvent(s2, e, 0) != hipSuccess) ev_failed = true;
   };
   std::vector<hipEvent_t> done(d->depth, nullptr);
   auto scale = [&](int l, int br) { return d->drop_scales ? d->drop_scales + ((size_t)l * 2 + br) * d->n_seq : nullptr; };
@@ -342,14 +380,19 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     RUN(gemm(s.gba[p] + rD, D, sht + o.w_proj_t, D, R, I, D, LAFS_EPI_BF16, s.d_o + rI, I, nullptr, st));
     if (d->n_groups > 1) {
       int s0 = seq_lo;
-      if (attn_two_streams) attn_fork(st);
-      for (int gi = g_lo; gi < g_hi; ++gi) {
-        RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, nseq >= 0 ? nseq : d->group_n_seq[gi],
-                               d->group_max_len[gi], d->heads, d->attn_scale, s.dqkv[p], 3 * I,
-                               attn_two_streams ? attn_stream_of(gi - g_lo, st) : st));
-        s0 += d->group_n_seq[gi];
+      if (attn_two_streams) {
+        FORKED(st, 2, for (int gi = g_lo; gi < g_hi; ++gi) {
+          TRY_F(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads,
+                                   d->attn_scale, s.dqkv[p], 3 * I, attn_stream_of(gi - g_lo, st)));
+          s0 += d->group_n_seq[gi];
+        });
+      } else {
+        for (int gi = g_lo; gi < g_hi; ++gi) {
+          RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, nseq >= 0 ? nseq : d->group_n_seq[gi],
+                                 d->group_max_len[gi], d->heads, d->attn_scale, s.dqkv[p], 3 * I, st));
+          s0 += d->group_n_seq[gi];
+        }
       }
-      if (attn_two_streams) attn_join(st);
     } else {
       RUN(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale,
                              s.dqkv[p], 3 * I, st));
@@ -377,12 +420,10 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   // stream's events does not.  -1 = no such part.
   auto section = [&](int l2, int l1) -> int {
     if (n_rr > 1) {
-      attn_fork(stream, n_rr);
-      for (int i = 0; i < n_rr; ++i) {
-        if (l2 >= 0) RUN(part2(l2, rr[i].r0, rr[i].R, rr[i].st));
-        if (l1 >= 0) RUN(part1(l1, rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
-      }
-      attn_join(stream, n_rr);
+      FORKED(stream, n_rr, for (int i = 0; i < n_rr; ++i) {
+        if (l2 >= 0) TRY_F(part2(l2, rr[i].r0, rr[i].R, rr[i].st));
+        if (l1 >= 0) TRY_F(part1(l1, rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
+      });
     } else {
       if (l2 >= 0) RUN(part2(l2, 0, T, stream));
       if (l1 >= 0) RUN(part1(l1, 0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
@@ -405,7 +446,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     it[3].A = s.dqkv[p]; it[3].B = b.h1; it[3].C = gr + o.w_qkv; it[3].colsum_a = o.b_qkv >= 0 ? gr + o.b_qkv : nullptr;
     for (auto& x : it) x.accumulate = d->wgrad_overwrite ? 0 : 1;
     RUN(lafs_wgrad_group(it, 4, T, two ? d->wgrad_workgroups : 0, c.wg_ws, (int64_t)c.wg_bytes, s2));
-    if (two) { done[l] = ev[evi++]; (void)hipEventRecord(done[l], s2); }
+    if (two) { done[l] = ev[evi++]; if (hipEventRecord(done[l], s2) != hipSuccess) ev_failed = true; }
     return LAFS_OK;
   };
   RUN(section(-1, layer_hi - 1));
@@ -414,12 +455,13 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     // The section below rewrites what layer l+1's weight gradient reads on s2 -- gbm[(l-1)&1] (by layer l's LayerNorm backward:
     // gbm is produced one layer EARLY) and du / gba / dqkv of parity (l-1)&1 (by layer l-1's first part) -- so that launch has to
     // have retired (the two parity buffers cover a lag of one layer, not two)
-    if (two && l + 1 < layer_hi) (void)hipStreamWaitEvent(stream, done[l + 1], 0);
+    if (two && l + 1 < layer_hi && hipStreamWaitEvent(stream, done[l + 1], 0) != hipSuccess) ev_failed = true;
     const int l1 = (l - 1 >= layer_lo) ? l - 1 : -1;
     RUN(section(l, l1));
     if (l1 >= 0) RUN(wgrad(l1));
   }
-  if (two) (void)hipStreamWaitEvent(stream, done[layer_lo], 0);                        // join (s2 is in-order)
+  if (two && hipStreamWaitEvent(stream, done[layer_lo], 0) != hipSuccess) ev_failed = true;      // join (s2 is in-order)
+  LAFS_CHECK_ARG(!ev_failed, "a HIP event call of the weight-gradient stream protocol failed");
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -62,6 +62,7 @@ class LafsPretrainEngine:
         if self.partfvit and (vit_s.with_land or vit_t.with_land):
             raise _lib.LafsHipError("LAFS pre-training uses with_land=False backbones (the landmark CNN is the frozen front-end)")
         self.sa = attach_arena(student, self.device)
+        _lib.lib().lafs_trunk_streams_init()             # side streams / events exist before anything is captured
         self.ta = getattr(teacher, "_lafs_arena", None)
         if self.ta is None:
             for p in teacher.parameters():

@@ -49,6 +49,7 @@ class FinetuneEngine:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena = attach_arena(backbone, self.device)
         self.arena.set_decay_groups(finetune_decay_group)
+        _lib.lib().lafs_trunk_streams_init()
         self.head = sharded_head
         self.C = backbone.loss.out_features if sharded_head is None else 8
         self.Cpad = (self.C + 127) // 128 * 128

@@ -134,7 +134,7 @@ class ViTSpec:
 
 class ViTState:
     """Buffers kept between forward and backward of one packed ViT pass."""
-    __slots__ = ("geom", "desc", "ws", "x_in", "patches", "cls_rows", "stats", "feat", "dropout")
+    __slots__ = ("geom", "desc", "ws", "x_in", "patches", "cls_rows", "stats", "feat", "dropout", "bwd_done")
 
 
 EMB_DROP_SITE = 0x40000000          # seed offset of the embedding dropout (the trunk sites use seed + 3*layer + {0,1,2})
@@ -151,6 +151,7 @@ def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, dr
     pre = spec.prefix
     st = ViTState()
     st.geom = geom
+    st.bwd_done = set()
     p_trunk, p_emb, dseed = dropout[:3] if dropout is not None else (0.0, 0.0, 0)
     dstep = dropout[3] if (dropout is not None and len(dropout) > 3) else None
     st.dropout = (p_trunk, p_emb, dseed, dstep)
@@ -200,7 +201,14 @@ def vit_backward_begin(arena, spec: ViTSpec, st: ViTState, dfeat, g_buf=None):
 
 
 def vit_backward_layers(st: ViTState, g, hi, lo, wgrad_stream=None):
-    """Blocks hi-1 .. lo of the trunk backward (weight-gradient GEMMs optionally on `wgrad_stream`)."""
+    """Blocks hi-1 .. lo of the trunk backward (weight-gradient GEMMs optionally on `wgrad_stream`).
+    With `wgrad_overwrite` the block weight gradients are WRITTEN, not accumulated (their zeroing is skipped, SEG_OVERWRITTEN): each
+    block may be walked once per forward -- a second pass would silently replace the first one's gradients, so it is refused."""
+    if st.desc.wgrad_overwrite:
+        again = st.bwd_done.intersection(range(lo, hi))
+        if again:
+            raise _lib.LafsHipError(f"trunk backward over blocks {sorted(again)} twice with written (not accumulated) weight gradients")
+        st.bwd_done.update(range(lo, hi))
     ws2 = C.c_void_p(wgrad_stream.cuda_stream) if wgrad_stream is not None else None
     call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo, ws2)
 
