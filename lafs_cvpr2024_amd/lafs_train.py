@@ -348,20 +348,30 @@ def train_one_epoch(engine, dino_loss, data_loader, lr_schedule, wd_schedule, mo
     tt = float(dino_loss.teacher_temp_schedule[epoch])
     n = len(data_loader)
     source = _Pipelined(data_loader, frontend, engine) if frontend is not None else data_loader
+    # The reference stops at the first non-finite loss (lafs_train.py:585-587, a host sync per step).  Here the host polls every 20
+    # steps; in between, every step's loss is added to a device-side accumulator (NaN / Inf are sticky in a sum), which is checked at
+    # each poll and once more at the end of the epoch -- BEFORE the caller writes the checkpoint: no poisoned step can be saved.
+    loss_acc = torch.zeros(1, device=engine.device)
+
+    def stop_if_poisoned(value):
+        if not math.isfinite(value):
+            print("Loss is {}, stopping training".format(value), force=True)
+            sys.exit(1)
     for it, (images, after) in enumerate(metric_logger.log_every(source, 100, header)):
         it = n * epoch + it
         loss = engine.step(images, lr=float(lr_schedule[it]), wd=float(wd_schedule[it]), momentum=float(momentum_schedule[it]),
                            teacher_temp=tt, epoch=epoch)
         if callable(after):
             after()                                         # front-end of the next batch, overlapping this step
-        if it % 20 == 0:                                   # the only host sync: loss sanity check (reference :585-587 does it every step)
+        loss_acc += loss.view(1)
+        if it % 20 == 0:                                   # the only host sync inside the epoch
             lv = float(loss.item())
-            if not math.isfinite(lv):
-                print("Loss is {}, stopping training".format(lv), force=True)
-                sys.exit(1)
+            stop_if_poisoned(lv)
+            stop_if_poisoned(float(loss_acc.item()))
             metric_logger.update(loss=lv)
         metric_logger.update(lr=float(lr_schedule[it]))
         metric_logger.update(wd=float(wd_schedule[it]))
+    stop_if_poisoned(float(loss_acc.item()))                # every step of the epoch was finite: the checkpoint may be written
     metric_logger.synchronize_between_processes()
     print("Averaged stats:", metric_logger)
     return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
