@@ -41,8 +41,9 @@ def _crops(B):
     return [torch.randn(B, 3, 112, 112, generator=g).clamp(-1, 1) for _ in range(2)] + [torch.randn(B, 3, 48, 48, generator=g).clamp(-1, 1) for _ in range(2)]
 
 
-def _worker(rank, world, port, out, use_graph):
+def _worker(rank, world, port, out, use_graph, wire="f32"):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["LAFS_GRAD_WIRE"] = wire
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if rank == 1:
@@ -82,6 +83,24 @@ def test_two_ranks_on_one_gpu_equal_single_process_on_the_full_batch(tmp_path, u
     assert float(d.median()) < 1e-6 and float((d > 1e-4).float().mean()) < 0.06 and float(d.max()) < 7e-3
     dt = (r0["teacher"] - eng.ta.master.cpu()).abs()
     assert float(dt.max()) < 1e-3
+
+
+def test_two_ranks_with_bf16_gradients_on_the_wire(tmp_path):
+    """LAFS_GRAD_WIRE=bf16 (opt-in): gradient slices are cast to bf16, all-reduced and cast back (half the bytes on the links).  The
+    replicas must stay bit-identical to each other (both receive the same sums) and close to the fp32-wire run: the first step's
+    losses are equal (forward only), later ones differ at the level of a bf16 rounding of the gradients."""
+    outs = {}
+    for wire in ("f32", "bf16"):
+        out = str(tmp_path / f"dp_{wire}")
+        mp.spawn(_worker, args=(2, _free_port(), out, True, wire), nprocs=2, join=True)
+        outs[wire] = (torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False))
+    a0, a1 = outs["bf16"]
+    assert torch.equal(a0["student"], a1["student"]) and torch.equal(a0["teacher"], a1["teacher"]) and torch.equal(a0["center"], a1["center"])
+    f0 = outs["f32"][0]
+    assert abs(a0["losses"][0] - f0["losses"][0]) < 1e-6 * abs(f0["losses"][0])
+    assert abs(a0["losses"][2] - f0["losses"][2]) < 2e-2 * abs(f0["losses"][2])
+    d = (a0["student"] - f0["student"]).abs()
+    assert 0 < float(d.max()) < 7e-3 and float(d.median()) < 1e-4             # it IS a different arithmetic, within Adam's step sizes
 
 
 def _pfc_worker(rank, world, port, out):
