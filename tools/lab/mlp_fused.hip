@@ -1,3 +1,9 @@
+// LAB KERNEL (round 3, NOT part of liblafs_hip.so): measured 1.4-1.8x SLOWER than the two launches it replaces -- student forward
+// 257.6 us against 101.9 + 84.3, backward 283.9 against 89.4 + 68.5, whole step 16.78 against 15.77 ms (tools/lab/NOTES.md: at one
+// wave per SIMD the MFMA work, the GELU epilogue, the LDS-DMA issue and the store stalls of an item serialise).  Kept as the record
+// of the experiment; `make -C tools/lab mlp_fused.o` compiles it (it was parity-checked against fp32 torch and bit-for-bit against
+// the two-launch path for the saved tensors while it was wired into the engine).
+//
 // Fused two-GEMM MLP kernels for gfx950 (embedding width 384): the hidden activation never round-trips through HBM between the GEMMs.
 //
 //   forward   x_out = x1 + s * (gelu(h2 W1^T + b1) W2^T + b2)          Mlp.forward + DropPath + residual
@@ -21,6 +27,18 @@
 #include <stdlib.h>
 #include "common.hpp"
 #include "lafs_hip.h"
+
+// (the C ABI this kernel had while it was in the library)
+typedef struct lafs_mlp_args {
+  const void* x; int ldx;
+  const void* w1; int ldw1; const float* b1;
+  const void* w2; int ldw2; const float* b2;
+  void* save_dgelu; void* save_act; int lds;
+  const float* resid; int ldr;
+  const float* seq_scale; const int32_t* row2seq;
+  void* out; int ldo;
+  int M, D, H;
+} lafs_mlp_args;
 
 namespace {
 
