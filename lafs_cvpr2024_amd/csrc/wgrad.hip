@@ -44,6 +44,14 @@ struct WgArgs {
 __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// LDS-DMA with a cache policy chosen at compile time (lab: 0 = default, 1 = nt, 2 = sc1, 3 = sc0 sc1, 4 = sc0)
+template <int POL> __device__ __forceinline__ void lds_dma16_pol(const void* gsrc, unsigned lds_base) {
+  if constexpr (POL == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(lds_base) : "memory");
+  else if constexpr (POL == 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" : : "v"(gsrc), "s"(lds_base) : "memory");
+  else if constexpr (POL == 3) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc0 sc1" : : "v"(gsrc), "s"(lds_base) : "memory");
+  else if constexpr (POL == 4) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc0" : : "v"(gsrc), "s"(lds_base) : "memory");
+  else lds_dma16_m0(gsrc, lds_base);
+}
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int KB = 32;                 // reduction rows per stage
@@ -51,9 +59,10 @@ constexpr int PANEL = KB * 128;        // one 64-column panel of a stage
 
 // Wave grid WM x WN, FA x FB 32x32 accumulator blocks per wave: output tile (32 FA WM) x (32 FB WN), 64 WM WN threads.
 // ABL: timing ablations for tools/lab (0 on the product path): 1 = no DMA after the prologue, 2 = no MFMA, 4 = no fragment reads,
-// 8 = fragments read once (MFMA-only loop), 16 = no wait / barrier in the steady loop
-template <int WM, int WN, int FA, int FB, int NS, int ABL = 0>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgArgs p) {
+// 8 = fragments read once (MFMA-only loop), 16 = no wait / barrier in the steady loop, 32 = every slice streams the rows of slice 0
+// (a fifth of the bytes: Infinity-Cache resident), 64 = the row pointers never advance (L2-resident stream)
+template <int WM, int WN, int FA, int FB, int NS, int OCC, int ABL = 0>
+__global__ __launch_bounds__(64 * WM * WN, OCC * (WM * WN) / 4) void wgrad_kernel(WgArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int T1 = 32 * FA * WM, T2 = 32 * FB * WN;
   static_assert(T1 % 64 == 0 && T2 % 64 == 0, "tile sides must be whole 64-column panels");
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
   constexpr int STAGE = NP * PANEL;
   constexpr int NCH = NP * 256;                                      // 16-byte pieces per stage
   constexpr int NR = (NCH + NTH - 1) / NTH;                          // LDS-DMA instructions per thread and stage
-  static_assert(NS >= 4 && NS * STAGE <= 160 * 1024, "ring does not fit the LDS");
+  static_assert(NS >= 3 && OCC * NS * STAGE <= 160 * 1024, "ring does not fit the LDS");
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,8 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
   // issues NR loads per stage, so one vmcnt immediate is right for all of them.
   const int drow = (tid >> 3) & 31;
   const int dcol = ((tid & 7) ^ (((drow >> 1) & 1) << 2)) * 8;
-  const bf16_t* dsrc[NR];            // column base of this thread's piece i (row 0)
-  const bf16_t* gp[NR];              // ... at the row it reads in the next stage to be issued (running pointer)
+  const bf16_t* gp[NR];              // this thread's piece i at the row it reads in the next stage to be issued (running pointer)
   int dld[NR]; unsigned ddst[NR];
   const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
 #pragma unroll
@@ -101,10 +109,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
     int q = i * NTH + tid;
     if (q >= NCH) q -= NCH;
     const int panel = __builtin_amdgcn_readfirstlane(q >> 8);
-    if (panel < PA) { const int c = n1_0 + panel * 64 + dcol; dsrc[i] = gA + (c < N1 ? c : 0); dld[i] = lda; }
-    else { const int c = n2_0 + (panel - PA) * 64 + dcol; dsrc[i] = gB + (c < N2 ? c : 0); dld[i] = ldb; }
+    const bf16_t* col;               // column base of the piece (row 0)
+    if (panel < PA) { const int c = n1_0 + panel * 64 + dcol; col = gA + (c < N1 ? c : 0); dld[i] = lda; }
+    else { const int c = n2_0 + (panel - PA) * 64 + dcol; col = gB + (c < N2 ? c : 0); dld[i] = ldb; }
     ddst[i] = smem_base + __builtin_amdgcn_readfirstlane((q & ~63) * 16);
-    gp[i] = dsrc[i] + (long)(mbeg + drow) * dld[i];
+    gp[i] = col + (long)(((ABL & 32) ? 0 : mbeg) + drow) * dld[i];
   }
   // Stages are issued in order; `ti` = next stage, `islot` = byte offset of its ring slot.  Only a stage that reaches past the
   // last row of the whole matrix needs its row indices clamped (rows past the SLICE but inside the matrix are real memory and
@@ -112,15 +121,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
   int ti = 0; unsigned islot = 0;
   const bool last_clamped = (mbeg + nk * KB > p.M);
   auto issue_piece = [&](int i) {
-    lds_dma16_m0(gp[i], ddst[i] + islot);
-    gp[i] += KB * dld[i];
+    lds_dma16_pol<(ABL >> 8) & 7>(gp[i], ddst[i] + islot);
+    if (!(ABL & 64)) gp[i] += KB * dld[i];
   };
   auto issue_done = [&]() { ++ti; islot += STAGE; if (islot == NS * STAGE) islot = 0; };
   auto issue = [&]() {
     if (last_clamped && ti == nk - 1) {
-      const long m = min(mbeg + ti * KB + drow, p.M - 1);
+      const long back = max(mbeg + ti * KB + drow - (p.M - 1), 0);     // rows past the end of the matrix re-read its last row
 #pragma unroll
-      for (int i = 0; i < NR; ++i) lds_dma16_m0(dsrc[i] + m * dld[i], ddst[i] + islot);
+      for (int i = 0; i < NR; ++i) lds_dma16_pol<(ABL >> 8) & 7>(gp[i] - back * dld[i], ddst[i] + islot);
     } else {
 #pragma unroll
       for (int i = 0; i < NR; ++i) issue_piece(i);
@@ -138,8 +147,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
   float cs[FA];
 #pragma unroll
   for (int a = 0; a < FA; ++a) cs[a] = 0.f;
+  // Bias gradient = column sums of A.  The tiles_n2 tiles of a row share A's columns and both wave columns of a workgroup hold
+  // the same A fragments: the half stage (t, half) is summed by the wave column wn == half of tile t % tiles_n2 only, so every
+  // wave of every workgroup carries the same small share.  (One tile per row doing all of it -- 50 VALU instructions per half
+  // stage in two of its waves -- made those workgroups fall behind the ones that share their operand panels: L2 hit rate
+  // 0.62 -> 0.49, fabric reads 620 -> 850 MB per ViT-S block, +20 us; tools/lab/NOTES.md.)
+  static_assert(WN == 2, "the bias-gradient share assumes two wave columns");
   float* const colsum = g_.colsum;
-  const bool do_colsum = (colsum != nullptr) && n2_0 == 0 && wn == 0;
+  const bool do_colsum = (colsum != nullptr);
+  int cs_wait = tile % g_.tiles_n2;                    // stages until this tile's turn
+  bool cs_mine = false;
+  auto cs_next = [&]() { cs_mine = do_colsum && cs_wait == 0; cs_wait = cs_wait == 0 ? g_.tiles_n2 - 1 : cs_wait - 1; };
 
   // ---- fragment addressing.  32x32x16 operand: lane (n = lane & 31, half h = lane >> 5) holds k = 8h .. 8h+7 of column n.
   // Two transpose reads give it: 16-lane group g = lane >> 4 covers columns (g & 1)*16 .. +15, rows 8h + 4j + 0..3 (j = 0, 1);
@@ -168,7 +186,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
   // the NR LDS-DMA pieces of the ring stage that is due (DMA).  With one wave per SIMD, whatever is issued outside those
   // shadows is lost matrix time (PMC: profiles/round2_wgrad_pmc.txt).
   auto group = [&](const bf16x8_t (&fa)[FA], const bf16x8_t (&fb)[FB], bf16x8_t (&na)[FA], bf16x8_t (&nb)[FB],
-                   const unsigned char* nsk, auto READS, auto DMA) {
+                   const unsigned char* nsk, auto READS, auto DMA, int half) {
     constexpr int NM = FA * FB, NF = FA + FB;
     if (ABL & (2 | 4)) {
       if (decltype(READS)::value) load_frags(na, nb, nsk);
@@ -202,11 +220,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    if (do_colsum) {                                  // bias gradient: this lane's 8 token rows of column n, summed
+    if (cs_mine && half == wn) {                      // bias gradient: this lane's 8 token rows of column n, summed
 #pragma unroll
       for (int a = 0; a < FA; ++a) {
+        typedef __bf16 bf16x2v_t __attribute__((ext_vector_type(2)));
         const uint4 w = __builtin_bit_cast(uint4, fa[a]);
-        cs[a] += (bf_lo(w.x) + bf_hi(w.x)) + (bf_lo(w.y) + bf_hi(w.y)) + (bf_lo(w.z) + bf_hi(w.z)) + (bf_lo(w.w) + bf_hi(w.w));
+        const bf16x2v_t one = __builtin_bit_cast(bf16x2v_t, 0x3f803f80u);        // v_dot2c_f32_bf16: cs += lo * 1 + hi * 1
+        cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w.x), one, cs[a], false);
+        cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w.y), one, cs[a], false);
+        cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w.z), one, cs[a], false);
+        cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w.w), one, cs[a], false);
       }
     }
   };
@@ -246,27 +269,29 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void wgrad_kernel(WgAr
   unsigned rslot = 0;                                 // ring slot (byte offset) of the stage being multiplied
   int t = 0;
   for (; t < nk - NS; ++t) {                          // steady state: full ring, never the clamped stage
-    group(a0, b0, a1, b1, smem + rslot + 16 * 128, Yes{}, No{});
+    cs_next();
+    group(a0, b0, a1, b1, smem + rslot + 16 * 128, Yes{}, No{}, 0);
     if (!(ABL & 16)) {
       wait_vm<(NS - 3) * NR>();
       __builtin_amdgcn_s_barrier();                  // everyone's pieces of stage t+1 landed; the slot of stage t-1 is free
     }
     __builtin_amdgcn_sched_barrier(0);
     rslot += STAGE; if (rslot == NS * STAGE) rslot = 0;
-    group(a1, b1, a0, b0, smem + rslot, Yes{}, Yes{});
+    group(a1, b1, a0, b0, smem + rslot, Yes{}, Yes{}, 1);
     issue_done();
   }
   for (; t < nk; ++t) {                               // ring drains
-    group(a0, b0, a1, b1, smem + rslot + 16 * 128, Yes{}, No{});
+    cs_next();
+    group(a0, b0, a1, b1, smem + rslot + 16 * 128, Yes{}, No{}, 0);
     if (t + 1 < nk) {
       wait_stage(min(nk - 2 - t, NS - 3));
       __builtin_amdgcn_s_barrier();
       if (ti < nk && !(ABL & 1)) issue();
       fix_tail(t + 1);
       rslot += STAGE; if (rslot == NS * STAGE) rslot = 0;
-      group(a1, b1, a0, b0, smem + rslot, Yes{}, No{});
+      group(a1, b1, a0, b0, smem + rslot, Yes{}, No{}, 1);
     } else {
-      group(a1, b1, a0, b0, smem, No{}, No{});
+      group(a1, b1, a0, b0, smem, No{}, No{}, 1);
     }
   }
 
@@ -340,8 +365,13 @@ struct Plan { int fa, fb, tiles, slices, mlen; int tile0[MAXG], tiles_n2[MAXG]; 
 // all GEMMs times the token slices fill the 256 CUs once.
 // max_wg: workgroups (= CUs, one 512-register workgroup each) the launch may occupy; a two-stream backward keeps part of the
 // chip free for the HBM-bound kernels of its other stream this way (0 = the whole chip)
+int wgrad_occ() {
+  static const int occ = [] { const char* e = getenv("LAFS_WGRAD_OCC"); return (e && atoi(e) == 2) ? 2 : 1; }();
+  return occ;
+}
 Plan make_plan(const lafs_wgrad_item* items, int n, int M, int max_wg) {
-  const int g_wgrad_cus = (max_wg >= 8 && max_wg <= 256) ? max_wg : 256;
+  const int occ = wgrad_occ();
+  const int g_wgrad_cus = occ * ((max_wg >= 8 && max_wg <= 256) ? max_wg : 256);
   // (4x4 blocks per wave = 256 accumulators leave hipcc no room: it spills the accumulators around the loop nest)
   static const int cand[4][2] = {{3, 3}, {4, 3}, {3, 4}, {2, 2}};
   Plan best = {};
@@ -350,6 +380,7 @@ Plan make_plan(const lafs_wgrad_item* items, int n, int M, int max_wg) {
   for (int c = 0; c < 4; ++c) {
     Plan pl = {};
     pl.fa = cand[c][0]; pl.fb = cand[c][1];
+    if (occ == 2 && pl.fa * pl.fb > 9) continue;
     for (int g = 0; g < n; ++g) {
       pl.tile0[g] = pl.tiles;
       pl.tiles_n2[g] = ceil_div(items[g].N2, 64 * pl.fb);
@@ -378,7 +409,22 @@ int64_t plan_bytes(const Plan& pl, const lafs_wgrad_item* items, int n) {
 template <int FA, int FB, int ABL>
 int launch(const WgArgs& a, hipStream_t s) {
   constexpr int NS = 5;                              // 2-3 stages (28-32 KiB each) in flight per CU
-  hipLaunchKernelGGL((wgrad_kernel<2, 2, FA, FB, NS, ABL>), dim3(a.nblk), dim3(256), 0, s, a);
+  if constexpr (FA * FB <= 9) {
+    if (wgrad_occ() == 2) {
+      hipLaunchKernelGGL((wgrad_kernel<2, 2, FA, FB, 3, 2, ABL>), dim3(a.nblk), dim3(256), 0, s, a);
+      LAFS_LAUNCH_CHECK();
+      return LAFS_OK;
+    }
+  }
+  if constexpr (FA * FB <= 9 && ABL != 0) {          // lab: a sixth ring stage (3 x 3 blocks: 6 x 24 KiB)
+    static const bool ns6 = getenv("LAFS_WGRAD_NS6") != nullptr;
+    if (ns6) {
+      hipLaunchKernelGGL((wgrad_kernel<2, 2, FA, FB, 6, 1, ABL>), dim3(a.nblk), dim3(256), 0, s, a);
+      LAFS_LAUNCH_CHECK();
+      return LAFS_OK;
+    }
+  }
+  hipLaunchKernelGGL((wgrad_kernel<2, 2, FA, FB, NS, 1, ABL>), dim3(a.nblk), dim3(256), 0, s, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
