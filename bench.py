@@ -64,8 +64,11 @@ def parse():
 
 
 def _time_on_stream(fn, iters):
-    """Average duration of fn() with HIP events on the stream the kernels are launched on (torch's current stream)."""
-    for _ in range(3):
+    """Average duration of fn() with HIP events on the stream the kernels are launched on (torch's current stream).
+    The warm-up is as long as the timed region: the shader clock needs tens of ms of load to settle (from idle it climbs, and a
+    sustained MFMA kernel then sits at the 1400 W cap around 1.57 GHz -- tools/lab/wgrad_clocks.sh), so a 30-launch sample
+    right after a pause reads up to 15 % slower than the steady rate (tools/lab/NOTES.md)."""
+    for _ in range(max(3, iters)):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
@@ -143,7 +146,7 @@ def _pmc_traffic(name):
         return None
 
 
-def roofline_wgrad_group(device, iters=30):
+def roofline_wgrad_group(device, iters=200):
     """The four weight gradients of one ViT-S block (student: M = 64*(2*197+8*37) = 44160 tokens) as the engine launches
     them: ONE lafs_wgrad_group call = wgrad_kernel<2,2,3,3,5> (240 workgroups: 48 tiles x 5 token slices) + the fold kernel.
     Algorithmic bytes per launch: every operand read once (8 bf16 matrices) + the four fp32 gradients written once."""
@@ -160,7 +163,7 @@ def roofline_wgrad_group(device, iters=30):
                  dur, flops, alg, _pmc_traffic("wgrad_group"))
 
 
-def roofline_fc1(device, iters=30):
+def roofline_fc1(device, iters=200):
     """Heaviest single launch of the NT GEMM family: student MLP fc1 (M = 44160, N = 1536, K = 384, bias+GELU epilogue writing
     u and gelu(u)).  Algorithmic bytes: A and W (bf16) read once, u and GELU(u) (bf16) written once."""
     from lafs_cvpr2024_amd import _lib, ops
@@ -175,7 +178,7 @@ def roofline_fc1(device, iters=30):
                  2.0 * M * N * K, (M * K + N * K + 2 * M * N) * 2.0, _pmc_traffic("fc1"))
 
 
-def roofline_fc2(device, iters=30):
+def roofline_fc2(device, iters=200):
     """Heaviest launch left on the tiled NT kernel: student MLP fc2 forward (M = 44160, N = 384, K = 1536, residual epilogue:
     x = x1 + DropPath(fc2(a) + b)).  Algorithmic bytes: A and W (bf16) read once, the fp32 residual read once, the fp32 output
     written once."""
@@ -213,7 +216,7 @@ def dominant_kernel_name():
     return "wgrad_kernel"
 
 
-def dominant_kernel_roofline(device, iters=30):
+def dominant_kernel_roofline(device, iters=200):
     dom = dominant_kernel_name()
     out = ROOFLINE_KERNELS[dom](device, iters)
     out["others"] = [fn(device, iters) for k, fn in ROOFLINE_KERNELS.items() if k != dom]

@@ -365,10 +365,13 @@ struct Plan { int fa, fb, tiles, slices, mlen; int tile0[MAXG], tiles_n2[MAXG]; 
 // all GEMMs times the token slices fill the 256 CUs once.
 // max_wg: workgroups (= CUs, one 512-register workgroup each) the launch may occupy; a two-stream backward keeps part of the
 // chip free for the HBM-bound kernels of its other stream this way (0 = the whole chip)
-int wgrad_occ() {
-  static const int occ = [] { const char* e = getenv("LAFS_WGRAD_OCC"); return (e && atoi(e) == 2) ? 2 : 1; }();
-  return occ;
-}
+// (Two workgroups per CU on three-stage rings -- OCC = 2, 256 registers per wave, twice the token slices -- were measured in
+// round 3: 233 against 194 us per ViT-S block; the lab instantiation is tools/lab/lab_wgrad.cpp's LAB_OCC2.)
+#ifdef LAFS_LAB_WGRAD_OCC2
+int wgrad_occ() { static const int occ = getenv("LAB_OCC2") ? 2 : 1; return occ; }
+#else
+constexpr int wgrad_occ() { return 1; }
+#endif
 Plan make_plan(const lafs_wgrad_item* items, int n, int M, int max_wg) {
   const int occ = wgrad_occ();
   const int g_wgrad_cus = occ * ((max_wg >= 8 && max_wg <= 256) ? max_wg : 256);
@@ -409,6 +412,7 @@ int64_t plan_bytes(const Plan& pl, const lafs_wgrad_item* items, int n) {
 template <int FA, int FB, int ABL>
 int launch(const WgArgs& a, hipStream_t s) {
   constexpr int NS = 5;                              // 2-3 stages (28-32 KiB each) in flight per CU
+#ifdef LAFS_LAB_WGRAD_OCC2
   if constexpr (FA * FB <= 9) {
     if (wgrad_occ() == 2) {
       hipLaunchKernelGGL((wgrad_kernel<2, 2, FA, FB, 3, 2, ABL>), dim3(a.nblk), dim3(256), 0, s, a);
@@ -416,6 +420,7 @@ int launch(const WgArgs& a, hipStream_t s) {
       return LAFS_OK;
     }
   }
+#endif
   if constexpr (FA * FB <= 9 && ABL != 0) {          // lab: a sixth ring stage (3 x 3 blocks: 6 x 24 KiB)
     static const bool ns6 = getenv("LAFS_WGRAD_NS6") != nullptr;
     if (ns6) {

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#define LAFS_LAB_WGRAD_OCC2 1
 #include "../../lafs_cvpr2024_amd/csrc/wgrad.hip"
 
 extern "C" void lafs_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
