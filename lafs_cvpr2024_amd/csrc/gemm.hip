@@ -428,8 +428,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
         if (EPI == EPI_BF16_GELU && (p.C == nullptr || !do_first)) {
           // forward-only pass (teacher): the pre-activation is not needed, only GELU(u) is written; second pass: already stored
         } else if (EPI == EPI_BF16_GELU && p.act == LAFS_GELU_SAVE_GRAD) {        // the first tensor is gelu'(u), not u
+          if (full) {
+            st16(c, pack_bf2(gelu_grad_f(w[0]), gelu_grad_f(w[1])), pack_bf2(gelu_grad_f(w[2]), gelu_grad_f(w[3])),
+                 pack_bf2(gelu_grad_f(w[4]), gelu_grad_f(w[5])), pack_bf2(gelu_grad_f(w[6]), gelu_grad_f(w[7])), ntst);
+          } else {
 #pragma unroll
-          for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) c[e] = f2bf(gelu_grad_f(w[e]));
+            for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(gelu_grad_f(w[e]));
+          }
         } else if (full) {
           st16(c, pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]), ntst);
         } else {
@@ -444,6 +449,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
           if DBG(p, 16384) c2 = c + 32;
           if (full && DBG(p, 128)) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+          } else if (drop.thresh && full) {              // dropout(gelu(u)): one 16-byte store like the plain form
+            float g[VPL];
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) g[e] = gelu_f(w[e]) * drop_mult(drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
+            st16(c2, pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]), pack_bf2(g[4], g[5]), pack_bf2(g[6], g[7]), ntst);
           } else if (drop.thresh) {
 #pragma unroll
             for (int e = 0; e < VPL; ++e)
