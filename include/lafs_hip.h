@@ -454,6 +454,26 @@ int lafs_bn_act_bwd_nchw(const float* x, const float* dy, const float* stat, con
 int lafs_augment_views(const uint8_t* images, const int32_t* params, const int32_t* table, int B, int K, float* views,
                        hipStream_t stream);
 
+/* RandAugment of the fine-tune loader (reference util/rand_aa_face.py:606-672 as FaceDataset builds it, face_pre_pro/
+ * dataloader_web.py:240-243 -- 'rand-m1-mstd0.5-inc1', train_largescale.py:506 -- applied per decoded sample at
+ * dataloader_web.py:342-346 / image_iter.py:324-329; Pillow arithmetic, bit-exact).  One record per image and layer, sampled on
+ * the host in the reference's random order (lafs_cvpr2024_amd/randaug.py):
+ *   op        -1 = layer not applied; 0..12 = AutoContrast, Equalize, Invert, Rotate, PosterizeIncreasing, ColorIncreasing,
+ *             ContrastIncreasing, BrightnessIncreasing, SharpnessIncreasing, ShearX, ShearY, TranslateXRel, TranslateYRel
+ *             (the order of _RAND_INCREASING_TRANSFORMS :560-576); 13 / 14 / 15 = the transposes Image.rotate substitutes for 180 / 90 /
+ *             270 degrees
+ *   resample  2 = PIL BILINEAR, 3 = BICUBIC (geometric ops)       iarg   Posterize: the byte mask ~(2^(8-bits) - 1)
+ *   farg      enhancement factor of Color / Contrast / Brightness / Sharpness (Image.blend's float alpha)
+ *   m[6]      the AFFINE matrix handed to Image.transform (output pixel centre -> source position), double precision
+ * images / out: u8 [B, H, W, 3] (chw = 0) or [B, 3, H, W] (chw = 1), 3 <= H, W and H * W <= 112 * 112; out may alias images. */
+typedef struct lafs_randaug_op {
+  int32_t op, resample, iarg;
+  float farg;
+  double m[6];
+} lafs_randaug_op;
+int lafs_randaug_apply(const uint8_t* images, uint8_t* out, const lafs_randaug_op* records, int B, int H, int W, int layers, int chw,
+                       hipStream_t stream);
+
 /* ------------------------------------------------------------------------------------------------------------------------
  * TRAINABLE landmark CNN of the fine-tune step (csrc/landmark_train.hip; reference face_pre_pro/mobilenet.py:224-313 trained through
  * ViT_face.py:679-711 by train_largescale.py:785-891).  Activations are NHWC bf16 [N H W, ld] matrices, ld = channel count padded

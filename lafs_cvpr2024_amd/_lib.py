@@ -30,6 +30,10 @@ class WgradItem(C.Structure):
                 ("N1", C.c_int), ("N2", C.c_int), ("accumulate", C.c_int), ("colsum_a", C.c_void_p)]
 
 
+class RandAugOp(C.Structure):
+    _fields_ = [("op", C.c_int32), ("resample", C.c_int32), ("iarg", C.c_int32), ("farg", C.c_float), ("m", C.c_double * 6)]
+
+
 class BlockOffsets(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_proj", "b_proj", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2",
@@ -132,6 +136,7 @@ _PROTOS = {
     "lafs_cnn_unpad_add_table": [vp, vp, vp, vp, i32, i32],
     "lafs_landmark_theta_bwd": [vp, vp, i32, i32, vp],
     "lafs_augment_views": [vp, vp, vp, i32, i32, vp],
+    "lafs_randaug_apply": [vp, vp, vp, i32, i32, i32, i32, i32],
     "lafs_landmark_theta": [vp, i32, i32, vp, f32, vp, i32, vp],
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],

@@ -1,0 +1,240 @@
+// Device-side RandAugment of the fine-tune loader (reference util/rand_aa_face.py as FaceDataset builds it:
+// face_pre_pro/dataloader_web.py:240-243, train_largescale.py:506, applied per sample at dataloader_web.py:342-346).  One workgroup
+// per image keeps the picture in LDS across the layers of its decision record (lafs_cvpr2024_amd/randaug.py samples the records
+// on the host in the reference's own random order); every operation follows Pillow's C code (ImageOps LUTs from the per-band
+// histogram, Blend.c float blend, Filter.c 3x3 float32 SMOOTH, Geometry.c affine with double-precision bilinear / bicubic taps)
+// so that the result is bit-identical to the PIL calls the reference makes (oracle/randaug.py is pinned against Pillow and against
+// the reference's transform; this kernel against the oracle).
+#include "common.hpp"
+#include "lafs_hip.h"
+
+// Pillow's results depend on every float / double operation being rounded on its own: no fused multiply-add in this file.
+#pragma STDC FP_CONTRACT OFF
+
+namespace {
+
+constexpr int MAXPIX = 112 * 112;
+constexpr int MAXBYTE = MAXPIX * 3;
+
+__device__ __forceinline__ int clip8i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int luma_l(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }
+
+// Image.blend(degenerate d, image v, alpha) (Blend.c): float arithmetic, truncation, clip only when extrapolating
+__device__ __forceinline__ int blend_f(int d, int v, float a, bool interp) {
+#pragma clang fp contract(off)
+  const float prod = a * (float)(v - d);
+  const float t = (float)d + prod;
+  if (interp) return (int)t;
+  if (t <= 0.0f) return 0;
+  if (t >= 255.0f) return 255;
+  return (int)t;
+}
+
+__device__ __forceinline__ int floor_c(double v) { return v >= 0.0 ? (int)v : (int)floor(v); }      // Geometry.c FLOOR
+
+__device__ __forceinline__ double cubic(double v1, double v2, double v3, double v4, double d) {    // Geometry.c BICUBIC
+#pragma clang fp contract(off)
+  const double p1 = v2;
+  const double p2 = -v1 + v3;
+  const double p3 = 2 * (v1 - v2) + v3 - v4;
+  const double p4 = -v1 + v2 - v3 + v4;
+  return p1 + d * (p2 + d * (p3 + d * p4));
+}
+
+// img.transform(size, AFFINE, m, resample, fillcolor=(128,128,128)): src -> dst (both HWC uint8 in LDS)
+__device__ void affine_op(const unsigned char* src, unsigned char* dst, int H, int W, const double* m, int resample) {
+#pragma clang fp contract(off)
+  for (int p = threadIdx.x; p < H * W; p += blockDim.x) {
+    const int yo = p / W, xo = p - yo * W;
+    const double xin = (double)xo + 0.5, yin = (double)yo + 0.5;
+    double xs = m[0] * xin + m[1] * yin + m[2];
+    double ys = m[3] * xin + m[4] * yin + m[5];
+    unsigned char* o = dst + p * 3;
+    if (xs < 0.0 || xs >= (double)W || ys < 0.0 || ys >= (double)H) { o[0] = o[1] = o[2] = 128; continue; }
+    xs -= 0.5; ys -= 0.5;
+    const int x = floor_c(xs), y = floor_c(ys);
+    const double dx = xs - (double)x, dy = ys - (double)y;
+    if (resample == 2) {                                       // BILINEAR
+      const int x0 = min(max(x, 0), W - 1) * 3, x1 = min(max(x + 1, 0), W - 1) * 3;
+      const unsigned char* r0 = src + min(max(y, 0), H - 1) * W * 3;
+      const unsigned char* r1 = src + min(max(y + 1, 0), H - 1) * W * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double a0 = r0[x0 + c], a1 = r0[x1 + c], b0 = r1[x0 + c], b1 = r1[x1 + c];
+        const double v1 = a0 + (a1 - a0) * dx;
+        const double v2 = b0 + (b1 - b0) * dx;
+        const double v = v1 + (v2 - v1) * dy;
+        o[c] = (unsigned char)(int)v;
+      }
+    } else {                                                   // BICUBIC
+      int xc[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) xc[k] = min(max(x - 1 + k, 0), W - 1) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double rv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned char* r = src + min(max(y - 1 + k, 0), H - 1) * W * 3 + c;
+          rv[k] = cubic((double)r[xc[0]], (double)r[xc[1]], (double)r[xc[2]], (double)r[xc[3]], dx);
+        }
+        const double v = cubic(rv[0], rv[1], rv[2], rv[3], dy);
+        o[c] = (unsigned char)(v <= 0.0 ? 0 : (v >= 255.0 ? 255 : (int)v));
+      }
+    }
+  }
+}
+
+// ImageFilter.SMOOTH (Filter.c ImagingFilter3x3, kernel (1 1 1 / 1 5 1 / 1 1 1) / 13 as float32): src -> dst, border copied
+__device__ void smooth_op(const unsigned char* src, unsigned char* dst, int H, int W) {
+#pragma clang fp contract(off)
+  const float k1 = 1.0f / 13.0f, k5 = 5.0f / 13.0f;
+  for (int e = threadIdx.x; e < H * W * 3; e += blockDim.x) {
+    const int p = e / 3, c = e - p * 3, y = p / W, x = p - y * W;
+    if (x == 0 || y == 0 || x == W - 1 || y == H - 1) { dst[e] = src[e]; continue; }
+    const unsigned char* up = src + ((y + 1) * W + x) * 3 + c;     // Filter.c walks the kernel from the row below upwards
+    const unsigned char* mid = src + (y * W + x) * 3 + c;
+    const unsigned char* dn = src + ((y - 1) * W + x) * 3 + c;
+    float ss = 0.5f;
+    ss = ss + (((float)up[-3] * k1 + (float)up[0] * k1) + (float)up[3] * k1);
+    ss = ss + (((float)mid[-3] * k1 + (float)mid[0] * k5) + (float)mid[3] * k1);
+    ss = ss + (((float)dn[-3] * k1 + (float)dn[0] * k1) + (float)dn[3] * k1);
+    dst[e] = (unsigned char)(ss <= 0.0f ? 0 : (ss >= 255.0f ? 255 : (int)ss));
+  }
+}
+
+// op codes: 0..12 = positions in the reference's _RAND_INCREASING_TRANSFORMS; 13..15 = Image.rotate's transposes
+enum { AUTOCONTRAST = 0, EQUALIZE, INVERT, ROTATE, POSTERIZE, COLOR, CONTRAST, BRIGHTNESS, SHARPNESS, SHEAR_X, SHEAR_Y, TRANS_X, TRANS_Y,
+       ROT180, ROT90, ROT270 };
+
+__global__ __launch_bounds__(512) void randaug_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                     const lafs_randaug_op* __restrict__ recs, int B, int H, int W, int layers, int chw) {
+#pragma clang fp contract(off)
+  extern __shared__ unsigned char lds[];                         // two pictures (the static limit is 64 KiB)
+  unsigned char* const buf0 = lds;
+  unsigned char* const buf1 = lds + MAXBYTE;
+  __shared__ int hist[3][256];
+  __shared__ unsigned char lut[3][256];
+  __shared__ int red[4];
+  const int b = blockIdx.x, npix = H * W, nbyte = npix * 3;
+  const unsigned char* src = in + (size_t)b * nbyte;
+  unsigned char* cur = buf0;
+  unsigned char* oth = buf1;
+  for (int e = threadIdx.x; e < nbyte; e += blockDim.x) {
+    if (chw) { const int c = e / npix, p = e - c * npix; cur[p * 3 + c] = src[e]; }
+    else cur[e] = src[e];
+  }
+  __syncthreads();
+  for (int l = 0; l < layers; ++l) {
+    const lafs_randaug_op r = recs[(size_t)b * layers + l];       // (uniform over the workgroup)
+    const int op = r.op;
+    if (op < 0) continue;                                        // layer not applied (probability 0.5), or an identity
+    if (op == AUTOCONTRAST || op == EQUALIZE) {
+      for (int i = threadIdx.x; i < 768; i += blockDim.x) (&hist[0][0])[i] = 0;
+      __syncthreads();
+      for (int e = threadIdx.x; e < nbyte; e += blockDim.x) atomicAdd(&hist[e % 3][cur[e]], 1);
+      __syncthreads();
+      if (threadIdx.x < 3) {                                     // one lane per band: 256-entry scans
+        const int c = threadIdx.x;
+        const int* h = hist[c];
+        if (op == AUTOCONTRAST) {                                // ImageOps.autocontrast, cutoff 0
+          int lo = 0, hi = 255;
+          while (lo < 256 && h[lo] == 0) ++lo;
+          while (hi >= 0 && h[hi] == 0) --hi;
+          if (hi <= lo) {
+            for (int i = 0; i < 256; ++i) lut[c][i] = (unsigned char)i;
+          } else {
+            const double scale = 255.0 / (double)(hi - lo);
+            const double offset = -(double)lo * scale;
+            for (int i = 0; i < 256; ++i) lut[c][i] = (unsigned char)clip8i((int)((double)i * scale + offset));
+          }
+        } else {                                                 // ImageOps.equalize
+          int nz = 0, last = 0, total = 0;
+          for (int i = 0; i < 256; ++i) if (h[i]) { ++nz; last = h[i]; total += h[i]; }
+          const int step = (total - last) / 255;
+          if (nz <= 1 || step == 0) {
+            for (int i = 0; i < 256; ++i) lut[c][i] = (unsigned char)i;
+          } else {
+            int n = step / 2;
+            for (int i = 0; i < 256; ++i) { lut[c][i] = (unsigned char)clip8i(n / step); n += h[i]; }
+          }
+        }
+      }
+      __syncthreads();
+      for (int e = threadIdx.x; e < nbyte; e += blockDim.x) cur[e] = lut[e % 3][cur[e]];
+    } else if (op == INVERT) {
+      for (int e = threadIdx.x; e < nbyte; e += blockDim.x) cur[e] = (unsigned char)(255 - cur[e]);
+    } else if (op == POSTERIZE) {
+      const unsigned char mask = (unsigned char)r.iarg;
+      for (int e = threadIdx.x; e < nbyte; e += blockDim.x) cur[e] = cur[e] & mask;
+    } else if (op == COLOR || op == CONTRAST || op == BRIGHTNESS) {
+      const float a = r.farg;
+      const bool interp = (a >= 0.0f && a <= 1.0f);
+      int mean = 0;
+      if (op == CONTRAST) {                                      // degenerate = int(mean luma + 0.5)
+        if (threadIdx.x == 0) red[0] = 0;
+        __syncthreads();
+        int part = 0;
+        for (int p = threadIdx.x; p < npix; p += blockDim.x) part += luma_l(cur[p * 3], cur[p * 3 + 1], cur[p * 3 + 2]);
+        atomicAdd(&red[0], part);
+        __syncthreads();
+        mean = (int)((double)red[0] / (double)npix + 0.5);
+      }
+      for (int p = threadIdx.x; p < npix; p += blockDim.x) {
+        const int cr = cur[p * 3], cg = cur[p * 3 + 1], cb = cur[p * 3 + 2];
+        int d;
+        if (op == BRIGHTNESS) d = 0;
+        else if (op == CONTRAST) d = mean;
+        else d = luma_l(cr, cg, cb);                             // Color: the pixel's own luma
+        cur[p * 3] = (unsigned char)blend_f(d, cr, a, interp);
+        cur[p * 3 + 1] = (unsigned char)blend_f(d, cg, a, interp);
+        cur[p * 3 + 2] = (unsigned char)blend_f(d, cb, a, interp);
+      }
+    } else if (op == SHARPNESS) {
+      const float a = r.farg;
+      const bool interp = (a >= 0.0f && a <= 1.0f);
+      smooth_op(cur, oth, H, W);
+      __syncthreads();
+      for (int e = threadIdx.x; e < nbyte; e += blockDim.x) cur[e] = (unsigned char)blend_f(oth[e], cur[e], a, interp);
+    } else if (op == ROT180 || op == ROT90 || op == ROT270) {    // Image.rotate -> transpose (90 / 270 only on square images)
+      for (int p = threadIdx.x; p < npix; p += blockDim.x) {
+        const int y = p / W, x = p - y * W;
+        int sy, sx;
+        if (op == ROT180) { sy = H - 1 - y; sx = W - 1 - x; }
+        else if (op == ROT90) { sy = x; sx = W - 1 - y; }        // counter-clockwise: out[y][x] = in[x][W-1-y]
+        else { sy = H - 1 - x; sx = y; }
+        const unsigned char* s = cur + (sy * W + sx) * 3;
+        oth[p * 3] = s[0]; oth[p * 3 + 1] = s[1]; oth[p * 3 + 2] = s[2];
+      }
+      unsigned char* t = cur; cur = oth; oth = t;
+    } else {                                                     // Rotate / ShearX / ShearY / TranslateXRel / TranslateYRel
+      affine_op(cur, oth, H, W, r.m, r.resample);
+      unsigned char* t = cur; cur = oth; oth = t;
+    }
+    __syncthreads();
+  }
+  unsigned char* dst = out + (size_t)b * nbyte;
+  for (int e = threadIdx.x; e < nbyte; e += blockDim.x) {
+    if (chw) { const int c = e / npix, p = e - c * npix; dst[e] = cur[p * 3 + c]; }
+    else dst[e] = cur[e];
+  }
+}
+
+}  // namespace
+
+extern "C" int lafs_randaug_apply(const uint8_t* images, uint8_t* out, const lafs_randaug_op* records, int B, int H, int W, int layers,
+                                  int chw, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(images && out && records && B > 0 && layers > 0, "bad operand");
+  LAFS_CHECK_ARG(H >= 3 && W >= 3 && H * W <= MAXPIX, "images of 3x3 up to 112x112 pixels (the picture lives in LDS)");
+  const size_t lds = 2 * (size_t)MAXBYTE;
+  static bool configured = false;
+  if (!configured) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(randaug_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { lafs_set_error("lafs_randaug_apply: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
+    configured = true;
+  }
+  hipLaunchKernelGGL(randaug_kernel, dim3(B), dim3(512), lds, stream, images, out, records, B, H, W, layers, chw);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}

@@ -7,7 +7,8 @@ Kept from the reference: flags that define the step (batch size, epochs, the lr 
 `acc_step/480 * lr * sqrt(world*bs/336) * 336`, weight decay 0.1 on >= 2-D tensors (:618-627; `--weight-decay` is parsed by the
 reference but never reaches its optimizer), mixup alpha/prob, acc_step=3 from supervised_config.py:37, warm-up(5 epochs)+cosine(eta_min 1e-6) LR, loading
 `ckpt['teacher']` of an SSL checkpoint with the 'encoder.|backbone.|module.' prefixes stripped and strict=False).
-Out of scope here: MXNet recordio datasets, RandAugment, LFW/CFP/AgeDB evaluation,
+Out of scope here: MXNet recordio datasets, the torchvision tensor transforms of FaceDataset
+(RandomResizedCrop / ColorJitter / RandomErasing on uint8 tensors: torchvision is absent, unpinnable), LFW/CFP/AgeDB evaluation,
 tensorboard; `--data synthetic` feeds uint8 batches of the right shape.
 """
 import argparse
@@ -50,6 +51,10 @@ def get_args_parser():
     p.add_argument("--model_dir", default="", type=str, help="LAFS checkpoint whose ['teacher'] weights initialise the backbone")
     p.add_argument("--pretrain_path", default="", type=str, help="stage-1 checkpoint with the landmark CNN (alias of --landmark_ckpt)")
     p.add_argument("--data", default="synthetic", type=str)
+    p.add_argument("--rand_au", default=False, type=utils.bool_flag,
+                   help="RandAugment of the reference's FaceDataset (rand_au=True, train_largescale.py:506) on the device")
+    p.add_argument("--rand_au_config", default="rand-m1-mstd0.5-inc1", type=str, help="config_str of train_largescale.py:506")
+    p.add_argument("--rand_mirror", default=False, type=utils.bool_flag, help="FaceDataset's random horizontal flip (image_iter.py:308-311)")
     p.add_argument("--steps_per_epoch", default=100, type=int)
     p.add_argument("--outdir", "-o", default=".", type=str)
     p.add_argument("--dist_url", default="env://", type=str)
@@ -136,11 +141,20 @@ def main(args):
     base_lr = cfg["acc_step"] / 480.0 * args.lr * math.sqrt(world * args.batch_size / 336.0) * 336
     n_it = args.steps_per_epoch
     gen = torch.Generator(device=device).manual_seed(cfg["SEED"] + utils.get_rank())
+    rand_au = None
+    if args.rand_au:                    # the loader's per-sample PIL RandAugment as ONE launch per batch (randaug.py / csrc/randaug.hip)
+        from .randaug import DeviceRandAugment
+        rand_au = DeviceRandAugment(args.rand_au_config, {"translate_const": 117}, seed=cfg["SEED"] + utils.get_rank())
     t0 = time.time()
     for epoch in range(args.epochs):
         for it in range(n_it):
             x = torch.randint(0, 256, (args.batch_size, 3, 112, 112), device=device, dtype=torch.uint8, generator=gen)
             y = torch.randint(0, args.num_class, (args.batch_size,), device=device, generator=gen)
+            if args.rand_mirror:        # _rd = random.randint(0, 1) per sample, flip along the width
+                flip = torch.randint(0, 2, (args.batch_size, 1, 1, 1), device=device, generator=gen).bool()
+                x = torch.where(flip, x.flip(3), x)
+            if rand_au is not None:
+                x = rand_au(x)
             lr = warmup_cosine(base_lr, epoch + it / n_it, cfg["WARMUP_EPOCH"], args.epochs)
             loss = engine.step(x, y, lr=lr, weight_decay=args.weight_decay)
             if it % 50 == 0:

@@ -84,6 +84,44 @@ def main():
     ref_utils, ref_vit, ref_lafs, ref_face, ref_mix = _import_reference()
     torch.set_num_threads(4)
 
+    # ---------------------------------------------------------------- F19 RandAugment of the fine-tune loader
+    # util/rand_aa_face.py as FaceDataset builds it (dataloader_web.py:240-243, train_largescale.py:506): 'rand-m1-mstd0.5-inc1',
+    # hparams {'translate_const': 117}; plus a strong 3-layer configuration so that every op is far from the identity.  Image i is
+    # transformed with random.seed(seed_i); np.random.seed(seed_i) set right before the call -- the decisions are reproducible.
+    print("F19 fine-tune RandAugment")
+    import random as _random
+    from PIL import Image as _Image
+    from util import rand_aa_face as ref_ra
+    g19 = np.random.RandomState(19)
+    yy, xx = np.mgrid[0:112, 0:112]
+    imgs19 = []
+    for k in range(40):
+        kind = k % 5
+        if kind == 0:
+            a = g19.randint(0, 256, (112, 112, 3))
+        elif kind == 1:
+            a = np.stack([(xx * (k + 1)) % 256, (yy * 2 + xx * k) % 256, (xx * yy // (k + 1)) % 256], -1)
+        elif kind == 2:
+            a = 40 + 150 * (0.5 + 0.5 * np.sin(xx[..., None] * 0.07 * (1 + np.arange(3)) + yy[..., None] * 0.05 + k))
+        elif kind == 3:
+            a = (g19.rand(112, 112, 3) ** 3) * 255
+        else:
+            a = np.clip(128 + 60 * g19.randn(14, 14, 3), 0, 255).repeat(8, 0).repeat(8, 1)
+        imgs19.append(np.asarray(a).astype(np.uint8))
+    imgs19 = np.stack(imgs19)
+    out19 = {}
+    for tag, cfgs in (("m1", "rand-m1-mstd0.5-inc1"), ("m9n3", "rand-m9-n3-mstd0.5-inc1")):
+        tr = ref_ra.rand_augment_transform(cfgs, {"translate_const": 117})
+        res = []
+        for i in range(len(imgs19)):
+            _random.seed(1900 + i); np.random.seed(1900 + i)
+            res.append(np.asarray(tr(_Image.fromarray(imgs19[i]))))
+        out19["out_" + tag] = np.stack(res)
+        out19["cfg_" + tag] = np.array(cfgs)
+    save("f19_randaugment", images=imgs19, seed0=np.int64(1900), **out19)
+    if ONLY == "f19":
+        return
+
     # ---------------------------------------------------------------- F1 VisionTransformer fwd/bwd
     # tiny geometry that the HIP kernels also accept (head_dim 64): D=128, 2 heads, depth 2, p=8,
     # pos table 28x28 (img_size 224) resampled to 14x14 and 6x6.

@@ -1,7 +1,8 @@
 #!/bin/bash
-# GPU box: per-kernel time of the C4 fine-tune step (bench.py --extras-only finetune) under rocprofv3 --kernel-trace --stats
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ft; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O -o ft --output-format csv -- python3 $R/bench.py --extras-only finetune > $O/bench.json 2> $O/err.txt
+# GPU box: per-kernel time of one of bench.py's extra workloads (default: the C4 fine-tune step) under rocprofv3 --kernel-trace --stats
+# usage: tools/profile_finetune_r3.sh [finetune|mynet|finetune_plain|partialfc]
+W=${1:-finetune}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ft_$W; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $O -o ft --output-format csv -- python3 $R/bench.py --extras-only $W > $O/bench.json 2> $O/err.txt
 cat $O/bench.json | cut -c1-300
 python3 - <<PY
 import csv, glob, re
