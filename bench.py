@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the roofline kernels' loops (for rocprofv3)")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels' loops (profiles of the step alone)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the non-headline workloads appended to the JSON line at 1 GPU (`extras`: the reference's real "
@@ -516,7 +517,8 @@ def main():
         if hb is not None:                           # measured HBM bytes of one step (committed PMC profile) over this run's time
             out["step_hbm_bytes"] = hb
             out["step_hbm_frac"] = round(hb / (ms * 1e-3) / 8e12, 4)
-        out["roofline"] = dominant_kernel_roofline(device)
+        if not args.no_roofline:
+            out["roofline"] = dominant_kernel_roofline(device)
         out["profile_provenance"] = PROFILE_NOTES       # which committed profile each read-back number came from (null = stale)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, nl, K, args.cpu_batch)

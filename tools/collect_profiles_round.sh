@@ -5,7 +5,7 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/profiles; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 # fingerprint of the kernel sources these profiles are measured on (bench.py prints read-back numbers only while it matches)
 python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.csrc_fingerprint())" > $O/csrc_sha.txt
-rocprofv3 --kernel-trace --stats -d $O/step -o step --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/step_bench.json 2> $O/step.err
+rocprofv3 --kernel-trace --stats -d $O/step -o step --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-roofline > $O/step_bench.json 2> $O/step.err
 rocprofv3 --kernel-trace --stats -d $O/dom -o dom --output-format csv -- python3 $R/bench.py --roofline-only > $O/dom_bench.json 2> $O/dom.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 $R/bench.py --roofline-only > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 $R/bench.py --roofline-only > /dev/null 2> $O/pmc_write.err

@@ -2,7 +2,7 @@
 # GPU box: kernel trace of the graph-replayed step (phase spans, tools/step_timeline.py) + fabric-read bytes of the grouped weight
 # gradient with and without the XCD map (bench.py --roofline-only under --pmc FETCH_SIZE, one pass per setting)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3prof; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $O/step -o step --output-format csv -- python3 $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extras > $O/step_bench.json 2> $O/step.err
+rocprofv3 --kernel-trace -d $O/step -o step --output-format csv -- python3 $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extras --no-roofline > $O/step_bench.json 2> $O/step.err
 python3 $R/tools/step_timeline.py $(find $O/step -name "*kernel_trace.csv" | head -1) > $O/timeline.txt 2>&1
 cat $O/timeline.txt
 for m in 0 1; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: per-kernel durations of the step with every stream serialised (no time-sharing between concurrent kernels).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/serial; mkdir -p $O; cd /tmp; export TMPDIR=/tmp; export LAFS_SINGLE_STREAM=1
-rocprofv3 --kernel-trace --stats -d $O -o serial --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-graph > $O/bench.json 2> $O/err.txt
+rocprofv3 --kernel-trace --stats -d $O -o serial --output-format csv -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-roofline --no-graph > $O/bench.json 2> $O/err.txt
 cat $O/bench.json | cut -c1-400
 python3 - <<PY
 import csv,glob,re

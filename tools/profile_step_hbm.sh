@@ -2,9 +2,9 @@
 # GPU box: HBM bytes moved by ONE training step (PMC FETCH_SIZE / WRITE_SIZE summed over every kernel of a step; eager
 # launches so that each kernel is its own dispatch record; separate passes per counter as the TCC slots require).
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/stephbm; mkdir -p $O; cd /tmp; export TMPDIR=/tmp; export LAFS_SINGLE_STREAM=1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o f --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $O/f.json 2> $O/f.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o w --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $O/w.json 2> $O/w.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/m -o m --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-graph > $O/m.json 2> $O/m.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o f --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-roofline --no-graph > $O/f.json 2> $O/f.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o w --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-roofline --no-graph > $O/w.json 2> $O/w.err
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES -d $O/m -o m --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-extras --no-roofline --no-graph > $O/m.json 2> $O/m.err
 python3 - <<PY
 import csv, glob, json
 out = {}
