@@ -336,9 +336,11 @@ class LafsPretrainEngine:
                     f()
             self._graphs = [g]
             return
+        # world > 1: the process group's watchdog thread polls its events while this thread captures -- thread-local capture mode
+        # keeps another thread's (legal) runtime calls from invalidating the capture
         for f in segs:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 f()
             pool = g.pool()
             graphs.append(g)
