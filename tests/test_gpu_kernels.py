@@ -507,3 +507,24 @@ def test_dropout_seed_from_a_device_step_counter_and_row_offsets():
     x2 = x.clone()
     call("lafs_dropout_f32", _p(x2), N, M, N, p, seed, _p(step))
     torch.testing.assert_close(x2, x * mask, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("name,M,dims", [("ViT-S block", 44160, [(384, 1536), (1536, 384), (384, 384), (1152, 384)]),
+                                         ("Part-fViT block, one row chain", 25216, [(768, 2048), (2048, 768), (768, 704), (2112, 768)])])
+def test_wgrad_group_under_the_engines_workgroup_caps_at_block_shapes(name, M, dims):
+    """The grouped weight gradient as the engines launch it beside the dgrad chain (max_workgroups 200; 0 = the whole chip; other caps
+    change tile shape and slice count), written and accumulated, with the bias-gradient column sums shared over tiles and wave
+    columns: against fp32 torch at the full block shapes."""
+    from lafs_cvpr2024_amd import ops
+    torch.manual_seed(0)
+    pairs = [(torch.randn(M, a, device="cuda").to(torch.bfloat16), torch.randn(M, b, device="cuda").to(torch.bfloat16)) for a, b in dims]
+    refs = [x.float().t() @ y.float() for x, y in pairs]
+    cref = [x.float().sum(0) for x, _ in pairs]
+    for cap in (0, 200, 96):
+        for acc in (False, True):
+            Cs = [torch.full((a, b), 0.5 if acc else 7.0, device="cuda") for a, b in dims]
+            cs = [torch.zeros(a, device="cuda") for a, _ in dims]
+            ops.wgrad_group([(x, y, c, acc, s) for (x, y), c, s in zip(pairs, Cs, cs)], max_workgroups=cap)
+            for c, r, s, sr in zip(Cs, refs, cs, cref):
+                assert float(((c - (0.5 if acc else 0.0)) - r).norm() / r.norm()) < 1e-4, (name, cap, acc, tuple(c.shape))
+                assert float((s - sr).norm() / sr.norm()) < 1e-4, (name, cap, acc, "colsum")
