@@ -159,7 +159,7 @@ def test_benchmark_composition_vit_small_droppath_against_the_oracle():
         if float(g.abs().max()) > 1e-9:
             errs[k] = rel_l2(named[k].grad * clip, g)
     assert len(errs) >= 150
-    gate_errors("ViT-S composition (K=100000, DropPath 0.1, row chains + K-resident + wide tiles)", errs, 3e-2)
+    gate_errors("ViT-S composition (K=100000, DropPath 0.1, row chains + K-resident + wide tiles)", errs, 2e-2)      # observed 1.08e-2
     # teacher EMA: (1 - m) * (student update): distributional, in units of lr * (1 - m)
     e = torch.cat([(teacher.state_dict()[k].cpu().double() - v.double()).abs().flatten() for k, v in st.teacher.items()
                    if "last_layer" not in k]).numpy()

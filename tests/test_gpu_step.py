@@ -21,7 +21,7 @@ DEV = "cuda"
 LN6 = partial(nn.LayerNorm, eps=1e-6)
 # per-tensor relative-L2 gate on bf16-MFMA gradients against the fp32 reference (depth-2 fixtures): 2x the worst error
 # observed on MI355X (DESIGN.md section 2 holds the observed table)
-GRAD_GATE = 6e-2          # observed: F5 3.0e-2 (step 1, qkv weight), F16 2.3e-2
+GRAD_GATE = 4e-2          # observed: F5 2.1e-2 / 2.7e-2 (steps 0 / 1; qkv weight), F16 2.3e-2 -- bf16 dL/dlogits at K = 512
 
 
 def rel_l2(a, b):
