@@ -85,6 +85,43 @@ def test_two_ranks_on_one_gpu_equal_single_process_on_the_full_batch(tmp_path, u
     assert float(dt.max()) < 1e-3
 
 
+def _rccl_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["LAFS_ONE_GRAPH"] = "0"               # the multi-rank launch structure: one graph per segment, collectives between them
+    os.environ["LAFS_REDUCE_SINGLE_RANK"] = "1"      # ... with the all-reduces really issued (RCCL, one rank)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    eng = _build(4, True)
+    assert len(eng._segments()) > 1 and eng.reducer.active
+    full = [c.cuda() for c in _crops(4)]
+    losses = [float(eng.step(full, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item()) for _ in range(3)]
+    assert not eng._one_graph and len(eng._graphs) > 1
+    t = torch.ones(1 << 20, device="cuda")
+    dist.all_reduce(t)                                # the backend is alive after the captured segments
+    torch.cuda.synchronize()
+    assert float(t.sum()) == float(1 << 20)
+    torch.save({"student": eng.sa.master.cpu(), "teacher": eng.ta.master.cpu(), "center": eng.dino_loss.center.cpu(), "losses": losses}, out)
+    dist.destroy_process_group()
+
+
+def test_multi_rank_launch_structure_over_rccl_with_one_rank(tmp_path):
+    """What one GPU can show of the RCCL path: init_process_group("nccl", device_id=...), the segmented graphs captured while the
+    process group's watchdog thread is alive, asynchronous RCCL all-reduces of the gradient slices and of the center sums issued
+    between the graph replays and waited for stream-side -- against the single-graph engine without a process group."""
+    out = str(tmp_path / "rccl1")
+    mp.spawn(_rccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    r = torch.load(out, weights_only=False)
+    eng = _build(4, True)
+    full = [c.cuda() for c in _crops(4)]
+    losses = [float(eng.step(full, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).item()) for _ in range(3)]
+    assert eng._one_graph
+    assert abs(r["losses"][0] - losses[0]) < 1e-6 * abs(losses[0])
+    assert abs(r["losses"][2] - losses[2]) < 5e-3 * abs(losses[2])
+    d = (r["student"] - eng.sa.master.cpu()).abs()
+    assert float(d.median()) < 1e-6 and float((d > 1e-4).float().mean()) < 0.06 and float(d.max()) < 7e-3
+    assert float((r["teacher"] - eng.ta.master.cpu()).abs().max()) < 1e-3
+
+
 def test_two_ranks_with_bf16_gradients_on_the_wire(tmp_path):
     """LAFS_GRAD_WIRE=bf16 (opt-in): gradient slices are cast to bf16, all-reduced and cast back (half the bytes on the links).  The
     replicas must stay bit-identical to each other (both receive the same sums) and close to the fp32-wire run: the first step's
