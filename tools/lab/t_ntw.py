@@ -1,4 +1,6 @@
-"""GPU box: the wide-tile NT kernel (gemm_ntw.hip) against the tiled kernel at the Part-fViT block shapes: results and time."""
+"""GPU box: the tiled NT kernel at the eight Part-fViT block shapes (time + output checksums).  The wide-tile lab kernel
+(tools/lab/gemm_ntw.hip) was measured with this script while it was wired into lafs_gemm_nt behind LAFS_NTW=0/1 (copy the two files into
+csrc/, include gemm_ntw.hpp in gemm.hip and call lafs_ntw_eligible / lafs_ntw_launch in front of the epilogue switch): NOTES.md."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C
