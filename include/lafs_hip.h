@@ -100,8 +100,14 @@ typedef struct lafs_gemm_nt_args {
 int lafs_gemm_nt_slices(int K, int splits);
 int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
 /* Which kernel lafs_gemm_nt runs for this request: 0 = the tiled LDS-DMA kernel (gemm.hip), 1 = the K-resident streaming kernel
- * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout). */
+ * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout), 2 = its
+ * ping-pong form (gemm_kpp.hip: one 8-wave workgroup per CU, the MFMA turn of one half beside the epilogue turn of the other;
+ * same requests, same results bit for bit). */
 int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
+/* Which epilogues of the K-resident route take the ping-pong kernel: bit mask 1 plain, 2 GELU, 4 residual, 8 GELU'; -1 = the
+ * value of LAFS_KPP in the environment (the default).  Returns the previous override.  Replaces nothing in the reference: it
+ * selects between two implementations of the same nn.Linear calls (vision_transformer.py:59-65, 75-90). */
+int lafs_set_kpp_mask(int mask);
 
 /* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
  * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0.

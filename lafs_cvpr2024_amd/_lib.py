@@ -147,6 +147,7 @@ _NO_STREAM = {
     "lafs_gemm_nt_slices": ([i32, i32], i32),
     "lafs_gemm_nt_route": ([C.POINTER(GemmNTArgs)], i32),
     "lafs_set_comm_cus": ([i32], i32),
+    "lafs_set_kpp_mask": ([i32], i32),
     "lafs_debug_set": ([i32], i32),
     "lafs_debug_get": ([], i32),
     "lafs_ablation_build": ([], i32),

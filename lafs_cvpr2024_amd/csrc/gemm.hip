@@ -796,7 +796,7 @@ int ksplit_len(int K, int splits) {
 
 extern "C" int lafs_gemm_nt_slices(int K, int splits) { return K >= 32 ? ceil_div(K, ksplit_len(K, splits)) : 1; }
 
-extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) { return (g != nullptr && lafs_kres_eligible(g)) ? 1 : 0; }
+extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) { return (g != nullptr && lafs_kres_eligible(g)) ? (lafs_kpp_selected(g) ? 2 : 1) : 0; }
 
 extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
@@ -819,7 +819,8 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   LAFS_CHECK_ARG(g->drop_p >= 0.f && g->drop_p < 1.f, "drop_p must be in [0, 1)");
   LAFS_CHECK_ARG(!(g->drop_p > 0.f) || ((long)g->M + g->drop_row0) * g->N < 4294967296L, "dropout needs (row0 + M) * N < 2^32");
   LAFS_CHECK_ARG(g->drop_row0 >= 0, "drop_row0 must be >= 0");
-  if (lafs_kres_eligible(g)) return lafs_kres_launch(g, stream);   // K = 384 streaming shapes of the ViT-S trunk (gemm_kres.hip)
+  if (lafs_kres_eligible(g))                                       // K = 384 streaming shapes of the ViT-S trunk (gemm_kres.hip / gemm_kpp.hip)
+    return lafs_kpp_selected(g) ? lafs_kpp_launch(g, stream) : lafs_kres_launch(g, stream);
   int splits = 1;
   a.klen = g->K;
   if (g->epilogue == LAFS_EPI_ATOMIC_F32 || (g->epilogue == LAFS_EPI_F32 && g->splits > 1)) {

@@ -1,0 +1,428 @@
+// K-resident PING-PONG GEMM for gfx950:  C[M,N] = epilogue(A[M,384] * W[N,384]^T)
+//
+// Same job as gemm_kres.hip (the cuBLAS GEMMs behind Attention.qkv / Attention.proj / Mlp.fc1 and the proj / fc2 input gradients
+// of the reference's ViT-S trunk, vision_transformer.py:59-65, 75-90), other execution structure.  gemm_kres.hip runs two
+// independent 4-wave workgroups per CU; the phase stamps of round 2/3 (profiles/lab_kres_phases.txt) show each wave as ONE
+// serial chain -- wait, LDS-DMA issue, 48 MFMAs, epilogue VALU, stores -- and the two chains of a SIMD do not interleave by
+// themselves (the ablations add up).  Here ONE 8-wave workgroup owns the CU and the interleaving is forced:
+//   * waves 0-3 (half A) and 4-7 (half B) sit pairwise on the same SIMDs; time is cut into phases by s_barrier; in every phase
+//     one half runs the MFMA turn of an item (two ring stages, 96 MFMAs per wave, plus the LDS-DMA issue of one later stage) while
+//     the other half runs the EPILOGUE turn of the item it finished one phase earlier (VALU + global stores, no LDS, no MFMA):
+//     matrix pipe beside VALU / vector memory on every SIMD, by construction;
+//   * both halves consume the SAME weight stages one phase apart (ring of six 24 KiB stages = three items): a 256-row unit per
+//     workgroup, so the L2 -> LDS weight traffic and the LDS-DMA issue per wave are half of gemm_kres.hip's;
+//   * a stage is requested four phases before its first reader, by the half that is in its EPILOGUE turn, at the top of the turn:
+//     the request is older than the turn's stores, so the counted vmcnt wait at the end of the turn never sits out a store, and
+//     the half in its MFMA turn issues no vector-memory instruction besides the few epilogue-operand loads;
+//   * resident token rows (32 per wave, 96 VGPRs) are (re)loaded per unit through the ring buffers by LDS-DMA, each wave its own
+//     rows into its own buffer (no barrier between landing and reading), six waves in the first round trip, the last two together
+//     with the first three weight stages in the second.
+// Lane ownership, weight-row interleave, bias-initialised accumulators and the store pattern (16 rows x 64 contiguous bytes per
+// instruction, the two stages of an item back to back = whole 128-byte lines) are gemm_kres.hip's.
+#include <stdlib.h>
+#include "common.hpp"
+#include "gemm_kres.hpp"
+
+namespace kpp {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+
+constexpr int KK = 384;
+constexpr int CPR = KK / 8;                // 16-byte chunks per row
+constexpr int ROWB = KK * 2;               // bytes per row
+constexpr int GROWS = 32;                  // weight rows per stage
+constexpr int STAGE = GROWS * ROWB;        // 24 KiB
+constexpr int NSTG = 6;                    // three items
+constexpr int NTH = 512, HTH = 256;
+constexpr int NDMA = STAGE / 16 / HTH;     // LDS-DMA instructions per thread of the issuing half and stage (6)
+constexpr int NROWDMA = STAGE / 16 / 64;   // LDS-DMA instructions of a wave fetching its own 32 rows (24)
+constexpr int NKK = KK / 32;
+constexpr int MAXN = 1536;
+constexpr int UROWS = 256;
+
+struct PArgs {
+  const bf16_t* A; const bf16_t* B;
+  int M, N, lda, ldb;
+  void* C; int ldc; void* C2; int ldc2;
+  const float* bias; const float* resid; int ldr;
+  const float* seq_scale; const int* row2seq;
+  const bf16_t* aux; int ldaux;
+  int cbn, items;
+  int save_grad;
+  unsigned long long* stamps;              // lab (ABL & 32): per workgroup and half 12 values {issue + bias, mfma, barrier wait, epilogue, vmcnt wait, barrier wait, whole run, items, segment prologues, segments}
+};
+#define PABL(bit) ((ABL & (bit)) != 0)
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void st16(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  const u32x4_t v = {a, b, c, d};
+  *reinterpret_cast<u32x4_t*>(p) = v;
+}
+__device__ __forceinline__ void st16f(void* p, float a, float b, float c, float d) {
+  const f32x4v_t v = {a, b, c, d};
+  *reinterpret_cast<f32x4v_t*>(p) = v;
+}
+
+// memory operations of one epilogue turn: S stores (active waves only) + P operand loads (issued in the MFMA turn before)
+template <int EPI, bool HAS_U> struct EpiOps {
+  static constexpr bool F32 = (EPI == LAFS_EPI_RESID_F32);
+  static constexpr int S = F32 ? 8 : ((EPI == LAFS_EPI_BF16_GELU && HAS_U) ? 8 : 4);
+  static constexpr int P = F32 ? 8 : ((EPI == LAFS_EPI_DGELU_BF16) ? 4 : 0);
+};
+
+// ABL (lab only, 0 in the library): 1 stores from lane 0 only, 2 no MFMA, 8 no epilogue math, 16 no fragment reads, 32 phase stamps,
+// 256 / 512 fragment reads 12 / 16 ahead of their MFMAs instead of 8
+template <int EPI, bool HAS_U, int ABL>
+__global__ __launch_bounds__(NTH, 2) void gemm_kpp_kernel(PArgs p) {
+  constexpr int S = EpiOps<EPI, HAS_U>::S, P = EpiOps<EPI, HAS_U>::P;
+  constexpr bool F32 = EpiOps<EPI, HAS_U>::F32;
+  constexpr bool AUX_IS_GRAD = (EPI == LAFS_EPI_DGELU_BF16) && !HAS_U;
+  constexpr int FD = PABL(512) ? 16 : (PABL(256) ? 12 : 8);   // fragment reads in flight ahead of their MFMAs
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
+  __shared__ __attribute__((aligned(16))) float sbias[MAXN];
+  const int tid = threadIdx.x, lane = tid & 63, htid = tid & (HTH - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, hw = wave & 3;
+  const int t = lane & 15, q = lane >> 4;
+  const int G = (int)gridDim.x, per = G >> 3;
+  const int id = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int ib = (int)((long)p.items * id / G), ie = (int)((long)p.items * (id + 1) / G);
+  if (ie <= ib) return;
+
+  for (int i = tid; i < p.N; i += NTH) sbias[i] = p.bias ? p.bias[i] : 0.f;
+  __syncthreads();
+
+  // LDS image of a stage (gemm_kres.hip): row rho = 48 chunks, logical chunk c at position c ^ (rho & 15); lane-linear for the DMA
+  int doff[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int x = i * HTH + htid, rho = x / CPR, cp = x % CPR, c = cp ^ (rho & 15);
+    const int s16 = rho & 15, gi = rho >> 4;
+    const int rowrel = F32 ? rho : (8 * (s16 >> 2) + 4 * gi + (s16 & 3));
+    doff[i] = (rowrel * p.ldb + c * 8) * 2;
+  }
+  const int cbn = p.cbn;
+  const unsigned lds0 = lds_addr_of(smem);
+  // stage s of a segment (local numbering) lives in ring buffer (((s >> 1) + 1) % 3) * 2 + (s & 1): buffers 0 and 1 stay free
+  // for the second round of row fetches while stages 0..3 land
+  auto bufof = [](int s) { return (((s >> 1) + 1) % 3) * 2 + (s & 1); };
+  auto issue = [&](int cb0, int s) {                  // weight stage s of the segment starting at column block cb0, by this half
+    const bf16_t* base = p.B + (size_t)((cb0 + (s >> 1)) * 64 + 32 * (s & 1)) * p.ldb;
+    const unsigned st = lds0 + bufof(s) * STAGE + hw * 1024;
+    fence();
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) lds_dma16_m0_s(base, (unsigned)doff[i], st + i * (HTH * 16));
+    fence();
+  };
+  // a piece is 64 lanes x 16 bytes, a row 768 bytes: pieces repeat every three (= four rows); per lane three (row, chunk) pairs
+  int rdr[3], rcp[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { rdr[r] = (64 * r + lane) / CPR; rcp[r] = (64 * r + lane) % CPR; }
+  auto issue_rows = [&](int mu, int buf) {            // this wave's 32 token rows as one stage image, all 24 pieces by this wave
+    const unsigned st = lds0 + buf * STAGE;
+    const int row0 = mu * UROWS + wave * 32;
+    fence();
+#pragma unroll 1
+    for (int g = 0; g < NROWDMA / 3; ++g) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int rho = 4 * g + rdr[r], c = rcp[r] ^ (rho & 15);
+        const int row = min(row0 + rho, p.M - 1);
+        lds_dma16_m0(p.A + (size_t)row * p.lda + c * 8, st + (3 * g + r) * 1024);
+      }
+    }
+    fence();
+  };
+
+  int foff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    foff[i] = t * ROWB + (((4 * i + q) ^ t) << 4);
+    asm volatile("" : "+v"(foff[i]));
+  }
+  bf16x8_t areg[2][NKK];
+  f32x4_t acc[2][2][2];                               // [stage of the item][weight row group][token block]
+  uint4 pre[P > 0 ? P : 1];
+  float sc[2] = {1.0f, 1.0f};
+
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, t_begin = 0, t_last = 0, t_pro = 0, n_seg = 0;   // issue, mfma, wait, epilogue, vmcnt wait, wait
+  auto lap = [&](int slot) {
+    if constexpr (PABL(32)) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[slot] += now - t_last;
+      t_last = now;
+    }
+  };
+  if constexpr (PABL(32)) t_begin = t_last = __builtin_amdgcn_s_memtime();
+
+  auto bias_init = [&](f32x4_t (&a)[2][2], int n0, int g) {
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      const int n = F32 ? n0 + 16 * (2 * g + gi) + 4 * q : n0 + 32 * g + 8 * q + 4 * gi;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) a[gi][b] = *reinterpret_cast<const f32x4_t*>(sbias + n);
+    }
+  };
+  auto mfma_stage = [&](int buf, f32x4_t (&a)[2][2]) {               // 48 MFMAs on one ring stage
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        bf16x8_t w = areg[gi][(kk + 1) % NKK];
+        if constexpr (!PABL(16)) w = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256 + gi * (16 * ROWB));
+        if constexpr (!PABL(2)) {
+          a[gi][0] = mfma16(w, areg[0][kk], a[gi][0]);
+          a[gi][1] = mfma16(w, areg[1][kk], a[gi][1]);
+        } else {
+          asm volatile("" :: "v"(w));
+        }
+      }
+    if constexpr (!PABL(2) && !PABL(16)) {
+      __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);
+#pragma unroll
+      for (int i = 0; i < 2 * NKK - FD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * FD, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto read_rows = [&](int buf) {
+    const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk)
+        areg[b][kk] = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256 + b * (16 * ROWB));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  int it = ib;
+  while (it < ie) {
+    // ------------------------------------------------------------------ one segment: items of ONE 256-row unit
+    const int mu = it / cbn, cb0 = it - mu * cbn;
+    const int n = min(ie, (mu + 1) * cbn) - it;       // items of this segment
+    const int ns = 2 * n;                             // its stages
+    const int m0 = mu * UROWS + wave * 32 + t;
+    const bool active = (mu * UROWS + wave * 32) < p.M;
+    if (EPI == LAFS_EPI_RESID_F32 && p.seq_scale != nullptr) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) sc[b] = p.seq_scale[p.row2seq[min(m0 + 16 * b, p.M - 1)]];
+    }
+    auto fetch = [&](int j) {                         // exactly P loads: the epilogue operand of local item j
+      if (P == 0) return;
+      const int n0 = (cb0 + j) * 64;
+#pragma unroll
+      for (int i = 0; i < P; ++i) {
+        const int b = i & 1, x = i >> 1;              // bf16: x = stage; fp32: x = stage * 2 + row group
+        const int mr = min(m0 + 16 * b, p.M - 1);
+        if (F32) pre[i] = *reinterpret_cast<const uint4*>(p.resid + (size_t)mr * p.ldr + n0 + 16 * x + 4 * q);
+        else pre[i] = *reinterpret_cast<const uint4*>(p.aux + (size_t)mr * p.ldaux + n0 + 32 * x + 8 * q);
+      }
+      fence();
+    };
+
+    // ---- segment prologue: rows of waves 0..5 -> buffers 0..5 (each wave reads what it fetched itself: no barrier in between);
+    // then rows of waves 6, 7 -> buffers 0, 1 together with weight stages 0, 1 (half A) and 2, 3 (half B) -> buffers 2..5
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();                     // every ring buffer is free (the previous segment drained)
+    if (wave < 6) {
+      issue_rows(mu, wave);
+      wait_vm<0>();
+      read_rows(wave);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wave >= 6) issue_rows(mu, wave - 6);
+    if (half == 0) { issue(cb0, 0); issue(cb0, 1); }
+    else if (ns > 2) { issue(cb0, 2); issue(cb0, 3); }
+    wait_vm<0>();
+    if (wave >= 6) read_rows(wave - 6);
+    __builtin_amdgcn_s_barrier();
+    if constexpr (PABL(32)) { const unsigned long long now = __builtin_amdgcn_s_memtime(); t_pro += now - t_last; t_last = now; n_seg += 1; }
+
+    // ---- phases: half A runs [M_0][E_0][M_1][E_1]...[idle], half B [idle][M_0][E_0]..., a barrier after every phase.  The half
+    // that is NOT in its MFMA turn requests weight stage phase + 4 at the start of the phase (so the half in its MFMA turn issues
+    // no LDS-DMA: its turn is LDS reads + MFMAs only, and the requests never queue behind stores of their own wave)
+    if (half == 1) {
+      if (4 < ns) issue(cb0, 4);
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      lap(5);
+    }
+    for (int j = 0; j < n; ++j) {
+      const int n0 = (cb0 + j) * 64;
+      // ---------------- MFMA turn of item j (phase 2 j + half)
+      bias_init(acc[0], n0, 0);
+      lap(0);
+      mfma_stage(bufof(2 * j), acc[0]);
+      bias_init(acc[1], n0, 1);
+      fetch(j);                                       // P loads, consumed a stage of MFMAs and a barrier later
+      mfma_stage(bufof(2 * j + 1), acc[1]);
+      lap(1);
+      __builtin_amdgcn_s_barrier();
+      lap(2);
+      // ---------------- epilogue turn of item j (phase 2 j + half + 1): request stage 2 j + half + 5 first
+      {
+        const int s = 2 * j + half + 5;
+        if (s < ns) issue(cb0, s);
+      }
+      lap(0);
+      fence();
+      if (active) {
+        const bool lab_lane0 = !PABL(1) || lane == 0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int m = m0 + 16 * b;
+          const bool rowok = (m < p.M) && lab_lane0;
+          if (F32) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {              // x = stage * 2 + row group: 16 columns each
+              const int g = x >> 1, gi = x & 1;
+              const int nn = n0 + 16 * x + 4 * q;
+              const uint4 r4 = pre[x * 2 + b];
+              float v0 = acc[g][gi][b][0], v1 = acc[g][gi][b][1], v2 = acc[g][gi][b][2], v3 = acc[g][gi][b][3];
+              if (!PABL(8)) {
+                v0 = __uint_as_float(r4.x) + sc[b] * v0; v1 = __uint_as_float(r4.y) + sc[b] * v1;
+                v2 = __uint_as_float(r4.z) + sc[b] * v2; v3 = __uint_as_float(r4.w) + sc[b] * v3;
+              }
+              if (rowok) st16f(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + nn, v0, v1, v2, v3);
+            }
+          } else {
+            float v[2][8];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              v[g][0] = acc[g][0][b][0]; v[g][1] = acc[g][0][b][1]; v[g][2] = acc[g][0][b][2]; v[g][3] = acc[g][0][b][3];
+              v[g][4] = acc[g][1][b][0]; v[g][5] = acc[g][1][b][1]; v[g][6] = acc[g][1][b][2]; v[g][7] = acc[g][1][b][3];
+              if (EPI == LAFS_EPI_DGELU_BF16 && !PABL(8)) {
+                const uint4 a4 = pre[g * 2 + b];
+                if constexpr (AUX_IS_GRAD) {
+                  v[g][0] *= bf_lo(a4.x); v[g][1] *= bf_hi(a4.x); v[g][2] *= bf_lo(a4.y); v[g][3] *= bf_hi(a4.y);
+                  v[g][4] *= bf_lo(a4.z); v[g][5] *= bf_hi(a4.z); v[g][6] *= bf_lo(a4.w); v[g][7] *= bf_hi(a4.w);
+                } else {
+                  v[g][0] *= gelu_grad_f(bf_lo(a4.x)); v[g][1] *= gelu_grad_f(bf_hi(a4.x)); v[g][2] *= gelu_grad_f(bf_lo(a4.y)); v[g][3] *= gelu_grad_f(bf_hi(a4.y));
+                  v[g][4] *= gelu_grad_f(bf_lo(a4.z)); v[g][5] *= gelu_grad_f(bf_hi(a4.z)); v[g][6] *= gelu_grad_f(bf_lo(a4.w)); v[g][7] *= gelu_grad_f(bf_hi(a4.w));
+                }
+              }
+            }
+            float dv[2][8];
+            const bool both = (EPI == LAFS_EPI_BF16_GELU) && HAS_U && p.save_grad && !PABL(8);
+            if (both) {
+#pragma unroll
+              for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { float gv; gelu_both_f(v[g][e], gv, dv[g][e]); v[g][e] = gv; }
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const int nn = n0 + 32 * g + 8 * q;
+                if (rowok) st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nn, pack_bf2(dv[g][0], dv[g][1]), pack_bf2(dv[g][2], dv[g][3]),
+                                pack_bf2(dv[g][4], dv[g][5]), pack_bf2(dv[g][6], dv[g][7]));
+              }
+            }
+            if ((EPI != LAFS_EPI_BF16_GELU || HAS_U) && !both) {
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const int nn = n0 + 32 * g + 8 * q;
+                if (rowok) st16(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + nn, pack_bf2(v[g][0], v[g][1]), pack_bf2(v[g][2], v[g][3]),
+                                pack_bf2(v[g][4], v[g][5]), pack_bf2(v[g][6], v[g][7]));
+              }
+            }
+            if (EPI == LAFS_EPI_BF16_GELU) {
+              if (!PABL(8) && !both) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[g][e] = gelu_f(v[g][e]);
+              }
+#pragma unroll
+              for (int g = 0; g < 2; ++g) {
+                const int nn = n0 + 32 * g + 8 * q;
+                if (rowok) st16(reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + nn, pack_bf2(v[g][0], v[g][1]), pack_bf2(v[g][2], v[g][3]),
+                                pack_bf2(v[g][4], v[g][5]), pack_bf2(v[g][6], v[g][7]));
+              }
+            }
+          }
+        }
+      }
+      lap(3);
+      fence();
+      // the stage requested at the top of this turn is older than the stores above: it has landed when at most they are pending
+      if (active) wait_vm<S>(); else wait_vm<0>();
+      lap(4);
+      __builtin_amdgcn_s_barrier();
+      lap(5);
+    }
+    if (half == 0) { __builtin_amdgcn_s_barrier(); lap(2); }
+    it += n;
+  }
+  if constexpr (PABL(32)) {
+    if (hw == 0 && lane == 0 && p.stamps != nullptr) {
+      unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 2 + half) * 12;
+      o[0] = tacc[0]; o[1] = tacc[1]; o[2] = tacc[2]; o[3] = tacc[3]; o[4] = tacc[4]; o[5] = tacc[5];
+      o[6] = __builtin_amdgcn_s_memtime() - t_begin; o[7] = (unsigned long long)(ie - ib); o[8] = t_pro; o[9] = n_seg;
+    }
+  }
+}
+
+template <int EPI, bool HAS_U, int ABL>
+int launch(const PArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_kpp_kernel<EPI, HAS_U, ABL>), dim3(grid), dim3(NTH), 0, s, a);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+template <int ABL>
+int kpp_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_override = 0, unsigned long long* stamps = nullptr) {
+  const int e = g->epilogue;
+  PArgs a;
+  a.A = (const bf16_t*)g->A; a.B = (const bf16_t*)g->B; a.M = g->M; a.N = g->N; a.lda = g->lda; a.ldb = g->ldb;
+  a.C = g->C; a.ldc = g->ldc; a.C2 = g->C2; a.ldc2 = g->ldc2;
+  a.bias = (e == LAFS_EPI_DGELU_BF16) ? nullptr : g->bias;
+  a.resid = g->resid; a.ldr = g->ldr; a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
+  a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux;
+  a.cbn = g->N / 64;
+  a.save_grad = (g->act == LAFS_GELU_SAVE_GRAD && (e == LAFS_EPI_BF16_GELU || e == LAFS_EPI_DGELU_BF16)) ? 1 : 0;
+  a.stamps = stamps;
+  const int mus = (g->M + UROWS - 1) / UROWS;
+  a.items = mus * a.cbn;
+  // one 8-wave workgroup per CU; equal contiguous item runs (at least ~4 items each)
+  int grid = 256;
+  while (grid > 8 && a.items / grid < 4) grid >>= 1;
+  if (grid_override > 0) grid = grid_override;
+  switch (e) {
+    case LAFS_EPI_BF16: return launch<LAFS_EPI_BF16, true, ABL>(a, grid, stream);
+    case LAFS_EPI_BF16_GELU:
+      return g->C != nullptr ? launch<LAFS_EPI_BF16_GELU, true, ABL>(a, grid, stream) : launch<LAFS_EPI_BF16_GELU, false, ABL>(a, grid, stream);
+    case LAFS_EPI_RESID_F32: return launch<LAFS_EPI_RESID_F32, true, ABL>(a, grid, stream);
+    default:
+      return a.save_grad ? launch<LAFS_EPI_DGELU_BF16, false, ABL>(a, grid, stream) : launch<LAFS_EPI_DGELU_BF16, true, ABL>(a, grid, stream);
+  }
+}
+
+}  // namespace kpp
+
+// LAFS_KPP = bit mask of the epilogues that take the ping-pong kernel instead of gemm_kres.hip (1 plain, 2 GELU, 4 residual,
+// 8 GELU'); the request must be K-resident-eligible in the first place.  lafs_set_kpp_mask overrides the environment at run time
+// (tests, A/B inside one process); -1 returns to the environment's value.
+static int g_kpp_override = -1;
+extern "C" int lafs_set_kpp_mask(int mask) {
+  const int old = g_kpp_override;
+  g_kpp_override = mask < 0 ? -1 : (mask & 15);
+  return old;
+}
+bool lafs_kpp_selected(const lafs_gemm_nt_args* g) {
+  static const int env_mask = [] { const char* v = getenv("LAFS_KPP"); return v != nullptr ? atoi(v) : 0; }();
+  static const int min_rows = [] { const char* v = getenv("LAFS_KPP_MIN_ROWS"); return v != nullptr ? atoi(v) : 2048; }();
+  const int mask = g_kpp_override >= 0 ? g_kpp_override : env_mask;
+  const int e = g->epilogue;
+  const int bit = e == LAFS_EPI_BF16 ? 1 : (e == LAFS_EPI_BF16_GELU ? 2 : (e == LAFS_EPI_RESID_F32 ? 4 : (e == LAFS_EPI_DGELU_BF16 ? 8 : 0)));
+  return (mask & bit) != 0 && g->M >= min_rows;
+}
+
+#ifndef LAFS_KPP_LAB
+int lafs_kpp_launch(const lafs_gemm_nt_args* g, hipStream_t stream) { return kpp::kpp_launch<0>(g, stream); }
+#endif

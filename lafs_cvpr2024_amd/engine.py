@@ -154,9 +154,10 @@ class LafsPretrainEngine:
         self.cut_offsets = [off(c) for c in self.cuts[1:]]                                   # arena offset where each run starts
         self.reducer = FlatReducer()
         if self.world > 1:
-            # the K-resident GEMM keeps two workgroups resident on every CU: leave some CUs to RCCL's kernels while gradients are on
-            # the wire (LAFS_COMM_CUS, default 16 of 256 in data-parallel runs; unmeasured on hardware: no multi-GPU box this round)
-            _lib.lib().lafs_set_comm_cus(int(os.environ.get("LAFS_COMM_CUS", "16")))
+            # LAFS_COMM_CUS=n (opt-in, default 0) shrinks the K-resident GEMM's grid by 2 n workgroups while gradients are on the
+            # wire.  It does not reserve CUs (the dispatcher still spreads the remaining workgroups over the chip) and has never been
+            # A/B-measured beside RCCL kernels, so it stays off until a multi-GPU box shows a gain.
+            _lib.lib().lafs_set_comm_cus(int(os.environ.get("LAFS_COMM_CUS", "0")))
         # Update pieces: ranges of the arena in the order their gradients become final -- the DINO head (31 of 53 M parameters at C2)
         # after the head backward, then each run of blocks after its segment of the trunk backward.  A piece's per-tensor norms,
         # clip + AdamW + teacher EMA + shadow refresh run on a stream of their own at the START of a later segment, beside that

@@ -72,16 +72,28 @@ def test_gemm_nt_epilogues(M, N, K):
     assert relerr(out, A.float() @ B.float().t()) < 2e-5 * math.sqrt(K)
 
 
+@pytest.fixture
+def kpp_mask(request):
+    """Route the K-resident requests to gemm_kres.hip (mask 0) or to its ping-pong form gemm_kpp.hip (mask 15) for one test."""
+    lib = _lib.lib()
+    old = lib.lafs_set_kpp_mask(request.param)
+    yield request.param
+    lib.lafs_set_kpp_mask(old)
+
+
+@pytest.mark.parametrize("kpp_mask", [0, 15], indirect=True)
 @pytest.mark.parametrize("M,N", [(2048 + 77, 384), (4096 + 5, 1152), (2560, 1536), (128 * 41 + 1, 1536), (128 * 70 + 33, 384)])
-def test_gemm_nt_k_resident_kernel(M, N):
-    """The K = 384 streaming shapes of the ViT-S trunk run on the K-resident kernel (gemm_kres.hip): every epilogue it covers
-    against fp32 torch, ragged row counts (last 128-row unit partly / wholly beyond M for some waves), in-place residual."""
+def test_gemm_nt_k_resident_kernel(M, N, kpp_mask):
+    """The K = 384 streaming shapes of the ViT-S trunk run on the K-resident kernels (gemm_kres.hip, and its ping-pong form
+    gemm_kpp.hip): every epilogue they cover against fp32 torch, ragged row counts (last row unit partly / wholly beyond M for
+    some waves), in-place residual."""
     K = 384
+    route = 2 if kpp_mask else 1
     A, B = rnd_bf(M, K, seed=11), rnd_bf(N, K, scale=0.1, seed=12)
     bias = torch.randn(N, generator=torch.Generator().manual_seed(13))
     ref = A.float() @ B.float().t() + bias
     Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
-    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 1, "expected the K-resident route"
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) == route, "expected the K-resident route"
     assert ops.gemm_nt(Ad[:1024], Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 0
     guard = 7.0
     out = torch.full((M + 64, N), guard, device=DEV, dtype=torch.bfloat16)
@@ -98,7 +110,7 @@ def test_gemm_nt_k_resident_kernel(M, N):
     sc = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9, 0.0, 1.0 / 0.9, 1.0 / 0.9, 1.0 / 0.9])
     resid = torch.randn(M, N, generator=torch.Generator().manual_seed(14))
     exp = resid + sc[row2seq.long()].unsqueeze(1) * ref
-    assert ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=resid.to(DEV), route_only=True) == 1
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=resid.to(DEV), route_only=True) == route
     out = ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=resid.to(DEV), seq_scale=sc.to(DEV), row2seq=row2seq.to(DEV))
     assert relerr(out, exp) < 2e-4
     inplace = resid.to(DEV)
@@ -107,7 +119,7 @@ def test_gemm_nt_k_resident_kernel(M, N):
     aux = rnd_bf(M, N, seed=15)
     x = aux.float().requires_grad_(True)
     F.gelu(x).sum().backward()
-    assert ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV), route_only=True) == 1
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV), route_only=True) == route
     out = ops.gemm_nt(Ad, Bd, _lib.EPI_DGELU_BF16, aux=aux.to(DEV))
     assert relerr(out.float(), (A.float() @ B.float().t()) * x.grad) < 1e-2
     # LAFS_GELU_SAVE_GRAD (what the trunk uses): gelu'(u) saved by the forward, multiplied in by the backward
