@@ -102,7 +102,8 @@ int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
 /* Which kernel lafs_gemm_nt runs for this request: 0 = the tiled LDS-DMA kernel (gemm.hip), 1 = the K-resident streaming kernel
  * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout), 2 = its
  * ping-pong form (gemm_kpp.hip: one 8-wave workgroup per CU, the MFMA turn of one half beside the epilogue turn of the other;
- * same requests, same results bit for bit). */
+ * same requests, same results bit for bit), 3 = the tiled kernel in its 128x384 / 12-wave form (whole N per workgroup: long
+ * reductions onto N = 384 whose tiles fit one round of the chip). */
 int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
 /* Which epilogues of the K-resident route take the ping-pong kernel: bit mask 1 plain, 2 GELU, 4 residual, 8 GELU'; -1 = the
  * value of LAFS_KPP in the environment (the default).  Returns the previous override.  Replaces nothing in the reference: it
@@ -294,12 +295,13 @@ int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_avg, float* 
                         const float* hyper, hipStream_t stream);
 /* The same two passes restricted to the tensors [seg_lo, seg_hi) = the chunks [chunk_lo, chunk_hi) (base pointers are those of the
  * whole arena): the engine updates a range of the arena as soon as its gradients are final, beside the rest of the backward. */
-int lafs_grad_sumsq_range(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int64_t chunk_lo, int64_t chunk_hi,
+int lafs_grad_sumsq_range(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int n_seg, int64_t chunk_lo, int64_t chunk_hi,
                           int seg_lo, int seg_hi, const float* hyper, float* chunk_sumsq, float* seg_sumsq, hipStream_t stream);
+/* n_chunks / n_seg are the sizes of the WHOLE arena: a range that leaves them is refused (LAFS_ESHAPE), not clipped. */
 int lafs_clip_adamw_ema_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* teacher,
-                              void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t chunk_lo, int64_t chunk_hi,
-                              const int32_t* seg_flags, int32_t* seg_step, int seg_lo, int seg_hi, const float* seg_sumsq,
-                              const float* hyper, hipStream_t stream);
+                              void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t n_chunks, int64_t chunk_lo,
+                              int64_t chunk_hi, const int32_t* seg_flags, int32_t* seg_step, int n_seg, int seg_lo, int seg_hi,
+                              const float* seg_sumsq, const float* hyper, hipStream_t stream);
 /* dst(bf16)[i] = src(f32)[i] */
 int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
 /* dst(f32)[i] = src(bf16)[i]   (gradients that travelled over the wire as bf16: LAFS_GRAD_WIRE=bf16, distributed.py) */

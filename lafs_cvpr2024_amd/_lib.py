@@ -94,8 +94,8 @@ _PROTOS = {
     "lafs_center_ema": [vp, vp, i32, f32, f32],
     "lafs_grad_sumsq": [vp, vp, i64, i32, vp, vp, vp],
     "lafs_clip_adamw_ema": [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp],
-    "lafs_grad_sumsq_range": [vp, vp, i64, i64, i64, i32, i32, vp, vp, vp],
-    "lafs_clip_adamw_ema_range": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, i32, i32, vp, vp],
+    "lafs_grad_sumsq_range": [vp, vp, i64, i32, i64, i64, i32, i32, vp, vp, vp],
+    "lafs_clip_adamw_ema_range": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, vp, vp, i32, i32, i32, vp, vp],
     "lafs_cast_bf16": [vp, vp, i64],
     "lafs_cast_f32": [vp, vp, i64],
     "lafs_droppath_scales": [vp, i32, i32, u32, vp, vp],

@@ -225,11 +225,9 @@ extern "C" int lafs_augment_views(const uint8_t* images, const int32_t* params, 
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(images && params && table && views && B > 0 && K > 0, "bad operand");
   const size_t lds = 3 * (size_t)NBYTE;
-  static bool configured = false;
-  if (!configured) {
+  {                                                   // per call (per-device attribute, cheap call): no process-wide flag
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(augment_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { lafs_set_error("lafs_augment_views: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
-    configured = true;
   }
   // one workgroup per CU (3 x 37 KB of LDS): 16 waves each to keep the CU busy
   hipLaunchKernelGGL(augment_kernel, dim3(B * K), dim3(1024), lds, stream, images, params, table, B, K, views);

@@ -709,6 +709,13 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict
 
 int g_debug_flags = 0;
 
+// 128x384 / 12-wave tiles (the whole N per workgroup) when the tiles fit one round of one workgroup per CU: see launch_nt
+bool wide_tile_shape(int M, int N, int splits) {
+  static const bool wide_on = [] { const char* v = getenv("LAFS_NT_WIDE"); return v == nullptr || v[0] != '0'; }();
+  const int mt = ceil_div(M, 128);
+  return wide_on && splits == 1 && N % 384 == 0 && mt * (N / 384) >= 160 && mt * (N / 384) <= 256;
+}
+
 template <int EPI>
 int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   // Shape heuristics from tools/bench_kernels.py on MI355X (ViT-S/B shapes):
@@ -763,9 +770,8 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   // 128x128 kernel; 345 tiles (student: a second round of 89) are slower, and so is a split into whole rounds here + the rest on
   // the 128x128 kernel (fc2 forward 92-98 against 83-86 us; tools/lab/nt_variants.py).  LAFS_NT_WIDE=0 switches it off (A/B).
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID_F32) {
-    static const bool wide_on = [] { const char* v = getenv("LAFS_NT_WIDE"); return v == nullptr || v[0] != '0'; }();
     const int mt = ceil_div(a.M, 128);
-    if (wide_on && bk64 && splits == 1 && a.N % 384 == 0 && mt * (a.N / 384) >= 160 && mt * (a.N / 384) <= 256) {
+    if (bk64 && wide_tile_shape(a.M, a.N, splits)) {
       hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 6>), dim3((unsigned)(mt * (a.N / 384)), 1, 1), dim3(768), 0, s, a);
       LAFS_LAUNCH_CHECK();
       return LAFS_OK;
@@ -796,7 +802,14 @@ int ksplit_len(int K, int splits) {
 
 extern "C" int lafs_gemm_nt_slices(int K, int splits) { return K >= 32 ? ceil_div(K, ksplit_len(K, splits)) : 1; }
 
-extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) { return (g != nullptr && lafs_kres_eligible(g)) ? (lafs_kpp_selected(g) ? 2 : 1) : 0; }
+extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) {
+  if (g == nullptr) return 0;
+  if (lafs_kres_eligible(g)) return lafs_kpp_selected(g) ? 2 : 1;
+  // the tiled kernel's 128x384 form (launch_nt): plain / residual epilogue, 64-deep stages (K % 64 == 0, K >= 640), no K split
+  const bool bk64 = g->K % 64 == 0 && g->K >= 640 && !(g_debug_flags & 2);
+  if ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_RESID_F32) && bk64 && wide_tile_shape(g->M, g->N, g->splits <= 1 ? 1 : g->splits)) return 3;
+  return 0;
+}
 
 extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   LAFS_CLEAR_ERROR();

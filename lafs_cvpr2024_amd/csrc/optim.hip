@@ -172,12 +172,12 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 // The training engine updates a range as soon as its gradients are final -- the DINO head while the trunk backward still runs,
 // each run of blocks while the next one is computed -- so that these HBM-bound passes overlap GEMM-heavy work instead of
 // forming a serial tail of the step.  Base pointers are those of the WHOLE arena.
-extern "C" int lafs_grad_sumsq_range(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int64_t chunk_lo, int64_t chunk_hi,
-                                     int seg_lo, int seg_hi, const float* hyper, float* chunk_sumsq, float* seg_sumsq,
+extern "C" int lafs_grad_sumsq_range(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int n_seg, int64_t chunk_lo,
+                                     int64_t chunk_hi, int seg_lo, int seg_hi, const float* hyper, float* chunk_sumsq, float* seg_sumsq,
                                      hipStream_t stream) {
   LAFS_CLEAR_ERROR();
-  LAFS_CHECK_ARG(grad && chunk_seg && hyper && chunk_sumsq && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31), "bad operand");
-  LAFS_CHECK_ARG(0 <= chunk_lo && chunk_lo < chunk_hi && chunk_hi <= n_chunks && 0 <= seg_lo && seg_lo < seg_hi, "bad range");
+  LAFS_CHECK_ARG(grad && chunk_seg && hyper && chunk_sumsq && seg_sumsq && n_chunks > 0 && n_chunks < (1ll << 31) && n_seg > 0, "bad operand");
+  LAFS_CHECK_ARG(0 <= chunk_lo && chunk_lo < chunk_hi && chunk_hi <= n_chunks && 0 <= seg_lo && seg_lo < seg_hi && seg_hi <= n_seg, "range outside the arena");
   const long nc = (long)(chunk_hi - chunk_lo);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3((unsigned)((nc + 3) / 4)), dim3(256), 0, stream, grad + chunk_lo * LAFS_CHUNK, nc,
                      chunk_sumsq + chunk_lo);
@@ -190,17 +190,19 @@ extern "C" int lafs_grad_sumsq_range(const float* grad, const int32_t* chunk_seg
 
 extern "C" int lafs_grad_sumsq(const float* grad, const int32_t* chunk_seg, int64_t n_chunks, int n_seg, const float* hyper,
                                float* chunk_sumsq, float* seg_sumsq, hipStream_t stream) {
-  return lafs_grad_sumsq_range(grad, chunk_seg, n_chunks, 0, n_chunks, 0, n_seg, hyper, chunk_sumsq, seg_sumsq, stream);
+  return lafs_grad_sumsq_range(grad, chunk_seg, n_chunks, n_seg, 0, n_chunks, 0, n_seg, hyper, chunk_sumsq, seg_sumsq, stream);
 }
 
 extern "C" int lafs_clip_adamw_ema_range(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* teacher,
-                                         void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t chunk_lo, int64_t chunk_hi,
-                                         const int32_t* seg_flags, int32_t* seg_step, int seg_lo, int seg_hi, const float* seg_sumsq,
-                                         const float* hyper, hipStream_t stream) {
+                                         void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t n_chunks, int64_t chunk_lo,
+                                         int64_t chunk_hi, const int32_t* seg_flags, int32_t* seg_step, int n_seg, int seg_lo, int seg_hi,
+                                         const float* seg_sumsq, const float* hyper, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && chunk_seg && seg_flags && seg_step && seg_sumsq && hyper, "null operand");
-  LAFS_CHECK_ARG(0 <= chunk_lo && chunk_lo < chunk_hi && chunk_hi < (1ll << 31) && 0 <= seg_lo && seg_lo < seg_hi, "bad range");
+  LAFS_CHECK_ARG(n_chunks > 0 && n_chunks < (1ll << 31) && n_seg > 0, "bad sizes");
+  LAFS_CHECK_ARG(0 <= chunk_lo && chunk_lo < chunk_hi && chunk_hi <= n_chunks && 0 <= seg_lo && seg_lo < seg_hi && seg_hi <= n_seg, "range outside the arena");
   hipLaunchKernelGGL(seg_step_kernel, dim3(ceil_div(seg_hi - seg_lo, 256)), dim3(256), 0, stream, seg_flags, seg_step, seg_lo, seg_hi, hyper);
+  LAFS_LAUNCH_CHECK();
   hipLaunchKernelGGL(clip_adamw_ema_kernel, dim3((unsigned)(chunk_hi - chunk_lo)), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq,
                      teacher, (bf16_t*)param_bf16, (bf16_t*)teacher_bf16, chunk_seg, seg_flags, seg_step, seg_sumsq, hyper, (long)chunk_lo);
   LAFS_LAUNCH_CHECK();
@@ -211,9 +213,10 @@ extern "C" int lafs_clip_adamw_ema(float* param, const float* grad, float* exp_a
                                    void* param_bf16, void* teacher_bf16, const int32_t* chunk_seg, int64_t n_chunks,
                                    const int32_t* seg_flags, int32_t* seg_step, int n_seg, const float* seg_sumsq,
                                    const float* hyper, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(n_chunks > 0 && n_seg > 0, "bad sizes");
-  return lafs_clip_adamw_ema_range(param, grad, exp_avg, exp_avg_sq, teacher, param_bf16, teacher_bf16, chunk_seg, 0, n_chunks, seg_flags,
-                                   seg_step, 0, n_seg, seg_sumsq, hyper, stream);
+  return lafs_clip_adamw_ema_range(param, grad, exp_avg, exp_avg_sq, teacher, param_bf16, teacher_bf16, chunk_seg, n_chunks, 0, n_chunks,
+                                   seg_flags, seg_step, n_seg, 0, n_seg, seg_sumsq, hyper, stream);
 }
 
 extern "C" int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream) {

@@ -228,11 +228,9 @@ extern "C" int lafs_randaug_apply(const uint8_t* images, uint8_t* out, const laf
   LAFS_CHECK_ARG(images && out && records && B > 0 && layers > 0, "bad operand");
   LAFS_CHECK_ARG(H >= 3 && W >= 3 && H * W <= MAXPIX, "images of 3x3 up to 112x112 pixels (the picture lives in LDS)");
   const size_t lds = 2 * (size_t)MAXBYTE;
-  static bool configured = false;
-  if (!configured) {
+  {                                                   // per call: the attribute is per device and the call is cheap; a process-wide flag is neither
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(randaug_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { lafs_set_error("lafs_randaug_apply: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e)); return (int)e; }
-    configured = true;
   }
   hipLaunchKernelGGL(randaug_kernel, dim3(B), dim3(512), lds, stream, images, out, records, B, H, W, layers, chw);
   LAFS_LAUNCH_CHECK();

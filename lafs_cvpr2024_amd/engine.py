@@ -169,6 +169,10 @@ class LafsPretrainEngine:
         seg_at = {self.sa.offsets[n]: i for i, n in enumerate(self.sa.names)}
         seg_at[self.sa.size] = self.sa.n_seg
         self.piece_segs = [(seg_at[lo], seg_at[hi]) for lo, hi in self.pieces]
+        chunk_seg = self.sa.chunk_seg.cpu()
+        for (lo, hi), (s_lo, s_hi) in zip(self.pieces, self.piece_segs):        # a piece is whole tensors: its first / last chunk carry its first / last segment
+            assert lo % _lib.CHUNK == 0 and hi % _lib.CHUNK == 0 and 0 <= s_lo < s_hi <= self.sa.n_seg
+            assert int(chunk_seg[lo // _lib.CHUNK]) == s_lo and int(chunk_seg[hi // _lib.CHUNK - 1]) == s_hi - 1, (lo, hi, s_lo, s_hi)
         n_segments = len(self.cuts) + 1                     # forward, the runs of the trunk backward, the final update
         slack = 1 if self.world > 1 else 0
         serial = os.environ.get("LAFS_OPT_OVERLAP", "1") == "0"          # A/B knob: every piece in the final segment
@@ -283,11 +287,11 @@ class LafsPretrainEngine:
         sa, ta = self.sa, self.ta
         (lo, hi), (s_lo, s_hi) = self.pieces[p], self.piece_segs[p]
         c_lo, c_hi = lo // _lib.CHUNK, hi // _lib.CHUNK
-        call("lafs_grad_sumsq_range", _p(sa.grad), _p(sa.chunk_seg), sa.n_chunks, c_lo, c_hi, s_lo, s_hi, _p(self.hyper),
+        call("lafs_grad_sumsq_range", _p(sa.grad), _p(sa.chunk_seg), sa.n_chunks, sa.n_seg, c_lo, c_hi, s_lo, s_hi, _p(self.hyper),
              _p(sa.chunk_sumsq), _p(sa.seg_sumsq))
         call("lafs_clip_adamw_ema_range", _p(sa.master), _p(sa.grad), _p(sa.exp_avg), _p(sa.exp_avg_sq), _p(ta.master),
-             _p(sa.shadow), _p(ta.shadow), _p(sa.chunk_seg), c_lo, c_hi, _p(sa.seg_flags), _p(sa.seg_step), s_lo, s_hi,
-             _p(sa.seg_sumsq), _p(self.hyper))
+             _p(sa.shadow), _p(ta.shadow), _p(sa.chunk_seg), sa.n_chunks, c_lo, c_hi, _p(sa.seg_flags), _p(sa.seg_step), sa.n_seg,
+             s_lo, s_hi, _p(sa.seg_sumsq), _p(self.hyper))
 
     def _seg_update(self):
         call("lafs_center_ema", _p(self.dino_loss.center), _p(self.colsum), self.K, 1.0 / (2 * self.B * self.world),

@@ -147,6 +147,43 @@ def test_c1_config_vit_tiny_step_matches_oracle(nl, K):
     assert float(errs.median()) < 1e-5 and float(errs.max()) < 5e-4 * 0.004 * 50      # EMA moves by (1-m)*|delta| <= 0.004*lr-ish
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_overlapped_update_pieces_equal_the_serial_tail(use_graph, monkeypatch):
+    """The optimizer runs in update pieces on a stream of their own beside later backward segments (LAFS_OPT_OVERLAP, default on);
+    LAFS_OPT_OVERLAP=0 runs every piece in the final segment.  Arithmetic and order within a tensor are the same in both, so the
+    per-tensor gradient norms, the student weights, the Adam moments and the EMA teacher must agree to fp32 round-off (the LayerNorm
+    parameter gradients are fp32 atomics: ~1e-7 run to run) -- an update that read a gradient slice before it was final would be
+    orders of magnitude off.  Two steps, so that the second forward runs on weights the overlapped update wrote."""
+    fx = load_golden("f5_lafs_step")
+    lrs, wds, moms = fx["hyper"].tolist()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LAFS_OPT_OVERLAP", mode)
+        student, teacher, crit, eng = _build(fx, use_graph)
+        if mode == "1":
+            assert len(set(eng.piece_runs_at)) > 1, "the overlapped schedule spreads the pieces over the segments"
+        else:
+            assert len(set(eng.piece_runs_at)) == 1
+        tt = crit.teacher_temp_schedule
+        losses = []
+        for s in range(2):
+            crops = [fx[f"s{s}.crop{i}"] for i in range(5)]
+            losses.append(float(eng.step(crops, lr=lrs[s], wd=wds[s], momentum=moms[s], teacher_temp=float(tt[s]), epoch=s).item()))
+        torch.cuda.synchronize()
+        res[mode] = dict(losses=losses, sumsq=eng.sa.seg_sumsq.clone(), master=eng.sa.master.clone(), m=eng.sa.exp_avg.clone(),
+                         v=eng.sa.exp_avg_sq.clone(), teacher=eng.ta.master.clone(), center=crit.center.clone())
+    a, b = res["1"], res["0"]
+    assert abs(a["losses"][0] - b["losses"][0]) <= 1e-6 * abs(b["losses"][0]) and abs(a["losses"][1] - b["losses"][1]) <= 1e-5 * abs(b["losses"][1]), (a["losses"], b["losses"])
+    torch.testing.assert_close(a["sumsq"], b["sumsq"], rtol=1e-4, atol=1e-12)
+    for k in ("m", "v", "center"):
+        torch.testing.assert_close(a[k], b[k], rtol=1e-4, atol=1e-9)
+    # weights: Adam's m / sqrt(v) flips sign where a gradient is round-off; bound the count and the size of such flips
+    for k in ("master", "teacher"):
+        d = (a[k] - b[k]).abs()
+        assert float(d.max()) <= 2.1 * sum(lrs[:2]), (k, float(d.max()))
+        assert float((d > 1e-6).float().mean()) < 2e-3, (k, float((d > 1e-6).float().mean()))
+
+
 def test_pinned_ring_uploads_survive_a_host_that_runs_ahead():
     """Per-step host->device uploads (hyper-parameters, augmentation records) while the GPU is far behind the host: every
     upload must deliver ITS values (a single reused pinned buffer would hand later steps' values to earlier steps)."""
