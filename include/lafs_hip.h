@@ -281,6 +281,7 @@ enum { LAFS_SEG_DECAY = 1, LAFS_SEG_LAST_LAYER = 2, LAFS_SEG_TRAINABLE = 4,
 enum { LAFS_HP_LR = 0, LAFS_HP_WD, LAFS_HP_BETA1, LAFS_HP_BETA2, LAFS_HP_EPS, LAFS_HP_CLIP, LAFS_HP_EMA_M,
        LAFS_HP_FREEZE_LAST, LAFS_HP_GRAD_SCALE, LAFS_HP_WD_LOW,
        LAFS_HP_STEP /* optimisation step count (as a float): seeds the per-step DropPath masks of a replayed graph */,
+       LAFS_HP_MIX_LAM /* mixup lambda of this fine-tune micro-step (lam_dev of lafs_mixup_normalize / lafs_margin_softmax_ce_bf16) */,
        LAFS_HP_COUNT = 16 };
 /* seg_sumsq(f32)[n_seg] = sum of (grad_scale*g)^2 per segment -- the per-tensor norms of utils.clip_gradients
  * (utils.py:132-141).  Two passes through chunk_sumsq(f32)[n_chunks] scratch, fixed summation order: no atomics, nothing
@@ -309,6 +310,9 @@ int lafs_cast_f32(const void* src, float* dst, int64_t n, hipStream_t stream);
 /* Data-parallel runs: leave `cus` compute units to the collective library's kernels -- the K-resident GEMM (otherwise two resident
  * workgroups on every CU) shrinks its grid to 2 * (256 - cus) workgroups.  0 (default) = the whole chip.  Returns the value set. */
 int lafs_set_comm_cus(int cus);
+/* dst(bf16)[c, r] = src(bf16)[r, c]: operand transposes of the fine-tune margin head (dL/dcos [B, C] -> [C, B] feeds both class-
+ * gradient GEMMs, train_largescale.py:820-867's autograd through ViT_face.py:49-89; was a torch .t().contiguous()). */
+int lafs_transpose_bf16(const void* src, int rows, int cols, int ld_src, void* dst, int ld_dst, hipStream_t stream);
 /* dst(bf16)[c, r] = src(f32)[r, c]   (W^T shadows used by the dgrad GEMMs) */
 int lafs_transpose_cast_bf16(const float* src, int rows, int cols, void* dst, int ld_dst, hipStream_t stream);
 /* All W^T shadows of an arena in ONE launch.  table(i64, device)[4*i..] = {src offset into master, rows, cols, dst offset
@@ -414,8 +418,22 @@ int lafs_shard_margin_rowsum(const float* cos, int ld, int B, int S, const int32
                              int margin_type, const float* gmax, float* rowsum, float* target_logit, hipStream_t stream);
 int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m, int margin_type,
                            const float* gmax, const float* Z, float grad_scale, hipStream_t stream);
-/* x(f32) [B,3,S,S]: x = lam*x + (1-lam)*flip_batch(x) in place, from u8 or f32 source with (x/255*2-1) folded in. */
-int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, hipStream_t stream);
+/* x(f32) [B,3,S,S]: x = lam*x + (1-lam)*flip_batch(x), from a u8 source with (x/255*2-1) folded in (util/mixup_my.py:189-200 on
+ * the loader's tensors, train_largescale.py:842-846).  lam_dev != NULL: lambda is read from DEVICE memory when the kernel runs (a
+ * captured fine-tune step replays with a new lambda per micro-step); otherwise `lam`. */
+int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, const float* lam_dev, hipStream_t stream);
+/* The fused margin-softmax + soft-target CE of lafs_margin_softmax_ce over (row, chunk) workgroups, for the captured fine-tune
+ * step: cos(f32) [B, ld] is READ-ONLY, dL/dcos leaves as bf16 in dcos [B, lddc] (pad columns [C, lddc) zeroed) -- the operand of
+ * the two class-gradient GEMMs; y2 == NULL: the mixup partner of row b is row B-1-b; lam_dev != NULL: lambda from device memory.
+ * row_ws f32 [B], part_ws f32 [B * 32].  Same references as lafs_margin_softmax_ce. */
+int lafs_margin_softmax_ce_bf16(const float* cos, int ld, int B, int C, const int32_t* y1, const int32_t* y2, float lam,
+                                const float* lam_dev, float s, float m, int margin_type, float loss_scale, void* dcos, int lddc,
+                                float* loss_out, float* row_ws, float* part_ws, hipStream_t stream);
+/* dst(i32)[n] = src(i64)[n]: the loader's int64 labels (train_largescale.py:842) into the kernels' index type without an ATen cast */
+int lafs_cast_i64_i32(const int64_t* src, int32_t* dst, int n, hipStream_t stream);
+/* Patch-vector gradient f32 [B, (S/8)^2, 192] -> image gradient f32 [B, 3, S, S]: the inverse re-indexing of lafs_patchify (the
+ * landmark branch differentiates through the patches, face_pre_pro/ViT_face.py:679-711; was a torch permute + copy). */
+int lafs_unpatchify_f32(const float* dpatch, int B, int S, int order, float* dimg, hipStream_t stream);
 /* ------------------------------------------------------------------------------------------------
  * Frozen landmark CNN, inference only (MobileNetV3-large trunk, face_pre_pro/mobilenet.py:224-313, called by
  * face_landmark_4simmin_glo_loc.forward, face_pre_pro/ViT_face.py:1338-1344).  NHWC bf16 activations, channel counts padded

@@ -57,7 +57,7 @@ ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = range(4)
 PATCH_ORDER_CHW, PATCH_ORDER_HWC = 0, 1
 CHUNK = 1024
 SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE, SEG_LOW_DECAY, SEG_OVERWRITTEN = 1, 2, 4, 8, 16
-HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE, HP_WD_LOW, HP_STEP = range(11)
+HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE, HP_WD_LOW, HP_STEP, HP_MIX_LAM = range(12)
 HP_COUNT = 16
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
@@ -138,7 +138,11 @@ _PROTOS = {
     "lafs_augment_views": [vp, vp, vp, i32, i32, vp],
     "lafs_randaug_apply": [vp, vp, vp, i32, i32, i32, i32, i32],
     "lafs_landmark_theta": [vp, i32, i32, vp, f32, vp, i32, vp],
-    "lafs_mixup_normalize": [vp, vp, i32, i32, f32],
+    "lafs_mixup_normalize": [vp, vp, i32, i32, f32, vp],
+    "lafs_margin_softmax_ce_bf16": [vp, i32, i32, i32, vp, vp, f32, vp, f32, f32, i32, f32, vp, i32, vp, vp, vp],
+    "lafs_cast_i64_i32": [vp, vp, i32],
+    "lafs_transpose_bf16": [vp, i32, i32, i32, vp, i32],
+    "lafs_unpatchify_f32": [vp, i32, i32, i32, vp],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],
     "lafs_patch_gather_bwd": [vp, vp, vp, i32, i32, i32, vp, vp],
 }

@@ -68,6 +68,117 @@ __global__ __launch_bounds__(256) void margin_ce_kernel(float* __restrict__ cosv
   }
 }
 
+// The same loss over (row, chunk) workgroups: one workgroup per row streams 824 KB twice at C = 205 990 and 128 rows leave half
+// the chip idle (556 us, latency-bound); NCH chunks per row fill it.  Pass 1: per-chunk (max, sum exp) of the margin logits; pass 2:
+// every workgroup folds its row's NCH partials, writes d loss / d cos of its chunk as bf16 (the operand format of the two
+// gradient GEMMs: no fp32 round trip, no separate cast) and chunk 0 the row loss.  cos is read-only.  y2 == nullptr: the mixup
+// partner of row b is row B-1-b (Mixup batch mode, util/mixup_my.py:189-200).  lam_dev != nullptr: lambda read from device memory.
+constexpr int MCE_NCH = 16;
+__device__ __forceinline__ void mce_labels(const int* y1, const int* y2, int b, int B, int& a1, int& a2) {
+  a1 = y1[b];
+  a2 = (y2 != nullptr) ? y2[b] : y1[B - 1 - b];
+}
+__global__ __launch_bounds__(256) void margin_ce_part_kernel(const float* __restrict__ cosv, int ld, int B, int C, const int* __restrict__ y1,
+                                                            const int* __restrict__ y2, float lam, const float* __restrict__ lam_dev, float s,
+                                                            float m, int type, float* __restrict__ part) {
+  __shared__ float sm[4], ss[4];
+  if (lam_dev != nullptr) lam = *lam_dev;
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const float* row = cosv + (size_t)b * ld;
+  int a1, a2;
+  mce_labels(y1, y2, b, B, a1, a2);
+  auto label = [&](int k) { return ((k == a1) ? lam : 0.f) + ((k == a2) ? (1.f - lam) : 0.f); };
+  const int per = ((C + MCE_NCH - 1) / MCE_NCH + 3) & ~3, k0 = ch * per, k1 = min(C, k0 + per);
+  float mx = -INFINITY, sum = 0.f;
+  for (int k = k0 + threadIdx.x; k < k1; k += 256) {
+    const float z = margin_logit(row[k], label(k), s, m, type);
+    if (z > mx) { sum = sum * __expf(mx - z) + 1.f; mx = z; } else { sum += __expf(z - mx); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float mo = __shfl_xor(mx, o, 64), so = __shfl_xor(sum, o, 64);
+    const float mn = fmaxf(mx, mo);
+    sum = (mn == -INFINITY) ? 0.f : sum * __expf(mx - mn) + so * __expf(mo - mn);
+    mx = mn;
+  }
+  if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = mx; ss[threadIdx.x >> 6] = sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    float S = 0.f;
+    for (int w = 0; w < 4; ++w) if (sm[w] != -INFINITY) S += ss[w] * __expf(sm[w] - M);
+    part[((size_t)b * MCE_NCH + ch) * 2] = M;
+    part[((size_t)b * MCE_NCH + ch) * 2 + 1] = S;
+  }
+}
+__global__ __launch_bounds__(256) void margin_ce_grad_kernel(const float* __restrict__ cosv, int ld, int B, int C, const int* __restrict__ y1,
+                                                            const int* __restrict__ y2, float lam, const float* __restrict__ lam_dev, float s,
+                                                            float m, int type, float gscale, const float* __restrict__ part,
+                                                            bf16_t* __restrict__ dcos, int lddc, float* __restrict__ row_loss) {
+  if (lam_dev != nullptr) lam = *lam_dev;
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const float* row = cosv + (size_t)b * ld;
+  int a1, a2;
+  mce_labels(y1, y2, b, B, a1, a2);
+  auto label = [&](int k) { return ((k == a1) ? lam : 0.f) + ((k == a2) ? (1.f - lam) : 0.f); };
+  float M = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < MCE_NCH; ++c) M = fmaxf(M, part[((size_t)b * MCE_NCH + c) * 2]);
+  float S = 0.f;
+#pragma unroll
+  for (int c = 0; c < MCE_NCH; ++c) {
+    const float mc = part[((size_t)b * MCE_NCH + c) * 2];
+    if (mc != -INFINITY) S += part[((size_t)b * MCE_NCH + c) * 2 + 1] * __expf(mc - M);
+  }
+  const float lse = M + __logf(S);
+  if (ch == 0 && threadIdx.x == 0) {
+    float dot = label(a1) * margin_logit(row[a1], label(a1), s, m, type);
+    if (a2 != a1) dot += label(a2) * margin_logit(row[a2], label(a2), s, m, type);
+    row_loss[b] = lse - dot;
+  }
+  const int per = ((C + MCE_NCH - 1) / MCE_NCH + 3) & ~3, k0 = ch * per, k1 = min(C, k0 + per);
+  bf16_t* drow = dcos + (size_t)b * lddc;
+  for (int k = k0 + 4 * threadIdx.x; k < k1; k += 1024) {           // 4 consecutive classes per thread: 16-byte loads, 8-byte stores
+    if (k + 3 < k1) {
+      const float4 c4 = *reinterpret_cast<const float4*>(row + k);
+      const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+      float g[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float y = label(k + e);
+        g[e] = gscale * (__expf(margin_logit(cv[e], y, s, m, type) - lse) - y) * margin_dlogit(cv[e], y, s, m, type);
+      }
+      *reinterpret_cast<uint2*>(drow + k) = make_uint2(pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]));
+    } else {
+      for (int e = 0; e < 4 && k + e < k1; ++e) {
+        const float c = row[k + e], y = label(k + e);
+        drow[k + e] = f2bf(gscale * (__expf(margin_logit(c, y, s, m, type) - lse) - y) * margin_dlogit(c, y, s, m, type));
+      }
+    }
+  }
+  // pad columns [C, lddc) of the gradient operand are zero (chunk NCH-1 owns them)
+  if (ch == MCE_NCH - 1)
+    for (int k = C + threadIdx.x; k < lddc; k += 256) drow[k] = 0;
+}
+
+__global__ __launch_bounds__(256) void cast_i64_i32_kernel(const long long* __restrict__ src, int* __restrict__ dst, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (int)src[i];
+}
+
+// patch-vector gradient [B, r*r, 192] -> image gradient [B, 3, 8r, 8r]: the inverse re-indexing of lafs_patchify
+// (order 0: '(c p1 p2)' vectors of the conv patch embedding, 1: '(p1 p2 c)' of Part-fViT's Rearrange)
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ dp, int B, int r, int order, float* __restrict__ dimg) {
+  const int S = 8 * r;
+  const size_t total = (size_t)B * 3 * S * S;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % S), y = (int)((i / S) % S), c = (int)((i / ((size_t)S * S)) % 3), b = (int)(i / ((size_t)3 * S * S));
+    const int pi = y >> 3, pj = x >> 3, u = y & 7, v = x & 7;
+    const int e = order == 1 ? (u * 8 + v) * 3 + c : c * 64 + u * 8 + v;
+    dimg[i] = dp[((size_t)b * r * r + pi * r + pj) * 192 + e];
+  }
+}
+
 __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, int n, float scale, float* __restrict__ out) {
   __shared__ float red[4];
   float a = 0.f;
@@ -79,7 +190,8 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ v, 
 }
 
 __global__ __launch_bounds__(256) void mixup_norm_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int B, size_t per,
-                                                        float lam) {
+                                                        float lam, const float* __restrict__ lam_dev) {
+  if (lam_dev != nullptr) lam = *lam_dev;                // a captured step reads this micro-step's lambda from device memory
   const size_t total = (size_t)B * per;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t b = i / per, r = i % per;
@@ -245,13 +357,48 @@ extern "C" int lafs_margin_softmax_ce(float* cos, int ld, int B, int C, const in
   return LAFS_OK;
 }
 
-extern "C" int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, hipStream_t stream) {
+extern "C" int lafs_margin_softmax_ce_bf16(const float* cos, int ld, int B, int C, const int32_t* y1, const int32_t* y2, float lam,
+                                           const float* lam_dev, float s, float m, int margin_type, float loss_scale, void* dcos, int lddc,
+                                           float* loss_out, float* row_ws, float* part_ws, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(cos && y1 && dcos && loss_out && row_ws && part_ws && B > 0 && C > 0 && ld >= C && lddc >= C, "bad operand");
+  LAFS_CHECK_ARG(ld % 4 == 0 && lddc % 4 == 0, "row strides must be multiples of 4 elements");
+  LAFS_CHECK_ARG(margin_type == 0 || margin_type == 1, "margin_type must be 0 (CosFace) or 1 (ArcFace)");
+  hipLaunchKernelGGL(margin_ce_part_kernel, dim3(MCE_NCH, B), dim3(256), 0, stream, cos, ld, B, C, y1, y2, lam, lam_dev, s, m, margin_type, part_ws);
+  LAFS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(margin_ce_grad_kernel, dim3(MCE_NCH, B), dim3(256), 0, stream, cos, ld, B, C, y1, y2, lam, lam_dev, s, m, margin_type,
+                     loss_scale / (float)B, part_ws, (bf16_t*)dcos, lddc, row_ws);
+  LAFS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, stream, row_ws, B, 1.0f / (float)B, loss_out);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cast_i64_i32(const int64_t* src, int32_t* dst, int n, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(src && dst && n > 0, "bad operand");
+  hipLaunchKernelGGL(cast_i64_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const long long*)src, dst, n);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_unpatchify_f32(const float* dpatch, int B, int S, int order, float* dimg, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(dpatch && dimg && B > 0 && S > 0 && S % 8 == 0 && (order == 0 || order == 1), "bad operand");
+  size_t blocks = ((size_t)B * 3 * S * S + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dpatch, B, S / 8, order, dimg);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_mixup_normalize(const uint8_t* src_u8, float* dst, int B, int S, float lam, const float* lam_dev, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(src_u8 && dst && B > 0 && S > 0, "bad operand");
   const size_t per = (size_t)3 * S * S;
   size_t blocks = ((size_t)B * per + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(mixup_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src_u8, dst, B, per, lam);
+  hipLaunchKernelGGL(mixup_norm_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src_u8, dst, B, per, lam, lam_dev);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

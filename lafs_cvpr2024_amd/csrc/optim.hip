@@ -166,7 +166,32 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
   }
 }
 
+// dst[c, r] = src[r, c], bf16 both sides; 64x64 tiles through LDS, 16-byte pieces on both sides when the shapes allow
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int rows, int cols, int lds_, bf16_t* __restrict__ dst,
+                                                            int ldd) {
+  __shared__ bf16_t tile[64][66];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int j = i >> 6, k = i & 63, r = r0 + j, c = c0 + k;
+    tile[j][k] = (r < rows && c < cols) ? src[(size_t)r * lds_ + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int j = i >> 6, k = i & 63, c = c0 + j, r = r0 + k;
+    if (c < cols && r < rows) dst[(size_t)c * ldd + r] = tile[k][j];
+  }
+}
+
 }  // namespace
+
+extern "C" int lafs_transpose_bf16(const void* src, int rows, int cols, int ld_src, void* dst, int ld_dst, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "bad operand");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3(ceil_div(cols, 64), ceil_div(rows, 64)), dim3(256), 0, stream, (const bf16_t*)src, rows, cols,
+                     ld_src, (bf16_t*)dst, ld_dst);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
 
 // Range forms: the tensors [seg_lo, seg_hi) = the chunks [chunk_lo, chunk_hi) of the arena (a tensor is a whole number of chunks).
 // The training engine updates a range as soon as its gradients are final -- the DINO head while the trunk backward still runs,

@@ -1,10 +1,16 @@
 """Fused Part-fViT + CosFace fine-tune micro-step (reference train_largescale.py:785-891) on the HIP kernels.
 
-    u8 batch -> (x/255*2-1) + batch mixup (one kernel) -> Part-fViT trunk -> L2-normalised embedding x L2-normalised class
-    centres (MFMA GEMM) -> fused margin + softmax + soft-target CE (the dense [B, C] mixup target is never built: it has
-    <= 2 non-zeros per row) -> backward -> every `acc_step` micro-steps: AdamW over the flat arena.
+    u8 batch -> (x/255*2-1) + batch mixup (one kernel) -> [trainable landmark CNN -> theta -> patch gather] -> Part-fViT trunk ->
+    L2-normalised embedding x L2-normalised class centres (MFMA GEMM) -> fused margin + softmax + soft-target CE (the dense [B, C]
+    mixup target is never built: it has <= 2 non-zeros per row) -> backward -> every `acc_step` micro-steps: AdamW over the flat arena.
+
+Round 4: every per-step tensor is allocated once, no ATen kernel is left in a micro-step (labels, DropPath masks, operand
+transposes, the image gradient re-indexing and the gradient zeroing are lafs_* launches), the mixup lambda / step counter are read
+from device memory, and the whole micro-step is ONE hipGraph (two captured variants: the first micro-step of an accumulation
+window WRITES the block and class-table weight gradients instead of accumulating into a zeroed 1 GB arena).  The block weight
+gradients can run on a second stream inside the graph (LAFS_FT_WGRAD_STREAM=1; measured neutral, off by default).  Data-parallel
+runs and the class-sharded head keep the eager form (their collectives sit between the kernels).
 """
-import math
 import os
 
 import numpy as np
@@ -35,9 +41,10 @@ def finetune_decay_group(name, param):
 
 class FinetuneEngine:
     def __init__(self, backbone: ViT_face_landmark_patch8, batch_size, acc_step=3, mixup_alpha=0.2, mixup_prob=0.1,
-                 s=64.0, m=0.4, margin_type=0, image_size=112, device=None, sharded_head=None):
+                 s=64.0, m=0.4, margin_type=0, image_size=112, device=None, sharded_head=None, use_graph=None):
         """margin_type 0 = CosFace (the reference), 1 = ArcFace (parity unpinned), on the dense `backbone.loss.weight` head;
-        `sharded_head` (a partial_fc.PartialFC) replaces it by the class-sharded head (hard labels: mixup is off)."""
+        `sharded_head` (a partial_fc.PartialFC) replaces it by the class-sharded head (hard labels: mixup is off).
+        use_graph: None = capture the micro-step whenever it is capturable (single rank, dense head; LAFS_FT_GRAPH=0 disables)."""
         if not isinstance(backbone, ViT_face_landmark_patch8) or (sharded_head is None and not hasattr(backbone, "loss")):
             raise _lib.LafsHipError("FinetuneEngine drives ViT_face_landmark_patch8(loss_type='CosFace') or a sharded head")
         if batch_size % 8:
@@ -54,10 +61,12 @@ class FinetuneEngine:
         self.C = backbone.loss.out_features if sharded_head is None else 8
         self.Cpad = (self.C + 127) // 128 * 128
         self.D = backbone.dim
+        self.S = image_size
         self.geom = Fn.geometry([(batch_size, image_size)], self.device)
-        dev = self.device
+        dev, a, m, B, D = self.device, self.arena, backbone, batch_size, self.D
         self.hyper = torch.zeros(_lib.HP_COUNT, device=dev, dtype=f32)
         self.hyper_ring = PinnedRing((_lib.HP_COUNT,), f32)     # asynchronous upload; a pageable copy would block the host
+        self._hp = {}                                            # host copy of the hyper-parameters (every upload rewrites the whole vector)
         # data parallelism (reference: DDP bucketed all-reduce overlapped with backward, train_largescale.py:676-677, 867): on the
         # last micro-step of an accumulation window the flat gradient goes out over RCCL in slices AS THE BACKWARD RETIRES
         # THEM -- the 0.6 GB margin head first (it is final before the trunk backward starts), then runs of blocks from the top,
@@ -65,91 +74,209 @@ class FinetuneEngine:
         # per micro-step is the same sum (no_sync semantics).
         self.reducer = FlatReducer()
         self.grad_slices = 4
-        names = backbone._spec.trunk.block_names
-        self.block0 = self.arena.offsets[names[0]["ln1_g"]]
-        self.block_off = [self.arena.offsets[n["ln1_g"]] for n in names] + [self.arena.offsets[backbone._spec.prefix + backbone._spec.final_g]]
-        hn = backbone._spec.prefix + "loss.weight"
-        self.head_off = self.arena.offsets[hn] if (sharded_head is None) else self.arena.size
+        names = m._spec.trunk.block_names
+        self.block0 = a.offsets[names[0]["ln1_g"]]
+        self.block_off = [a.offsets[n["ln1_g"]] for n in names] + [a.offsets[m._spec.prefix + m._spec.final_g]]
+        self.wname = m._spec.prefix + "loss.weight"
+        self.head_off = a.offsets[self.wname] if (sharded_head is None) else a.size
         self._reduced = False
-        self.ones = torch.ones(self.C, device=dev, dtype=f32)
-        self.x = torch.empty(batch_size, 3, image_size, image_size, device=dev, dtype=f32)
-        self.cos = torch.empty(batch_size, self.Cpad, device=dev, dtype=f32)
-        self.dcos = torch.zeros(batch_size, self.Cpad, device=dev, dtype=bf16)
-        self.wn = torch.empty(self.Cpad, self.D, device=dev, dtype=bf16)
-        self.inv_w = torch.empty(self.C, device=dev, dtype=f32)
-        self.dwn = torch.zeros(self.Cpad, self.D, device=dev, dtype=f32)
+        # tensors whose gradient is WRITTEN by its producer on the first micro-step of an accumulation window (block weights: wgrad
+        # fold with accumulate = 0; class table: weight-norm backward): that micro-step zeroes only the others (lafs_zero_chunks)
+        flags = a.seg_flags.cpu().tolist()
+        over = {nm[k] for nm in names for k in ("w_qkv", "w_proj", "w_fc1", "w_fc2")}
+        if sharded_head is None:
+            over.add(self.wname)
+        for i, name in enumerate(a.names):
+            if name in over:
+                flags[i] |= _lib.SEG_OVERWRITTEN
+        a.seg_flags.copy_(torch.tensor(flags, dtype=torch.int32))
+        # ---- static buffers of a micro-step
+        S = image_size
+        self.in_u8 = torch.zeros(B, 3, S, S, device=dev, dtype=torch.uint8)
+        self.y1 = torch.zeros(B, device=dev, dtype=torch.int32)
+        self.x = torch.empty(B, 3, S, S, device=dev, dtype=f32)
+        self.img_in = torch.empty(B, 3, S, S, device=dev, dtype=f32)
         self.loss = torch.zeros(1, device=dev, dtype=f32)
-        self.row_ws = torch.empty(batch_size, device=dev, dtype=f32)
-        self.micro = 0
+        self.g_buf = torch.empty(self.geom.n_tok, D, device=dev, dtype=f32)
+        self.x_in = torch.empty(self.geom.n_tok, D, device=dev, dtype=f32)
+        self.x_out = torch.empty(self.geom.n_tok, D, device=dev, dtype=f32)
+        self.demb = torch.empty(B, D, device=dev, dtype=f32)
+        self.drop = (torch.empty(m.depth, 2, self.geom.n_seq, device=dev, dtype=f32) if m.drop_path_rate else None)
+        self.keep = (torch.full((m.depth,), 1.0 - m.drop_path_rate, device=dev, dtype=f32) if m.drop_path_rate else None)
+        self.drop_seed = 0x0F17E
+        self.pos_rows = a.view(a.master, m._spec.prefix + "pos_embedding").view(-1, D)[: self.geom.npatch(0) + 1]
+        self.dpos_rows = a.view(a.grad, m._spec.prefix + "pos_embedding").view(-1, D)[: self.geom.npatch(0) + 1]
+        if sharded_head is None:
+            self.ones = torch.ones(self.C, device=dev, dtype=f32)
+            self.cos = torch.empty(B, self.Cpad, device=dev, dtype=f32)
+            self.dcos = torch.zeros(B, self.Cpad, device=dev, dtype=bf16)
+            self.dcos_t = torch.zeros(self.Cpad, B, device=dev, dtype=bf16)
+            self.wn = torch.empty(self.Cpad, D, device=dev, dtype=bf16)
+            self.inv_w = torch.empty(self.C, device=dev, dtype=f32)
+            self.dwn = torch.empty(self.Cpad, D, device=dev, dtype=f32)
+            self.row_ws = torch.empty(B, device=dev, dtype=f32)
+            self.part_ws = torch.empty(B * 32, device=dev, dtype=f32)
+            self.xn = torch.empty(B, D, device=dev, dtype=bf16)
+            self.xn_t = torch.empty(D, B, device=dev, dtype=bf16)
+            self.inv_x = torch.empty(B, device=dev, dtype=f32)
+            self.dxn = torch.empty(B, D, device=dev, dtype=f32)
+            self.dxn_ws = ops.wgrad_workspace(self.Cpad, B, D, dev)                 # d(emb_n): reduction over the classes
+            self.dwn_ws = None if B % 32 == 0 else ops.wgrad_workspace(B, self.Cpad, D, dev)
+        self.dmosaic = torch.empty(B, 3, S, S, device=dev, dtype=f32) if m.with_land else None
+        self.dth = None
+        self.micro = 0                                   # micro-steps taken (seeds the per-step masks)
+        self._since_opt = 0                              # ... since the last optimizer step
+        # optimizer_step leaves the (dead) gradients in place: the next micro-step zeroes / overwrites them itself.  True restores
+        # "gradients are zero after a step" for callers that inspect arena.grad / p.grad afterwards (a 1 GB memset per step at C4)
+        self.zero_after_step = False
         # trainable landmark branch: the HIP training plan (landmark_train.HipLandmarkTrainer) whenever the model is in training mode
         # (BatchNorm batch statistics, Dropout(0.5)); an eval-mode model -- and LAFS_FT_CNN=torch, for A/B runs -- takes the nn.Module
         # on torch autograd
         self.cnn = None
-        if backbone.with_land and os.environ.get("LAFS_FT_CNN", "hip") == "hip":
+        if m.with_land and os.environ.get("LAFS_FT_CNN", "hip") == "hip":
             from .landmark_train import HipLandmarkTrainer
-            self.cnn = HipLandmarkTrainer(backbone, self.arena, batch_size, image_size, device=dev)
-            backbone.register_state_dict_pre_hook(lambda *a, **k: self.cnn.flush_batches_tracked())
+            self.cnn = HipLandmarkTrainer(m, a, batch_size, image_size, device=dev)
+            self.cnn.step_dev = self.hyper[_lib.HP_STEP:]
+            m.register_state_dict_pre_hook(lambda *a_, **k_: self.cnn.flush_batches_tracked())
+        # streams / graphs
+        # LAFS_FT_WGRAD_STREAM=1: the blocks' weight-gradient GEMMs on a second stream (inside the graph).  Measured at C4 on one box:
+        # 27.24 ms with it, 27.03 without (eager 27.35) -- like the LAFS step, the kernels beside each other slow down by what the
+        # overlap saves -- so it is off by default; tests/test_gpu_finetune.py holds the two-stream step against the one-stream one.
+        single = os.environ.get("LAFS_SINGLE_STREAM") == "1" or os.environ.get("LAFS_FT_WGRAD_STREAM", "0") != "1"
+        self.side_stream = None if single else torch.cuda.Stream(device=dev)
+        self.wgrad_workgroups = int(os.environ.get("LAFS_FT_WGRAD_WG", "0"))
+        if use_graph is None:
+            use_graph = os.environ.get("LAFS_FT_GRAPH", "1") != "0"
+        self.use_graph = bool(use_graph) and self.world == 1 and sharded_head is None
+        self._graphs = {}
+        self._pool = None
+        self._ws = None
 
+    # ------------------------------------------------------------------ host side of a micro-step
     def draw_lambda(self):
         if np.random.rand() < self.mixup_prob:
             return float(np.random.beta(self.mixup_alpha, self.mixup_alpha))
         return 1.0
 
+    def _upload_hyper(self, kw):
+        self._hp.update(kw)
+
+        def fill(h):
+            h.zero_()
+            for k, v in self._hp.items():
+                h[k] = v
+        self.hyper_ring.upload(self.hyper, fill)
+
+    def _stage(self, inputs_u8, labels):
+        """Copy the batch into the static buffers the captured step reads (no ATen math: one copy, one lafs_cast_i64_i32)."""
+        if inputs_u8.shape != self.in_u8.shape or inputs_u8.dtype != torch.uint8:
+            raise _lib.LafsHipError(f"expected a uint8 batch of shape {tuple(self.in_u8.shape)}")
+        self.in_u8.copy_(inputs_u8, non_blocking=True)
+        lab = labels if labels.is_cuda else labels.to(self.device, non_blocking=True)
+        if lab.dtype == torch.int64:
+            call("lafs_cast_i64_i32", _p(lab.contiguous()), _p(self.y1), self.B)
+        else:
+            self.y1.copy_(lab.to(torch.int32))
+
+    def _capturable(self):
+        m = self.model
+        return self.use_graph and (not m.with_land or (self.cnn is not None and m.training))
+
     def micro_step(self, inputs_u8, labels, lam=None):
         """One forward/backward on a uint8 NCHW batch.  Gradients accumulate in the arena (loss pre-divided by acc_step)."""
-        a, m, B, D, dev = self.arena, self.model, self.B, self.D, self.device
+        a, m = self.arena, self.model
         a.ensure_fresh()
         lam = self.draw_lambda() if lam is None else float(lam)
         if self.head is not None:
             lam = 1.0                                    # the sharded head takes hard labels
-        call("lafs_mixup_normalize", _p(inputs_u8.contiguous()), _p(self.x), B, self.x.shape[-1], lam)
-        y1 = labels.to(dev, torch.int32).contiguous()
-        y2 = y1.flip(0).contiguous()
-        pos = a.view(a.master, m._spec.prefix + "pos_embedding").view(-1, D)[: self.geom.npatch(0) + 1]
-        drop = m._sample_drop_scales(self.geom) if m.training else None
-        img_in, theta = self.x, None
+        self._stage(inputs_u8, labels)
+        self._labels = labels
+        self._upload_hyper({_lib.HP_MIX_LAM: lam, _lib.HP_STEP: float(self.micro + 1)})
+        first = (self._since_opt == 0)                   # first micro-step since the last optimizer step: gradients are written, not accumulated
+        if self._capturable():
+            key = (first, bool(m.training))
+            g = self._graphs.get(key)
+            if g is None:
+                g = self._capture(first)
+                self._graphs[key] = g
+            g.replay()
+        else:
+            self._body(first)
+        self.micro += 1
+        self._since_opt += 1
+        return self.loss
+
+    def _capture(self, first):
+        if self.cnn is not None:
+            self.cnn.mark_stale()                        # the operand refresh becomes part of the graph: every replay sees fresh weights
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self._pool):
+            self._body(first)
+        if self._pool is None:
+            self._pool = g.pool()
+        return g
+
+    # ------------------------------------------------------------------ the device side (capturable: lafs_* launches only)
+    def _body(self, first):
+        a, m, B, D, dev = self.arena, self.model, self.B, self.D, self.device
+        hp = self.hyper
+        if first:                                        # gradient of everything no kernel overwrites <- 0
+            call("lafs_zero_chunks", _p(a.grad), _p(a.chunk_seg), _p(a.seg_flags), a.n_chunks, _lib.SEG_OVERWRITTEN)
+        call("lafs_mixup_normalize", _p(self.in_u8), _p(self.x), B, self.S, 1.0, _p(hp[_lib.HP_MIX_LAM:]))
+        drop = None
+        if m.training and self.drop is not None:         # Residual_droppath: the same rate on both branches of every layer (:106-112)
+            call("lafs_droppath_scales", _p(self.keep), m.depth, self.geom.n_seq, self.drop_seed, _p(hp[_lib.HP_STEP:]), _p(self.drop))
+            drop = self.drop
+        dropout = None
+        if m.training and (m.dropout_rate > 0.0 or m.emb_dropout_rate > 0.0):
+            dropout = (m.dropout_rate, m.emb_dropout_rate, m._drop_seed0, hp[_lib.HP_STEP:])
+        img_in, theta, th = self.x, None, None
         self._cnn_hip = m.with_land and self.cnn is not None and m.training
         if m.with_land:
             # trainable landmark regressor -> one-launch patch gather (ViT_face.py:679-711)
             theta = self.cnn.forward(self.x) if self._cnn_hip else m.landmarks(self.x)
             m.theta = theta
             th = theta.detach().contiguous()
-            img_in = torch.empty_like(self.x)
-            call("lafs_patch_gather_fwd", _p(self.x), _p(th), B, self.x.shape[-1], th.shape[1], _p(img_in))
-        emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [pos], drop, save=True, dropout=m._next_dropout())
+            img_in = self.img_in
+            call("lafs_patch_gather_fwd", _p(self.x), _p(th), B, self.S, th.shape[1], _p(img_in))
+        if self._ws is None:
+            probe = Fn.make_trunk_desc(a, m._spec.trunk, self.geom, drop, with_grad=True)
+            self._ws = Fn.trunk_workspace(probe, True, dev)
+        emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [self.pos_rows], drop, save=True, dropout=dropout, ws=self._ws,
+                                    x_in=self.x_in, x_out=self.x_out, wgrad_overwrite=first,
+                                    wgrad_workgroups=self.wgrad_workgroups if self.side_stream is not None else 0)
         if self.head is not None:
             # class-sharded head: all-gather embeddings, local logits, exchanged softmax statistics, reduce-scatter of dE.
             # demb is the gradient of the GLOBAL-batch mean loss, so the later all-reduce of the backbone gradients is a SUM.
-            loss, demb = self.head.forward_backward(emb, labels, grad_scale=1.0 / self.acc_step)
-            self.loss = loss.detach().view(1)
-            self._backward_trunk(st, demb, th if m.with_land else None, theta)
-            self.micro += 1
-            return self.loss
-        # cosine logits
-        xn = torch.empty(B, D, device=dev, dtype=bf16); inv_x = torch.empty(B, device=dev, dtype=f32)
-        call("lafs_l2norm_fwd", _p(emb), D, _p(xn), D, _p(inv_x), B, D)
-        wname = m._spec.prefix + "loss.weight"
-        call("lafs_weightnorm_fwd", _p(a.view(a.master, wname)), _p(self.ones), self.C, self.Cpad, D, _p(self.wn), None, self.Cpad,
+            loss, demb = self.head.forward_backward(emb, self._labels, grad_scale=1.0 / self.acc_step)
+            self.loss.copy_(loss.detach().view(1))
+            self._backward_trunk(st, demb, th, theta)
+            return
+        # ---- margin head (face_pre_pro/ViT_face.py:49-89 + timm SoftTargetCrossEntropy, train_largescale.py:820)
+        call("lafs_l2norm_fwd", _p(emb), D, _p(self.xn), D, _p(self.inv_x), B, D)
+        call("lafs_weightnorm_fwd", _p(a.view(a.master, self.wname)), _p(self.ones), self.C, self.Cpad, D, _p(self.wn), None, self.Cpad,
              _p(self.inv_w))
-        ops.gemm_nt(xn, self.wn, _lib.EPI_F32, out=self.cos, n_cols=self.Cpad)
-        # margin + softmax + soft-target CE, forward and d/dcos in place
-        call("lafs_margin_softmax_ce", _p(self.cos), self.Cpad, B, self.C, _p(y1), _p(y2), lam, self.s, self.m, self.margin_type,
-             1.0 / self.acc_step, _p(self.loss), _p(self.row_ws))
-        ops.scale_cast_bf16(self.cos, out=self.dcos)
-        # d(emb_n) = dcos @ Wn (reduction over the classes), d(Wn) = dcos^T @ emb_n (reduction over the batch)
-        dxn = torch.zeros(B, D, device=dev, dtype=f32)
-        ops.gemm_tn_acc(self.dcos.t().contiguous(), self.wn, dxn)
-        self.dwn.zero_()
-        ops.gemm_tn_acc(self.dcos, xn, self.dwn, splits=1)
-        call("lafs_weightnorm_bwd", _p(self.dwn), _p(a.view(a.master, wname)), _p(self.ones), _p(self.inv_w), self.C, D,
-             _p(a.view(a.grad, wname)), None, 1)
-        demb = torch.empty(B, D, device=dev, dtype=f32)
-        call("lafs_l2norm_bwd", _p(emb), D, _p(dxn), D, _p(inv_x), _p(demb), D, B, D)
+        ops.gemm_nt(self.xn, self.wn, _lib.EPI_F32, out=self.cos, n_cols=self.Cpad)
+        # margin + softmax + soft-target CE; d/dcos leaves as bf16 (the operand of the two class-gradient GEMMs); the mixup partner of
+        # row b is row B-1-b, lambda comes from device memory
+        call("lafs_margin_softmax_ce_bf16", _p(self.cos), self.Cpad, B, self.C, _p(self.y1), None, 1.0, _p(hp[_lib.HP_MIX_LAM:]), self.s,
+             self.m, self.margin_type, 1.0 / self.acc_step, _p(self.dcos), self.Cpad, _p(self.loss), _p(self.row_ws), _p(self.part_ws))
+        call("lafs_transpose_bf16", _p(self.dcos), B, self.Cpad, self.Cpad, _p(self.dcos_t), B)
+        # d(emb_n) [B, D] = dcos @ Wn: reduction over the classes = the token axis of the wide-tile weight-gradient kernel (slices
+        # + fold: no atomics, no zero fill)
+        ops.wgrad(self.dcos_t, self.wn, self.dxn, accumulate=False, workspace=self.dxn_ws)
+        # d(Wn) [C, D] = dcos^T @ emb_n: reduction over the batch (128): an NT GEMM that writes the 633 MB matrix once
+        if self.dwn_ws is None:
+            call("lafs_transpose_bf16", _p(self.xn), B, D, D, _p(self.xn_t), B)
+            ops.gemm_nt(self.dcos_t, self.xn_t, _lib.EPI_F32, out=self.dwn)
+        else:
+            ops.wgrad(self.dcos, self.xn, self.dwn, accumulate=False, workspace=self.dwn_ws)
+        call("lafs_weightnorm_bwd", _p(self.dwn), _p(a.view(a.master, self.wname)), _p(self.ones), _p(self.inv_w), self.C, D,
+             _p(a.view(a.grad, self.wname)), None, 0 if first else 1)
+        call("lafs_l2norm_bwd", _p(emb), D, _p(self.dxn), D, _p(self.inv_x), _p(self.demb), D, B, D)
         if self._reduce_now():
             self.reducer.launch(a.grad[self.head_off:])          # margin head (+ anything behind it): final from here on
-        self._backward_trunk(st, demb, th if m.with_land else None, theta)
-        self.micro += 1
-        return self.loss
+        self._backward_trunk(st, self.demb, th, theta)
 
     def _reduce_now(self):
         """True on the micro-step that completes an accumulation window of a data-parallel run."""
@@ -159,16 +286,16 @@ class FinetuneEngine:
         """Final norm + all blocks; with DP on the window's last micro-step in `grad_slices` runs, each run's gradient range
         handed to RCCL as soon as it has been enqueued."""
         a, m = self.arena, self.model
-        g = Fn.vit_backward_begin(a, m._spec, st, demb)
+        g = Fn.vit_backward_begin(a, m._spec, st, demb, g_buf=self.g_buf)
         depth = m.depth
         if not self._reduce_now():
-            Fn.vit_backward_layers(st, g, depth, 0)
+            Fn.vit_backward_layers(st, g, depth, 0, wgrad_stream=self.side_stream)
             return g
         ns = max(1, min(self.grad_slices, depth))
         cuts = [depth - (depth * k) // ns for k in range(ns + 1)]
         hi = self.head_off
         for k in range(ns):
-            Fn.vit_backward_layers(st, g, cuts[k], cuts[k + 1])
+            Fn.vit_backward_layers(st, g, cuts[k], cuts[k + 1], wgrad_stream=self.side_stream)
             lo = self.block_off[cuts[k + 1]]
             if cuts[k + 1] > 0:                                  # the range below block 0 still waits for the embedding / CNN gradients
                 self.reducer.launch(a.grad[lo:hi])
@@ -179,24 +306,24 @@ class FinetuneEngine:
     def _backward_trunk(self, st, demb, th, theta):
         a, m, B, D = self.arena, self.model, self.B, self.D
         reduce_now = self._reduce_now()
+        g = self._trunk_layers_backward(st, demb)
         if m.with_land:
-            g = self._trunk_layers_backward(st, demb)
-            dpos, dx = Fn.vit_backward_end(a, m._spec, st, g, want_dx=True)
-            dmosaic = Fn.unpatchify_grad(dx[0], m._spec.patch_order).contiguous()
-            dth = torch.empty_like(th)
-            call("lafs_patch_gather_bwd", _p(self.x), _p(th), _p(dmosaic), B, self.x.shape[-1], th.shape[1], _p(dth), None)
+            _, dx = Fn.vit_backward_end(a, m._spec, st, g, want_dx=True, dpos_out=[self.dpos_rows])
+            call("lafs_unpatchify_f32", _p(dx[0]), B, self.S, m._spec.patch_order, _p(self.dmosaic))
+            if self.dth is None:
+                self.dth = torch.empty_like(th)
+            call("lafs_patch_gather_bwd", _p(self.x), _p(th), _p(self.dmosaic), B, self.S, th.shape[1], _p(self.dth), None)
             if self._cnn_hip:
-                self.cnn.backward(dth)                   # into the arena's stn.* / output_layer.* gradients
+                self.cnn.backward(self.dth)              # into the arena's stn.* / output_layer.* gradients
             else:
-                theta.backward(dth)                      # torch autograd: p.grad are views of the arena
+                theta.backward(self.dth)                 # torch autograd: p.grad are views of the arena
         else:
-            g = self._trunk_layers_backward(st, demb)
-            dpos = Fn.vit_backward_end(a, m._spec, st, g)
-        a.view(a.grad, m._spec.prefix + "pos_embedding").view(-1, D)[: dpos[0].shape[0]] += dpos[0]
+            Fn.vit_backward_end(a, m._spec, st, g, dpos_out=[self.dpos_rows])
         if reduce_now:                                           # what is left: block 0's run + embedding + landmark CNN
             self.reducer.launch(a.grad[: self._hi_left])
             self._reduced = True
 
+    # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, lr, weight_decay=0.1, beta1=0.9, beta2=0.999, eps=1e-8):
         """AdamW over every tensor (decay only on >= 2-D tensors, train_largescale.py:122-173); all-reduces the flat gradient
         first when running data-parallel (the reference's DDP does it on every micro-step, :676-677)."""
@@ -209,20 +336,22 @@ class FinetuneEngine:
             self._reduced = False
         # dense head: every rank's loss is its local mean -> average; sharded head: gradients of the global mean -> sum
         gscale = 1.0 if self.head is not None else 1.0 / self.world
-
-        def fill(h):
-            h.zero_()
-            h[_lib.HP_LR], h[_lib.HP_WD], h[_lib.HP_BETA1], h[_lib.HP_BETA2], h[_lib.HP_EPS] = lr, weight_decay, beta1, beta2, eps
-            h[_lib.HP_GRAD_SCALE], h[_lib.HP_WD_LOW] = gscale, LOW_WEIGHT_DECAY
-        self.hyper_ring.upload(self.hyper, fill)
+        self._upload_hyper({_lib.HP_LR: lr, _lib.HP_WD: weight_decay, _lib.HP_BETA1: beta1, _lib.HP_BETA2: beta2, _lib.HP_EPS: eps,
+                            _lib.HP_GRAD_SCALE: gscale, _lib.HP_WD_LOW: LOW_WEIGHT_DECAY})
         if self.head is not None:
             self.head.optimizer_step(lr, weight_decay, beta1, beta2, eps)
         call("lafs_clip_adamw_ema", _p(a.master), _p(a.grad), _p(a.exp_avg), _p(a.exp_avg_sq), None, _p(a.shadow), None,
              _p(a.chunk_seg), a.n_chunks, _p(a.seg_flags), _p(a.seg_step), a.n_seg, _p(a.seg_sumsq), _p(self.hyper))
         a.refresh_transposed()
-        a.zero_grad()
+        if self.zero_after_step:
+            ops.zero_(a.grad)
         if self.cnn is not None:
             self.cnn.mark_stale()                        # the master weights changed in place: new operand images next forward
+        self._since_opt = 0
+
+    def zero_grad(self):
+        ops.zero_(self.arena.grad)
+        self._since_opt = 0
 
     def step(self, inputs_u8, labels, lr, weight_decay=0.1):
         """micro_step + optimizer step every acc_step micro-steps (train_largescale.py:842-891)."""

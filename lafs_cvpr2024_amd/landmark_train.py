@@ -151,6 +151,7 @@ class HipLandmarkTrainer:
         self.step = 0
         self.seed = 0x1A2D
         self.n_forward = 0                     # training forwards since the last flush of num_batches_tracked
+        self.step_dev = None                   # device step counter of a captured step (see forward)
         self.fixed_drop = None                 # parity hook: dropout factors f32 [N, 160] (0 or 1/(1-p)) instead of the counter-based mask
         self.keep_trace, self.trace = False, []   # parity hook: clones of every block's incoming / intermediate / outgoing gradients
         self._alloc()
@@ -287,7 +288,9 @@ class HipLandmarkTrainer:
         call("lafs_cnn_pool_train", _p(cur), N, HW, self.p_last, _p(B["feat"]), self.p_last)
         # Dropout(0.5) (training) + Linear(160, 2 r r): counter-based mask of (seed + 7919 step), regenerated in the backward
         call("lafs_cast_f32", _p(B["feat"]), _p(B["featf"]), B["feat"].numel())
-        self.drop_seed = (self.seed + 7919 * self.step) & 0xFFFFFFFF
+        # host counter: seed + 7919 * step per forward; with `step_dev` (a DEVICE float, e.g. hyper[HP_STEP] of a captured fine-tune
+        # step) the kernels add 7919 * step themselves, so a replayed graph draws a new mask every micro-step
+        self.drop_seed = self.seed if self.step_dev is not None else (self.seed + 7919 * self.step) & 0xFFFFFFFF
         self.step += 1
         self._dropout(B["featf"])
         call("lafs_cast_bf16", _p(B["featf"]), _p(B["featd"]), B["featf"].numel())
@@ -303,7 +306,7 @@ class HipLandmarkTrainer:
         if self.fixed_drop is not None:
             buf.mul_(self.fixed_drop.to(buf.device, buf.dtype))
         elif self.model.training and self.drop_p > 0:
-            call("lafs_dropout_f32", _p(buf), self.p_last, self.N, self.p_last, self.drop_p, self.drop_seed, None)
+            call("lafs_dropout_f32", _p(buf), self.p_last, self.N, self.p_last, self.drop_p, self.drop_seed, _p(self.step_dev))
 
     def flush_batches_tracked(self):
         """nn.BatchNorm2d.num_batches_tracked of every BatchNorm of the trunk += the training forwards run since the last flush
