@@ -275,6 +275,39 @@ def cpu_baseline(arch_dims, n_local, K, batch, timed=2):
     return out
 
 
+def partfvit_pass_flops(n_seq, n_tok_seq, dim=768, heads=11, mlp=2048, depth=12):
+    """Forward FLOPs of one Part-fViT trunk pass over n_seq sequences of n_tok_seq tokens (GEMMs + attention; the patch embedding
+    192 -> dim included): the algorithmic count, 2 m n k per GEMM."""
+    T, inner = n_seq * n_tok_seq, heads * 64
+    per_layer = 2.0 * T * dim * (3 * inner) + 2.0 * T * inner * dim + 2 * 2.0 * T * dim * mlp + 4.0 * n_seq * heads * n_tok_seq * n_tok_seq * 64
+    return depth * per_layer + 2.0 * T * 192 * dim
+
+
+def roofline_partfvit_dgrad(device, M, iters=100):
+    """Dominant kernel of both Part-fViT workloads in the serialised profiles (profiles/round4_finetune_kernel_table.txt,
+    round4_mynet_kernel_table.txt): gemm_nt_kernel<BF16,2,64> -- the plain input-gradient GEMMs; its largest instance is the fc1
+    input gradient dH2 = dU W1 (M tokens, N = 768, K = 2048).  Algorithmic bytes: dU and W1^T (bf16) read once, dH2 (bf16) written."""
+    from lafs_cvpr2024_amd import _lib, ops
+    N, K = 768, 2048
+    A = torch.randn(M, K, device=device).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=device) * 0.02).to(torch.bfloat16)
+    out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    dur = _time_on_stream(lambda: ops.gemm_nt(A, W, _lib.EPI_BF16, out=out), iters)
+    return _roof(f"gemm_nt_kernel<BF16,2,64> M={M} N=768 K=2048 (Part-fViT fc1 input gradient, tiled LDS-DMA kernel)", dur,
+                 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0)
+
+
+def _extra_evidence(out, flops, dt, device, M):
+    out["step_tflops"] = round(flops / dt / 1e12, 1)
+    out["step_mfma_frac"] = round(flops / dt / 2.5e15, 4)
+    out["step_flops_algorithmic"] = round(flops / 1e12, 3)
+    try:
+        out["roofline"] = roofline_partfvit_dgrad(device, M)
+    except Exception as e:
+        out["roofline"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 def extra_mynet_pretrain(device, B=64, nl=8, K=100000, steps=12, warmup=4):
     """NON-headline: the pair the reference actually pre-trains (lafs_train.py:300-335, --arch mynet): Part-fViT dim 768 / depth 12 /
     11 heads / mlp 2048 student AND teacher with dropout 0.1 + DropPath 0.1 live in both, [B, n, 192] landmark-patch tokens,
@@ -302,9 +335,16 @@ def extra_mynet_pretrain(device, B=64, nl=8, K=100000, steps=12, warmup=4):
     for _ in range(steps):
         loss = one()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    return {"workload": f"Part-fViT (768/12/11/2048) LAFS pair, dropout 0.1 + DropPath 0.1 live in student and teacher, 2g+{nl}l crops, "
-                        f"batch {B}, out_dim {K}, hipGraph {bool(eng._graphs)}", "ms_per_step": round(dt * 1e3, 2),
-            "face_crops_per_s": round(B * (2 + nl) / dt, 1), "steps": steps, "warmup": warmup, "loss": round(float(loss.item()), 4)}
+    out = {"workload": f"Part-fViT (768/12/11/2048) LAFS pair, dropout 0.1 + DropPath 0.1 live in student and teacher, 2g+{nl}l crops, "
+                       f"batch {B}, out_dim {K}, hipGraph {bool(eng._graphs)}", "ms_per_step": round(dt * 1e3, 2),
+           "face_crops_per_s": round(B * (2 + nl) / dt, 1), "steps": steps, "warmup": warmup, "loss": round(float(loss.item()), 4)}
+    # algorithmic FLOPs: student forward + backward (3x) over 2 global (197 tokens) + nl local (37 tokens) views, teacher forward over
+    # the 2 global ones, DINO heads (dim -> 2048 -> 2048 -> 256 -> K) on 10 B / 2 B rows
+    f_s = partfvit_pass_flops(2 * B, 197) + partfvit_pass_flops(nl * B, 37)
+    f_t = partfvit_pass_flops(2 * B, 197)
+    head = lambda rows: 2.0 * rows * (dim * 2048 + 2048 * 2048 + 2048 * 256 + 256 * K)
+    flops = 3 * (f_s + head((2 + nl) * B)) + f_t + head(2 * B)
+    return _extra_evidence(out, flops, dt, device, B * (2 * 197 + nl * 37))
 
 
 def extra_finetune(device, head="CosFace", with_land=True, dropout=0.1, B=128, C=205990, steps=12, warmup=4):
@@ -332,9 +372,14 @@ def extra_finetune(device, head="CosFace", with_land=True, dropout=0.1, B=128, C
     for _ in range(steps):
         loss = eng.step(x, y, lr=1e-4)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    return {"workload": f"Part-fViT ViT-B + {head} fine-tune step, batch {B}, {C} classes, with_land={with_land}, dropout={dropout}"
-                        + (", sample_rate 0.1" if sharded else ""), "ms_per_step": round(dt * 1e3, 2),
-            "images_per_s": round(B / dt, 1), "steps": steps, "warmup": warmup, "loss": round(float(loss.item()), 4)}
+    out = {"workload": f"Part-fViT ViT-B + {head} fine-tune step, batch {B}, {C} classes, with_land={with_land}, dropout={dropout}"
+                       + (", sample_rate 0.1" if sharded else "") + f", hipGraph {bool(eng._graphs)}", "ms_per_step": round(dt * 1e3, 2),
+           "images_per_s": round(B / dt, 1), "steps": steps, "warmup": warmup, "loss": round(float(loss.item()), 4)}
+    # algorithmic FLOPs: trunk forward + backward (3x) + the class-table GEMMs (cos, d emb, d W: 3 x 2 B C D; the sampled head scores
+    # 10 % of the centres); the landmark CNN (~0.3 GFLOP per image forward) is left out of the count
+    cls = C * (0.1 if sharded else 1.0)
+    flops = 3 * partfvit_pass_flops(B, 197) + 3 * 2.0 * B * cls * 768
+    return _extra_evidence(out, flops, dt, device, B * 197)
 
 
 EXTRAS = {"mynet": lambda d: extra_mynet_pretrain(d),

@@ -87,6 +87,9 @@ typedef struct lafs_gemm_nt_args {
                                       when the kernel runs -- a captured hipGraph then draws a new mask on every replay            */
   int drop_row0;                   /* this launch's row 0 is row drop_row0 of the mask (a launch over a row sub-range of a batch) */
   int act;                         /* BF16_ACT: LAFS_ACT_*.  BF16_GELU / DGELU_BF16: LAFS_GELU_SAVE_GRAD (see below) */
+  int operand_f16;                 /* 1: A, B, a 16-bit C and the BF16_ACT residual (aux) are IEEE fp16 instead of bf16 (BF16 / BF16_ACT /
+                                      F32 epilogues, no K split): the trainable landmark CNN runs in the reference's autocast
+                                      format (train_largescale.py:803-804; v_mfma_f32_16x16x32_f16, same rate) */
 } lafs_gemm_nt_args;
 
 /* act = LAFS_GELU_SAVE_GRAD with LAFS_EPI_BF16_GELU: C receives gelu'(u) (bf16) instead of the pre-activation u; with
@@ -149,6 +152,9 @@ int64_t lafs_wgrad_group_workspace_bytes(const lafs_wgrad_item* items, int n_ite
 int lafs_wgrad_group(const lafs_wgrad_item* items, int n_items, int M, int max_workgroups, void* workspace,
                      int64_t workspace_bytes, hipStream_t stream);
 int64_t lafs_wgrad_workspace_bytes(int M, int N1, int N2);
+/* lafs_wgrad with fp16 operands (the landmark CNN's activations and activation gradients, see lafs_gemm_nt_args::operand_f16). */
+int lafs_wgrad_f16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+                   int accumulate, float* colsum_a, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 int lafs_wgrad(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
                int accumulate, float* colsum_a, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
@@ -508,20 +514,32 @@ int lafs_randaug_apply(const uint8_t* images, uint8_t* out, const lafs_randaug_o
  * ------------------------------------------------------------------------------------------------------------------------ */
 /* 3x3 stride-2 pad-1 stem as im2col rows: x f32 NCHW [N,3,S,S] -> P bf16 [N (S/2)^2, 32], column (c, ky, kx), columns 27..31 zero. */
 int lafs_cnn_im2col_stem(const float* x, int N, int S, void* P, hipStream_t stream);
-/* nn.BatchNorm2d in TRAINING mode over the rows of x bf16 [R, ldx]:
- *   lafs_cnn_bn_stats : sums(f32)[0..C) += column sums, sums[C..2C) += column sums of squares (caller zeroes `sums`);
+/* Round 4: every 16-bit tensor of this plan (activations, operand images, activation gradients -- "bf16" in the comments below is
+ * historical) is IEEE fp16, the format of the reference's autocast run (train_largescale.py:803-804); its GEMMs are lafs_gemm_nt
+ * with operand_f16 = 1 and lafs_wgrad_f16.  Activation gradients are scaled by a per-call power of two derived on the device
+ * (lafs_cnn_grad_scale) and un-scaled where they leave the 16-bit domain (grad_scale arguments below; NULL = no scaling).
+ * nn.BatchNorm2d in TRAINING mode over the rows of x fp16 [R, ldx]:
+ *   lafs_cnn_bn_stats : sums(f64)[0..C) += column sums, sums[C..2C) += column sums of squares (caller zeroes `sums`); fp64: mean and
+ *                       E[x^2] - mean^2 are formed in double, the order of the atomics stays below fp32 resolution;
  *   lafs_cnn_bn_apply : y = act((x - mean) rstd gamma + beta) (+ resid), biased batch variance; stat(f32)[2C] = {mean, rstd} for the
  *                       backward; running_mean / running_var (NULL or both) get the momentum update with the unbiased variance;
- *   lafs_cnn_bn_bwd   : dz = (dy + add_nc[n, c] / HW) act'(z) with z recomputed from x; dx(bf16) = gamma rstd (dz - mean(dz) -
- *                       xhat mean(dz xhat)); dgamma += sum dz xhat, dbeta += sum dz (arena gradients, may be NULL);
- *                       dsums(f32)[2C] = caller-zeroed scratch.  add_nc bf16 [N, ldadd] (the squeeze-excite pooling gradient) or NULL. */
-int lafs_cnn_bn_stats(const void* x, int ldx, int64_t R, int C, float* sums, hipStream_t stream);
-int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const float* sums, const float* gamma, const float* beta, float eps,
+ *   lafs_cnn_bn_bwd   : dz = (dy + add_nc[n, c] / HW) act'(z) with z recomputed from x; dx(fp16) = gamma rstd (dz - mean(dz) -
+ *                       xhat mean(dz xhat)); dgamma += sum dz xhat / scale, dbeta += sum dz / scale (arena gradients, may be NULL);
+ *                       dsums(f64)[2C] = caller-zeroed scratch.  add_nc fp16 [N, ldadd] (the squeeze-excite pooling gradient) or NULL. */
+int lafs_cnn_bn_stats(const void* x, int ldx, int64_t R, int C, double* sums, hipStream_t stream);
+int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const double* sums, const float* gamma, const float* beta, float eps,
                       float momentum, float* running_mean, float* running_var, int act, const void* resid, int ldr, void* y, int ldy,
                       float* stat, hipStream_t stream);
 int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
-                    const float* beta, int act, const void* add_nc, int ldadd, int HW, float* dsums, void* dx, int lddx,
-                    float* dgamma, float* dbeta, hipStream_t stream);
+                    const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
+                    float* dgamma, float* dbeta, const float* grad_scale, hipStream_t stream);
+/* scale(f32, device)[2] = {s, 1/s}, s = the power of two <= target / max |g| (1 for an all-zero or non-finite gradient): the loss
+ * scaling of the reference's GradScaler (train_largescale.py:803-867), decided per call on the device so that a captured step needs
+ * no host round trip.  lafs_cnn_cast_pad_f16: dst(fp16)[r, c] = src(f32)[r, c] * scale[0], pad columns [cols, ld) zero.
+ * lafs_cnn_cast_f16_f32: dst(f32)[i] = src(fp16)[i]. */
+int lafs_cnn_grad_scale(const float* g, int64_t n, float target, float* scale, hipStream_t stream);
+int lafs_cnn_cast_pad_f16(const float* src, int rows, int cols, void* dst, int ld, const float* scale, hipStream_t stream);
+int lafs_cnn_cast_f16_f32(const void* src, float* dst, int64_t n, hipStream_t stream);
 /* Depthwise k x k convolution (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) on NHWC bf16.  w = tap-major fp32 image [k*k][ld] of
  * the module's [C][1][k][k] tensor (lafs_cnn_dw_layout_table: table[8 e ..] = {src offset, C, k*k, dst offset, ld}, 256 elements per
  * workgroup); forward; backward = dx(bf16) and dw(f32, += into a tap-major image [k*k][ld] that lafs_cnn_unpad_add_table folds,
@@ -549,7 +567,7 @@ int lafs_cnn_pad_cast_table(const float* master, void* dst, const int64_t* table
 /* Padded fp32 weight gradients folded into the arena, ONE launch: table[8 e ..] = {src offset, rows, cols, src ld, grad offset,
  * transpose, ...}; 256 elements per workgroup.  transpose: the source image is [cols][ld] (tap-major depthwise gradients). */
 int lafs_cnn_unpad_add_table(const float* padded, float* grad, const int64_t* table, const int32_t* starts, int n_entries, int n_blocks,
-                             hipStream_t stream);
+                             const float* grad_scale, hipStream_t stream);
 /* Backward of theta = (t - min) / (max - min) * 111 per image (ViT_face.py:698-706), incl. the paths through min and max. */
 int lafs_landmark_theta_bwd(const float* t, const float* dtheta, int B, int n, float* dt, hipStream_t stream);
 

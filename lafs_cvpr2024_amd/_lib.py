@@ -22,7 +22,7 @@ class GemmNTArgs(C.Structure):
                 ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
                 ("aux", C.c_void_p), ("ldaux", C.c_int), ("pos", C.c_void_p), ("npatch", C.c_int),
                 ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
-                ("drop_step", C.c_void_p), ("drop_row0", C.c_int), ("act", C.c_int)]
+                ("drop_step", C.c_void_p), ("drop_row0", C.c_int), ("act", C.c_int), ("operand_f16", C.c_int)]
 
 
 class WgradItem(C.Structure):
@@ -71,6 +71,7 @@ _PROTOS = {
     "lafs_reduce_partials": [vp, i64, i32, i64, vp],
     "lafs_sum_slices": [vp, i64, i32, i64, vp],
     "lafs_wgrad": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i64],
+    "lafs_wgrad_f16": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i64],
     "lafs_wgrad_group": [C.POINTER(WgradItem), i32, i32, i32, vp, i64],
     "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
     "lafs_layernorm_fwd": [vp, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32],
@@ -123,7 +124,7 @@ _PROTOS = {
     "lafs_cnn_im2col_stem": [vp, i32, i32, vp],
     "lafs_cnn_bn_stats": [vp, i32, i64, i32, vp],
     "lafs_cnn_bn_apply": [vp, i32, i64, i32, vp, vp, vp, f32, f32, vp, vp, i32, vp, i32, vp, i32, vp],
-    "lafs_cnn_bn_bwd": [vp, i32, vp, i32, i64, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, vp],
+    "lafs_cnn_bn_bwd": [vp, i32, vp, i32, i64, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, vp],
     "lafs_cnn_dwconv_train_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "lafs_cnn_dwconv_train_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "lafs_cnn_scale_act_out": [vp, vp, i32, i32, i32, i32, i32, vp],
@@ -133,7 +134,10 @@ _PROTOS = {
     "lafs_cnn_pad_cast_table": [vp, vp, vp, vp, i32, i32],
     "lafs_cnn_dw_layout_table": [vp, vp, vp, vp, i32, i32],
     "lafs_cnn_pool_train": [vp, i32, i32, i32, vp, i32],
-    "lafs_cnn_unpad_add_table": [vp, vp, vp, vp, i32, i32],
+    "lafs_cnn_unpad_add_table": [vp, vp, vp, vp, i32, i32, vp],
+    "lafs_cnn_grad_scale": [vp, i64, f32, vp],
+    "lafs_cnn_cast_pad_f16": [vp, i32, i32, vp, i32, vp],
+    "lafs_cnn_cast_f16_f32": [vp, vp, i64],
     "lafs_landmark_theta_bwd": [vp, vp, i32, i32, vp],
     "lafs_augment_views": [vp, vp, vp, i32, i32, vp],
     "lafs_randaug_apply": [vp, vp, vp, i32, i32, i32, i32, i32],

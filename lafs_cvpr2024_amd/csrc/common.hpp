@@ -150,6 +150,24 @@ __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- fp16 storage (IEEE half, 10-bit mantissa): the trainable landmark CNN keeps its activations, operand images and activation
+// gradients in fp16 like the reference's autocast run (train_largescale.py:803-804) -- gfx950 runs f16 MFMA at the bf16 rate, and
+// batch-statistics BatchNorm on this network is 8x less sensitive to fp16 roundings than to bf16 ones (tests/test_gpu_finetune.py F18).
+// The containers stay bf16_t / bf16x8_t (raw 16-bit lanes); only the interpretation differs.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ float h2f(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ bf16_t f2h(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi) {
+  f16x2_t v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float h_lo(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+__device__ __forceinline__ float h_hi(uint32_t w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+__device__ __forceinline__ f32x4_t mfma16_f16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
 // ---- LDS-DMA (global_load_lds_dwordx4) issued from inline asm.  Each lane supplies its own 16-byte source; the destination
 // is lds_base (wave-uniform byte address inside the workgroup's LDS, carried in M0) + 16 * lane.  Why asm and not
 // __builtin_amdgcn_global_load_lds: hipcc's wait-count pass knows the builtin writes LDS and drains the whole DMA queue

@@ -57,6 +57,7 @@ struct NTArgs {
   const float* seq_scale; const int* row2seq;
   const bf16_t* aux; int ldaux;
   const float* pos; int npatch;
+  int f16;                          // operands / 16-bit outputs are fp16 (lafs_gemm_nt_args::operand_f16)
   int dbg;                          // timing ablations (lafs_debug_set): 16 = no epilogue stores, 32 = no MFMA/ds_read
   DropCfg drop;                     // element dropout on the linear's output (RESID_F32) / on GELU(u) (BF16_GELU, DGELU_BF16)
   int act;                          // BF16_ACT: LAFS_ACT_*
@@ -124,8 +125,14 @@ template <int BK> __device__ __forceinline__ int nt_swzk(int row) { return BK ==
 // L2->LDS traffic of 128x128 per flop).
 // PERSIST (lab build only, see launch_nt): the grid is one residency wave of workgroups and each walks virtual blocks b,
 // b + grid, b + 2 grid, ...; while a workgroup stores tile j it already has the first ring stages of tile j+1 in flight.
-template <int EPI, int WM, int BK, int WN = 2, bool PERSIST = false>
+// F16: operands (and a 16-bit output / residual) are IEEE fp16 instead of bf16 -- the trainable landmark CNN's plan
+// (landmark_train.py); instantiated for the plain, activation and fp32 epilogues on 128x128 tiles only.
+template <int EPI, int WM, int BK, int WN = 2, bool PERSIST = false, bool F16 = false>
 __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2)))) void gemm_nt_kernel(NTArgs p) {
+  static_assert(!F16 || EPI == EPI_BF16 || EPI == EPI_BF16_ACT || EPI == EPI_F32, "fp16 operands: plain / activation / fp32 epilogues only");
+  auto PK2 = [](float lo, float hi) { return F16 ? pack_h2(lo, hi) : pack_bf2(lo, hi); };
+  auto CV1 = [](float x) { return F16 ? f2h(x) : f2bf(x); };
+  auto LD1 = [](bf16_t h) { return F16 ? h2f(h) : bf2f(h); };
   const DropCfg drop = drop_resolve(p.drop);
   constexpr int THREADS = WM * WN * 64, BMT = WM * 64, BN = WN * 64;
   constexpr bool PIN32 = (WM == 2);                   // (the 8-wave variants run at the 128-register cap: pinning spills there)
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = mfma16(fb[j], fa[i], acc[j][i]);
+        for (int i = 0; i < 4; ++i) acc[j][i] = F16 ? mfma16_f16(fb[j], fa[i], acc[j][i]) : mfma16(fb[j], fa[i], acc[j][i]);
     }
     // 64-deep stages at two waves per SIMD (the long-K GEMMs of the trunk): pin the 16 fragment reads ahead of the 32 MFMAs that
     // consume them -- left alone, hipcc issues them in batches of 2-6 behind s_waitcnt lgkmcnt(0) and exposes the LDS latency four or
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
         if (p.aux != nullptr) {
           const bf16_t* ax = p.aux + (size_t)m * p.ldaux + n;
 #pragma unroll
-          for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) w[e] += bf2f(ax[e]);
+          for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) w[e] += LD1(ax[e]);
         }
 #pragma unroll
         for (int e = 0; e < VPL; ++e) w[e] = act_f(w[e], p.act);
@@ -436,10 +443,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
             for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(gelu_grad_f(w[e]));
           }
         } else if (full) {
-          st16(c, pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]), ntst);
+          st16(c, PK2(w[0], w[1]), PK2(w[2], w[3]), PK2(w[4], w[5]), PK2(w[6], w[7]), ntst);
         } else {
 #pragma unroll
-          for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(w[e]);
+          for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = CV1(w[e]);
         }
         if (EPI == EPI_BF16_GELU && !DBG(p, 64) && do_second) {
           bf16_t* c2 = reinterpret_cast<bf16_t*>(p.C2) + (size_t)m * p.ldc2 + n;
@@ -735,6 +742,15 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
     LAFS_LAUNCH_CHECK();
     return LAFS_OK;
   }
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_ACT || EPI == EPI_F32) {
+    if (a.f16) {                                     // fp16 operands (landmark CNN training plan): 128x128 tiles, no K split
+      const bool bk = (a.klen % 64 == 0) && a.klen >= 640;
+      if (bk) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 2, false, true>), dim3((unsigned)t2, 1, 1), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 32, 2, false, true>), dim3((unsigned)t2, 1, 1), dim3(256), 0, s, a);
+      LAFS_LAUNCH_CHECK();
+      return LAFS_OK;
+    }
+  }
   bool bk64 = (a.klen % 64 == 0) && a.klen >= 640 && (splits == 1 || a.K % 64 == 0);    // K = 704 / 768 (ViT-B) included: 5-15 % over 32-deep stages
   int wm = (!bk64 && a.N >= 1024 && a.M >= 4096) ? 4 : 2;
   if (g_debug_flags & 2) wm = 2;
@@ -829,6 +845,9 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
 #endif
   a.drop = make_drop(g->drop_p, g->drop_seed, g->drop_step, (unsigned)g->drop_row0 * (unsigned)g->N);
   a.act = g->act;
+  a.f16 = g->operand_f16 ? 1 : 0;
+  LAFS_CHECK_ARG(!a.f16 || ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_BF16_ACT || g->epilogue == LAFS_EPI_F32) && g->splits <= 1),
+                 "fp16 operands: plain / activation / fp32 epilogue, no K split");
   LAFS_CHECK_ARG(g->drop_p >= 0.f && g->drop_p < 1.f, "drop_p must be in [0, 1)");
   LAFS_CHECK_ARG(!(g->drop_p > 0.f) || ((long)g->M + g->drop_row0) * g->N < 4294967296L, "dropout needs (row0 + M) * N < 2^32");
   LAFS_CHECK_ARG(g->drop_row0 >= 0, "drop_row0 must be >= 0");

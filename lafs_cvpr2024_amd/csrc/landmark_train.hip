@@ -12,7 +12,14 @@
 //     backward, the 3x3 stem as im2col rows, and the min-max landmark scaling backward are the bandwidth-bound kernels below;
 //   * weights stay fp32 in the parameter arena; padded bf16 operand copies (W and W^T) are refreshed by ONE table-driven launch per
 //     optimizer step, padded fp32 weight gradients are folded back into the arena by ONE table-driven launch per micro-step.
-// fp32 accumulation everywhere; activations are rounded to bf16 between layers (the ViT trunk's precision).
+// fp32 accumulation everywhere.  Round 4: activations, operand images and activation gradients are IEEE fp16 (round 3: bf16) -- the
+// format of the reference's own autocast run (train_largescale.py:803-804); gfx950 runs f16 MFMA at the bf16 rate, and on this
+// freshly initialised batch-statistics network fp16 roundings move the regressor by ~1 % where bf16 ones moved it by 9 % (F18).
+// Gradients are scaled into fp16's range by a per-call factor derived ON THE DEVICE from max |d loss / d t| (lafs_cnn_grad_scale)
+// and un-scaled where they leave the 16-bit domain (BatchNorm affine gradients, the fold of the padded weight gradients).
+// BatchNorm sums are accumulated in fp64 (per-block fp32 partials, one fp64 atomic each): mean and E[x^2] - mean^2 are formed in
+// double, so neither the cancellation nor the order of the atomics reaches the fp32 statistics.
+// (The containers keep the names bf16_t / uint4 of the other files: raw 16-bit lanes.)
 #include "common.hpp"
 #include "lafs_hip.h"
 
@@ -21,11 +28,11 @@ namespace {
 inline unsigned blocks_for(long total) { return (unsigned)((total + 255) / 256); }
 
 __device__ __forceinline__ void unpack8(const uint4& v, float (&f)[8]) {
-  f[0] = bf_lo(v.x); f[1] = bf_hi(v.x); f[2] = bf_lo(v.y); f[3] = bf_hi(v.y);
-  f[4] = bf_lo(v.z); f[5] = bf_hi(v.z); f[6] = bf_lo(v.w); f[7] = bf_hi(v.w);
+  f[0] = h_lo(v.x); f[1] = h_hi(v.x); f[2] = h_lo(v.y); f[3] = h_hi(v.y);
+  f[4] = h_lo(v.z); f[5] = h_hi(v.z); f[6] = h_lo(v.w); f[7] = h_hi(v.w);
 }
 __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
-  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+  return make_uint4(pack_h2(f[0], f[1]), pack_h2(f[2], f[3]), pack_h2(f[4], f[5]), pack_h2(f[6], f[7]));
 }
 // derivative of the block non-linearities w.r.t. their INPUT z (MobileNetV3: relu, x relu6(x+3)/6, relu6(x+3)/6)
 __device__ __forceinline__ float act_grad_f(float z, int act) {
@@ -60,16 +67,17 @@ __global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restric
   uint4* o = reinterpret_cast<uint4*>(P + (size_t)idx * 32);
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    o[k] = make_uint4(pack_bf2(v[8 * k], v[8 * k + 1]), pack_bf2(v[8 * k + 2], v[8 * k + 3]), pack_bf2(v[8 * k + 4], v[8 * k + 5]),
-                      pack_bf2(v[8 * k + 6], v[8 * k + 7]));
+    o[k] = make_uint4(pack_h2(v[8 * k], v[8 * k + 1]), pack_h2(v[8 * k + 2], v[8 * k + 3]), pack_h2(v[8 * k + 4], v[8 * k + 5]),
+                      pack_h2(v[8 * k + 6], v[8 * k + 7]));
 }
 
 // Column reductions over the rows of bf16 [R, ld] matrices.  Thread layout: GB channel groups (8 channels each) x 256 / GB row lanes,
 // GB = 4, 8, 16 or 32 (the smallest that covers ld / 8, or 32 with grid.y tiles for wider matrices): at 32 channels a wave reads
 // 16 whole rows = 1 KiB contiguous, and every thread of the workgroup has work (a fixed 32-group layout left 7 of 8 threads idle
-// on the early, largest layers of the trunk).  Two sums per channel, LDS tree over the row lanes, fp32 atomics into out[0..C), [C..2C).
+// on the early, largest layers of the trunk).  Two sums per channel, LDS tree over the row lanes (a fixed order: the workgroup's partial is deterministic), ONE fp64 atomic per channel and workgroup into
+// out[0..C), [C..2C): the order of the atomics moves the sums at the 1e-16 level, far below the fp32 statistics derived from them.
 template <typename F>
-__device__ __forceinline__ void col_reduce2(int GB, int C, long R, int rows_per_block, float* __restrict__ out, F body) {
+__device__ __forceinline__ void col_reduce2(int GB, int C, long R, int rows_per_block, double* __restrict__ out, F body) {
   __shared__ float red[256][17];                       // (+1: the tree below walks columns of 16 floats)
   const int RL = 256 / GB;
   const int gl = threadIdx.x % GB, rl = threadIdx.x / GB;
@@ -94,14 +102,14 @@ __device__ __forceinline__ void col_reduce2(int GB, int C, long R, int rows_per_
   for (int i = threadIdx.x; i < GB * 16; i += 256) {
     const int half = i / (GB * 8), j = i % (GB * 8);     // j = channel offset inside this block's GB * 8 channels
     const int cc = blockIdx.y * GB * 8 + j;
-    if (cc < C) atomicAdd(out + half * C + cc, red[j >> 3][half * 8 + (j & 7)]);
+    if (cc < C) atomicAdd(out + half * C + cc, (double)red[j >> 3][half * 8 + (j & 7)]);      // global_atomic_add_f64
   }
 }
 inline int group_block(int ld) { const int g = ld / 8; return g <= 4 ? 4 : (g <= 8 ? 8 : (g <= 16 ? 16 : 32)); }
 
 // BatchNorm statistics: sums[c] += sum_r x[r,c], sums[C + c] += sum_r x[r,c]^2
 __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, int ldx, long R, int C, int rows_per_block, int GB,
-                                                       float* __restrict__ sums) {
+                                                       double* __restrict__ sums) {
   col_reduce2(GB, C, R, rows_per_block, sums, [&](int c, long ra, long rb, int step, float (&s1)[8], float (&s2)[8]) {
     long r = ra;
     for (; r + 3 * (long)step < rb; r += 4 * (long)step) {                 // four rows in flight per thread
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
 
 // BatchNorm apply (training): y = act(x scale + shift) (+ resid) with scale = rstd gamma, shift = beta - mean scale staged in LDS
 // once per workgroup; block 0 also writes stat = {mean[C], rstd[C]} and updates the running statistics.  Pad channels (>= C) -> 0.
-__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, int ldx, long R, int C, const float* __restrict__ sums,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, int ldx, long R, int C, const double* __restrict__ sums,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                        float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                        int act, const bf16_t* __restrict__ resid, int ldr, bf16_t* __restrict__ y, int ldy,
@@ -135,11 +143,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
   extern __shared__ float sc[];                          // [2 ldy]: scale, shift
   const int C8 = ldy >> 3;
   const long total = R * C8;
-  const float invR = 1.0f / (float)R;
+  const double invR = 1.0 / (double)R;
   for (int c = threadIdx.x; c < ldy; c += 256) {
     float scale = 0.f, shift = 0.f;
     if (c < C) {
-      const float m = sums[c] * invR, var = fmaxf(sums[C + c] * invR - m * m, 0.f), rs = rsqrtf(var + eps);
+      const double md = sums[c] * invR, vd = fmax(sums[C + c] * invR - md * md, 0.0);       // fp64: no cancellation at |mean| >> std
+      const float m = (float)md, var = (float)vd, rs = (float)(1.0 / sqrt(vd + (double)eps));
       scale = rs * gamma[c]; shift = beta[c] - m * scale;
       if (blockIdx.x == 0) {
         stat[c] = m; stat[C + c] = rs;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                             long R, int C, const float* __restrict__ stat, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int act, const bf16_t* __restrict__ add,
-                                                            int ldadd, int HW, int rows_per_block, int GB, float* __restrict__ dsums) {
+                                                            int ldadd, int HW, int rows_per_block, int GB, double* __restrict__ dsums) {
   col_reduce2(GB, C, R, rows_per_block, dsums, [&](int c, long ra, long rb, int step, float (&s1)[8], float (&s2)[8]) {
     float m[8], rs[8], ga[8], be[8];
 #pragma unroll
@@ -210,17 +219,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
                                                            long R, int C, const float* __restrict__ stat, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int act, const bf16_t* __restrict__ add,
-                                                           int ldadd, int HW, const float* __restrict__ dsums, bf16_t* __restrict__ dx,
-                                                           int lddx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                           int ldadd, int HW, const double* __restrict__ dsums, bf16_t* __restrict__ dx,
+                                                           int lddx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           const float* __restrict__ gscale) {
   extern __shared__ float sc[];                          // [6 lddx]: mean, rstd, gamma, beta, sum dz / R, sum dz xhat / R
   const int C8 = lddx >> 3;
   const long total = R * C8;
-  const float invR = 1.0f / (float)R, invHW = 1.0f / (float)HW;
+  const double invR = 1.0 / (double)R;
+  const float invHW = 1.0f / (float)HW;
   for (int c = threadIdx.x; c < lddx; c += 256) {
     const bool ok = c < C;
     sc[c] = ok ? stat[c] : 0.f; sc[lddx + c] = ok ? stat[C + c] : 0.f; sc[2 * lddx + c] = ok ? gamma[c] : 0.f;
-    sc[3 * lddx + c] = ok ? beta[c] : 0.f; sc[4 * lddx + c] = ok ? dsums[c] * invR : 0.f; sc[5 * lddx + c] = ok ? dsums[C + c] * invR : 0.f;
-    if (ok && blockIdx.x == 0 && dgamma != nullptr) { dgamma[c] += dsums[C + c]; dbeta[c] += dsums[c]; }
+    sc[3 * lddx + c] = ok ? beta[c] : 0.f; sc[4 * lddx + c] = ok ? (float)(dsums[c] * invR) : 0.f; sc[5 * lddx + c] = ok ? (float)(dsums[C + c] * invR) : 0.f;
+    if (ok && blockIdx.x == 0 && dgamma != nullptr) {      // the affine gradients leave the scaled 16-bit domain here: x 1 / scale
+      const double inv = gscale != nullptr ? (double)gscale[1] : 1.0;
+      dgamma[c] += (float)(dsums[C + c] * inv); dbeta[c] += (float)(dsums[c] * inv);
+    }
   }
   __syncthreads();
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -473,12 +487,12 @@ __global__ __launch_bounds__(256) void act_bwd_post_kernel(const float* __restri
                                                            long n, int act, bf16_t* __restrict__ out) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float yv = bf2f(y[i]);
-  const float d = dy_f32 != nullptr ? dy_f32[i] : bf2f(dy_bf[i]);
+  const float yv = h2f(y[i]);
+  const float d = dy_f32 != nullptr ? dy_f32[i] : h2f(dy_bf[i]);
   float g = 1.f;
   if (act == 1) g = yv > 0.f ? 1.f : 0.f;
   else if (act == 3) g = (yv > 0.f && yv < 1.f) ? (1.f / 6.f) : 0.f;
-  out[i] = f2bf(d * g);
+  out[i] = f2h(d * g);
 }
 // dx[n, p, c] = dfeat[n, c] / HW   (backward of the final average pool)
 __global__ __launch_bounds__(256) void pool_bwd_kernel(const bf16_t* __restrict__ dfeat, int ldf, int N, int HW, int ld, bf16_t* __restrict__ dx) {
@@ -511,7 +525,7 @@ __global__ __launch_bounds__(256) void pad_cast_table_kernel(const float* __rest
     if (i >= prow * ld) return;
     const long dr = i / ld, dc = i % ld;
     const long sr = tr ? dc : dr, scol = tr ? dr : dc;
-    dst[doff + i] = (sr < rows && scol < cols) ? f2bf(master[src + sr * cols + scol]) : (bf16_t)0;
+    dst[doff + i] = (sr < rows && scol < cols) ? f2h(master[src + sr * cols + scol]) : (bf16_t)0;
   }
 }
 // depthwise weight images: entry = {src offset (floats into master), C, k*k, dst offset (floats), ld}: dst[t][c] = src[c][t], pad 0
@@ -529,7 +543,7 @@ __global__ __launch_bounds__(256) void dw_layout_table_kernel(const float* __res
 // gradient fold: entry = {padded src offset (floats), rows, cols, src ld, arena grad offset, transpose}: grad[r][c] += src[r][c]
 // (transpose: the source image is [cols][ld] tap-major and grad[r][c] += src[c][r]: depthwise weight gradients)
 __global__ __launch_bounds__(256) void unpad_add_table_kernel(const float* __restrict__ padded, float* __restrict__ grad, const long* __restrict__ table,
-                                                              const int* __restrict__ starts, int n_ent) {
+                                                              const int* __restrict__ starts, int n_ent, const float* __restrict__ gscale) {
   int lo = 0, hi = n_ent;
   while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
   const long* e = table + 8 * lo;
@@ -537,7 +551,8 @@ __global__ __launch_bounds__(256) void unpad_add_table_kernel(const float* __res
   const long i = (long)(blockIdx.x - starts[lo]) * 256 + threadIdx.x;
   if (i >= rows * cols) return;
   const long r = i / cols, c = i % cols;
-  grad[goff + i] += tr ? padded[src + c * ld + r] : padded[src + r * ld + c];
+  const float inv = gscale != nullptr ? gscale[1] : 1.f;               // un-scale: see lafs_cnn_grad_scale
+  grad[goff + i] += inv * (tr ? padded[src + c * ld + r] : padded[src + r * ld + c]);
 }
 
 // ---- backward of the per-image min-max scaling theta = (t - min) / (max - min) * 111 (ViT_face.py:698-706): the gradient also
@@ -584,6 +599,36 @@ __global__ __launch_bounds__(256) void theta_bwd_kernel(const float* __restrict_
   }
 }
 
+// ---- gradient scale: scale[0] = target / max |g| (1 when the gradient is all zero or not finite), scale[1] = 1 / scale[0]; one
+// workgroup (the gradient of the raw regressor output is a few thousand floats)
+__global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ g, long n, float target, float* __restrict__ scale) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(g[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float s = (m > 0.f && m < 3.0e38f) ? target / m : 1.f;
+    s = exp2f(floorf(log2f(s)));                                       // a power of two: scaling and un-scaling are exact
+    scale[0] = s; scale[1] = 1.0f / s;
+  }
+}
+// dst(fp16)[r, c] = src(f32)[r, c] * scale[0] for c < cols, 0 for cols <= c < ld   (scale == nullptr: 1)
+__global__ __launch_bounds__(256) void cast_pad_f16_kernel(const float* __restrict__ src, int rows, int cols, bf16_t* __restrict__ dst, int ld,
+                                                           const float* __restrict__ scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows * ld) return;
+  const int r = (int)(i / ld), c = (int)(i % ld);
+  const float s = scale != nullptr ? scale[0] : 1.f;
+  dst[i] = c < cols ? f2h(src[(size_t)r * cols + c] * s) : (bf16_t)0;
+}
+__global__ __launch_bounds__(256) void cast_f16_f32_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = h2f(src[i]);
+}
+
 #define K_DISPATCH(KERNEL, ...)                                    \
   do {                                                             \
     if (k == 3) hipLaunchKernelGGL((KERNEL<3>), __VA_ARGS__);      \
@@ -606,7 +651,7 @@ extern "C" int lafs_cnn_im2col_stem(const float* x, int N, int S, void* P, hipSt
   return LAFS_OK;
 }
 
-extern "C" int lafs_cnn_bn_stats(const void* x, int ldx, int64_t R, int C, float* sums, hipStream_t stream) {
+extern "C" int lafs_cnn_bn_stats(const void* x, int ldx, int64_t R, int C, double* sums, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(x && sums && R > 0 && C > 0 && ldx >= C && ldx % 8 == 0, "bad operand");
   const int rpb = rows_per_block_for(R), GB = group_block(ldx);
@@ -616,7 +661,7 @@ extern "C" int lafs_cnn_bn_stats(const void* x, int ldx, int64_t R, int C, float
   return LAFS_OK;
 }
 
-extern "C" int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const float* sums, const float* gamma, const float* beta, float eps,
+extern "C" int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const double* sums, const float* gamma, const float* beta, float eps,
                                  float momentum, float* running_mean, float* running_var, int act, const void* resid, int ldr, void* y,
                                  int ldy, float* stat, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
@@ -632,8 +677,8 @@ extern "C" int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const
 }
 
 extern "C" int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
-                               const float* beta, int act, const void* add_nc, int ldadd, int HW, float* dsums, void* dx, int lddx,
-                               float* dgamma, float* dbeta, hipStream_t stream) {
+                               const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
+                               float* dgamma, float* dbeta, const float* grad_scale, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(dy && x && stat && gamma && beta && dsums && dx && R > 0 && C > 0 && HW > 0, "null operand");
   LAFS_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && lddx >= C && lddy >= lddx && ldx >= lddx, "bad strides");
@@ -646,7 +691,7 @@ extern "C" int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx,
   long blocks = (R * (lddx / 8) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 6 * lddx * sizeof(float), stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (long)R,
-                     C, stat, gamma, beta, act, (const bf16_t*)add_nc, ldadd, HW, dsums, (bf16_t*)dx, lddx, dgamma, dbeta);
+                     C, stat, gamma, beta, act, (const bf16_t*)add_nc, ldadd, HW, dsums, (bf16_t*)dx, lddx, dgamma, dbeta, grad_scale);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -754,10 +799,35 @@ extern "C" int lafs_cnn_pad_cast_table(const float* master, void* dst, const int
 }
 
 extern "C" int lafs_cnn_unpad_add_table(const float* padded, float* grad, const int64_t* table, const int32_t* starts, int n_entries, int n_blocks,
-                                        hipStream_t stream) {
+                                        const float* grad_scale, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(padded && grad && table && starts && n_entries > 0 && n_blocks > 0, "bad operand");
-  hipLaunchKernelGGL(unpad_add_table_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, padded, grad, (const long*)table, starts, n_entries);
+  hipLaunchKernelGGL(unpad_add_table_kernel, dim3((unsigned)n_blocks), dim3(256), 0, stream, padded, grad, (const long*)table, starts, n_entries,
+                     grad_scale);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_grad_scale(const float* g, int64_t n, float target, float* scale, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(g && scale && n > 0 && target > 0.f, "bad operand");
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(256), 0, stream, g, (long)n, target, scale);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_cast_pad_f16(const float* src, int rows, int cols, void* dst, int ld, const float* scale, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld >= cols, "bad operand");
+  hipLaunchKernelGGL(cast_pad_f16_kernel, dim3(blocks_for((long)rows * ld)), dim3(256), 0, stream, src, rows, cols, (bf16_t*)dst, ld, scale);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_cast_f16_f32(const void* src, float* dst, int64_t n, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(src && dst && n > 0, "bad operand");
+  hipLaunchKernelGGL(cast_f16_f32_kernel, dim3(blocks_for((long)n)), dim3(256), 0, stream, (const bf16_t*)src, dst, (long)n);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

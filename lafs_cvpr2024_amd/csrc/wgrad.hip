@@ -41,9 +41,11 @@ struct WgArgs {
   int n_items, M, mlen, slices, tiles, nblk;          // tiles: all GEMMs together
 };
 
-__device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+template <bool F16> __device__ __forceinline__ f32x16_t mfma32(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+constexpr int WG_F16 = 65536;          // ABL bit: operands are fp16 (lafs_wgrad_f16: the trainable landmark CNN); everything else as bf16
 // LDS-DMA with a cache policy chosen at compile time (lab: 0 = default, 1 = nt, 2 = sc1, 3 = sc0 sc1, 4 = sc0)
 template <int POL> __device__ __forceinline__ void lds_dma16_pol(const void* gsrc, unsigned lds_base) {
   if constexpr (POL == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(lds_base) : "memory");
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC * (WM * WN) / 4) void wgrad_kerne
 #pragma unroll
       for (int b = 0; b < FB; ++b) {
         const int k = a * FB + b;
-        acc[a][b] = mfma32(fa[a], fb[b], acc[a][b]);
+        acc[a][b] = mfma32<(ABL & WG_F16) != 0>(fa[a], fb[b], acc[a][b]);
         if (decltype(READS)::value && !(ABL & 8)) {
 #pragma unroll
           for (int f = 0; f < NF; ++f)
@@ -225,11 +227,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC * (WM * WN) / 4) void wgrad_kerne
       for (int a = 0; a < FA; ++a) {
         typedef __bf16 bf16x2v_t __attribute__((ext_vector_type(2)));
         const uint4 w = __builtin_bit_cast(uint4, fa[a]);
+        if constexpr ((ABL & WG_F16) != 0) {
+          cs[a] += (h_lo(w.x) + h_hi(w.x)) + (h_lo(w.y) + h_hi(w.y)) + (h_lo(w.z) + h_hi(w.z)) + (h_lo(w.w) + h_hi(w.w));
+        } else {
         const bf16x2v_t one = __builtin_bit_cast(bf16x2v_t, 0x3f803f80u);        // v_dot2c_f32_bf16: cs += lo * 1 + hi * 1
         cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w.x), one, cs[a], false);
         cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w.y), one, cs[a], false);
         cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w.z), one, cs[a], false);
         cs[a] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, w.w), one, cs[a], false);
+        }
       }
     }
   };
@@ -421,7 +427,7 @@ int launch(const WgArgs& a, hipStream_t s) {
     }
   }
 #endif
-  if constexpr (FA * FB <= 9 && ABL != 0) {          // lab: a sixth ring stage (3 x 3 blocks: 6 x 24 KiB)
+  if constexpr (FA * FB <= 9 && (ABL & ~WG_F16) != 0) {          // lab: a sixth ring stage (3 x 3 blocks: 6 x 24 KiB)
     static const bool ns6 = getenv("LAFS_WGRAD_NS6") != nullptr;
     if (ns6) {
       hipLaunchKernelGGL((wgrad_kernel<2, 2, FA, FB, 6, 1, ABL>), dim3(a.nblk), dim3(256), 0, s, a);
@@ -496,6 +502,15 @@ extern "C" int64_t lafs_wgrad_group_workspace_bytes(const lafs_wgrad_item* items
 extern "C" int lafs_wgrad_group(const lafs_wgrad_item* items, int n_items, int M, int max_workgroups, void* workspace,
                                 int64_t workspace_bytes, hipStream_t stream) {
   return group_impl<0>(items, n_items, M, max_workgroups, workspace, workspace_bytes, stream);
+}
+
+// fp16 operands (the trainable landmark CNN's activations / activation gradients): same kernel, v_mfma_f32_32x32x16_f16
+extern "C" int lafs_wgrad_f16(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N1, int N2,
+                              int accumulate, float* colsum_a, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  lafs_wgrad_item it = {};
+  it.A = A; it.lda = lda; it.B = B; it.ldb = ldb; it.C = C; it.ldc = ldc; it.N1 = N1; it.N2 = N2;
+  it.accumulate = accumulate; it.colsum_a = colsum_a;
+  return group_impl<WG_F16>(&it, 1, M, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" int64_t lafs_wgrad_workspace_bytes(int M, int N1, int N2) {

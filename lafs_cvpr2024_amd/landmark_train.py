@@ -4,7 +4,8 @@ Part-fViT with ``with_land=True`` -- the model train_largescale.py:432,542-561 r
 with a MobileNetV3-large trunk that is TRAINED with the rest of the network (reference face_pre_pro/mobilenet.py:224-313,
 ViT_face.py:679-711): BatchNorm in training mode, Dropout(0.5) in front of the regressor, gradients arriving through the
 patch gather.  Rounds 1-2 ran this branch on torch autograd over MIOpen (~700 launches, 10 of 34 ms per step at batch 128).
-Here it is a launch plan over NHWC bf16 activations (channels padded to 32, csrc/landmark_train.hip):
+Here it is a launch plan over NHWC fp16 activations (the reference's autocast format; channels padded to 32,
+csrc/landmark_train.hip; round 3 stored bf16 and sat 9 % from the fp32 reference where fp16 sits at ~1 %):
 
     forward   im2col stem -> [1x1 conv = lafs_gemm_nt -> BN statistics -> BN apply + activation] ... depthwise kernels, squeeze-
               excite (pool, two small GEMMs, rescale), project conv + BN + residual ... pool -> Dropout -> Linear -> min-max theta
@@ -12,7 +13,7 @@ Here it is a launch plan over NHWC bf16 activations (channels padded to 32, csrc
               weight, lafs_gemm_nt on W^T shadows for the input gradients, depthwise data / weight gradients, SE backward
 
 Parameters stay fp32 in the fine-tune arena (no copies: gamma / beta / depthwise weights are read in place, their gradients
-accumulated in place); the padded bf16 operand images of the 1x1 / FC weights are refreshed by one table-driven launch whenever the
+accumulated in place); the padded fp16 operand images of the 1x1 / FC weights are refreshed by one table-driven launch whenever the
 arena's master weights changed, the padded weight gradients folded into the arena by one launch per backward.
 """
 import ctypes as C
@@ -23,7 +24,8 @@ import torch.nn as nn
 from . import _lib, ops
 from .ops import _p, call
 
-f32, bf16 = torch.float32, torch.bfloat16
+f32, h16 = torch.float32, torch.float16      # 16-bit storage of this plan: IEEE fp16 (round 3: bf16), see csrc/landmark_train.hip
+GRAD_TARGET = 1024.0                          # max |scaled gradient| entering the CNN backward (power-of-two scale chosen on the device)
 
 
 def _pad32(c):
@@ -38,6 +40,14 @@ def _act_code(m):
     if isinstance(m, nn.Hardsigmoid):
         return _lib.ACT_HSIGMOID
     return _lib.ACT_NONE
+
+
+def _bn_momentum(bn):
+    """nn.BatchNorm2d(momentum=None) means a cumulative moving average (factor 1 / num_batches_tracked), which this plan's constant
+    factor cannot express: refuse it instead of substituting a value (the reference's MobileNetV3 uses the default 0.1)."""
+    if bn.momentum is None:
+        raise _lib.LafsHipError("HipLandmarkTrainer: BatchNorm2d(momentum=None) (cumulative average) is not supported")
+    return float(bn.momentum)
 
 
 class _Tables:
@@ -92,7 +102,7 @@ class HipLandmarkTrainer:
 
         def bn_spec(prefix, bn, C):
             s = dict(C=C, g=off(prefix + ".weight"), b=off(prefix + ".bias"), rm=bn.running_mean, rv=bn.running_var, eps=float(bn.eps),
-                     mom=0.1 if bn.momentum is None else float(bn.momentum), nbt=bn.num_batches_tracked, sums=sums[0], dsums=sums[0] + 2 * C,
+                     mom=_bn_momentum(bn), nbt=bn.num_batches_tracked, sums=sums[0], dsums=sums[0] + 2 * C,
                      stat=None)
             sums[0] += 4 * C
             return s
@@ -144,9 +154,10 @@ class HipLandmarkTrainer:
         self.wdw = torch.zeros(T.dw_size, device=dev, dtype=f32)
         self.dw_grad_lo = min(L["dw"][1] for L in self.blocks)             # the depthwise gradient images are zeroed every backward
         self.dw_grad_hi = max(L["dw"][1] + ((L["k"] ** 2 * L["pe"] + 63) // 64 * 64) for L in self.blocks)
-        self.wbf = torch.zeros(T.cast_size, device=dev, dtype=bf16)
+        self.wbf = torch.zeros(T.cast_size, device=dev, dtype=h16)
         self.gpad = torch.zeros(T.grad_size, device=dev, dtype=f32)
-        self.bn_ws = torch.zeros(sums[0], device=dev, dtype=f32)
+        self.bn_ws = torch.zeros(sums[0], device=dev, dtype=torch.float64)     # BatchNorm sums: fp64 (exact enough to be order-independent)
+        self.gscale = torch.ones(2, device=dev, dtype=f32)                       # {scale, 1 / scale} of this backward's gradients (device)
         self._versions = None
         self.step = 0
         self.seed = 0x1A2D
@@ -170,7 +181,7 @@ class HipLandmarkTrainer:
         return C.c_void_p(self.arena.grad.data_ptr() + 4 * offset)
 
     def _ws(self, offset):
-        return C.c_void_p(self.bn_ws.data_ptr() + 4 * offset)
+        return C.c_void_p(self.bn_ws.data_ptr() + 8 * offset)
 
     def _dww(self, L):                          # tap-major weight image / gradient image of a block's depthwise convolution
         return C.c_void_p(self.wdw.data_ptr() + 4 * L["dw"][0])
@@ -186,7 +197,7 @@ class HipLandmarkTrainer:
     def _alloc(self):
         N, dev = self.N, self.device
         H = self.S // 2
-        mk = lambda rows, ld: torch.empty(rows, ld, device=dev, dtype=bf16)
+        mk = lambda rows, ld: torch.empty(rows, ld, device=dev, dtype=h16)
         B = dict(P=mk(N * H * H, 32), s_raw=mk(N * H * H, 32), x0=mk(N * H * H, 32), layers=[])
         wmax = 0
         wb = lambda M, n1, n2: max(int(_lib.lib().lafs_wgrad_workspace_bytes(M, n1, n2)), 0)
@@ -212,14 +223,14 @@ class HipLandmarkTrainer:
         B["theta"] = torch.empty(N, self.n_out // 2, 2, device=dev, dtype=f32)
         B["zero_noise"] = torch.zeros(N, self.n_out // 2, 2, device=dev, dtype=f32)
         B["dt"] = torch.empty(N, self.n_out, device=dev, dtype=f32)
-        B["dt_bf"] = torch.zeros(N, self.p_out, device=dev, dtype=bf16)
+        B["dt_bf"] = torch.zeros(N, self.p_out, device=dev, dtype=h16)
         B["dfeatf"] = torch.empty(N, self.p_last, device=dev, dtype=f32)
         B["dfeat"] = mk(N, self.p_last)
         # gradient ping-pong buffers, sized for the largest activation
         big = max(max(d["R"] * L["pe"], d["Ro"] * L["po"], d["R"] * L["pi"]) for d, L in zip(B["layers"], self.blocks))
-        B["ga"] = torch.empty(big, device=dev, dtype=bf16)
-        B["gb"] = torch.empty(big, device=dev, dtype=bf16)
-        B["gc"] = torch.empty(big, device=dev, dtype=bf16)
+        B["ga"] = torch.empty(big, device=dev, dtype=h16)
+        B["gb"] = torch.empty(big, device=dev, dtype=h16)
+        B["gc"] = torch.empty(big, device=dev, dtype=h16)
         wmax = max(wmax, wb(N, self.p_out, self.p_last))
         B["wg_ws"] = torch.empty(max(wmax, 16) // 4, device=dev, dtype=f32)
         self.B = B
@@ -236,13 +247,13 @@ class HipLandmarkTrainer:
     def _bn_bwd(self, spec, dy, x, R, act, dx, add_nc=None, HW=1):
         call("lafs_cnn_bn_bwd", _p(dy), dy.shape[1], _p(x), x.shape[1], R, spec["C"], _p(spec["stat"]), self._m(spec["g"]), self._m(spec["b"]), act,
              _p(add_nc), add_nc.shape[1] if add_nc is not None else 0, HW, self._ws(spec["dsums"]), _p(dx), dx.shape[1], self._g(spec["g"]),
-             self._g(spec["b"]))
+             self._g(spec["b"]), _p(self.gscale))
 
     def _wgrad(self, dy, x, cs):
         """padded dW [po, pi] = dy^T x into the gradient image of conv spec `cs` (folded into the arena at the end of backward)."""
         gw = self._gw(cs["gw"], cs["po"], cs["pi"])
         ws = self.B["wg_ws"]
-        call("lafs_wgrad", _p(dy), dy.shape[1], _p(x), x.shape[1], _p(gw), cs["pi"], dy.shape[0], cs["po"], cs["pi"], 0, None, _p(ws),
+        call("lafs_wgrad_f16", _p(dy), dy.shape[1], _p(x), x.shape[1], _p(gw), cs["pi"], dy.shape[0], cs["po"], cs["pi"], 0, None, _p(ws),
              ws.numel() * 4)
 
     # ------------------------------------------------------------------ forward
@@ -257,7 +268,7 @@ class HipLandmarkTrainer:
         if self._versions != ver or getattr(self, "_stale", True):
             self.refresh_operands()
             self._versions, self._stale = ver, False
-        call("lafs_fill_zero", _p(self.bn_ws), self.bn_ws.numel() * 4)
+        call("lafs_fill_zero", _p(self.bn_ws), self.bn_ws.numel() * 8)
         self.x_in = x.contiguous()
         H0 = self.S // 2
         R0 = N * H0 * H0
@@ -287,13 +298,13 @@ class HipLandmarkTrainer:
         HW = self.H_last * self.H_last
         call("lafs_cnn_pool_train", _p(cur), N, HW, self.p_last, _p(B["feat"]), self.p_last)
         # Dropout(0.5) (training) + Linear(160, 2 r r): counter-based mask of (seed + 7919 step), regenerated in the backward
-        call("lafs_cast_f32", _p(B["feat"]), _p(B["featf"]), B["feat"].numel())
+        call("lafs_cnn_cast_f16_f32", _p(B["feat"]), _p(B["featf"]), B["feat"].numel())
         # host counter: seed + 7919 * step per forward; with `step_dev` (a DEVICE float, e.g. hyper[HP_STEP] of a captured fine-tune
         # step) the kernels add 7919 * step themselves, so a replayed graph draws a new mask every micro-step
         self.drop_seed = self.seed if self.step_dev is not None else (self.seed + 7919 * self.step) & 0xFFFFFFFF
         self.step += 1
         self._dropout(B["featf"])
-        call("lafs_cast_bf16", _p(B["featf"]), _p(B["featd"]), B["featf"].numel())
+        call("lafs_cnn_cast_pad_f16", _p(B["featf"]), N, self.p_last, _p(B["featd"]), self.p_last, None)
         ops.gemm_nt(B["featd"], self._w(self.head["w"], self.p_out, self.p_last)[: self.n_out], _lib.EPI_F32,
                     bias=a.view(a.master, "output_layer.1.bias"), out=B["t"])
         n_full = self.n_out // 2
@@ -327,18 +338,22 @@ class HipLandmarkTrainer:
         n_full = self.n_out // 2
         call("lafs_landmark_theta_bwd", _p(B["t"]), _p(dtheta.contiguous()), N, self.n_out, _p(B["dt"]))
         call("lafs_fill_zero", C.c_void_p(self.gpad.data_ptr() + 4 * self.dw_grad_lo), (self.dw_grad_hi - self.dw_grad_lo) * 4)
-        ops.scale_cast_bf16(B["dt"], out=B["dt_bf"])                      # [N, n_out] -> bf16 image [N, p_out] (pad columns stay zero)
+        # loss scaling (the reference's GradScaler, train_largescale.py:803-867): the gradient enters the fp16 backward multiplied by
+        # the power of two that brings its largest entry to ~GRAD_TARGET, chosen on the device; it is divided out where gradients
+        # leave the 16-bit domain (BatchNorm affine gradients, the fold of the padded weight gradients)
+        call("lafs_cnn_grad_scale", _p(B["dt"]), B["dt"].numel(), GRAD_TARGET, _p(self.gscale))
+        call("lafs_cnn_cast_pad_f16", _p(B["dt"]), N, self.n_out, _p(B["dt_bf"]), self.p_out, _p(self.gscale))
         # head: dW, db, d(feature)
         hd = self.head
         gw = self._gw(hd["gw"], hd["po"], hd["pi"])
         gb = self.gpad[self.head_gb: self.head_gb + self.p_out]
         call("lafs_fill_zero", _p(gb), self.p_out * 4)
         ws = B["wg_ws"]
-        call("lafs_wgrad", _p(B["dt_bf"]), self.p_out, _p(B["featd"]), self.p_last, _p(gw), hd["pi"], N, hd["po"], hd["pi"], 0, _p(gb), _p(ws),
+        call("lafs_wgrad_f16", _p(B["dt_bf"]), self.p_out, _p(B["featd"]), self.p_last, _p(gw), hd["pi"], N, hd["po"], hd["pi"], 0, _p(gb), _p(ws),
              ws.numel() * 4)
         ops.gemm_nt(B["dt_bf"], self._w(hd["wt"], hd["pi"], hd["po"]), _lib.EPI_F32, out=B["dfeatf"])
         self._dropout(B["dfeatf"])
-        call("lafs_cast_bf16", _p(B["dfeatf"]), _p(B["dfeat"]), B["dfeatf"].numel())
+        call("lafs_cnn_cast_pad_f16", _p(B["dfeatf"]), N, self.p_last, _p(B["dfeat"]), self.p_last, None)
         HW = self.H_last * self.H_last
         Dl, Ll = B["layers"][-1], self.blocks[-1]
         view = lambda buf, rows, ld: buf[: rows * ld].view(rows, ld)
@@ -408,7 +423,8 @@ class HipLandmarkTrainer:
         self._bn_bwd(st["bn"], dy, B["s_raw"], R0, st["act"], ds_raw)
         self._wgrad(ds_raw, B["P"], st["conv"])
         # fold every padded weight gradient into the arena
-        call("lafs_cnn_unpad_add_table", _p(self.gpad), _p(a.grad), _p(self.fold_table), _p(self.fold_starts), self.n_fold, self.fold_nblk)
+        call("lafs_cnn_unpad_add_table", _p(self.gpad), _p(a.grad), _p(self.fold_table), _p(self.fold_starts), self.n_fold, self.fold_nblk,
+             _p(self.gscale))
 
     def mark_stale(self):
         """The optimizer changed the master weights in place (no torch version bump): refresh the operand images next forward."""

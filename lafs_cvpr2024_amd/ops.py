@@ -48,16 +48,18 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
             route_only=False):
     """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*).  skip_pre (BF16_GELU): write only
     GELU(u), as the forward-only teacher pass does; route_only: return lafs_gemm_nt_route for this request instead of running it."""
-    _chk(A, bf16, "A"); _chk(B, bf16, "B")
+    # 16-bit operand format: bf16 everywhere except the trainable landmark CNN's plan, which runs on fp16 (operand_f16)
+    h16 = torch.float16 if A.dtype == torch.float16 else bf16
+    _chk(A, h16, "A"); _chk(B, h16, "B")
     M, K = A.shape
     N = B.shape[0] if n_cols is None else n_cols
     f32_out = epilogue in (_lib.EPI_RESID_F32, _lib.EPI_F32, _lib.EPI_ATOMIC_F32, _lib.EPI_EMBED_F32)
     if out is None:
         rows = M if out_rows is None else out_rows
-        out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if f32_out else bf16)
+        out = torch.empty(rows, N, device=A.device, dtype=torch.float32 if f32_out else h16)
         if epilogue == _lib.EPI_ATOMIC_F32:
             zero_(out)
-    _chk(out, torch.float32 if f32_out else bf16, "out")
+    _chk(out, torch.float32 if f32_out else h16, "out")
     if epilogue == _lib.EPI_BF16_GELU and out2 is None:
         out2 = torch.empty(M, N, device=A.device, dtype=bf16)
     a = _lib.GemmNTArgs()
@@ -66,6 +68,7 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     a.drop_p, a.drop_seed = float(drop_p), int(drop_seed) & 0xFFFFFFFF
     a.drop_step, a.drop_row0 = (drop_step.data_ptr() if drop_step is not None else None), int(drop_row0)
     a.act = int(act)
+    a.operand_f16 = 1 if h16 == torch.float16 else 0
     a.C, a.ldc = out.data_ptr(), _ld(out)
     if out2 is not None:
         _chk(out2, bf16, "out2"); a.C2, a.ldc2 = out2.data_ptr(), _ld(out2)
@@ -77,7 +80,7 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
         _chk(seq_scale, torch.float32, "seq_scale"); _chk(row2seq, torch.int32, "row2seq")
         a.seq_scale, a.row2seq = seq_scale.data_ptr(), row2seq.data_ptr()
     if aux is not None:
-        _chk(aux, bf16, "aux"); a.aux, a.ldaux = aux.data_ptr(), _ld(aux)
+        _chk(aux, h16, "aux"); a.aux, a.ldaux = aux.data_ptr(), _ld(aux)
     if pos is not None:
         _chk(pos, torch.float32, "pos"); a.pos, a.npatch = pos.data_ptr(), npatch
     a.splits = splits
@@ -107,12 +110,13 @@ def wgrad_workspace(M, N1, N2, device):
 
 def wgrad(A, B, C, accumulate=True, colsum=None, workspace=None):
     """C[N1,N2] (f32) = (accumulate ? C : 0) + A[M,N1]^T @ B[M,N2] on the wide-tile kernel (csrc/wgrad.hip)."""
-    _chk(A, bf16, "A"); _chk(B, bf16, "B"); _chk(C, torch.float32, "C")
+    h16 = torch.float16 if A.dtype == torch.float16 else bf16
+    _chk(A, h16, "A"); _chk(B, h16, "B"); _chk(C, torch.float32, "C")
     M, N1 = A.shape
     N2 = B.shape[1]
     if workspace is None:
         workspace = wgrad_workspace(M, N1, N2, A.device)
-    call("lafs_wgrad", _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N1, N2, int(bool(accumulate)), _p(colsum),
+    call("lafs_wgrad_f16" if h16 == torch.float16 else "lafs_wgrad", _p(A), _ld(A), _p(B), _ld(B), _p(C), _ld(C), M, N1, N2, int(bool(accumulate)), _p(colsum),
          _p(workspace), workspace.numel() * workspace.element_size())
     return C
 

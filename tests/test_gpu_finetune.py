@@ -115,9 +115,11 @@ def test_captured_finetune_step_equals_the_eager_single_stream_step(with_land, m
     """The fine-tune micro-step as hipGraphs with the block weight gradients on a second stream (the default) against the same engine
     run eagerly on ONE stream: three accumulation windows of two micro-steps with live dropout / DropPath / mixup.  Without the
     landmark branch the two must agree to fp32 round-off (a buffer reused while the second stream still reads it -- the hazard round
-    3's side-stream experiment ran into -- shows up at the percent level).  With the trainable landmark branch the comparison is
-    held against the branch's own run-to-run noise, measured in the same test (two eager runs): its batch-statistics BatchNorms
-    accumulate with fp32 atomics and the min-max scaling of the landmarks amplifies their order."""
+    3's side-stream experiment ran into -- shows up at the percent level).  With the trainable landmark branch the losses before
+    the first update agree as tightly (its BatchNorm sums are fp64 since round 4: the forward is deterministic); after updates the
+    comparison is held against the branch's own run-to-run noise, measured in the same test (two eager runs): gradient atomics
+    (depthwise weight gradients, bias column sums) through Adam's first steps and a batch-statistics CNN that amplifies weight
+    perturbations ~100x."""
     from conftest import det_fill_random
     from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
     B, C = 16, 3000
@@ -147,7 +149,7 @@ def test_captured_finetune_step_equals_the_eager_single_stream_step(with_land, m
     a, b, b2 = res["graph"], res["eager"], res["eager2"]
     noise = max(abs(x - y) / abs(y) for x, y in zip(b2["losses"], b["losses"]))
     print(f"[finetune graph vs eager, with_land={with_land}] losses", a["losses"], b["losses"], "eager run-to-run", noise)
-    tol0 = 1e-5 if not with_land else max(5e-4, 5 * noise)
+    tol0 = 1e-5          # before the first update: the forward is deterministic with and without the landmark branch (fp64 BatchNorm sums)
     assert abs(a["losses"][0] - b["losses"][0]) < tol0 * abs(b["losses"][0]) and abs(a["losses"][1] - b["losses"][1]) < tol0 * abs(b["losses"][1])
     for x, y in zip(a["losses"][2:], b["losses"][2:]):          # after updates: Adam's first steps amplify atomics-order noise
         assert abs(x - y) < max(2e-3, 5 * noise) * abs(y), (a["losses"], b["losses"])
@@ -754,10 +756,15 @@ def _ste_bf16(t):
     return t + (t.to(torch.bfloat16).float() - t).detach()
 
 
+def _ste_f16(t):
+    """straight-through IEEE fp16 rounding: what the HIP plan stores (round 4) and what the reference's autocast run computes in"""
+    return t + (t.to(torch.float16).float() - t).detach()
+
+
 def test_landmark_cnn_training_plan_stage_by_stage():
     """Kernel correctness of the trainable landmark branch's HIP plan (landmark_train.py), batch 8: EVERY stage of the forward and
-    of the backward against the same stage stated in torch (fp32 ops, a bf16 rounding wherever the plan stores bf16), each stage fed
-    the PLAN'S OWN inputs.  End-to-end comparisons of two 16-bit pipelines cannot be tight here: bf16 roundings that fall on the
+    of the backward against the same stage stated in torch (fp32 ops, an fp16 rounding wherever the plan stores fp16), each stage fed
+    the PLAN'S OWN inputs.  End-to-end comparisons of two 16-bit pipelines cannot be tight here: roundings that fall on the
     other side of a boundary in 0.01 % of the elements decorrelate the two runs' rounding noise within a few blocks (measured:
     1e-5 per stage in isolation, 4 % end to end; tools/lab/debug_cnn_train.py) -- the network-level distance to the reference is the
     subject of the F18 test below.  Also: accumulation over two micro-steps, operand refresh after a weight change."""
@@ -776,7 +783,13 @@ def test_landmark_cnn_training_plan_stage_by_stage():
     theta = tr.forward(x).clone()
     tr.backward(dth)
     torch.cuda.synchronize()
-    rnd = _ste_bf16
+    rnd = _ste_f16
+    # the plan's activation gradients carry the power-of-two loss scale chosen on the device: bring the recorded ones back to units
+    S = float(tr.gscale[0])
+    assert S >= 1.0 and abs(float(tr.gscale[1]) * S - 1.0) < 1e-6 and float(np.log2(S)) == int(np.log2(S)), S
+    for T_ in tr.trace:
+        for k_ in list(T_):
+            T_[k_] = T_[k_].float() / S
     nchw = lambda buf, H, C: buf.view(B, H, H, -1)[..., :C].permute(0, 3, 1, 2).float().contiguous()
     named = dict(m.named_parameters())
     feats = m.stn.features
@@ -851,13 +864,13 @@ def test_landmark_cnn_training_plan_stage_by_stage():
     g_y, g_wh, g_bh = grads(th, [y_last, m.output_layer[1].weight, m.output_layer[1].bias], dth)
     bwd["d(y_last)"] = rel_l2(nchw(trace[-1]["dy"], Hl, 160), g_y)
     pgrad("output_layer.1.weight", g_wh); pgrad("output_layer.1.bias", g_bh)
-    gate_errors("landmark CNN plan, forward stages", fwd, 2e-3)
-    gate_errors("landmark CNN plan, backward stages (activation gradients)", bwd, 1.5e-2)
+    gate_errors("landmark CNN plan, forward stages", fwd, 4e-4)                                   # observed 8.6e-5 (fp16; bf16 was 2e-3)
+    gate_errors("landmark CNN plan, backward stages (activation gradients)", bwd, 1.5e-3)          # observed 3.1e-4 (bf16: 6.5e-3)
     # BatchNorm affine gradients are plain column sums of dz (xhat): where the terms cancel (a shift that the next squeeze-excite
-    # or BatchNorm mostly removes) the fp32 summation order of the atomics shows at the 1e-2 level relative to the small result
+    # or BatchNorm mostly removes) round 3's fp32 atomics showed at the 1e-2 level; the fp64 sums of round 4 do not
     bn_affine = {k: v for k, v in par.items() if k.endswith((".1.weight", ".1.bias", ".4.weight", ".4.bias", ".8.weight", ".8.bias"))}
-    gate_errors("landmark CNN plan, BatchNorm affine gradients per stage", bn_affine, 8e-2)
-    gate_errors("landmark CNN plan, weight gradients per stage", {k: v for k, v in par.items() if k not in bn_affine}, 1.5e-2)
+    gate_errors("landmark CNN plan, BatchNorm affine gradients per stage", bn_affine, 2.5e-3)      # observed 4.6e-4 (fp64 sums; bf16 + fp32 atomics: 2.5e-2)
+    gate_errors("landmark CNN plan, weight gradients per stage", {k: v for k, v in par.items() if k not in bn_affine}, 2e-3)   # observed 4.3e-4
     assert len(par) == 156 and len(bwd) >= 60 and len(fwd) >= 75              # every CNN tensor, every stage
     assert float((m.stn.features[0][1].running_mean - rm0).abs().max()) > 0          # running statistics were updated
     # a second micro-step ACCUMULATES into the same gradient arena (two runs are not bit-identical: the BatchNorm sums are fp32
@@ -888,12 +901,12 @@ def test_f18_hip_training_plan_of_the_landmark_cnn_against_the_reference():
     """The plan against the REFERENCE's own train-mode run of the landmark branch (F18: ViT_face.py:679-706 with BatchNorm batch
     statistics, Dropout(0.5) mask recorded, backward from a given d(loss)/d(theta)): raw regressor, landmarks, gradients of every
     kind of tensor (stem, depthwise, 1x1, squeeze-excite FCs, BatchNorm affine, regressor), gradient norms of ALL tensors, running
-    statistics.  The tolerances are those of ANY 16-bit evaluation of this algorithm, which the test measures itself: the same branch
-    stated in torch with straight-through bf16 roundings sits 9 % (regressor) / up to 0.45 rel-L2, cosine 0.91 (gradients) from the
-    fp32 reference, and with fp16 roundings -- what the reference's own GPU run does under autocast, train_largescale.py:803-804 --
-    1 % / 0.41 / 0.92: batch-statistics BatchNorm on a freshly initialised MobileNetV3 amplifies rounding noise, and the min-max
-    scaling routes gradient through arg-min / arg-max, which a 1 % change of the regressor re-selects.  The plan is gated at 1.5x
-    the bf16 statement's own distance (kernel correctness is the stage-by-stage test above)."""
+    statistics.  Round 4: the plan stores fp16 -- the format the reference's own GPU run computes in under autocast
+    (train_largescale.py:803-804) -- so it is held ABSOLUTELY: regressor within 2 % of the fp32 reference, landmarks within 0.5 px
+    on average, and within 1.3x of the distance the same branch stated in torch with straight-through fp16 roundings has (the
+    yardstick, measured here; the bf16 statement of round 3 -- 9 % / 1.5 px -- is printed beside it).  The gradient tolerances stay
+    those of ANY 16-bit evaluation: the min-max scaling routes gradient through arg-min / arg-max, which a 1 % change of the
+    regressor re-selects (fp16 statement: up to 0.41 rel-L2, cosine 0.92)."""
     from conftest import det_fill_random
     fx = load_golden("f18_landmark_train")
 
@@ -905,10 +918,11 @@ def test_f18_hip_training_plan_of_the_landmark_cnn_against_the_reference():
     named = dict(m.named_parameters())
     gref = sub(fx, "g.")
     cosine = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten().cpu().double(), b.flatten().double(), dim=0))
-    # this build's fp32 statement == the reference; its bf16 statement = the yardstick
+    # this build's fp32 statement == the reference; its fp16 statement = the yardstick
     t32, th32 = _landmark_branch_torch(m, x, keep, lambda t: t)
     assert rel_l2(t32, fx["t"]) < 1e-3 and float((th32.detach().cpu() - fx["theta"]).abs().max()) < 0.1
-    tb, thb = _landmark_branch_torch(m, x, keep, _ste_bf16)
+    tb16, _ = _landmark_branch_torch(m, x, keep, _ste_bf16)
+    tb, thb = _landmark_branch_torch(m, x, keep, _ste_f16)
     (thb * dth).sum().backward()
     yard_t = rel_l2(tb, fx["t"])
     yard_g = {k: rel_l2(named[k].grad, g) for k, g in gref.items()}
@@ -922,11 +936,12 @@ def test_f18_hip_training_plan_of_the_landmark_cnn_against_the_reference():
     d = (theta.cpu() - fx["theta"]).abs()
     errs = {k: rel_l2(named[k].grad, g) for k, g in gref.items()}
     cos = {k: cosine(named[k].grad, g) for k, g in gref.items()}
-    print(f"[F18] regressor rel-L2: plan {e_t:.3e}, bf16 torch statement {yard_t:.3e}; landmarks mean {float(d.mean()):.2f} px, max "
-          f"{float(d.max()):.2f} px; worst gradient rel-L2: plan {max(errs.values()):.3f}, statement {max(yard_g.values()):.3f}; "
-          f"min cosine: plan {min(cos.values()):.3f}, statement {min(yard_c.values()):.3f}")
-    assert e_t < 1.5 * yard_t + 0.02 and float(d.mean()) < 3.0 and float(d.max()) < 20.0, (e_t, yard_t)
-    assert max(errs.values()) < 1.5 * max(yard_g.values()) + 0.05, (errs, yard_g)
+    print(f"[F18] regressor rel-L2: plan {e_t:.3e}, fp16 torch statement {yard_t:.3e} (bf16 statement {rel_l2(tb16, fx['t']):.3e}); landmarks "
+          f"mean {float(d.mean()):.2f} px, max {float(d.max()):.2f} px; worst gradient rel-L2: plan {max(errs.values()):.3f}, statement "
+          f"{max(yard_g.values()):.3f}; min cosine: plan {min(cos.values()):.3f}, statement {min(yard_c.values()):.3f}; loss scale {float(tr.gscale[0]):.0f}")
+    assert e_t < 0.02 and e_t < 1.3 * yard_t + 0.003, (e_t, yard_t)
+    assert float(d.mean()) < 0.5 and float(d.max()) < 6.0, (float(d.mean()), float(d.max()))
+    assert max(errs.values()) < 1.3 * max(yard_g.values()) + 0.05, (errs, yard_g)
     assert min(cos.values()) > min(yard_c.values()) - 0.08, (cos, yard_c)
     # gradient norms of ALL tensors.  (A BatchNorm bias whose output only feeds a 1x1 convolution + batch-statistics BatchNorm has
     # an exactly zero gradient -- the shift is removed again by the next mean subtraction -- which the reference reproduces down to
