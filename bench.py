@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the roofline kernels' loops (for rocprofv3)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels' loops (profiles of the step alone)")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=64, help="batch of the CPU oracle leg (default: the metric's own batch; ~12 s per step on 32 threads)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the non-headline workloads appended to the JSON line at 1 GPU (`extras`: the reference's real "
                          "pre-training pair --arch mynet, and the C4 fine-tune step)")

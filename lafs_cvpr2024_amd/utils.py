@@ -86,22 +86,24 @@ def clip_gradients(model, clip):
     """Per-tensor L2 clipping through torch ops (API parity with reference utils.py:132-141; the training engine
     uses the fused lafs_clip_adamw_ema kernel instead and never calls this)."""
     norms = []
-    for _, p in model.named_parameters():
-        if p.grad is not None:
-            n = p.grad.data.norm(2)
-            norms.append(n.item())
-            c = clip / (n + 1e-6)
-            if c < 1:
-                p.grad.data.mul_(c)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.grad is None:
+                continue
+            gnorm = float(p.grad.norm(2))
+            norms.append(gnorm)
+            if clip < gnorm + 1e-6:                         # per-tensor coefficient min(1, clip / (norm + 1e-6))
+                p.grad.mul_(clip / (gnorm + 1e-6))
     return norms
 
 
 def cancel_gradients_last_layer(epoch, model, freeze_last_layer):
-    if epoch >= freeze_last_layer:
-        return
-    for n, p in model.named_parameters():
-        if "last_layer" in n:
-            p.grad = None
+    """During the first `freeze_last_layer` epochs the DINO head's last layer takes no gradient (reference utils.py:144-149); the
+    fused engine does the same through LAFS_SEG_LAST_LAYER / hyper[LAFS_HP_FREEZE_LAST]."""
+    if epoch < freeze_last_layer:
+        for name, p in model.named_parameters():
+            if "last_layer" in name:
+                p.grad = None
 
 
 def has_batchnorms(model):
@@ -113,42 +115,47 @@ def trunc_normal_(tensor, mean=0., std=1., a=-2., b=2.):
     return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)
 
 
+_FLAG_WORDS = {"on": True, "true": True, "1": True, "off": False, "false": False, "0": False}
+
+
 def bool_flag(s):
-    if s.lower() in {"off", "false", "0"}:
-        return False
-    if s.lower() in {"on", "true", "1"}:
-        return True
-    raise argparse.ArgumentTypeError("invalid value for a boolean flag")
+    """argparse type of the reference's on/off switches (utils.py:186-198)."""
+    try:
+        return _FLAG_WORDS[s.lower()]
+    except KeyError:
+        raise argparse.ArgumentTypeError("invalid value for a boolean flag") from None
 
 
 def fix_random_seeds(seed=31):
+    """Seeds torch (all devices) and numpy, as the reference's entry points do before building models (utils.py:144-149)."""
+    np.random.seed(seed)
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
-    np.random.seed(seed)
 
 
 # --------------------------------------------------------------------------------------------- checkpoints
 def restart_from_checkpoint(ckp_path, run_variables=None, **kwargs):
-    """Load whatever keys of ``kwargs`` exist in the checkpoint (strict=False) and restore run variables
-    (reference utils.py:152-184)."""
+    """Resume hook with the reference's contract (utils.py:152-184): every keyword names a checkpoint entry and the object that
+    takes it (`load_state_dict`, non-strict where the object accepts the flag); `run_variables` is updated in place with the
+    scalar entries it lists (e.g. `epoch`).  A missing file is not an error: the run starts fresh."""
     if not os.path.isfile(ckp_path):
         return
-    print("Found checkpoint at {}".format(ckp_path))
-    checkpoint = torch.load(ckp_path, map_location="cpu", weights_only=False)
-    for key, value in kwargs.items():
-        if key in checkpoint and value is not None:
-            try:
-                msg = value.load_state_dict(checkpoint[key], strict=False)
-            except TypeError:
-                msg = value.load_state_dict(checkpoint[key])
-            print("=> loaded '{}' from checkpoint '{}' with msg {}".format(key, ckp_path, msg))
-        else:
-            print("=> key '{}' not found in checkpoint: '{}'".format(key, ckp_path))
-    if run_variables is not None:
-        for var_name in run_variables:
-            if var_name in checkpoint:
-                run_variables[var_name] = checkpoint[var_name]
+    ckpt = torch.load(ckp_path, map_location="cpu", weights_only=False)
+    print(f"Found checkpoint at {ckp_path}")
+    for name, target in kwargs.items():
+        if target is None or name not in ckpt:
+            print(f"=> key '{name}' not found in checkpoint: '{ckp_path}'")
+            continue
+        state = ckpt[name]
+        try:
+            report = target.load_state_dict(state, strict=False)
+        except TypeError:                                   # optimizers / loss objects without a `strict` argument
+            report = target.load_state_dict(state)
+        print(f"=> loaded '{name}' from checkpoint '{ckp_path}' with msg {report}")
+    for name in (run_variables or {}):
+        if name in ckpt:
+            run_variables[name] = ckpt[name]
 
 
 def save_on_master(*args, **kwargs):
