@@ -90,6 +90,10 @@ typedef struct lafs_gemm_nt_args {
   int operand_f16;                 /* 1: A, B, a 16-bit C and the BF16_ACT residual (aux) are IEEE fp16 instead of bf16 (BF16 / BF16_ACT /
                                       F32 epilogues, no K split): the trainable landmark CNN runs in the reference's autocast
                                       format (train_largescale.py:803-804; v_mfma_f32_16x16x32_f16, same rate) */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;   /* RESID_F32 with ln_out != NULL (N == 384, K % 64 == 0, no dropout): */
+  void* ln_out; int ld_ln_out;     /* bf16 [M, N] = LayerNorm(C) with gamma / beta -- the NEXT nn.LayerNorm of the block chain
+                                      (vision_transformer.py:99,103,107-113) computed by the 128x384 tile that owns the whole rows, */
+  float* ln_stats;                 /* f32 [M, 2] {mean, rstd} for lafs_layernorm_bwd (may be NULL); saves a pass over the fp32 rows */
 } lafs_gemm_nt_args;
 
 /* act = LAFS_GELU_SAVE_GRAD with LAFS_EPI_BF16_GELU: C receives gelu'(u) (bf16) instead of the pre-activation u; with

@@ -22,7 +22,9 @@ class GemmNTArgs(C.Structure):
                 ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
                 ("aux", C.c_void_p), ("ldaux", C.c_int), ("pos", C.c_void_p), ("npatch", C.c_int),
                 ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
-                ("drop_step", C.c_void_p), ("drop_row0", C.c_int), ("act", C.c_int), ("operand_f16", C.c_int)]
+                ("drop_step", C.c_void_p), ("drop_row0", C.c_int), ("act", C.c_int), ("operand_f16", C.c_int),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p), ("ld_ln_out", C.c_int),
+                ("ln_stats", C.c_void_p)]
 
 
 class WgradItem(C.Structure):

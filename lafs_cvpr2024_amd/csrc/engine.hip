@@ -114,8 +114,11 @@ int check_desc(const lafs_trunk_desc* d) {
 int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
          hipStream_t s, void* C2 = nullptr, int ldc2 = 0, const float* resid = nullptr, int ldr = 0,
          const float* seq_scale = nullptr, const int32_t* row2seq = nullptr, const void* aux = nullptr, int ldaux = 0,
-         float drop_p = 0.f, uint32_t drop_seed = 0, int act = 0, const float* drop_step = nullptr, int drop_row0 = 0) {
+         float drop_p = 0.f, uint32_t drop_seed = 0, int act = 0, const float* drop_step = nullptr, int drop_row0 = 0,
+         const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 0.f, void* ln_out = nullptr, int ld_ln = 0,
+         float* ln_stats = nullptr) {
   lafs_gemm_nt_args g = {};
+  g.ln_gamma = ln_g; g.ln_beta = ln_b; g.ln_eps = ln_eps; g.ln_out = ln_out; g.ld_ln_out = ld_ln; g.ln_stats = ln_stats;
   g.drop_p = drop_p; g.drop_seed = drop_seed; g.act = act; g.drop_step = drop_step; g.drop_row0 = drop_row0;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.epilogue = epi;
   g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.resid = resid; g.ldr = ldr;
@@ -271,7 +274,21 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   const int n_rr = row_ranges(d, stream, rr);
   // rows [r0, r0 + R) = the sequences of groups [g_lo, g_hi) (seq_lo = index of their first sequence) on stream st
   // (nseq >= 0: ONE attention launch over nseq sequences of group g_lo -- a row range of a split pass)
+  // LayerNorm fused into the producer of its input (round 4): where the residual GEMM runs on 128x384 tiles (D == 384, no element
+  // dropout) the tile owns whole rows and writes LN(x) beside x -- the next block's norm1 from fc2 (bit 1), this block's norm2 from
+  // the projection (bit 2, which moves the projection from the K-resident kernel to the tiled one).  LAFS_LN_FUSE=<mask>, default 1.
+  // Per launch on one MI355X (tools/lab/t_ln_fuse.py; GEMM + lafs_layernorm_fwd -> fused): fc2 at 25 216 rows 45.0 + 12.4 -> 50.4 us,
+  // projection 24.2 + 12.2 -> 30.9 us (25 216 rows) and 26.6 + 11.8 -> 29.8 us (18 944 rows); where the 128x384 tiles do not fill one
+  // round of the chip the fused form LOSES (fc2 at 18 944 rows = 148 tiles: 30.5 + 11.5 -> 49.3 us; 44 160 rows = 345 tiles: 103 ->
+  // 121 us), so a chain fuses per GEMM only inside those bounds.  IN THE STEP the per-launch gains do not arrive: 15.44 / 15.49 ms
+  // without, 15.47 / 15.48 (mask 1), 15.57 / 15.51 (2), 15.53 / 15.60 (3) on one box -- a 12-wave workgroup per CU beside the other
+  // chains costs what the saved pass over x buys (tools/lab/NOTES.md) -- so it is OFF by default: LAFS_LN_FUSE=<mask> switches it on,
+  // tests/test_gpu_kernels.py holds the fused epilogue against GEMM + lafs_layernorm_fwd.
+  static const int ln_fuse_env = [] { const char* v = getenv("LAFS_LN_FUSE"); return v != nullptr ? atoi(v) : 0; }();
+  const int ln_fuse_ok = (D == 384 && I % 64 == 0 && M % 64 == 0 && !(d->dropout_p > 0.f)) ? ln_fuse_env : 0;
   auto chain = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
+    const int mt = (R + 127) / 128;
+    const int ln_fuse = ((ln_fuse_ok & 1) && mt >= 160 && mt <= 256 ? 1 : 0) | ((ln_fuse_ok & 2) && mt >= 96 && mt <= 256 ? 2 : 0);
     const float* cur = x_in;
     for (int l = 0; l < d->depth; ++l) {
       const lafs_block_offsets& o = d->blocks[l];
@@ -284,8 +301,9 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       else if (save_for_backward) nxt = c.layers[l + 1].x0;
       else nxt = (cur == c.xalt) ? x_out : c.xalt;            // ping-pong; never aliases x_in
       const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
-      RUN(lafs_layernorm_fwd(cur + rD, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1 + rD, D, nullptr, 0, b.st1 + 2 * (size_t)r0,
-                             R, D, st));
+      if (!((ln_fuse & 1) && l > 0))                        // (fused: written by the previous block's fc2)
+        RUN(lafs_layernorm_fwd(cur + rD, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1 + rD, D, nullptr, 0, b.st1 + 2 * (size_t)r0,
+                               R, D, st));
       RUN(gemm(b.h1 + rD, D, sh + o.w_qkv, D, R, 3 * I, D, LAFS_EPI_BF16, b.qkv + 3 * rI, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, st));
       if (g_hi - g_lo > 1 || d->n_groups > 1) {               // one launch per crop resolution, each with its own tile shape
         int s0 = seq_lo;                                      // (the attention kernels address tokens through cu_seqlens: base pointers)
@@ -307,17 +325,31 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       }
       const float dp = d->dropout_p;
       const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
-      RUN(gemm(b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
-               r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0));
-      RUN(lafs_layernorm_fwd(b.x1 + rD, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D, nullptr, 0, b.st2 + 2 * (size_t)r0,
-                             R, D, st));
+      if (ln_fuse & 2) {
+        RUN(gemm(b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
+                 r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D,
+                 b.st2 + 2 * (size_t)r0));
+      } else {
+        RUN(gemm(b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
+                 r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0));
+        RUN(lafs_layernorm_fwd(b.x1 + rD, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D, nullptr, 0, b.st2 + 2 * (size_t)r0,
+                               R, D, st));
+      }
       // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
       // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
       // becomes one multiply per value
       RUN(gemm(b.h2 + rD, D, sh + o.w_fc1, D, R, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u + rM : nullptr, M, d->master + o.b_fc1, st,
                b.a + rM, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
-      RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
-               r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
+      if ((ln_fuse & 1) && l + 1 < d->depth) {              // fc2 + residual + the NEXT block's norm1
+        const lafs_block_offsets& on = d->blocks[l + 1];
+        const LayerBuf& bn = c.layers[save_for_backward ? l + 1 : 0];
+        RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
+                 r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0, d->master + on.ln1_g, d->master + on.ln1_b, d->ln_eps, bn.h1 + rD, D,
+                 bn.st1 + 2 * (size_t)r0));
+      } else {
+        RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
+                 r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
+      }
       cur = nxt;
     }
     return LAFS_OK;

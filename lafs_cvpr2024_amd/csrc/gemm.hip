@@ -58,6 +58,8 @@ struct NTArgs {
   const bf16_t* aux; int ldaux;
   const float* pos; int npatch;
   int f16;                          // operands / 16-bit outputs are fp16 (lafs_gemm_nt_args::operand_f16)
+  const float* ln_g; const float* ln_b; float ln_eps;      // RESID_F32 on the 128x384 tile: LayerNorm of the output rows fused in
+  bf16_t* ln_h; int ldh; float* ln_stats;                   // (ln_h == nullptr: off) -> h = LN(C) as bf16, stats {mean, rstd} per row
   int dbg;                          // timing ablations (lafs_debug_set): 16 = no epilogue stores, 32 = no MFMA/ds_read
   DropCfg drop;                     // element dropout on the linear's output (RESID_F32) / on GELU(u) (BF16_GELU, DGELU_BF16)
   int act;                          // BF16_ACT: LAFS_ACT_*
@@ -497,6 +499,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
           for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) w[e] += ps[e];
         }
+        if constexpr (EPI == EPI_RESID_F32 && WN == 6) {       // the fused LayerNorm below reads the finished rows from the accumulators
+#pragma unroll
+          for (int e = 0; e < VPL; ++e) acc[q][i][e] = w[e];
+        }
         // F32 with the K axis split over blockIdx.z: every slice stores its own [M][ldc] image (lafs_sum_slices folds them)
         float* c = reinterpret_cast<float*>(p.C) + (EPI == EPI_F32 ? (size_t)blockIdx.z * p.M * p.ldc : 0) + orow * p.ldc + n;
         if (full) {
@@ -510,6 +516,65 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
   }
   };
   epilogue();
+  // ---- fused LayerNorm of the rows just written (128x384 tile = whole rows of a 384-wide residual stream): the next block's
+  // norm1 / this block's norm2 (vision_transformer.py:99,103,107-113) without a second pass over x.  Same arithmetic as
+  // ln_fwd_kernel (two passes: mean, then centred squares); a row's 384 values sit in 6 waves x 4 lanes x 16 registers.
+  if constexpr (EPI == EPI_RESID_F32 && WN == 6) {
+    if (p.ln_h != nullptr) {
+      float* red = reinterpret_cast<float*>(smem);          // [128 rows][8] partials (6 used), twice
+      const float invn = 1.0f / (float)p.N;
+      float mean[4], rstd[4];
+      __syncthreads();                                      // every wave is out of the operand ring
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += (acc[j][i][0] + acc[j][i][1]) + (acc[j][i][2] + acc[j][i][3]);
+        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
+        if (fq == 0) red[(wr * 64 + i * 16 + frow) * 8 + wc] = sum;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* r8 = red + (wr * 64 + i * 16 + frow) * 8;
+        mean[i] = (((r8[0] + r8[1]) + (r8[2] + r8[3])) + (r8[4] + r8[5])) * invn;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float dlt = acc[j][i][r] - mean[i]; sq = fmaf(dlt, dlt, sq); }
+        sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
+        if (fq == 0) red[1024 + (wr * 64 + i * 16 + frow) * 8 + wc] = sq;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* r8 = red + 1024 + (wr * 64 + i * 16 + frow) * 8;
+        rstd[i] = rsqrtf((((r8[0] + r8[1]) + (r8[2] + r8[3])) + (r8[4] + r8[5])) * invn + p.ln_eps);
+      }
+      const int nc = n0 + wc * 64 + fq * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + nc + j * 16);
+        const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + nc + j * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + wr * 64 + i * 16 + frow;
+          if (m >= p.M) continue;
+          const float o0 = (acc[j][i][0] - mean[i]) * rstd[i] * g4.x + b4.x, o1 = (acc[j][i][1] - mean[i]) * rstd[i] * g4.y + b4.y;
+          const float o2 = (acc[j][i][2] - mean[i]) * rstd[i] * g4.z + b4.z, o3 = (acc[j][i][3] - mean[i]) * rstd[i] * g4.w + b4.w;
+          *reinterpret_cast<uint2*>(p.ln_h + (size_t)m * p.ldh + nc + j * 16) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+        }
+      }
+      if (wc == 0 && fq == 0 && p.ln_stats != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + wr * 64 + i * 16 + frow;
+          if (m < p.M) { p.ln_stats[2 * (size_t)m] = mean[i]; p.ln_stats[2 * (size_t)m + 1] = rstd[i]; }
+        }
+      }
+    }
+  }
 #ifdef LAFS_ABLATE
   STAMP(2);
   if (p.stamps && !PERSIST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -785,6 +850,14 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   // ... when its tiles fit ONE round of one workgroup per CU: 197 tiles (teacher, M = 25216) run 12-17 % faster than on the
   // 128x128 kernel; 345 tiles (student: a second round of 89) are slower, and so is a split into whole rounds here + the rest on
   // the 128x128 kernel (fc2 forward 92-98 against 83-86 us; tools/lab/nt_variants.py).  LAFS_NT_WIDE=0 switches it off (A/B).
+  if constexpr (EPI == EPI_RESID_F32) {
+    if (a.ln_h != nullptr) {                            // fused LayerNorm: the tile has to own whole rows
+      LAFS_CHECK_ARG(a.N == 384 && a.klen % 64 == 0 && splits == 1, "the fused LayerNorm needs N == 384, K % 64 == 0 and no K split (128x384 tiles)");
+      hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 6>), dim3((unsigned)ceil_div(a.M, 128), 1, 1), dim3(768), 0, s, a);
+      LAFS_LAUNCH_CHECK();
+      return LAFS_OK;
+    }
+  }
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID_F32) {
     const int mt = ceil_div(a.M, 128);
     if (bk64 && wide_tile_shape(a.M, a.N, splits)) {
@@ -820,6 +893,7 @@ extern "C" int lafs_gemm_nt_slices(int K, int splits) { return K >= 32 ? ceil_di
 
 extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) {
   if (g == nullptr) return 0;
+  if (g->ln_out != nullptr) return 3;
   if (lafs_kres_eligible(g)) return lafs_kpp_selected(g) ? 2 : 1;
   // the tiled kernel's 128x384 form (launch_nt): plain / residual epilogue, 64-deep stages (K % 64 == 0, K >= 640), no K split
   const bool bk64 = g->K % 64 == 0 && g->K >= 640 && !(g_debug_flags & 2);
@@ -845,6 +919,9 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
 #endif
   a.drop = make_drop(g->drop_p, g->drop_seed, g->drop_step, (unsigned)g->drop_row0 * (unsigned)g->N);
   a.act = g->act;
+  a.ln_g = g->ln_gamma; a.ln_b = g->ln_beta; a.ln_eps = g->ln_eps; a.ln_h = (bf16_t*)g->ln_out; a.ldh = g->ld_ln_out; a.ln_stats = g->ln_stats;
+  LAFS_CHECK_ARG(a.ln_h == nullptr || (g->epilogue == LAFS_EPI_RESID_F32 && a.ln_g && a.ln_b && a.ldh % 4 == 0 && a.ldh >= g->N && g->drop_p == 0.f),
+                 "ln_out: residual epilogue with gamma / beta, ld_ln_out % 4 == 0, no element dropout");
   a.f16 = g->operand_f16 ? 1 : 0;
   LAFS_CHECK_ARG(!a.f16 || ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_BF16_ACT || g->epilogue == LAFS_EPI_F32) && g->splits <= 1),
                  "fp16 operands: plain / activation / fp32 epilogue, no K split");

@@ -449,7 +449,7 @@ bool lafs_kres_eligible(const lafs_gemm_nt_args* g) {
   const int e = g->epilogue;
   const int bit = e == LAFS_EPI_BF16 ? 1 : (e == LAFS_EPI_BF16_GELU ? 2 : (e == LAFS_EPI_RESID_F32 ? 4 : (e == LAFS_EPI_DGELU_BF16 ? 8 : 0)));
   if (!(mask & bit)) return false;
-  if (g->splits > 1 || g->operand_f16) return false;
+  if (g->splits > 1 || g->operand_f16 || g->ln_out != nullptr) return false;      // (fused LayerNorm: the 128x384 tiled kernel owns whole rows)
   if (g->K != KK || g->N % 64 != 0 || g->N > MAXN || g->N < 64 || g->M < 2048) return false;
   if (!(e == LAFS_EPI_BF16 || e == LAFS_EPI_BF16_GELU || e == LAFS_EPI_RESID_F32 || e == LAFS_EPI_DGELU_BF16)) return false;
   if (g->drop_p > 0.f) return false;

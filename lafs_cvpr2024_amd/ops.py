@@ -45,7 +45,7 @@ def zeros(*shape, device, dtype=torch.float32):
 
 def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=None, seq_scale=None, row2seq=None,
             aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0, act=0, skip_pre=False, drop_step=None, drop_row0=0,
-            route_only=False):
+            route_only=False, ln=None):
     """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*).  skip_pre (BF16_GELU): write only
     GELU(u), as the forward-only teacher pass does; route_only: return lafs_gemm_nt_route for this request instead of running it."""
     # 16-bit operand format: bf16 everywhere except the trainable landmark CNN's plan, which runs on fp16 (operand_f16)
@@ -84,6 +84,11 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     if pos is not None:
         _chk(pos, torch.float32, "pos"); a.pos, a.npatch = pos.data_ptr(), npatch
     a.splits = splits
+    if ln is not None:                 # (gamma f32 [N], beta f32 [N], eps, out bf16 [M, N], stats f32 [M, 2] or None): LayerNorm(C) fused in
+        g_, b_, eps_, h_, st_ = ln
+        _chk(g_, torch.float32, "ln gamma"); _chk(b_, torch.float32, "ln beta"); _chk(h_, bf16, "ln out")
+        a.ln_gamma, a.ln_beta, a.ln_eps, a.ln_out, a.ld_ln_out = g_.data_ptr(), b_.data_ptr(), float(eps_), h_.data_ptr(), _ld(h_)
+        a.ln_stats = st_.data_ptr() if st_ is not None else None
     if skip_pre and epilogue == _lib.EPI_BF16_GELU:
         a.C = None
     if route_only:

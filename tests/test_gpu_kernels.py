@@ -133,6 +133,41 @@ def test_gemm_nt_k_resident_kernel(M, N, kpp_mask):
     assert ops.gemm_nt(Ad, Bd, _lib.EPI_F32, splits=2, route_only=True) == 0
 
 
+@pytest.mark.parametrize("M,K", [(128 * 9 + 37, 1536), (640, 384), (25216, 1536)])
+def test_gemm_nt_residual_epilogue_with_fused_layernorm(M, K):
+    """lafs_gemm_nt(RESID_F32, ln_out=...): the 128x384 tile owns whole rows of the 384-wide residual stream and writes LayerNorm(x)
+    (bf16) and the row statistics beside x -- against the unfused pair (the same GEMM + lafs_layernorm_fwd): x identical, statistics to
+    fp32 round-off, the bf16 rows equal up to single roundings; ragged last tile, DropPath scales, in-place residual."""
+    N = 384
+    A, B = rnd_bf(M, K, seed=21), rnd_bf(N, K, scale=0.05, seed=22)
+    g = torch.Generator().manual_seed(23)
+    bias, gamma, beta = torch.randn(N, generator=g), 1 + 0.2 * torch.randn(N, generator=g), 0.3 * torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    nseq = 11
+    row2seq = (torch.arange(M) * nseq // M).int()
+    sc = torch.tensor([0.0 if i % 4 == 1 else 1.0 / 0.9 for i in range(nseq)])
+    kw = dict(bias=bias.to(DEV), seq_scale=sc.to(DEV), row2seq=row2seq.to(DEV))
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    x_ref = ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, resid=resid.to(DEV), **kw)
+    h_ref, _, st_ref = ops.layernorm_fwd(x_ref, gamma.to(DEV), beta.to(DEV), 1e-6)
+    guard = 3.0
+    h = torch.full((M + 8, N), guard, device=DEV, dtype=torch.bfloat16)
+    st = torch.full((M + 8, 2), guard, device=DEV)
+    x = resid.to(DEV).clone()                                                    # in place, like the trunk's residual stream
+    ln = (gamma.to(DEV), beta.to(DEV), 1e-6, h[:M], st[:M])
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, resid=x, out=x, ln=ln, route_only=True, **kw) == 3
+    ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, resid=x, out=x, ln=ln, **kw)
+    assert torch.equal(x, x_ref)
+    torch.testing.assert_close(st[:M], st_ref.view(M, 2), rtol=2e-5, atol=2e-6)
+    d = (h[:M].float() - h_ref.float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= 2.0 ** -7 * float(h_ref.float().abs().max()), (float((d > 0).float().mean()), float(d.max()))
+    assert torch.all(h[M:] == guard) and torch.all(st[M:] == guard), "rows beyond M were written"
+    # and against the definition
+    xr = resid + sc[row2seq.long()].unsqueeze(1) * (A.float() @ B.float().t() + bias)
+    href = torch.nn.functional.layer_norm(xr, (N,), gamma, beta, 1e-6)
+    assert relerr(h[:M].float(), href) < 1e-2
+
+
 _TILED_SNIPPET = """
 import torch, torch.nn.functional as F
 from lafs_cvpr2024_amd import _lib, ops
