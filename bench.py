@@ -297,10 +297,15 @@ def roofline_partfvit_dgrad(device, M, iters=100):
                  2.0 * M * N * K, (M * K + N * K + M * N) * 2.0)
 
 
+EXTRA_ROOFLINE = True            # --no-roofline: the extras' kernel tables under rocprofv3 must not contain the roofline loops
+
+
 def _extra_evidence(out, flops, dt, device, M):
     out["step_tflops"] = round(flops / dt / 1e12, 1)
     out["step_mfma_frac"] = round(flops / dt / 2.5e15, 4)
     out["step_flops_algorithmic"] = round(flops / 1e12, 3)
+    if not EXTRA_ROOFLINE:
+        return out
     try:
         out["roofline"] = roofline_partfvit_dgrad(device, M)
     except Exception as e:
@@ -460,6 +465,9 @@ def main():
     if args.roofline_only:
         print(json.dumps({"roofline": dominant_kernel_roofline(device, iters=200)}))
         return
+    if args.no_roofline:
+        global EXTRA_ROOFLINE
+        EXTRA_ROOFLINE = False
     if args.extras_only:
         print(json.dumps({"extras": run_extras(device, [k for k in args.extras_only.split(",") if k])}))
         return

@@ -3,7 +3,7 @@
 # writes gpurun_out/r4/<workload>_kernel_table.txt (copied to profiles/round4_<workload>_kernel_table.txt by hand)
 # usage: tools/profile_finetune_r4.sh [finetune|mynet|finetune_plain|partialfc]
 W=${1:-finetune}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4/prof_$W; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $O -o ft --output-format csv -- python3 $R/bench.py --extras-only $W > $O/bench.json 2> $O/err.txt
+rocprofv3 --kernel-trace --stats -d $O -o ft --output-format csv -- python3 $R/bench.py --extras-only $W --no-roofline > $O/bench.json 2> $O/err.txt
 python3 - <<PY > $R/gpurun_out/r4/${W}_kernel_table.txt
 import csv, glob, re, json
 print(open("$O/bench.json").read().strip()[:600])
