@@ -362,6 +362,10 @@ typedef struct lafs_trunk_desc {
   const float* dropout_step;          /* NULL or DEVICE pointer to the step counter added (x 7919) to dropout_seed inside the kernels */
   int wgrad_overwrite;                /* != 0: the block weight gradients are WRITTEN (not accumulated): the caller zeroes only the
                                          other tensors (lafs_zero_chunks, LAFS_SEG_OVERWRITTEN) and runs one backward per step */
+  int wgrad_defer;                    /* != 0: lafs_trunk_backward launches NO weight-gradient GEMMs and keeps every layer's operands
+                                         (dY of fc2 / fc1 / proj / qkv) in slots of their own -- the workspace grows by depth - 2 sets --
+                                         until lafs_trunk_wgrad launches them, e.g. beside work that leaves the chip idle (the
+                                         fine-tune step's landmark-CNN backward, train_largescale.py:785-891) */
 } lafs_trunk_desc;
 
 /* Bytes of activation workspace for a forward with (1) / without (0) saving activations for backward. */
@@ -386,6 +390,11 @@ int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, float* x_out
  * events, so the call is still hipGraph-capturable and complete on `stream` when it returns to stream order). */
 int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
                         int layer_lo, hipStream_t wgrad_stream, hipStream_t stream);
+/* The weight gradients (and bias gradients) of blocks layer_hi-1 .. layer_lo that a lafs_trunk_backward with d->wgrad_defer set
+ * left out: one grouped launch per block on `stream` (at most d->wgrad_workgroups workgroups each), reading the per-layer operand
+ * slots of `workspace`.  Same kernels, same operands, same accumulate / overwrite rule as the immediate form: identical results.
+ * Replaces autograd's dW = dY^T X of the block linears (vision_transformer.py:59-65, 75-90; face_pre_pro/ViT_face.py:126-149). */
+int lafs_trunk_wgrad(const lafs_trunk_desc* d, void* workspace, int layer_hi, int layer_lo, hipStream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Step glue that used to run on ATen / rocBLAS inside the captured step (csrc/stepglue.hip)

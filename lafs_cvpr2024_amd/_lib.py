@@ -51,7 +51,7 @@ class TrunkDesc(C.Structure):
                 ("master", C.c_void_p), ("shadow", C.c_void_p), ("shadow_t", C.c_void_p), ("grad", C.c_void_p),
                 ("blocks", C.POINTER(BlockOffsets)),
                 ("n_groups", C.c_int), ("group_n_seq", C.c_int * 4), ("group_max_len", C.c_int * 4), ("wgrad_workgroups", C.c_int),
-                ("dropout_step", C.c_void_p), ("wgrad_overwrite", C.c_int)]
+                ("dropout_step", C.c_void_p), ("wgrad_overwrite", C.c_int), ("wgrad_defer", C.c_int)]
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32, EPI_BF16_ACT = range(8)
@@ -110,6 +110,7 @@ _PROTOS = {
     "lafs_transpose_cast_table": [vp, vp, vp, vp, i32, i32],
     "lafs_trunk_forward": [C.POINTER(TrunkDesc), vp, vp, vp, i32],
     "lafs_trunk_backward": [C.POINTER(TrunkDesc), vp, vp, vp, i32, i32, vp],
+    "lafs_trunk_wgrad": [C.POINTER(TrunkDesc), vp, i32, i32],
     "lafs_margin_softmax_ce": [vp, i32, i32, i32, vp, vp, f32, f32, f32, i32, f32, vp, vp],
     "lafs_shard_margin_rowmax": [vp, i32, i32, i32, vp, f32, f32, i32, vp],
     "lafs_shard_margin_rowsum": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, vp],

@@ -19,9 +19,11 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 struct LayerBuf {
   float* x0; float* st1; bf16_t* h1; bf16_t* qkv; float* lse; bf16_t* o; float* x1; float* st2; bf16_t* h2; bf16_t* u; bf16_t* a;
 };
-struct Scratch {             // [2]: alternate by layer parity so the wgrad stream may lag one layer behind
-  bf16_t* gbm[2]; bf16_t* gba[2]; bf16_t* du[2]; bf16_t* dqkv[2]; bf16_t* dh; bf16_t* d_o;
+struct Scratch {             // operands of the weight gradients: two slots used by layer parity (the wgrad stream may lag one layer behind),
+  std::vector<bf16_t*> gbm, gba, du, dqkv;   // or one slot per layer when the weight gradients are deferred (lafs_trunk_desc::wgrad_defer)
+  bf16_t* dh; bf16_t* d_o;
 };
+inline int wg_slot(const lafs_trunk_desc* d, int l) { return d->wgrad_defer ? l : (l & 1); }
 struct Carve {
   std::vector<LayerBuf> layers;   // depth entries when saving, 1 otherwise (reused)
   float* xalt;                    // ping-pong residual buffer for the no-save path
@@ -64,7 +66,9 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
   }
   c.xalt = save ? nullptr : (float*)take(T * D * 4);
   if (save) {
-    for (int q = 0; q < 2; ++q) {
+    const int nslot = d->wgrad_defer ? d->depth : 2;
+    c.s.gbm.resize(nslot); c.s.gba.resize(nslot); c.s.du.resize(nslot); c.s.dqkv.resize(nslot);
+    for (int q = 0; q < nslot; ++q) {
       c.s.gbm[q] = (bf16_t*)take(T * D * 2);
       c.s.gba[q] = (bf16_t*)take(T * D * 2);
       c.s.du[q] = (bf16_t*)take(T * M * 2);
@@ -363,6 +367,24 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   return LAFS_OK;
 }
 
+// The block's four weight gradients: ONE grouped launch, once all their operands exist.  Its 48 (ViT-S) output tiles x 5 token
+// slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four separate launches (csrc/wgrad.hip)
+static int block_wgrad(const lafs_trunk_desc* d, const Carve& c, int l, int max_wg, hipStream_t st) {
+  const lafs_block_offsets& o = d->blocks[l];
+  const LayerBuf& b = c.layers[l];
+  const Scratch& s = c.s;
+  const int p = wg_slot(d, l);
+  float* gr = d->grad;
+  lafs_wgrad_item it[4];
+  block_wgrad_shapes(d, it);
+  it[0].A = s.gbm[p]; it[0].B = b.a; it[0].C = gr + o.w_fc2; it[0].colsum_a = gr + o.b_fc2;
+  it[1].A = s.du[p]; it[1].B = b.h2; it[1].C = gr + o.w_fc1; it[1].colsum_a = gr + o.b_fc1;
+  it[2].A = s.gba[p]; it[2].B = b.o; it[2].C = gr + o.w_proj; it[2].colsum_a = gr + o.b_proj;
+  it[3].A = s.dqkv[p]; it[3].B = b.h1; it[3].C = gr + o.w_qkv; it[3].colsum_a = o.b_qkv >= 0 ? gr + o.b_qkv : nullptr;
+  for (auto& x : it) x.accumulate = d->wgrad_overwrite ? 0 : 1;
+  return lafs_wgrad_group(it, 4, d->n_tok, max_wg, c.wg_ws, (int64_t)c.wg_bytes, st);
+}
+
 extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, float* g, void* workspace, int layer_hi,
                                    int layer_lo, hipStream_t wgrad_stream, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
@@ -374,7 +396,8 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   const bf16_t* sht = reinterpret_cast<const bf16_t*>(d->shadow_t);
   float* gr = d->grad;
   const Scratch& s = c.s;
-  const bool two = (wgrad_stream != nullptr) && (wgrad_stream != stream);
+  const bool defer = d->wgrad_defer != 0;     // no weight-gradient launches here: lafs_trunk_wgrad issues them later from the per-layer slots
+  const bool two = !defer && (wgrad_stream != nullptr) && (wgrad_stream != stream);
   hipStream_t s2 = two ? wgrad_stream : stream;
   const int nl = layer_hi - layer_lo;
   RowRange rr[4];
@@ -392,14 +415,14 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   auto scale = [&](int l, int br) { return d->drop_scales ? d->drop_scales + ((size_t)l * 2 + br) * d->n_seq : nullptr; };
   const float dp = d->dropout_p;
   auto dseed = [&](int l, int site) { return d->dropout_seed + 3u * (uint32_t)l + (uint32_t)site; };
-  RUN(lafs_scale_cast_bf16(g, D, s.gbm[(layer_hi - 1) & 1], D, scale(layer_hi - 1, 1), d->row2seq, T, D, dp, dseed(layer_hi - 1, 2),
+  RUN(lafs_scale_cast_bf16(g, D, s.gbm[wg_slot(d, layer_hi - 1)], D, scale(layer_hi - 1, 1), d->row2seq, T, D, dp, dseed(layer_hi - 1, 2),
                            d->dropout_step, 0, stream));
   // rows [r0, r0 + R) of layer l from the GELU' input gradient to the attention backward (groups [g_lo, g_hi), first sequence
   // seq_lo; nseq >= 0: one attention launch over nseq sequences of group g_lo) on stream st
   auto part1 = [&](int l, int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
     const lafs_block_offsets& o = d->blocks[l];
     const LayerBuf& b = c.layers[l];
-    const int p = l & 1;
+    const int p = wg_slot(d, l);
     const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
     const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
     // ---- MLP branch ----
@@ -436,13 +459,13 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const lafs_block_offsets& o = d->blocks[l];
     const LayerBuf& b = c.layers[l];
     const float* x0 = (l == 0) ? x_in : b.x0;
-    const int p = l & 1;
+    const int p = wg_slot(d, l);
     const bool more = l > 0;
     const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I;
     const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
     RUN(gemm(s.dqkv[p] + 3 * rI, 3 * I, sht + o.w_qkv_t, 3 * I, R, D, 3 * I, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
     RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, x0 + rD, D, b.st1 + 2 * (size_t)r0, d->master + o.ln1_g, g + rD, D, 1,
-                           more ? s.gbm[(l - 1) & 1] + rD : nullptr, D, more ? scale(l - 1, 1) : nullptr, r2s, gr + o.ln1_g, gr + o.ln1_b, R, D,
+                           more ? s.gbm[wg_slot(d, l - 1)] + rD : nullptr, D, more ? scale(l - 1, 1) : nullptr, r2s, gr + o.ln1_g, gr + o.ln1_b, R, D,
                            more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, d->dropout_step, r0, st));
     return LAFS_OK;
   };
@@ -466,18 +489,9 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   // output tiles x 5 token slices fill the chip together: 4x fewer slices -> 4x less partial-sum traffic than four separate
   // launches (csrc/wgrad.hip)
   auto wgrad = [&](int l) -> int {
-    const lafs_block_offsets& o = d->blocks[l];
-    const LayerBuf& b = c.layers[l];
-    const int p = l & 1;
+    if (defer) return LAFS_OK;
     fork();
-    lafs_wgrad_item it[4];
-    block_wgrad_shapes(d, it);
-    it[0].A = s.gbm[p]; it[0].B = b.a; it[0].C = gr + o.w_fc2; it[0].colsum_a = gr + o.b_fc2;
-    it[1].A = s.du[p]; it[1].B = b.h2; it[1].C = gr + o.w_fc1; it[1].colsum_a = gr + o.b_fc1;
-    it[2].A = s.gba[p]; it[2].B = b.o; it[2].C = gr + o.w_proj; it[2].colsum_a = gr + o.b_proj;
-    it[3].A = s.dqkv[p]; it[3].B = b.h1; it[3].C = gr + o.w_qkv; it[3].colsum_a = o.b_qkv >= 0 ? gr + o.b_qkv : nullptr;
-    for (auto& x : it) x.accumulate = d->wgrad_overwrite ? 0 : 1;
-    RUN(lafs_wgrad_group(it, 4, T, two ? d->wgrad_workgroups : 0, c.wg_ws, (int64_t)c.wg_bytes, s2));
+    RUN(block_wgrad(d, c, l, two ? d->wgrad_workgroups : 0, s2));
     if (two) { done[l] = ev[evi++]; if (hipEventRecord(done[l], s2) != hipSuccess) ev_failed = true; }
     return LAFS_OK;
   };
@@ -495,5 +509,16 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   if (two && hipStreamWaitEvent(stream, done[layer_lo], 0) != hipSuccess) ev_failed = true;      // join (s2 is in-order)
   LAFS_CHECK_ARG(!ev_failed, "a HIP event call of the weight-gradient stream protocol failed");
   LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_trunk_wgrad(const lafs_trunk_desc* d, void* workspace, int layer_hi, int layer_lo, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  RUN(check_desc(d));
+  LAFS_CHECK_ARG(workspace && d->grad, "null buffer");
+  LAFS_CHECK_ARG(d->wgrad_defer != 0, "lafs_trunk_wgrad needs a descriptor with wgrad_defer set (per-layer operand slots)");
+  LAFS_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= d->depth, "bad layer range");
+  const Carve c = carve(d, workspace, 1);
+  for (int l = layer_hi - 1; l >= layer_lo; --l) RUN(block_wgrad(d, c, l, d->wgrad_workgroups, stream));
   return LAFS_OK;
 }

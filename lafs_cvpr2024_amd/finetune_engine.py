@@ -145,6 +145,16 @@ class FinetuneEngine:
         single = os.environ.get("LAFS_SINGLE_STREAM") == "1" or os.environ.get("LAFS_FT_WGRAD_STREAM", "0") != "1"
         self.side_stream = None if single else torch.cuda.Stream(device=dev)
         self.wgrad_workgroups = int(os.environ.get("LAFS_FT_WGRAD_WG", "0"))
+        # Deferred weight gradients (single GPU, HIP landmark plan): the trunk backward launches only its input-gradient chain and keeps
+        # every block's dY operands; the twelve grouped weight-gradient launches then run on a second stream BESIDE the landmark
+        # CNN's backward -- ~300 small launch-latency-sized kernels that leave most of the chip idle -- capped to
+        # LAFS_FT_DEFER_WG workgroups so that the CNN's kernels find free CUs.  Measured at C4 (tools/lab/NOTES.md): the same launches
+        # cost 4.5 ms in front of the CNN backward and 2.75 ms beside it.  LAFS_FT_WGRAD_DEFER=0 restores the immediate form.
+        self.defer = (self.cnn is not None and self.world == 1 and sharded_head is None and self.side_stream is None
+                      and os.environ.get("LAFS_SINGLE_STREAM") != "1" and os.environ.get("LAFS_FT_WGRAD_DEFER", "1") != "0")
+        self.defer_stream = torch.cuda.Stream(device=dev) if self.defer else None
+        if self.defer:
+            self.wgrad_workgroups = int(os.environ.get("LAFS_FT_DEFER_WG", "128"))
         if use_graph is None:
             use_graph = os.environ.get("LAFS_FT_GRAPH", "1") != "0"
         self.use_graph = bool(use_graph) and self.world == 1 and sharded_head is None
@@ -240,11 +250,13 @@ class FinetuneEngine:
             img_in = self.img_in
             call("lafs_patch_gather_fwd", _p(self.x), _p(th), B, self.S, th.shape[1], _p(img_in))
         if self._ws is None:
-            probe = Fn.make_trunk_desc(a, m._spec.trunk, self.geom, drop, with_grad=True)
+            probe = Fn.make_trunk_desc(a, m._spec.trunk, self.geom, drop, with_grad=True, wgrad_defer=self.defer,
+                                       wgrad_workgroups=self.wgrad_workgroups if self.defer else 0)
             self._ws = Fn.trunk_workspace(probe, True, dev)
         emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [self.pos_rows], drop, save=True, dropout=dropout, ws=self._ws,
                                     x_in=self.x_in, x_out=self.x_out, wgrad_overwrite=first,
-                                    wgrad_workgroups=self.wgrad_workgroups if self.side_stream is not None else 0)
+                                    wgrad_workgroups=self.wgrad_workgroups if (self.side_stream is not None or self.defer) else 0,
+                                    wgrad_defer=self.defer)
         if self.head is not None:
             # class-sharded head: all-gather embeddings, local logits, exchanged softmax statistics, reduce-scatter of dE.
             # demb is the gradient of the GLOBAL-batch mean loss, so the later all-reduce of the backbone gradients is a SUM.
@@ -265,18 +277,28 @@ class FinetuneEngine:
         # d(emb_n) [B, D] = dcos @ Wn: reduction over the classes = the token axis of the wide-tile weight-gradient kernel (slices
         # + fold: no atomics, no zero fill)
         ops.wgrad(self.dcos_t, self.wn, self.dxn, accumulate=False, workspace=self.dxn_ws)
-        # d(Wn) [C, D] = dcos^T @ emb_n: reduction over the batch (128): an NT GEMM that writes the 633 MB matrix once
+        # d(Wn) and the weight-norm backward of the class table (~0.55 ms of HBM-bound work at C4) gate nothing in the trunk backward:
+        # with deferred weight gradients they follow those on the second stream, beside the landmark CNN's backward
+        self._head_first = first
+        if not (self.defer and self._cnn_hip and os.environ.get("LAFS_FT_DEFER_HEAD", "1") != "0"):
+            self._head_param_grads()
+            self._head_first = None
+        call("lafs_l2norm_bwd", _p(emb), D, _p(self.dxn), D, _p(self.inv_x), _p(self.demb), D, B, D)
+        if self._reduce_now():
+            self.reducer.launch(a.grad[self.head_off:])          # margin head (+ anything behind it): final from here on
+        self._backward_trunk(st, self.demb, th, theta)
+
+    def _head_param_grads(self):
+        """d(Wn) [C, D] = dcos^T @ emb_n (reduction over the batch: an NT GEMM that writes the 633 MB matrix once) and the weight-norm
+        backward into the class table's gradient (written on the first micro-step of a window, accumulated after)."""
+        a, B, D = self.arena, self.B, self.D
         if self.dwn_ws is None:
             call("lafs_transpose_bf16", _p(self.xn), B, D, D, _p(self.xn_t), B)
             ops.gemm_nt(self.dcos_t, self.xn_t, _lib.EPI_F32, out=self.dwn)
         else:
             ops.wgrad(self.dcos, self.xn, self.dwn, accumulate=False, workspace=self.dwn_ws)
         call("lafs_weightnorm_bwd", _p(self.dwn), _p(a.view(a.master, self.wname)), _p(self.ones), _p(self.inv_w), self.C, D,
-             _p(a.view(a.grad, self.wname)), None, 0 if first else 1)
-        call("lafs_l2norm_bwd", _p(emb), D, _p(self.dxn), D, _p(self.inv_x), _p(self.demb), D, B, D)
-        if self._reduce_now():
-            self.reducer.launch(a.grad[self.head_off:])          # margin head (+ anything behind it): final from here on
-        self._backward_trunk(st, self.demb, th, theta)
+             _p(a.view(a.grad, self.wname)), None, 0 if self._head_first else 1)
 
     def _reduce_now(self):
         """True on the micro-step that completes an accumulation window of a data-parallel run."""
@@ -307,6 +329,17 @@ class FinetuneEngine:
         a, m, B, D = self.arena, self.model, self.B, self.D
         reduce_now = self._reduce_now()
         g = self._trunk_layers_backward(st, demb)
+        deferred = bool(st.desc.wgrad_defer)
+        cur = torch.cuda.current_stream()
+        if deferred and self._cnn_hip:                   # the blocks' weight gradients: beside everything from here to the end of the CNN backward
+            self.defer_stream.wait_stream(cur)
+            with torch.cuda.stream(self.defer_stream):
+                Fn.vit_wgrad_layers(st, m.depth, 0)
+                if getattr(self, "_head_first", None) is not None:
+                    self._head_param_grads()
+                    self._head_first = None
+        elif deferred:                                   # (eval-mode model / torch CNN: nothing to hide them behind)
+            Fn.vit_wgrad_layers(st, m.depth, 0)
         if m.with_land:
             _, dx = Fn.vit_backward_end(a, m._spec, st, g, want_dx=True, dpos_out=[self.dpos_rows])
             call("lafs_unpatchify_f32", _p(dx[0]), B, self.S, m._spec.patch_order, _p(self.dmosaic))
@@ -319,6 +352,8 @@ class FinetuneEngine:
                 theta.backward(self.dth)                 # torch autograd: p.grad are views of the arena
         else:
             Fn.vit_backward_end(a, m._spec, st, g, dpos_out=[self.dpos_rows])
+        if deferred and self._cnn_hip:
+            cur.wait_stream(self.defer_stream)
         if reduce_now:                                           # what is left: block 0's run + embedding + landmark CNN
             self.reducer.launch(a.grad[: self._hi_left])
             self._reduced = True

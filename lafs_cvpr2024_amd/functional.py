@@ -80,7 +80,7 @@ class TrunkSpec:
 
 
 def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=None, with_grad=True, dropout_p=0.0, dropout_seed=0,
-                    wgrad_overwrite=False, wgrad_workgroups=0, dropout_step=None):
+                    wgrad_overwrite=False, wgrad_workgroups=0, dropout_step=None, wgrad_defer=False):
     """Build the C descriptor (keeps the ctypes block array alive on the returned object)."""
     blocks = (_lib.BlockOffsets * spec.depth)()
     for i, nm in enumerate(spec.block_names):
@@ -102,6 +102,7 @@ def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=No
     d.grad = arena.grad.data_ptr() if (with_grad and arena.grad is not None) else None
     d.blocks = C.cast(blocks, C.POINTER(_lib.BlockOffsets))
     d.wgrad_overwrite = 1 if wgrad_overwrite else 0
+    d.wgrad_defer = 1 if wgrad_defer else 0
     d.wgrad_workgroups = int(wgrad_workgroups)
     if 1 < len(geom.groups) <= 4:                        # one attention launch per crop resolution
         d.n_groups = len(geom.groups)
@@ -141,7 +142,7 @@ EMB_DROP_SITE = 0x40000000          # seed offset of the embedding dropout (the 
 
 
 def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, drop_scales=None, save=True,
-                ws=None, x_in=None, x_out=None, dropout=None, wgrad_overwrite=False, wgrad_workgroups=0):
+                ws=None, x_in=None, x_out=None, dropout=None, wgrad_overwrite=False, wgrad_workgroups=0, wgrad_defer=False):
     """imgs: list of fp32 NCHW tensors (one per group); pos_tokens: list of fp32 [npatch+1, D] per group.
     dropout: None or (p_trunk, p_embedding, seed[, step]): element dropout of Part-fViT (counter-based masks, see lafs_hip.h);
     `step`: a DEVICE float tensor whose value x 7919 is added to the seed inside the kernels (graph-captured steps).
@@ -156,7 +157,7 @@ def vit_forward(arena, spec: ViTSpec, geom: PackedGeometry, imgs, pos_tokens, dr
     dstep = dropout[3] if (dropout is not None and len(dropout) > 3) else None
     st.dropout = (p_trunk, p_emb, dseed, dstep)
     st.desc = make_trunk_desc(arena, spec.trunk, geom, drop_scales, with_grad=save, dropout_p=p_trunk, dropout_seed=dseed,
-                              wgrad_overwrite=wgrad_overwrite, wgrad_workgroups=wgrad_workgroups, dropout_step=dstep)
+                              wgrad_overwrite=wgrad_overwrite, wgrad_workgroups=wgrad_workgroups, dropout_step=dstep, wgrad_defer=wgrad_defer)
     st.ws = ws if ws is not None else trunk_workspace(st.desc, save, dev)
     st.x_in = x_in if x_in is not None else torch.empty(geom.n_tok, D, device=dev, dtype=f32)
     if x_out is None:
@@ -211,6 +212,17 @@ def vit_backward_layers(st: ViTState, g, hi, lo, wgrad_stream=None):
         st.bwd_done.update(range(lo, hi))
     ws2 = C.c_void_p(wgrad_stream.cuda_stream) if wgrad_stream is not None else None
     call("lafs_trunk_backward", C.byref(st.desc), _p(st.x_in), _p(g), _p(st.ws), hi, lo, ws2)
+
+
+def vit_wgrad_layers(st: ViTState, hi, lo):
+    """The weight gradients of blocks hi-1 .. lo that a backward with `wgrad_defer` left out (lafs_trunk_wgrad), on the current
+    stream: the caller places them beside whatever leaves the chip idle."""
+    if not st.desc.wgrad_defer:
+        raise _lib.LafsHipError("vit_wgrad_layers: the forward was not run with wgrad_defer")
+    missing = set(range(lo, hi)) - st.bwd_done if st.desc.wgrad_overwrite else set()
+    if missing:
+        raise _lib.LafsHipError(f"deferred weight gradients of blocks {sorted(missing)} requested before their backward ran")
+    call("lafs_trunk_wgrad", C.byref(st.desc), _p(st.ws), hi, lo)
 
 
 def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g, want_dx=False, dpos_out=None):

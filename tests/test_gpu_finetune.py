@@ -159,6 +159,51 @@ def test_captured_finetune_step_equals_the_eager_single_stream_step(with_land, m
     assert float(d.max()) <= 3 * 2.2 * 1e-3 and frac < max(2e-2, 1.5 * frac_n + 1e-3), (float(d.max()), frac, frac_n)
 
 
+def test_deferred_block_weight_gradients_equal_the_immediate_ones(monkeypatch):
+    """The captured fine-tune micro-step with the trunk's weight gradients DEFERRED (lafs_trunk_wgrad on a second stream beside the
+    landmark CNN's backward, the default with the HIP landmark plan) against the immediate form (LAFS_FT_WGRAD_DEFER=0): same kernels on
+    the same operands, so after a window of two micro-steps (first one writes, second one accumulates; dropout / DropPath / mixup live)
+    the loss and every gradient of the transformer trunk must be IDENTICAL (embedding / margin head: to fp32 round-off) -- an operand slot reused
+    before its deferred launch has read it shows up here."""
+    from conftest import det_fill_random
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    B, C = 16, 3000
+    res = {}
+    for defer in ("1", "0"):
+        torch.manual_seed(4)
+        model = ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=C, image_size=112, patch_size=8, dim=128, depth=4,
+                                         heads=2, mlp_dim=256, dropout=0.1, emb_dropout=0.1, with_land=True, drop_path_rate=0.1)
+        det_fill_random(model.stn); det_fill_random(model.output_layer)
+        model.train()
+        monkeypatch.setenv("LAFS_FT_WGRAD_STREAM", "0")
+        monkeypatch.setenv("LAFS_FT_WGRAD_DEFER", defer)
+        monkeypatch.setenv("LAFS_FT_DEFER_WG", "0")     # (a workgroup cap changes the number of token slices = the fp32 summation order)
+        eng = FinetuneEngine(model, B, acc_step=2, device=DEV, use_graph=True)
+        assert eng.defer == (defer == "1")
+        g = torch.Generator(device=DEV).manual_seed(9)
+        losses = []
+        for it in range(2):
+            u8 = torch.randint(0, 256, (B, 3, 112, 112), device=DEV, dtype=torch.uint8, generator=g)
+            y = torch.randint(0, C, (B,), device=DEV, generator=g)
+            losses.append(float(eng.micro_step(u8, y, lam=(0.3 if it == 0 else 1.0)).item()))
+        torch.cuda.synchronize()
+        assert len(eng._graphs) == 2
+        res[defer] = dict(losses=losses, grads={k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    a, b = res["1"], res["0"]
+    assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+    n_trunk = 0
+    for k, ga in a["grads"].items():
+        if k.startswith("stn.") or k.startswith("output_layer."):
+            continue                                   # the landmark CNN's own gradients carry atomics-order noise (checked elsewhere)
+        if k.startswith("transformer.") and ".norm." not in k and k.endswith(".weight"):     # the linears' weights: what the deferred launches write
+            assert torch.equal(ga, b["grads"][k]), (k, float((ga - b["grads"][k]).abs().max()))
+        else:                                          # (bias / LayerNorm affine / patch-embedding gradients are summed with atomics: fp32 round-off)
+            assert float((ga - b["grads"][k]).abs().max()) <= 1e-6 * float(ga.abs().max()), k
+        n_trunk += k.startswith("transformer.") and ".norm." not in k and k.endswith(".weight")
+    assert n_trunk >= 4 * 4
+    assert float(a["grads"]["transformer.layers.0.0.fn.fn.to_qkv.weight"].abs().max()) > 0
+
+
 @pytest.mark.parametrize("lam", [1.0, 0.3])
 def test_finetune_micro_step_against_oracle(lam):
     """u8 batch -> mixup -> Part-fViT -> CosFace -> soft-target CE -> backward, HIP engine vs CPU oracle (autograd)."""
