@@ -110,7 +110,8 @@ int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
  * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout), 2 = its
  * ping-pong form (gemm_kpp.hip: one 8-wave workgroup per CU, the MFMA turn of one half beside the epilogue turn of the other;
  * same requests, same results bit for bit), 3 = the tiled kernel in its 128x384 / 12-wave form (whole N per workgroup: long
- * reductions onto N = 384 whose tiles fit one round of the chip). */
+ * reductions onto N = 384 whose tiles fit one round of the chip), 4 = the tiled kernel with 160-row tiles (long reductions whose
+ * 128-row tiles would spill into one more round of the 512 workgroup slots than 160-row ones need). */
 int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
 /* Which epilogues of the K-resident route take the ping-pong kernel: bit mask 1 plain, 2 GELU, 4 residual, 8 GELU'; -1 = the
  * value of LAFS_KPP in the environment (the default).  Returns the previous override.  Replaces nothing in the reference: it

@@ -129,14 +129,16 @@ template <int BK> __device__ __forceinline__ int nt_swzk(int row) { return BK ==
 // b + grid, b + 2 grid, ...; while a workgroup stores tile j it already has the first ring stages of tile j+1 in flight.
 // F16: operands (and a 16-bit output / residual) are IEEE fp16 instead of bf16 -- the trainable landmark CNN's plan
 // (landmark_train.py); instantiated for the plain, activation and fp32 epilogues on 128x128 tiles only.
-template <int EPI, int WM, int BK, int WN = 2, bool PERSIST = false, bool F16 = false>
+template <int EPI, int WM, int BK, int WN = 2, bool PERSIST = false, bool F16 = false, int MB = 4>
 __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM == 2) ? (BK == 32 ? 3 : 2) : (BK == 32 ? 4 : 2)))) void gemm_nt_kernel(NTArgs p) {
   static_assert(!F16 || EPI == EPI_BF16 || EPI == EPI_BF16_ACT || EPI == EPI_F32, "fp16 operands: plain / activation / fp32 epilogues only");
   auto PK2 = [](float lo, float hi) { return F16 ? pack_h2(lo, hi) : pack_bf2(lo, hi); };
   auto CV1 = [](float x) { return F16 ? f2h(x) : f2bf(x); };
   auto LD1 = [](bf16_t h) { return F16 ? h2f(h) : bf2f(h); };
   const DropCfg drop = drop_resolve(p.drop);
-  constexpr int THREADS = WM * WN * 64, BMT = WM * 64, BN = WN * 64;
+  static_assert(MB == 4 || (WM == 2 && WN == 2 && BK == 64 && !PERSIST), "tall tiles: 2 x 2 waves on 64-deep stages only");
+  constexpr int RW = MB * 16;                         // rows per wave: MB 16-row MFMA blocks (4: 128-row tiles at WM = 2; 5: 160-row tiles)
+  constexpr int THREADS = WM * WN * 64, BMT = WM * RW, BN = WN * 64;
   constexpr bool PIN32 = (WM == 2);                   // (the 8-wave variants run at the 128-register cap: pinning spills there)
   constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
   constexpr int ROWB = BK * 2;                        // bytes per LDS row
@@ -190,39 +192,39 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
   };
   Src src;
 
-  f32x4_t acc[4][4];                                 // [j: column group][i: row tile]
+  f32x4_t acc[4][MB];                                // [j: column group][i: row tile]
 
   const int frow = lane & 15, fq = lane >> 4;
-  int arow[4], brow[4];
+  int arow[MB], brow[4];
 
   auto compute = [&](int t) {
     if DBG(p, 32) return;
     const unsigned char* st = smem + (t % NSTG) * STAGE;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
-      bf16x8_t fa[4], fb[4];
+      bf16x8_t fa[MB], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(st + arow[i] * ROWB + (((kk * 4 + fq) ^ nt_swzk<BK>(arow[i])) << 4));
-        fb[i] = *reinterpret_cast<const bf16x8_t*>(st + BMT * ROWB + brow[i] * ROWB + (((kk * 4 + fq) ^ nt_swzk<BK>(brow[i])) << 4));
+      for (int i = 0; i < (MB > 4 ? MB : 4); ++i) {
+        if (i < MB) fa[i] = *reinterpret_cast<const bf16x8_t*>(st + arow[i] * ROWB + (((kk * 4 + fq) ^ nt_swzk<BK>(arow[i])) << 4));
+        if (i < 4) fb[i] = *reinterpret_cast<const bf16x8_t*>(st + BMT * ROWB + brow[i] * ROWB + (((kk * 4 + fq) ^ nt_swzk<BK>(brow[i])) << 4));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = F16 ? mfma16_f16(fb[j], fa[i], acc[j][i]) : mfma16(fb[j], fa[i], acc[j][i]);
+        for (int i = 0; i < MB; ++i) acc[j][i] = F16 ? mfma16_f16(fb[j], fa[i], acc[j][i]) : mfma16(fb[j], fa[i], acc[j][i]);
     }
     // 64-deep stages at two waves per SIMD (the long-K GEMMs of the trunk): pin the 16 fragment reads ahead of the 32 MFMAs that
     // consume them -- left alone, hipcc issues them in batches of 2-6 behind s_waitcnt lgkmcnt(0) and exposes the LDS latency four or
     // five times per stage (the same finding as in gemm_kres.hip)
     if constexpr (BK == 64 && WM == 2 && WN == 2) {
-      if (!DBG(p, 32)) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      if (!DBG(p, 32)) {                                 // 2 (MB + 4) reads, 8 MB MFMAs per stage
+        __builtin_amdgcn_sched_group_barrier(0x100, MB + 4, 0);
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
+        for (int x = 0; x < MB + 4; ++x) {
           __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8 * MB - 2 * (MB + 4), 0);
       }
     } else if constexpr (BK == 32 && WN == 2 && PIN32) {
       if (!DBG(p, 32)) {                               // 32-deep stages: 8 reads, 16 MFMAs
@@ -256,14 +258,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
     for (int i = 0; i < NMAX; ++i) ldsoff[i] = (i * THREADS + w_ * 64) * 16;       // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { arow[i] = (w_ / WN) * 64 + i * 16 + (l_ & 15); brow[i] = (w_ % WN) * 64 + i * 16 + (l_ & 15); }
+    for (int i = 0; i < (MB > 4 ? MB : 4); ++i) {
+      if (i < MB) arow[i] = (w_ / WN) * RW + i * 16 + (l_ & 15);
+      if (i < 4) brow[i] = (w_ % WN) * 64 + i * 16 + (l_ & 15);
+    }
   }
   if (!PERSIST || !primed) locate(vb, src);
   m0 = src.m0; n0 = src.n0;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MB; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   if (NSTG == 3) {
     if (!primed) {
       if (nk > 0) issue(src, 0);
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(acc[j][i]));
+      for (int i = 0; i < MB; ++i) asm volatile("" :: "v"(acc[j][i]));
     return;
   }
   float bias[16];
@@ -329,8 +334,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
   constexpr bool PRE = (EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16);
   uint4 pre[PRE ? NG : 1], cur[PRE ? NG : 1];
   auto prefetch = [&](int i) {
-    if (!PRE || i >= 4) return;
-    const int mi = m0 + wr * 64 + i * 16 + frow;
+    if (!PRE || i >= MB) return;
+    const int mi = m0 + wr * RW + i * 16 + frow;
     if (mi >= p.M) return;
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
@@ -341,17 +346,19 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
     }
   };
   prefetch(0);
-  float scv[4] = {1.0f, 1.0f, 1.0f, 1.0f};              // DropPath scales of the 4 rows: two dependent loads each, issued together
+  float scv[MB];                                        // DropPath scales of the MB rows: two dependent loads each, issued together
+#pragma unroll
+  for (int i = 0; i < MB; ++i) scv[i] = 1.0f;
   if (EPI == EPI_RESID_F32 && p.seq_scale != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int mi = m0 + wr * 64 + i * 16 + frow;
+    for (int i = 0; i < MB; ++i) {
+      const int mi = m0 + wr * RW + i * 16 + frow;
       if (mi < p.M) scv[i] = p.seq_scale[p.row2seq[mi]];
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wr * 64 + i * 16 + frow;
+  for (int i = 0; i < MB; ++i) {
+    const int m = m0 + wr * RW + i * 16 + frow;
     if (PRE) {
 #pragma unroll
       for (int q = 0; q < NG; ++q) cur[q] = pre[q];
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
         // ablation (timing only, values land in the wrong places): every store instruction covers 8 full 128-byte lines
         // (8 rows x 64 columns of the wave's 64x64 tile) instead of 16 half lines
         const bool fullline = DBG(p, 2097152) && VPL == 8;
-        const size_t flrow = (size_t)(m0 + wr * 64 + (i * NG + q) * 8 + (lane >> 3));
+        const size_t flrow = (size_t)(m0 + wr * RW + (i * NG + q) * 8 + (lane >> 3));
         if (fullline) c = reinterpret_cast<bf16_t*>(p.C) + min(flrow, (size_t)p.M - 1) * p.ldc + n0 + wc * 64 + (lane & 7) * 8;
 #endif
         // experiment (debug flag 16384): u and GELU(u) interleaved in 64-byte pieces of ONE [M, 2N] buffer, so the two stores
@@ -526,17 +533,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
       float mean[4], rstd[4];
       __syncthreads();                                      // every wave is out of the operand ring
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < MB; ++i) {
         float sum = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) sum += (acc[j][i][0] + acc[j][i][1]) + (acc[j][i][2] + acc[j][i][3]);
         sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
-        if (fq == 0) red[(wr * 64 + i * 16 + frow) * 8 + wc] = sum;
+        if (fq == 0) red[(wr * RW + i * 16 + frow) * 8 + wc] = sum;
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* r8 = red + (wr * 64 + i * 16 + frow) * 8;
+      for (int i = 0; i < MB; ++i) {
+        const float* r8 = red + (wr * RW + i * 16 + frow) * 8;
         mean[i] = (((r8[0] + r8[1]) + (r8[2] + r8[3])) + (r8[4] + r8[5])) * invn;
         float sq = 0.f;
 #pragma unroll
@@ -544,12 +551,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
           for (int r = 0; r < 4; ++r) { const float dlt = acc[j][i][r] - mean[i]; sq = fmaf(dlt, dlt, sq); }
         sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
-        if (fq == 0) red[1024 + (wr * 64 + i * 16 + frow) * 8 + wc] = sq;
+        if (fq == 0) red[1024 + (wr * RW + i * 16 + frow) * 8 + wc] = sq;
       }
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* r8 = red + 1024 + (wr * 64 + i * 16 + frow) * 8;
+      for (int i = 0; i < MB; ++i) {
+        const float* r8 = red + 1024 + (wr * RW + i * 16 + frow) * 8;
         rstd[i] = rsqrtf((((r8[0] + r8[1]) + (r8[2] + r8[3])) + (r8[4] + r8[5])) * invn + p.ln_eps);
       }
       const int nc = n0 + wc * 64 + fq * 4;
@@ -558,8 +565,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
         const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + nc + j * 16);
         const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + nc + j * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = m0 + wr * 64 + i * 16 + frow;
+        for (int i = 0; i < MB; ++i) {
+          const int m = m0 + wr * RW + i * 16 + frow;
           if (m >= p.M) continue;
           const float o0 = (acc[j][i][0] - mean[i]) * rstd[i] * g4.x + b4.x, o1 = (acc[j][i][1] - mean[i]) * rstd[i] * g4.y + b4.y;
           const float o2 = (acc[j][i][2] - mean[i]) * rstd[i] * g4.z + b4.z, o3 = (acc[j][i][3] - mean[i]) * rstd[i] * g4.w + b4.w;
@@ -568,8 +575,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
       }
       if (wc == 0 && fq == 0 && p.ln_stats != nullptr) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int m = m0 + wr * 64 + i * 16 + frow;
+        for (int i = 0; i < MB; ++i) {
+          const int m = m0 + wr * RW + i * 16 + frow;
           if (m < p.M) { p.ln_stats[2 * (size_t)m] = mean[i]; p.ln_stats[2 * (size_t)m + 1] = rstd[i]; }
         }
       }
@@ -782,6 +789,19 @@ __global__ __launch_bounds__(256) void sum_slices_kernel(const float* __restrict
 int g_debug_flags = 0;
 
 // 128x384 / 12-wave tiles (the whole N per workgroup) when the tiles fit one round of one workgroup per CU: see launch_nt
+// 160-row tiles (MB = 5) instead of 128-row ones where they save a round of workgroup slots.  The tiled kernel keeps two workgroups per
+// CU, so a launch costs whole rounds of 512 tiles: tools/lab/t_quant.py measures the staircase (fc1 input gradient of ViT-S, N = 384,
+// K = 1536: 1023 tiles 50.8 us, 1035 tiles 63.4 us; Part-fViT N = 768, K = 2048: 2046 tiles 122 us, 2052 tiles 135 us).  A 160-row
+// tile costs ~1.2x a 128-row one (1.25x the MFMAs, 1.125x the staging): taken when rounds(160) x 1.2 < rounds(128).
+// LAFS_NT_TALL=0 switches it off (A/B).
+bool tall_tile_shape(int M, int N, int splits) {
+  static const bool tall_on = [] { const char* v = getenv("LAFS_NT_TALL"); return v == nullptr || v[0] != '0'; }();
+  if (!tall_on || splits != 1) return false;
+  const long tn = ceil_div(N, 128);
+  const long r128 = ceil_div((long)ceil_div(M, 128) * tn, 512L), r160 = ceil_div((long)ceil_div(M, 160) * tn, 512L);
+  return 6 * r160 < 5 * r128;
+}
+
 bool wide_tile_shape(int M, int N, int splits) {
   static const bool wide_on = [] { const char* v = getenv("LAFS_NT_WIDE"); return v == nullptr || v[0] != '0'; }();
   const int mt = ceil_div(M, 128);
@@ -866,6 +886,13 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
       return LAFS_OK;
     }
   }
+  if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16) {
+    if (bk64 && wm == 2 && tall_tile_shape(a.M, a.N, splits)) {
+      hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 2, false, false, 5>), dim3((unsigned)(ceil_div(a.M, 160) * tn), 1, 1), dim3(256), 0, s, a);
+      LAFS_LAUNCH_CHECK();
+      return LAFS_OK;
+    }
+  }
   if (wm == 4) {
     if (bk64) hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 64>), dim3((unsigned)t4 / splits, 1, splits), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((gemm_nt_kernel<EPI, 4, 32>), dim3((unsigned)t4 / splits, 1, splits), dim3(512),
@@ -898,6 +925,10 @@ extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) {
   // the tiled kernel's 128x384 form (launch_nt): plain / residual epilogue, 64-deep stages (K % 64 == 0, K >= 640), no K split
   const bool bk64 = g->K % 64 == 0 && g->K >= 640 && !(g_debug_flags & 2);
   if ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_RESID_F32) && bk64 && wide_tile_shape(g->M, g->N, g->splits <= 1 ? 1 : g->splits)) return 3;
+  // ... and its 160-row form where that saves a round of workgroup slots (bf16 operands; plain, GELU, residual and GELU' epilogues)
+  if ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_BF16_GELU || g->epilogue == LAFS_EPI_RESID_F32 || g->epilogue == LAFS_EPI_DGELU_BF16) &&
+      bk64 && !g->operand_f16 && tall_tile_shape(g->M, g->N, g->splits <= 1 ? 1 : g->splits))
+    return 4;
   return 0;
 }
 

@@ -72,6 +72,60 @@ def test_gemm_nt_epilogues(M, N, K):
     assert relerr(out, A.float() @ B.float().t()) < 2e-5 * math.sqrt(K)
 
 
+@pytest.mark.parametrize("M,N,K", [(128 * 103 + 37, 640, 640), (25216, 768, 2048)])
+def test_gemm_nt_tall_tiles(M, N, K):
+    """Long reductions whose 128-row tiles would spill into one more round of the 512 workgroup slots run on 160-row tiles (route 4).
+    Every epilogue of that form -- plain, GELU pair (u / gelu'(u) first tensor), residual + DropPath scale + element dropout, GELU' --
+    against fp32 torch, and BIT-IDENTICAL to the 128-row kernel on a row prefix small enough to take that route (same k order per
+    output element); rows past M stay untouched."""
+    A, B = rnd_bf(M, K, seed=21), rnd_bf(N, K, scale=0.1, seed=22)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(23))
+    ref = A.float() @ B.float().t() + bias
+    Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
+    Ms = 2048 + 5
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 4, "expected the 160-row tile route"
+    assert ops.gemm_nt(Ad[:Ms], Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 0
+    guard = 7.0
+
+    def run(epi, rows, **kw):
+        f32 = epi == _lib.EPI_RESID_F32
+        out = torch.full((rows + 192, N), guard, device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+        kw = {k: (v[:rows] if (torch.is_tensor(v) and v.dim() == 2 and v.shape[0] == M) else v) for k, v in kw.items()}
+        if "row2seq" in kw:
+            kw["row2seq"] = kw["row2seq"][:rows]
+        res = ops.gemm_nt(Ad[:rows], Bd, epi, out=out[:rows], **kw)
+        assert float((out[rows:].float() - guard).abs().max()) == 0.0, "rows past M were written"
+        return res
+
+    for epi, kw, check in (
+            (_lib.EPI_BF16, dict(bias=bd), lambda o: relerr(o.float(), ref) < 1e-2),
+            (_lib.EPI_DGELU_BF16, dict(aux=rnd_bf(M, N, seed=25).to(DEV), act=1), None)):
+        full, sub = run(epi, M, **kw), run(epi, Ms, **kw)
+        assert torch.equal(full[:Ms], sub)
+        if check is not None:
+            assert check(full)
+    # GELU pair, both first-tensor forms
+    for act in (0, 1):
+        o2f = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); o2s = torch.empty(Ms, N, device=DEV, dtype=torch.bfloat16)
+        uf = run(_lib.EPI_BF16_GELU, M, bias=bd, out2=o2f, act=act)[0]
+        us = run(_lib.EPI_BF16_GELU, Ms, bias=bd, out2=o2s, act=act)[0]
+        assert torch.equal(uf[:Ms], us) and torch.equal(o2f[:Ms], o2s)
+        assert relerr(o2f.float(), F.gelu(ref)) < 1e-2
+        if act == 0:
+            assert relerr(uf.float(), ref) < 1e-2
+    # residual + DropPath scale + element dropout
+    nseq = 7
+    row2seq = (torch.arange(M) * nseq // M).int().to(DEV)
+    sc = torch.tensor([0.0, 1.0 / 0.9, 1.0 / 0.9, 0.0, 1.0 / 0.9, 1.0 / 0.9, 1.0 / 0.9]).to(DEV)
+    resid = torch.randn(M, N, generator=torch.Generator().manual_seed(24)).to(DEV)
+    for p_drop in (0.0, 0.1):
+        kw = dict(bias=bd, resid=resid, seq_scale=sc, row2seq=row2seq, drop_p=p_drop, drop_seed=77)
+        full, sub = run(_lib.EPI_RESID_F32, M, **kw), run(_lib.EPI_RESID_F32, Ms, **kw)
+        assert torch.equal(full[:Ms], sub)
+        if p_drop == 0.0:
+            assert relerr(full, resid.cpu() + sc.cpu()[row2seq.cpu().long()].unsqueeze(1) * ref) < 1e-4
+
+
 @pytest.fixture
 def kpp_mask(request):
     """Route the K-resident requests to gemm_kres.hip (mask 0) or to its ping-pong form gemm_kpp.hip (mask 15) for one test."""
