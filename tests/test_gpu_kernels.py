@@ -72,7 +72,7 @@ def test_gemm_nt_epilogues(M, N, K):
     assert relerr(out, A.float() @ B.float().t()) < 2e-5 * math.sqrt(K)
 
 
-@pytest.mark.parametrize("M,N,K", [(128 * 103 + 37, 640, 640), (25216, 768, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128 * 103 + 37, 640, 640), (128 * 103 + 37, 704, 768), (25216, 768, 2048)])
 def test_gemm_nt_tall_tiles(M, N, K):
     """Long reductions whose 128-row tiles would spill into one more round of the 512 workgroup slots run on 160-row tiles (route 4).
     Every epilogue of that form -- plain, GELU pair (u / gelu'(u) first tensor), residual + DropPath scale + element dropout, GELU' --
