@@ -24,10 +24,10 @@ template <int LPR> __device__ __forceinline__ float row_sum(float v) {
 // ---------------------------------------------------------------- backward
 // LPR lanes own a row: lane l (within the row group) holds float4 at columns l*4 + LPR*4*i, i < NI (D = NI * LPR * 4).
 // PERS: 0 = grid covers the rows once (no loop, no prefetch), 1 = grid-stride with the next row group's operands requested a trip ahead.
-template <int D, int LPR, int NW, int PERS>
+template <int D, int LPR, int NW, int PERS, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void ln_bwd(const bf16_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
                                                   const float* __restrict__ gamma, float* __restrict__ g_io, bf16_t* __restrict__ gb,
-                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+                                                  float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, float* __restrict__ g_out = nullptr) {
   constexpr int NI = (D + LPR * 4 - 1) / (LPR * 4), RPW = 64 / LPR;
   __shared__ float red[NW * RPW][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -41,14 +41,14 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd(const bf16_t* __restrict__ dy,
   }
   struct RowIn { float4 xv[NI] = {}, old[NI] = {}; uint2 dw[NI] = {}; float mean, rstd; };
   auto load_row = [&](int row, RowIn& r) {
-    r.mean = stats[2 * row]; r.rstd = stats[2 * row + 1];
+    if (ABL & 8) { r.mean = 0.f; r.rstd = 1.f; } else { r.mean = stats[2 * row]; r.rstd = stats[2 * row + 1]; }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = l * 4 + LPR * 4 * i;
       if (on(i)) {
         r.xv[i] = *reinterpret_cast<const float4*>(x + (size_t)row * D + c);
         r.dw[i] = *reinterpret_cast<const uint2*>(dy + (size_t)row * D + c);
-        r.old[i] = *reinterpret_cast<const float4*>(g_io + (size_t)row * D + c);
+        if (!(ABL & 16)) r.old[i] = *reinterpret_cast<const float4*>(g_io + (size_t)row * D + c);
       }
     }
   };
@@ -62,8 +62,10 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd(const bf16_t* __restrict__ dy,
       const float4 xv = cur.xv[i];
       d[i] = make_float4(bf_lo(cur.dw[i].x), bf_hi(cur.dw[i].x), bf_lo(cur.dw[i].y), bf_hi(cur.dw[i].y));
       xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      if (!(ABL & 1)) {
       ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
       ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+      }
       d[i].x *= gam[i].x; d[i].y *= gam[i].y; d[i].z *= gam[i].z; d[i].w *= gam[i].w;
       s1 += d[i].x + d[i].y + d[i].z + d[i].w;
       s2 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd(const bf16_t* __restrict__ dy,
       float4 o = make_float4(rstd * (d[i].x - m1 - xh[i].x * m2), rstd * (d[i].y - m1 - xh[i].y * m2),
                              rstd * (d[i].z - m1 - xh[i].z * m2), rstd * (d[i].w - m1 - xh[i].w * m2));
       o.x += cur.old[i].x; o.y += cur.old[i].y; o.z += cur.old[i].z; o.w += cur.old[i].w;
-      *reinterpret_cast<float4*>(g_io + (size_t)row * D + c) = o;
-      *reinterpret_cast<uint2*>(gb + (size_t)row * D + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
+      *reinterpret_cast<float4*>(((ABL & 2) ? g_out : g_io) + (size_t)row * D + c) = o;
+      if (!(ABL & 4)) *reinterpret_cast<uint2*>(gb + (size_t)row * D + c) = make_uint2(pack_bf2(o.x, o.y), pack_bf2(o.z, o.w));
     }
   };
   const int stride = gridDim.x * NW * RPW;
@@ -211,6 +213,8 @@ void run_shape(int rows, int nset) {
   // forward (writes the statistics the backward reads)
 #define FWD(LPR, NW, PERS, GRID, label) \
   report("fwd " label, time_us([&](int r) { const Set& t = sets[r % nset]; hipLaunchKernelGGL((ln_fwd<D, LPR, NW, PERS>), dim3(GRID), dim3(NW * 64), 0, 0, t.x, gamma, beta, 1e-6f, t.y, t.stats, rows); }, reps), 6.0)
+#define BWDA(ABL, BYTES, label) \
+  report("bwd " label, time_us([&](int r) { const Set& t = sets[r % nset]; const Set& u = sets[(r + 1) % nset]; hipLaunchKernelGGL((ln_bwd<D, 64, (D == 384 ? 16 : 8), 1, ABL>), dim3(D == 384 ? 256 : 512), dim3((D == 384 ? 16 : 8) * 64), 0, 0, t.dy, t.x, t.stats, gamma, t.g, t.gb, dg, db, rows, u.g); }, reps), BYTES)
 #define BWD(LPR, NW, PERS, GRID, label) \
   report("bwd " label, time_us([&](int r) { const Set& t = sets[r % nset]; hipLaunchKernelGGL((ln_bwd<D, LPR, NW, PERS>), dim3(GRID), dim3(NW * 64), 0, 0, t.dy, t.x, t.stats, gamma, t.g, t.gb, dg, db, rows); }, reps), 14.0)
   FWD(64, 4, 0, (rows + 3) / 4, "product: row per wave, 4-wave groups, one trip");
@@ -237,6 +241,14 @@ void run_shape(int rows, int nset) {
     BWD(64, 4, 1, 1024, "row per wave, 1024 x 4 waves, prefetch 1");
     BWD(64, 4, 1, 512, "row per wave, 512 x 4 waves, prefetch 1");
   }
+  BWDA(0, 14.0, "ablation base (product form)");
+  BWDA(1, 14.0, "no gamma / beta sums");
+  BWDA(2, 14.0, "g written to another buffer (no read-modify-write)");
+  BWDA(4, 12.0, "no bf16 copy store");
+  BWDA(8, 14.0, "no statistics loads");
+  BWDA(16, 10.0, "no load of the incoming g");
+  BWDA(1 | 8, 14.0, "no sums, no statistics loads");
+  BWDA(4 | 16, 8.0, "no bf16 store, no g load: x + dy in, g out");
   for (auto& t : sets) { (void)hipFree(t.x); (void)hipFree(t.g); (void)hipFree(t.stats); (void)hipFree(t.dy); (void)hipFree(t.gb); (void)hipFree(t.y); }
 }
 
