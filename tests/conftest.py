@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _release_gpu_memory_between_tests(request):
+    """GPU tests build whole engines (hipGraph pools of several GB each): drop what a test leaves behind before the next one starts, so
+    that the suite's footprint is one test's, whatever order the tests run in.  LAFS_TEST_MEM=1 prints the allocator's state per test."""
+    yield
+    if torch.cuda.is_available() and request.node.get_closest_marker("gpu") is not None:
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if os.environ.get("LAFS_TEST_MEM") == "1":
+            free, total = torch.cuda.mem_get_info()
+            print(f"\n[mem] after {request.node.name}: allocated {torch.cuda.memory_allocated() / 2**30:.1f} GiB, reserved "
+                  f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB, device free {free / 2**30:.1f} of {total / 2**30:.1f} GiB", flush=True)
+
+
 def load_golden(name):
     """Return {key: torch tensor} for tests/golden/<name>.npz (numeric arrays only -> tensors)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)

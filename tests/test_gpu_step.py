@@ -577,7 +577,7 @@ def test_row_chains_equal_the_single_chain(tmp_path):
         out[mode] = torch.load(f)
     la, lb = out["2"]["losses"], out["0"]["losses"]
     assert abs(la[0] - lb[0]) < 1e-6 * abs(lb[0]), (la, lb)            # same weights: the forward is the same arithmetic
-    assert abs(la[1] - lb[1]) < 2e-5 * abs(lb[1]), (la, lb)            # one update apart: atomics-order noise of the gradients
+    assert abs(la[1] - lb[1]) < 2e-4 * abs(lb[1]), (la, lb)            # one update apart: atomics-order noise of the gradients (seen up to ~3e-5)
     for a, b in zip(la[2:], lb[2:]):                                     # then Adam's first steps (lr * sign of a near-zero gradient)
         assert abs(a - b) < 5e-3 * abs(b), (la, lb)                      # amplify that noise; a race would be orders above this
     for name in ("teacher", "student"):
