@@ -169,3 +169,35 @@ def test_mynet_optimizer_index_order_is_the_reference_adamw_order():
     opt = torch.optim.AdamW(groups)
     sd = opt.state_dict()
     assert [len(g["params"]) for g in sd["param_groups"]] == [len(reg), len(noreg)]
+
+
+def test_gemm_route_selection_on_the_benchmark_shapes():
+    """lafs_gemm_nt_route is host logic (no launch): which kernel form every long GEMM of the three measured workloads takes.
+    0 = 128x128 tiles, 1 = K-resident, 3 = 128x384 wide tile (its tiles fit one round of the chip), 4 = 160-row tiles (one round of
+    the 512 workgroup slots less than 128-row tiles would need)."""
+    import ctypes as C
+    from lafs_cvpr2024_amd import _lib
+    try:
+        h = _lib.lib()
+    except Exception as e:                                  # pragma: no cover
+        pytest.skip(f"library not built: {e}")
+
+    def route(M, N, K, epi):
+        a = _lib.GemmNTArgs()
+        a.M, a.N, a.K, a.epilogue, a.splits = M, N, K, epi, 1
+        a.lda, a.ldb, a.ldc, a.ldc2, a.ldr, a.ldaux = K, K, N, N, N, N
+        a.A = a.B = a.C = a.C2 = a.resid = a.aux = 1 << 20          # (never dereferenced: the route is a function of shapes and presence)
+        return int(h.lafs_gemm_nt_route(C.byref(a)))
+
+    B16, GELU, RES, DG = _lib.EPI_BF16, _lib.EPI_BF16_GELU, _lib.EPI_RESID_F32, _lib.EPI_DGELU_BF16
+    # ViT-S step (C2): two row chains of 25 216 / 18 944 rows
+    assert route(25216, 1152, 384, B16) in (1, 2) and route(18944, 1536, 384, GELU) in (1, 2)        # K = 384: K-resident
+    assert route(25216, 384, 1536, RES) == 3 and route(25216, 384, 1152, B16) == 3                    # 197 wide tiles: one round
+    assert route(18944, 384, 1536, RES) == 0 and route(18944, 384, 1536, B16) == 0                    # 444 tiles: one round of 128x128
+    assert route(44160, 384, 1536, B16) == 4                                                          # merged rows: 1035 -> 828 tiles
+    # Part-fViT (ViT-B: C4 fine-tune at 25 216 rows, the mynet pair's chains)
+    for epi, N, K in ((B16, 768, 2048), (B16, 768, 2112), (B16, 704, 768), (RES, 768, 2048), (RES, 768, 704), (GELU, 2048, 768), (DG, 2048, 768)):
+        assert route(25216, N, K, epi) == 4, (N, K, epi)                                              # 3 -> 2 / 7 -> 5 rounds
+    assert route(25216, 2112, 768, B16) == 0                                                          # 17 column tiles: 7 rounds either way
+    assert route(18944, 768, 2048, B16) == 0                                                          # 888 tiles: 2 rounds either way
+    assert route(1024, 768, 2048, B16) == 0
