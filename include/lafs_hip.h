@@ -6,7 +6,10 @@
  * implicit device kernels behind one reference call site (cited as file:line, relative to the reference
  * root).  Conventions:
  *   - plain pointers and sizes only (device pointers unless stated), no torch types;
- *   - the CALLER allocates every buffer including workspaces; the library keeps no device state;
+ *   - the CALLER allocates every buffer including workspaces; the library keeps no process-wide device state and reads no
+ *     environment variable: the few device objects it needs itself (side streams and events of the trunk passes) and its
+ *     kernel-selection options live in a caller-owned per-device context, lafs_ctx (below); calls that share no context and no
+ *     buffer are independent (re-entrant per stream);
  *   - every function enqueues work on `stream` and never synchronises the device;
  *   - return value: 0 = success, < 0 = bad argument (see lafs_last_error()), > 0 = hipError_t;
  *   - "bf16" = raw 16-bit bfloat16, "f32" = IEEE float; row-major everywhere, ld* in ELEMENTS.
@@ -45,6 +48,33 @@ int lafs_debug_get(void);
 int lafs_ablation_build(void);
 /* Thread-local text of the last error returned on this thread ("" if none). */
 const char* lafs_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-device context.  The reference has no counterpart: its modules issue every op on torch's current stream from one Python
+ * thread per rank (lafs_train.py:513-613).  This library forks a trunk pass over side streams of its own (row chains, weight
+ * gradients), so it needs streams / events that live across calls; they belong to a handle the CALLER creates and destroys.
+ *   lafs_ctx_create(device)  device < 0 = the current one.  Creates three non-blocking side streams, their fork / join events and a
+ *                            pool of 64 events now (never inside a hipGraph capture); NULL on failure (lafs_last_error()).
+ *   lafs_ctx_destroy         after every graph that captured work of this context has been destroyed.
+ *   lafs_ctx_set / _get      kernel-selection options (defaults = the measured-best settings; the others exist for A/B runs).
+ * A NULL context is legal wherever one is accepted: compiled-in default options, no side streams (everything on `stream`).
+ * Two contexts share nothing: engines built on different contexts may be driven from different host threads and streams. */
+typedef struct lafs_ctx lafs_ctx;
+enum {
+  LAFS_OPT_SIDE_STREAMS = 0,   /* 1: row chains / attention groups / weight gradients may use the context's side streams; 0: caller's stream only */
+  LAFS_OPT_ROW_CHAINS = 1,     /* 1, 2 (default) or 4 chains of launches over the crop-resolution groups' rows (csrc/engine.hip) */
+  LAFS_OPT_KRES_MASK = 2,      /* epilogues routed to the K-resident GEMM: 1 plain, 2 GELU, 4 residual, 8 GELU' (default 15) */
+  LAFS_OPT_KRES_MIN_ITEMS = 3, /* least items per workgroup run of the K-resident GEMM (default 4) */
+  LAFS_OPT_NT_WIDE = 4,        /* tiled GEMM: 128x384 tiles where they fit one round of the chip (default 1) */
+  LAFS_OPT_NT_TALL = 5,        /* tiled GEMM: 160-row tiles where they save a round of workgroup slots (default 1) */
+  LAFS_OPT_COMM_CUS = 6,       /* data-parallel runs: CUs left to the collective library's kernels by the K-resident GEMM (default 0) */
+  LAFS_OPT_NT_BIG = 7,         /* tiled GEMM: 256x256 one-workgroup-per-CU tiles for the wide long-K shapes (default 1) */
+  LAFS_OPT_COUNT = 8
+};
+lafs_ctx* lafs_ctx_create(int device);
+void lafs_ctx_destroy(lafs_ctx* ctx);
+int lafs_ctx_set(lafs_ctx* ctx, int opt, int value);
+int lafs_ctx_get(const lafs_ctx* ctx, int opt);
 
 /* ------------------------------------------------------------------------------------------------
  * GEMMs (nn.Linear / nn.Conv2d(k=s=p) forward, dgrad, wgrad)
@@ -90,10 +120,7 @@ typedef struct lafs_gemm_nt_args {
   int operand_f16;                 /* 1: A, B, a 16-bit C and the BF16_ACT residual (aux) are IEEE fp16 instead of bf16 (BF16 / BF16_ACT /
                                       F32 epilogues, no K split): the trainable landmark CNN runs in the reference's autocast
                                       format (train_largescale.py:803-804; v_mfma_f32_16x16x32_f16, same rate) */
-  const float* ln_gamma; const float* ln_beta; float ln_eps;   /* RESID_F32 with ln_out != NULL (N == 384, K % 64 == 0, no dropout): */
-  void* ln_out; int ld_ln_out;     /* bf16 [M, N] = LayerNorm(C) with gamma / beta -- the NEXT nn.LayerNorm of the block chain
-                                      (vision_transformer.py:99,103,107-113) computed by the 128x384 tile that owns the whole rows, */
-  float* ln_stats;                 /* f32 [M, 2] {mean, rstd} for lafs_layernorm_bwd (may be NULL); saves a pass over the fp32 rows */
+  const lafs_ctx* ctx;             /* kernel-selection options (NULL = defaults) */
 } lafs_gemm_nt_args;
 
 /* act = LAFS_GELU_SAVE_GRAD with LAFS_EPI_BF16_GELU: C receives gelu'(u) (bf16) instead of the pre-activation u; with
@@ -107,16 +134,12 @@ typedef struct lafs_gemm_nt_args {
 int lafs_gemm_nt_slices(int K, int splits);
 int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
 /* Which kernel lafs_gemm_nt runs for this request: 0 = the tiled LDS-DMA kernel (gemm.hip), 1 = the K-resident streaming kernel
- * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout), 2 = its
- * ping-pong form (gemm_kpp.hip: one 8-wave workgroup per CU, the MFMA turn of one half beside the epilogue turn of the other;
- * same requests, same results bit for bit), 3 = the tiled kernel in its 128x384 / 12-wave form (whole N per workgroup: long
- * reductions onto N = 384 whose tiles fit one round of the chip), 4 = the tiled kernel with 160-row tiles (long reductions whose
- * 128-row tiles would spill into one more round of the 512 workgroup slots than 160-row ones need). */
+ * (gemm_kres.hip: K == 384, N % 64 == 0, N <= 1536, M >= 2048, plain / GELU / GELU' / residual epilogue, no dropout, bf16 operands),
+ * 3 = the tiled kernel in its 128x384 / 12-wave form (whole N per workgroup: long reductions onto N = 384 whose tiles fit one
+ * round of the chip), 4 = the tiled kernel with 160-row tiles (long reductions whose 128-row tiles would spill into one more
+ * round of the 512 workgroup slots than 160-row ones need), 5 = the 256x256 one-workgroup-per-CU kernel (gemm_big.hip).
+ * Mirrors lafs_gemm_nt's own decisions, including its operand-format and validation order. */
 int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
-/* Which epilogues of the K-resident route take the ping-pong kernel: bit mask 1 plain, 2 GELU, 4 residual, 8 GELU'; -1 = the
- * value of LAFS_KPP in the environment (the default).  Returns the previous override.  Replaces nothing in the reference: it
- * selects between two implementations of the same nn.Linear calls (vision_transformer.py:59-65, 75-90). */
-int lafs_set_kpp_mask(int mask);
 
 /* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
  * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0.
@@ -137,7 +160,8 @@ int lafs_sum_slices(const float* part, int64_t part_stride, int n_part, int64_t 
  * One 4-wave workgroup per CU (one wave per SIMD, 512 registers) owns a (64 FA) x (64 FB) tile of v_mfma_f32_32x32x16_bf16
  * blocks (192x192 .. 256x256) over one slice of the token axis and STORES its fp32 tile into `workspace`
  * ([slices][N1][N2] f32 per GEMM); a fold kernel then writes C: no atomics, and with accumulate = 0 the gradient buffer needs
- * no memset.  colsum_a as in lafs_gemm_tn_acc (f32 atomics into a pre-zeroed vector).
+ * no memset.  colsum_a (f32 [N1]) += column sums of A: every (slice, tile, wave column) stores its share into the workspace and
+ * the fold kernel adds the shares in a fixed order (deterministic; fp32 atomics before round 5).
  * lafs_wgrad_group runs up to 8 such GEMMs that share the token count M (the four weight gradients of one transformer block)
  * as ONE launch + ONE fold: the tiles of all GEMMs fill the chip together, so the token axis is cut into 4x fewer slices --
  * 4x less partial-sum traffic, 4x longer main loops per workgroup.
@@ -183,7 +207,18 @@ int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int l
                        const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
                        void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
                        float* dgamma, float* dbeta, int rows, int D, float drop_p, uint32_t drop_seed,
-                       const float* drop_step, int drop_row0, hipStream_t stream);
+                       const float* drop_step, int drop_row0, float* part_out, hipStream_t stream);
+/* Deterministic parameter gradients: with part_out != NULL (f32 [lafs_layernorm_bwd_parts(rows, D)][2][D]) the launch stores every
+ * workgroup's gamma / beta sums into a slot of its own and leaves dgamma / dbeta alone (they may be NULL);
+ * lafs_layernorm_bwd_fold then adds the slots of up to 4 launches per LayerNorm (the row chains of a trunk pass) in a fixed order:
+ * dgamma[c] += sum, dbeta[c] += sum.  Without part_out the sums leave as one fp32 atomic per column and workgroup. */
+#define LAFS_LN_FOLD_MAX 24
+typedef struct lafs_ln_fold_item {
+  const float* part[4]; int n_parts[4];      /* unused entries: NULL / 0 */
+  float* dgamma; float* dbeta;
+} lafs_ln_fold_item;
+int lafs_layernorm_bwd_parts(int rows, int D);
+int lafs_layernorm_bwd_fold(const lafs_ln_fold_item* items, int n_items, int D, hipStream_t stream);
 
 /* gb(bf16)[r,:] = bf16(seq_scale[row2seq[r]] * g(f32)[r,:])  (seq_scale NULL -> plain cast). */
 int lafs_scale_cast_bf16(const float* g, int ldg, void* gb, int ldgb, const float* seq_scale,
@@ -318,9 +353,6 @@ int lafs_clip_adamw_ema_range(float* param, const float* grad, float* exp_avg, f
 int lafs_cast_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
 /* dst(f32)[i] = src(bf16)[i]   (gradients that travelled over the wire as bf16: LAFS_GRAD_WIRE=bf16, distributed.py) */
 int lafs_cast_f32(const void* src, float* dst, int64_t n, hipStream_t stream);
-/* Data-parallel runs: leave `cus` compute units to the collective library's kernels -- the K-resident GEMM (otherwise two resident
- * workgroups on every CU) shrinks its grid to 2 * (256 - cus) workgroups.  0 (default) = the whole chip.  Returns the value set. */
-int lafs_set_comm_cus(int cus);
 /* dst(bf16)[c, r] = src(bf16)[r, c]: operand transposes of the fine-tune margin head (dL/dcos [B, C] -> [C, B] feeds both class-
  * gradient GEMMs, train_largescale.py:820-867's autograd through ViT_face.py:49-89; was a torch .t().contiguous()). */
 int lafs_transpose_bf16(const void* src, int rows, int cols, int ld_src, void* dst, int ld_dst, hipStream_t stream);
@@ -367,14 +399,11 @@ typedef struct lafs_trunk_desc {
                                          (dY of fc2 / fc1 / proj / qkv) in slots of their own -- the workspace grows by depth - 2 sets --
                                          until lafs_trunk_wgrad launches them, e.g. beside work that leaves the chip idle (the
                                          fine-tune step's landmark-CNN backward, train_largescale.py:785-891) */
+  lafs_ctx* ctx;                      /* side streams / events / options of these passes (NULL: caller's stream only, default options) */
 } lafs_trunk_desc;
 
 /* Bytes of activation workspace for a forward with (1) / without (0) saving activations for backward. */
 int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save_for_backward);
-/* Creates the library's side streams and events (row chains, attention groups, weight-gradient protocol) now instead of on first
- * use: engines call it once at construction, so that nothing is created inside a hipGraph capture.  Returns 1 when the side streams
- * are in use, 0 when LAFS_ATTN_STREAM=0 / LAFS_SINGLE_STREAM=1 keep everything on the caller's stream. */
-int lafs_trunk_streams_init(void);
 /* Number of independent chains of launches (row ranges of the token batch, one stream each) the trunk passes of this descriptor
  * run as: 2 when there are two crop-resolution groups of >= 4096 full-length rows each (csrc/engine.hip:
  * row_ranges), else 1.  Tests assert the route they mean to cover. */
@@ -428,16 +457,19 @@ int lafs_margin_softmax_ce(float* cos, int ld, int B, int C, const int32_t* y1, 
                            hipStream_t stream);
 /* Class-sharded margin softmax (PartialFC; PARITY UNPINNED: absent from the reference, ViT_face.py:645-649 is a commented
  * import; semantics follow InsightFace partial_fc_v2).  cos(f32) [B, ld] over this rank's S (sampled) class centres;
- * y_local(i32)[B] = local index of the target or -1.  Three passes with the cross-rank statistics exchanged in between
- * (all-reduce MAX of rowmax, all-reduce SUM of rowsum and target_logit):  z = margin logits;
- *   rowmax[b] = max_k z ;  rowsum[b] = sum_k exp(z - gmax[b]), target_logit[b] = z_target or 0 ;
- *   grad (in place) cos <- grad_scale * (exp(z - gmax)/Z - onehot) * dz/dcos. */
-int lafs_shard_margin_rowmax(const float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
-                             int margin_type, float* rowmax, hipStream_t stream);
-int lafs_shard_margin_rowsum(const float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
-                             int margin_type, const float* gmax, float* rowsum, float* target_logit, hipStream_t stream);
-int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m, int margin_type,
-                           const float* gmax, const float* Z, float grad_scale, hipStream_t stream);
+ * y_local(i32)[B] = local index of the target or -1.  Soft (mixup) targets as the reference always feeds its margin head
+ * (train_largescale.py:802; dense lam e_y1 + (1 - lam) e_y2 entering the margin itself, ViT_face.py:69-73): y2_local(i32)[B] = local
+ * index of the mixup partner's class or -1, lam(f32)[B] = the row's lambda (NULL: 1); y2_local == NULL: hard labels.  CosFace only.
+ * Three passes with the cross-rank statistics exchanged in between (all-reduce MAX of rowmax, all-reduce SUM of rowsum and
+ * target_logit):  z = margin logits s (cos - m y);
+ *   rowmax[b] = max_k z ;  rowsum[b] = sum_k exp(z - gmax[b]), target_logit[b] = sum over the targets this rank owns of y_k z_k ;
+ *   grad (in place) cos <- grad_scale * (exp(z - gmax)/Z - y) * dz/dcos.      loss_b = log Z + gmax - target_logit. */
+int lafs_shard_margin_rowmax(const float* cos, int ld, int B, int S, const int32_t* y_local, const int32_t* y2_local, const float* lam,
+                             float s, float m, int margin_type, float* rowmax, hipStream_t stream);
+int lafs_shard_margin_rowsum(const float* cos, int ld, int B, int S, const int32_t* y_local, const int32_t* y2_local, const float* lam,
+                             float s, float m, int margin_type, const float* gmax, float* rowsum, float* target_logit, hipStream_t stream);
+int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_local, const int32_t* y2_local, const float* lam, float s,
+                           float m, int margin_type, const float* gmax, const float* Z, float grad_scale, hipStream_t stream);
 /* x(f32) [B,3,S,S]: x = lam*x + (1-lam)*flip_batch(x), from a u8 source with (x/255*2-1) folded in (util/mixup_my.py:189-200 on
  * the loader's tensors, train_largescale.py:842-846).  lam_dev != NULL: lambda is read from DEVICE memory when the kernel runs (a
  * captured fine-tune step replays with a new lambda per micro-step); otherwise `lam`. */
@@ -547,11 +579,19 @@ int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const double* su
 int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
                     const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
                     float* dgamma, float* dbeta, const float* grad_scale, hipStream_t stream);
-/* scale(f32, device)[2] = {s, 1/s}, s = the power of two <= target / max |g| (1 for an all-zero or non-finite gradient): the loss
- * scaling of the reference's GradScaler (train_largescale.py:803-867), decided per call on the device so that a captured step needs
- * no host round trip.  lafs_cnn_cast_pad_f16: dst(fp16)[r, c] = src(f32)[r, c] * scale[0], pad columns [cols, ld) zero.
+/* Loss scaling and overflow guard of the fp16 backward -- the reference's torch.cuda.amp.GradScaler (train_largescale.py:739,
+ * 803-804, 867-880: scale, skip the step on inf / NaN, back the scale off, grow it again) decided on the device, so that a captured
+ * step needs no host round trip.
+ *   lafs_cnn_grad_scale: scale(f32, device)[0..1] = {s, 1/s}, s = the power of two <= target / max |g|, clamped to [2^-24, 2^24]
+ *     (1 for an all-zero gradient).  has_state != 0: scale is the 8-float state {s, 1/s, target, found_inf, skipped, clean, -, -}:
+ *     the target is state[2] when that is > 0 (else the argument), and found_inf is RESET to "g itself holds inf / NaN".
+ *   lafs_cnn_grad_guard (after the backward, over the CNN's gradient range of the arena): found_inf |= any non-finite entry;
+ *     found_inf: the range is zeroed (this accumulation window's CNN update is dropped; AdamW's moments stay finite), target
+ *     halves (>= 1), skipped += 1; otherwise 2000 clean backwards in a row double the target again (<= target_max).
+ * lafs_cnn_cast_pad_f16: dst(fp16)[r, c] = src(f32)[r, c] * scale[0], pad columns [cols, ld) zero.
  * lafs_cnn_cast_f16_f32: dst(f32)[i] = src(fp16)[i]. */
-int lafs_cnn_grad_scale(const float* g, int64_t n, float target, float* scale, hipStream_t stream);
+int lafs_cnn_grad_scale(const float* g, int64_t n, float target, float* scale, int has_state, hipStream_t stream);
+int lafs_cnn_grad_guard(float* grad, int64_t n, float* state, float target_max, hipStream_t stream);
 int lafs_cnn_cast_pad_f16(const float* src, int rows, int cols, void* dst, int ld, const float* scale, hipStream_t stream);
 int lafs_cnn_cast_f16_f32(const void* src, float* dst, int64_t n, hipStream_t stream);
 /* Depthwise k x k convolution (k in {3,5}, stride in {1,2}, pad (k-1)/2, no bias) on NHWC bf16.  w = tap-major fp32 image [k*k][ld] of

@@ -23,13 +23,16 @@ class GemmNTArgs(C.Structure):
                 ("aux", C.c_void_p), ("ldaux", C.c_int), ("pos", C.c_void_p), ("npatch", C.c_int),
                 ("splits", C.c_int), ("drop_p", C.c_float), ("drop_seed", C.c_uint32),
                 ("drop_step", C.c_void_p), ("drop_row0", C.c_int), ("act", C.c_int), ("operand_f16", C.c_int),
-                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p), ("ld_ln_out", C.c_int),
-                ("ln_stats", C.c_void_p)]
+                ("ctx", C.c_void_p)]
 
 
 class WgradItem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
                 ("N1", C.c_int), ("N2", C.c_int), ("accumulate", C.c_int), ("colsum_a", C.c_void_p)]
+
+
+class LnFoldItem(C.Structure):
+    _fields_ = [("part", C.c_void_p * 4), ("n_parts", C.c_int * 4), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
 
 
 class RandAugOp(C.Structure):
@@ -51,7 +54,7 @@ class TrunkDesc(C.Structure):
                 ("master", C.c_void_p), ("shadow", C.c_void_p), ("shadow_t", C.c_void_p), ("grad", C.c_void_p),
                 ("blocks", C.POINTER(BlockOffsets)),
                 ("n_groups", C.c_int), ("group_n_seq", C.c_int * 4), ("group_max_len", C.c_int * 4), ("wgrad_workgroups", C.c_int),
-                ("dropout_step", C.c_void_p), ("wgrad_overwrite", C.c_int), ("wgrad_defer", C.c_int)]
+                ("dropout_step", C.c_void_p), ("wgrad_overwrite", C.c_int), ("wgrad_defer", C.c_int), ("ctx", C.c_void_p)]
 
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32, EPI_BF16_ACT = range(8)
@@ -61,6 +64,7 @@ CHUNK = 1024
 SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE, SEG_LOW_DECAY, SEG_OVERWRITTEN = 1, 2, 4, 8, 16
 HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE, HP_WD_LOW, HP_STEP, HP_MIX_LAM = range(12)
 HP_COUNT = 16
+OPT_SIDE_STREAMS, OPT_ROW_CHAINS, OPT_KRES_MASK, OPT_KRES_MIN_ITEMS, OPT_NT_WIDE, OPT_NT_TALL, OPT_COMM_CUS, OPT_NT_BIG = range(8)
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
@@ -77,7 +81,8 @@ _PROTOS = {
     "lafs_wgrad_group": [C.POINTER(WgradItem), i32, i32, i32, vp, i64],
     "lafs_colsum_bf16_acc": [vp, i32, i32, i32, vp],
     "lafs_layernorm_fwd": [vp, i32, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32],
-    "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, u32, vp, i32],
+    "lafs_layernorm_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, i32, vp, i32, vp, vp, vp, vp, i32, i32, f32, u32, vp, i32, vp],
+    "lafs_layernorm_bwd_fold": [C.POINTER(LnFoldItem), i32, i32],
     "lafs_scale_cast_bf16": [vp, i32, vp, i32, vp, vp, i32, i32, f32, u32, vp, i32],
     "lafs_dropout_f32": [vp, i32, i32, i32, f32, u32, vp],
     "lafs_debug_dropout_mask": [i32, i32, f32, u32, vp],
@@ -112,9 +117,9 @@ _PROTOS = {
     "lafs_trunk_backward": [C.POINTER(TrunkDesc), vp, vp, vp, i32, i32, vp],
     "lafs_trunk_wgrad": [C.POINTER(TrunkDesc), vp, i32, i32],
     "lafs_margin_softmax_ce": [vp, i32, i32, i32, vp, vp, f32, f32, f32, i32, f32, vp, vp],
-    "lafs_shard_margin_rowmax": [vp, i32, i32, i32, vp, f32, f32, i32, vp],
-    "lafs_shard_margin_rowsum": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, vp],
-    "lafs_shard_margin_grad": [vp, i32, i32, i32, vp, f32, f32, i32, vp, vp, f32],
+    "lafs_shard_margin_rowmax": [vp, i32, i32, i32, vp, vp, vp, f32, f32, i32, vp],
+    "lafs_shard_margin_rowsum": [vp, i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, vp],
+    "lafs_shard_margin_grad": [vp, i32, i32, i32, vp, vp, vp, f32, f32, i32, vp, vp, f32],
     "lafs_cnn_stem": [vp, vp, vp, i32, i32, i32, vp, i32],
     "lafs_cnn_dwconv": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "lafs_cnn_pool": [vp, i32, i32, i32, vp, i32],
@@ -138,7 +143,8 @@ _PROTOS = {
     "lafs_cnn_dw_layout_table": [vp, vp, vp, vp, i32, i32],
     "lafs_cnn_pool_train": [vp, i32, i32, i32, vp, i32],
     "lafs_cnn_unpad_add_table": [vp, vp, vp, vp, i32, i32, vp],
-    "lafs_cnn_grad_scale": [vp, i64, f32, vp],
+    "lafs_cnn_grad_scale": [vp, i64, f32, vp, i32],
+    "lafs_cnn_grad_guard": [vp, i64, vp, f32],
     "lafs_cnn_cast_pad_f16": [vp, i32, i32, vp, i32, vp],
     "lafs_cnn_cast_f16_f32": [vp, vp, i64],
     "lafs_landmark_theta_bwd": [vp, vp, i32, i32, vp],
@@ -157,8 +163,10 @@ _NO_STREAM = {
     "lafs_version": ([], i32),
     "lafs_gemm_nt_slices": ([i32, i32], i32),
     "lafs_gemm_nt_route": ([C.POINTER(GemmNTArgs)], i32),
-    "lafs_set_comm_cus": ([i32], i32),
-    "lafs_set_kpp_mask": ([i32], i32),
+    "lafs_ctx_create": ([i32], vp),
+    "lafs_ctx_destroy": ([vp], None),
+    "lafs_ctx_set": ([vp, i32, i32], i32),
+    "lafs_ctx_get": ([vp, i32], i32),
     "lafs_debug_set": ([i32], i32),
     "lafs_debug_get": ([], i32),
     "lafs_ablation_build": ([], i32),
@@ -166,7 +174,7 @@ _NO_STREAM = {
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),
     "lafs_trunk_row_ranges": ([C.POINTER(TrunkDesc)], i32),
-    "lafs_trunk_streams_init": ([], i32),
+    "lafs_layernorm_bwd_parts": ([i32, i32], i32),
     "lafs_wgrad_workspace_bytes": ([i32, i32, i32], i64),
     "lafs_wgrad_group_workspace_bytes": ([C.POINTER(WgradItem), i32, i32, i32], i64),
 }
@@ -202,6 +210,67 @@ def lib():
         if flags:
             h.lafs_debug_set(int(flags, 0))
     return _lib
+
+
+class Ctx:
+    """Owner of one lafs_ctx (include/lafs_hip.h): the side streams / events of the trunk passes and the kernel-selection options.
+    One per engine; the environment is read HERE, never inside the library: LAFS_SINGLE_STREAM=1 / LAFS_ATTN_STREAM=0 (no side
+    streams), LAFS_ROW_CHAINS, LAFS_KRES, LAFS_KRES_MIN_ITEMS, LAFS_NT_WIDE, LAFS_NT_TALL, LAFS_NT_BIG, LAFS_COMM_CUS."""
+
+    def __init__(self, device=None, options=None, from_env=True):
+        import torch
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
+        self.handle = lib().lafs_ctx_create(int(idx))
+        if not self.handle:
+            raise LafsHipError("lafs_ctx_create failed: " + lib().lafs_last_error().decode("utf-8", "replace"))
+        opts = dict(self.env_options() if from_env else {})
+        opts.update(options or {})
+        for k, v in opts.items():
+            self.set(k, v)
+
+    @staticmethod
+    def env_options():
+        e, o = os.environ, {}
+        if e.get("LAFS_SINGLE_STREAM") == "1" or e.get("LAFS_ATTN_STREAM") == "0":
+            o[OPT_SIDE_STREAMS] = 0
+        for name, key in (("LAFS_ROW_CHAINS", OPT_ROW_CHAINS), ("LAFS_KRES", OPT_KRES_MASK), ("LAFS_KRES_MIN_ITEMS", OPT_KRES_MIN_ITEMS),
+                          ("LAFS_NT_WIDE", OPT_NT_WIDE), ("LAFS_NT_TALL", OPT_NT_TALL), ("LAFS_NT_BIG", OPT_NT_BIG),
+                          ("LAFS_COMM_CUS", OPT_COMM_CUS)):
+            if e.get(name) not in (None, ""):
+                o[key] = int(e[name])
+        return o
+
+    def set(self, opt, value):
+        check(lib().lafs_ctx_set(self.handle, int(opt), int(value)), "lafs_ctx_set")
+
+    def get(self, opt):
+        return int(lib().lafs_ctx_get(self.handle, int(opt)))
+
+    def close(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h and _lib is not None:
+            _lib.lafs_ctx_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_ctx(device=None):
+    """The process's default context of `device` (module-level ops and autograd wrappers; engines own theirs)."""
+    import torch
+    idx = torch.cuda.current_device() if device is None else (torch.device(device).index or 0)
+    c = _default_ctx.get(idx)
+    if c is None:
+        c = _default_ctx[idx] = Ctx(torch.device("cuda", idx))
+    return c
 
 
 def check(rc, what):

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include "common.hpp"
 #include "lafs_hip.h"
+#include "ctx.hpp"
 
 namespace {
 
@@ -26,6 +27,8 @@ struct Scratch {             // operands of the weight gradients: two slots used
 inline int wg_slot(const lafs_trunk_desc* d, int l) { return d->wgrad_defer ? l : (l & 1); }
 struct Carve {
   std::vector<LayerBuf> layers;   // depth entries when saving, 1 otherwise (reused)
+  std::vector<float*> ln_part;    // [layer][norm 1 | 2][row chain 0..3]: per-workgroup gamma / beta sums of the LayerNorm backward
+  size_t ln_part_floats;          // (lafs_layernorm_bwd part_out; lafs_layernorm_bwd_fold adds them in a fixed order)
   float* xalt;                    // ping-pong residual buffer for the no-save path
   Scratch s;
   void* wg_ws; size_t wg_bytes;   // slice partials of the grouped weight-gradient launch (lafs_wgrad_group)
@@ -76,6 +79,9 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
     }
     c.s.dh = (bf16_t*)take(T * D * 2);
     c.s.d_o = (bf16_t*)take(T * I * 2);
+    c.ln_part_floats = (size_t)lafs_layernorm_bwd_parts(d->n_tok, d->dim) * 2 * D;
+    c.ln_part.resize((size_t)d->depth * 2 * 4);
+    for (auto& q : c.ln_part) q = (float*)take(c.ln_part_floats * 4);
     lafs_wgrad_item it[4];
     block_wgrad_shapes(d, it);
     // (the single-stream backward uses the whole chip: size for whichever plan needs more)
@@ -85,6 +91,7 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
     c.wg_ws = take(c.wg_bytes > 0 ? c.wg_bytes : 256);
   } else {
     c.s = Scratch{};
+    c.ln_part_floats = 0;
     c.wg_ws = nullptr; c.wg_bytes = 0;
   }
   c.bytes = off;
@@ -115,14 +122,12 @@ int check_desc(const lafs_trunk_desc* d) {
     if (rc_ != LAFS_OK) return rc_;      \
   } while (0)
 
-int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
+int gemm(const lafs_ctx* cx, const void* A, int lda, const void* B, int ldb, int M, int N, int K, int epi, void* C, int ldc, const float* bias,
          hipStream_t s, void* C2 = nullptr, int ldc2 = 0, const float* resid = nullptr, int ldr = 0,
          const float* seq_scale = nullptr, const int32_t* row2seq = nullptr, const void* aux = nullptr, int ldaux = 0,
-         float drop_p = 0.f, uint32_t drop_seed = 0, int act = 0, const float* drop_step = nullptr, int drop_row0 = 0,
-         const float* ln_g = nullptr, const float* ln_b = nullptr, float ln_eps = 0.f, void* ln_out = nullptr, int ld_ln = 0,
-         float* ln_stats = nullptr) {
+         float drop_p = 0.f, uint32_t drop_seed = 0, int act = 0, const float* drop_step = nullptr, int drop_row0 = 0) {
   lafs_gemm_nt_args g = {};
-  g.ln_gamma = ln_g; g.ln_beta = ln_b; g.ln_eps = ln_eps; g.ln_out = ln_out; g.ld_ln_out = ld_ln; g.ln_stats = ln_stats;
+  g.ctx = cx;
   g.drop_p = drop_p; g.drop_seed = drop_seed; g.act = act; g.drop_step = drop_step; g.drop_row0 = drop_row0;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K; g.epilogue = epi;
   g.C = C; g.ldc = ldc; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.resid = resid; g.ldr = ldr;
@@ -132,38 +137,20 @@ int gemm(const void* A, int lda, const void* B, int ldb, int M, int N, int K, in
 
 }  // namespace
 
-// Side stream for the attention launches of the second and later crop-resolution groups: the 197-token and the 37-token launch
-// of a layer are independent (both read the qkv GEMM's output, both feed the projection) and latency-bound on their own
-// (profiles/round2_attention_pmc.txt: waves waiting 53-67 % of the time), so they run beside each other.  Created on first use
-// (the engines warm up eagerly before they capture); LAFS_ATTN_STREAM=0 or LAFS_SINGLE_STREAM=1 keeps everything on `stream`.
-struct AttnSide {
-  hipStream_t s = nullptr, sx[2] = {nullptr, nullptr};      // s: second attention group / second row range; sx: third and fourth row ranges
-  hipEvent_t fork = nullptr, join = nullptr, joinx[2] = {nullptr, nullptr};
-  bool on = false;
-  int chains = 2;                                            // row ranges of the trunk passes (LAFS_ROW_CHAINS: 0 / 1 = one chain, 2, 4)
-};
-static AttnSide& attn_side() {
-  static AttnSide a = [] {
-    AttnSide x;
-    const char* v = getenv("LAFS_ATTN_STREAM");
-    const char* ss = getenv("LAFS_SINGLE_STREAM");
-    if ((v != nullptr && v[0] == '0') || (ss != nullptr && ss[0] == '1')) return x;
-    if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return x;
-    if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess) return x;
-    if (hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return x;
-    for (int i = 0; i < 2; ++i) {
-      if (hipStreamCreateWithFlags(&x.sx[i], hipStreamNonBlocking) != hipSuccess) return x;
-      if (hipEventCreateWithFlags(&x.joinx[i], hipEventDisableTiming) != hipSuccess) return x;
-    }
-    const char* c = getenv("LAFS_ROW_CHAINS");
-    x.chains = (c == nullptr) ? 2 : ((c[0] == '4') ? 4 : ((c[0] == '0' || c[0] == '1') ? 1 : 2));
-    x.on = true;
-    return x;
-  }();
-  return a;
+// Side streams for the attention launches of the second and later crop-resolution groups and for the row chains: the 197-token and
+// the 37-token launch of a layer are independent (both read the qkv GEMM's output, both feed the projection) and latency-bound on
+// their own (profiles/round2_attention_pmc.txt: waves waiting 53-67 % of the time), so they run beside each other.  The streams and
+// events belong to the descriptor's lafs_ctx (created with it, before anything is captured); without a context -- or with
+// LAFS_OPT_SIDE_STREAMS = 0 -- everything stays on `stream`.
+static inline lafs_ctx* side_ctx(const lafs_trunk_desc* d) {
+  lafs_ctx* c = d->ctx;
+  return (c != nullptr && c->streams_ok && c->opt[LAFS_OPT_SIDE_STREAMS] != 0) ? c : nullptr;
 }
 // stream of group gi's attention launch; call attn_fork before the first launch and attn_join after the last one
-static hipStream_t attn_stream_of(int gi, hipStream_t stream) { return (gi > 0 && attn_side().on) ? attn_side().s : stream; }
+static hipStream_t attn_stream_of(const lafs_trunk_desc* d, int gi, hipStream_t stream) {
+  lafs_ctx* c = side_ctx(d);
+  return (gi > 0 && c != nullptr) ? c->side[0] : stream;
+}
 #define HIP_TRY(call)                                                                         \
   do {                                                                                        \
     const hipError_t e_ = (call);                                                             \
@@ -172,34 +159,31 @@ static hipStream_t attn_stream_of(int gi, hipStream_t stream) { return (gi > 0 &
       return (int)e_;                                                                         \
     }                                                                                         \
   } while (0)
-static int attn_fork(hipStream_t stream, int n = 2) {        // n streams in all: `stream`, s, sx[0], sx[1]
-  AttnSide& a = attn_side();
-  if (!a.on) return LAFS_OK;
-  HIP_TRY(hipEventRecord(a.fork, stream));
-  HIP_TRY(hipStreamWaitEvent(a.s, a.fork, 0));
-  for (int i = 0; i + 2 < n; ++i) HIP_TRY(hipStreamWaitEvent(a.sx[i], a.fork, 0));
+static int attn_fork(const lafs_trunk_desc* d, hipStream_t stream, int n = 2) {        // n streams in all: `stream`, side[0..2]
+  lafs_ctx* a = side_ctx(d);
+  if (a == nullptr) return LAFS_OK;
+  HIP_TRY(hipEventRecord(a->fork, stream));
+  for (int i = 0; i + 1 < n; ++i) HIP_TRY(hipStreamWaitEvent(a->side[i], a->fork, 0));
   return LAFS_OK;
 }
 // (always reached once a fork has been issued -- also on the error path of the forked work: side streams left forked inside a
 // hipGraph capture would make the capture fail later with an unrelated error)
-static int attn_join(hipStream_t stream, int n = 2) {
-  AttnSide& a = attn_side();
-  if (!a.on) return LAFS_OK;
-  HIP_TRY(hipEventRecord(a.join, a.s));
-  HIP_TRY(hipStreamWaitEvent(stream, a.join, 0));
-  for (int i = 0; i + 2 < n; ++i) {
-    HIP_TRY(hipEventRecord(a.joinx[i], a.sx[i]));
-    HIP_TRY(hipStreamWaitEvent(stream, a.joinx[i], 0));
+static int attn_join(const lafs_trunk_desc* d, hipStream_t stream, int n = 2) {
+  lafs_ctx* a = side_ctx(d);
+  if (a == nullptr) return LAFS_OK;
+  for (int i = 0; i + 1 < n; ++i) {
+    HIP_TRY(hipEventRecord(a->join[i], a->side[i]));
+    HIP_TRY(hipStreamWaitEvent(stream, a->join[i], 0));
   }
   return LAFS_OK;
 }
 // forked region: run `body`, join in any case, report the first failure
 #define FORKED(stream, n, body)                 \
   do {                                          \
-    RUN(attn_fork(stream, n));                  \
+    RUN(attn_fork(d, stream, n));               \
     int rc_f = LAFS_OK;                         \
     do { body } while (0);                      \
-    const int rc_j = attn_join(stream, n);      \
+    const int rc_j = attn_join(d, stream, n);   \
     if (rc_f != LAFS_OK) return rc_f;           \
     if (rc_j != LAFS_OK) return rc_j;           \
   } while (0)
@@ -212,14 +196,15 @@ static int attn_join(hipStream_t stream, int n = 2) {
 // two groups of full-length sequences (element-dropout masks are indexed by absolute rows: drop_row0); else one range.
 struct RowRange { int r0, R, gi, seq_lo, nseq; hipStream_t st; };
 static int row_ranges(const lafs_trunk_desc* d, hipStream_t stream, RowRange (&rr)[4]) {
-  AttnSide& a = attn_side();
+  lafs_ctx* a = side_ctx(d);
   rr[0] = {0, d->n_tok, 0, 0, d->n_seq, stream};
-  if (!a.on || a.chains < 2 || d->n_groups != 2) return 1;
+  const int chains = a != nullptr ? a->opt[LAFS_OPT_ROW_CHAINS] : 1;
+  if (a == nullptr || chains < 2 || d->n_groups != 2) return 1;
   const int T0 = d->group_n_seq[0] * d->group_max_len[0], T1 = d->group_n_seq[1] * d->group_max_len[1];
   if (T0 + T1 != d->n_tok || T0 < 4096 || T1 < 4096) return 1;
-  hipStream_t st[4] = {stream, a.s, a.sx[0], a.sx[1]};
+  hipStream_t st[4] = {stream, a->side[0], a->side[1], a->side[2]};
   int n = 0;
-  const int parts = (a.chains == 4 && d->group_n_seq[0] >= 2 && d->group_n_seq[1] >= 2) ? 2 : 1;
+  const int parts = (chains == 4 && d->group_n_seq[0] >= 2 && d->group_n_seq[1] >= 2) ? 2 : 1;
   int row = 0, seq = 0;
   for (int gi = 0; gi < 2; ++gi) {
     const int ns = d->group_n_seq[gi], len = d->group_max_len[gi];
@@ -238,24 +223,6 @@ extern "C" int64_t lafs_trunk_workspace_bytes(const lafs_trunk_desc* d, int save
   return (int64_t)carve(d, nullptr, save_for_backward).bytes;
 }
 
-// Events for the two-stream backward (weight gradients run on `wgrad_stream` concurrently with the dgrad / attention /
-// LayerNorm chain).  Lazily created, reused on every call; the only process-wide state of the library.
-static std::vector<hipEvent_t>& event_pool(size_t n) {
-  static std::vector<hipEvent_t> pool;
-  while (pool.size() < n) {
-    hipEvent_t e;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
-    pool.push_back(e);
-  }
-  return pool;
-}
-
-extern "C" int lafs_trunk_streams_init(void) {
-  (void)attn_side();                      // creates the side streams / events now: never lazily inside a hipGraph capture
-  (void)event_pool(64);
-  return attn_side().on ? 1 : 0;
-}
-
 extern "C" int lafs_trunk_row_ranges(const lafs_trunk_desc* d) {
   if (check_desc(d) != LAFS_OK) return -1;
   RowRange rr[4];
@@ -268,6 +235,7 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   RUN(check_desc(d));
   LAFS_CHECK_ARG(x_in && x_out && workspace, "null buffer");
   const Carve c = carve(d, workspace, save_for_backward);
+  const lafs_ctx* cx = d->ctx;
   const int T = d->n_tok, D = d->dim, I = d->inner, M = d->mlp;
   const bf16_t* sh = reinterpret_cast<const bf16_t*>(d->shadow);
   // Nothing in the forward mixes token rows of different sequences: with two crop-resolution groups of full-length sequences
@@ -278,21 +246,7 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   const int n_rr = row_ranges(d, stream, rr);
   // rows [r0, r0 + R) = the sequences of groups [g_lo, g_hi) (seq_lo = index of their first sequence) on stream st
   // (nseq >= 0: ONE attention launch over nseq sequences of group g_lo -- a row range of a split pass)
-  // LayerNorm fused into the producer of its input (round 4): where the residual GEMM runs on 128x384 tiles (D == 384, no element
-  // dropout) the tile owns whole rows and writes LN(x) beside x -- the next block's norm1 from fc2 (bit 1), this block's norm2 from
-  // the projection (bit 2, which moves the projection from the K-resident kernel to the tiled one).  LAFS_LN_FUSE=<mask>, default 1.
-  // Per launch on one MI355X (tools/lab/t_ln_fuse.py; GEMM + lafs_layernorm_fwd -> fused): fc2 at 25 216 rows 45.0 + 12.4 -> 50.4 us,
-  // projection 24.2 + 12.2 -> 30.9 us (25 216 rows) and 26.6 + 11.8 -> 29.8 us (18 944 rows); where the 128x384 tiles do not fill one
-  // round of the chip the fused form LOSES (fc2 at 18 944 rows = 148 tiles: 30.5 + 11.5 -> 49.3 us; 44 160 rows = 345 tiles: 103 ->
-  // 121 us), so a chain fuses per GEMM only inside those bounds.  IN THE STEP the per-launch gains do not arrive: 15.44 / 15.49 ms
-  // without, 15.47 / 15.48 (mask 1), 15.57 / 15.51 (2), 15.53 / 15.60 (3) on one box -- a 12-wave workgroup per CU beside the other
-  // chains costs what the saved pass over x buys (tools/lab/NOTES.md) -- so it is OFF by default: LAFS_LN_FUSE=<mask> switches it on,
-  // tests/test_gpu_kernels.py holds the fused epilogue against GEMM + lafs_layernorm_fwd.
-  static const int ln_fuse_env = [] { const char* v = getenv("LAFS_LN_FUSE"); return v != nullptr ? atoi(v) : 0; }();
-  const int ln_fuse_ok = (D == 384 && I % 64 == 0 && M % 64 == 0 && !(d->dropout_p > 0.f)) ? ln_fuse_env : 0;
   auto chain = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
-    const int mt = (R + 127) / 128;
-    const int ln_fuse = ((ln_fuse_ok & 1) && mt >= 160 && mt <= 256 ? 1 : 0) | ((ln_fuse_ok & 2) && mt >= 96 && mt <= 256 ? 2 : 0);
     const float* cur = x_in;
     for (int l = 0; l < d->depth; ++l) {
       const lafs_block_offsets& o = d->blocks[l];
@@ -305,16 +259,15 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       else if (save_for_backward) nxt = c.layers[l + 1].x0;
       else nxt = (cur == c.xalt) ? x_out : c.xalt;            // ping-pong; never aliases x_in
       const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
-      if (!((ln_fuse & 1) && l > 0))                        // (fused: written by the previous block's fc2)
-        RUN(lafs_layernorm_fwd(cur + rD, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1 + rD, D, nullptr, 0, b.st1 + 2 * (size_t)r0,
-                               R, D, st));
-      RUN(gemm(b.h1 + rD, D, sh + o.w_qkv, D, R, 3 * I, D, LAFS_EPI_BF16, b.qkv + 3 * rI, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, st));
+      RUN(lafs_layernorm_fwd(cur + rD, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1 + rD, D, nullptr, 0, b.st1 + 2 * (size_t)r0,
+                             R, D, st));
+      RUN(gemm(cx, b.h1 + rD, D, sh + o.w_qkv, D, R, 3 * I, D, LAFS_EPI_BF16, b.qkv + 3 * rI, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, st));
       if (g_hi - g_lo > 1 || d->n_groups > 1) {               // one launch per crop resolution, each with its own tile shape
         int s0 = seq_lo;                                      // (the attention kernels address tokens through cu_seqlens: base pointers)
         if (attn_two_streams) {
           FORKED(st, 2, for (int gi = g_lo; gi < g_hi; ++gi) {
             TRY_F(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads, d->attn_scale, b.o, I,
-                                     b.lse, attn_stream_of(gi - g_lo, st)));
+                                     b.lse, attn_stream_of(d, gi - g_lo, st)));
             s0 += d->group_n_seq[gi];
           });
         } else {
@@ -329,31 +282,17 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       }
       const float dp = d->dropout_p;
       const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
-      if (ln_fuse & 2) {
-        RUN(gemm(b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
-                 r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D,
-                 b.st2 + 2 * (size_t)r0));
-      } else {
-        RUN(gemm(b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
-                 r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0));
-        RUN(lafs_layernorm_fwd(b.x1 + rD, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D, nullptr, 0, b.st2 + 2 * (size_t)r0,
-                               R, D, st));
-      }
+      RUN(gemm(cx, b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
+               r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0));
+      RUN(lafs_layernorm_fwd(b.x1 + rD, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D, nullptr, 0, b.st2 + 2 * (size_t)r0,
+                             R, D, st));
       // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
       // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
       // becomes one multiply per value
-      RUN(gemm(b.h2 + rD, D, sh + o.w_fc1, D, R, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u + rM : nullptr, M, d->master + o.b_fc1, st,
+      RUN(gemm(cx, b.h2 + rD, D, sh + o.w_fc1, D, R, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u + rM : nullptr, M, d->master + o.b_fc1, st,
                b.a + rM, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
-      if ((ln_fuse & 1) && l + 1 < d->depth) {              // fc2 + residual + the NEXT block's norm1
-        const lafs_block_offsets& on = d->blocks[l + 1];
-        const LayerBuf& bn = c.layers[save_for_backward ? l + 1 : 0];
-        RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
-                 r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0, d->master + on.ln1_g, d->master + on.ln1_b, d->ln_eps, bn.h1 + rD, D,
-                 bn.st1 + 2 * (size_t)r0));
-      } else {
-        RUN(gemm(b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
-                 r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
-      }
+      RUN(gemm(cx, b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
+               r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
       cur = nxt;
     }
     return LAFS_OK;
@@ -392,18 +331,21 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   LAFS_CHECK_ARG(x_in && g && workspace && d->shadow_t && d->grad, "null buffer");
   LAFS_CHECK_ARG(0 <= layer_lo && layer_lo < layer_hi && layer_hi <= d->depth, "bad layer range");
   const Carve c = carve(d, workspace, 1);
+  const lafs_ctx* cx = d->ctx;
   const int T = d->n_tok, D = d->dim, I = d->inner, M = d->mlp;
   const bf16_t* sht = reinterpret_cast<const bf16_t*>(d->shadow_t);
   float* gr = d->grad;
   const Scratch& s = c.s;
   const bool defer = d->wgrad_defer != 0;     // no weight-gradient launches here: lafs_trunk_wgrad issues them later from the per-layer slots
-  const bool two = !defer && (wgrad_stream != nullptr) && (wgrad_stream != stream);
+  // (the two-stream protocol takes its events from the context's pool: without a context the weight gradients stay on `stream`)
+  const bool two = !defer && (wgrad_stream != nullptr) && (wgrad_stream != stream) && d->ctx != nullptr && d->ctx->streams_ok;
   hipStream_t s2 = two ? wgrad_stream : stream;
   const int nl = layer_hi - layer_lo;
   RowRange rr[4];
   const int n_rr = row_ranges(d, stream, rr);
-  std::vector<hipEvent_t>& ev = event_pool(two ? (size_t)2 * nl + 1 : 0);
-  LAFS_CHECK_ARG(!two || ev.size() >= (size_t)2 * nl + 1, "could not create HIP events");
+  static std::vector<hipEvent_t> no_events;
+  std::vector<hipEvent_t>& ev = two ? d->ctx->pool : no_events;
+  LAFS_CHECK_ARG(!two || ev.size() >= (size_t)2 * nl + 1, "the context's event pool is too small for this layer range");
   int evi = 0;
   bool ev_failed = false;                  // a failed event call of the two-stream protocol (reported at the end of the call)
   auto fork = [&]() {                      // work enqueued on s2 after this sees everything enqueued on `stream` so far
@@ -419,26 +361,27 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
                            d->dropout_step, 0, stream));
   // rows [r0, r0 + R) of layer l from the GELU' input gradient to the attention backward (groups [g_lo, g_hi), first sequence
   // seq_lo; nseq >= 0: one attention launch over nseq sequences of group g_lo) on stream st
-  auto part1 = [&](int l, int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
+  auto part1 = [&](int l, int ci, int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
     const lafs_block_offsets& o = d->blocks[l];
     const LayerBuf& b = c.layers[l];
     const int p = wg_slot(d, l);
     const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
     const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
     // ---- MLP branch ----
-    RUN(gemm(s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
+    RUN(gemm(cx, s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
              nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
-    RUN(gemm(s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
+    RUN(gemm(cx, s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
     RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, b.x1 + rD, D, b.st2 + 2 * (size_t)r0, d->master + o.ln2_g, g + rD, D, 1, s.gba[p] + rD, D,
-                           scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), d->dropout_step, r0, st));
+                           scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), d->dropout_step, r0,
+                           c.ln_part[((size_t)l * 2 + 1) * 4 + ci], st));
     // ---- attention branch ----
-    RUN(gemm(s.gba[p] + rD, D, sht + o.w_proj_t, D, R, I, D, LAFS_EPI_BF16, s.d_o + rI, I, nullptr, st));
+    RUN(gemm(cx, s.gba[p] + rD, D, sht + o.w_proj_t, D, R, I, D, LAFS_EPI_BF16, s.d_o + rI, I, nullptr, st));
     if (d->n_groups > 1) {
       int s0 = seq_lo;
       if (attn_two_streams) {
         FORKED(st, 2, for (int gi = g_lo; gi < g_hi; ++gi) {
           TRY_F(lafs_attention_bwd(b.qkv, 3 * I, b.o, I, s.d_o, I, b.lse, d->cu_seqlens + s0, d->group_n_seq[gi], d->group_max_len[gi], d->heads,
-                                   d->attn_scale, s.dqkv[p], 3 * I, attn_stream_of(gi - g_lo, st)));
+                                   d->attn_scale, s.dqkv[p], 3 * I, attn_stream_of(d, gi - g_lo, st)));
           s0 += d->group_n_seq[gi];
         });
       } else {
@@ -455,7 +398,7 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     return LAFS_OK;
   };
   // ... and from the qkv input gradient to the LayerNorm backward that produces layer l-1's upstream gradient gbm[(l-1)&1]
-  auto part2 = [&](int l, int r0, int R, hipStream_t st) -> int {
+  auto part2 = [&](int l, int ci, int r0, int R, hipStream_t st) -> int {
     const lafs_block_offsets& o = d->blocks[l];
     const LayerBuf& b = c.layers[l];
     const float* x0 = (l == 0) ? x_in : b.x0;
@@ -463,10 +406,10 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const bool more = l > 0;
     const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I;
     const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
-    RUN(gemm(s.dqkv[p] + 3 * rI, 3 * I, sht + o.w_qkv_t, 3 * I, R, D, 3 * I, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
+    RUN(gemm(cx, s.dqkv[p] + 3 * rI, 3 * I, sht + o.w_qkv_t, 3 * I, R, D, 3 * I, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
     RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, x0 + rD, D, b.st1 + 2 * (size_t)r0, d->master + o.ln1_g, g + rD, D, 1,
                            more ? s.gbm[wg_slot(d, l - 1)] + rD : nullptr, D, more ? scale(l - 1, 1) : nullptr, r2s, gr + o.ln1_g, gr + o.ln1_b, R, D,
-                           more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, d->dropout_step, r0, st));
+                           more ? dp : 0.f, more ? dseed(l - 1, 2) : 0u, d->dropout_step, r0, c.ln_part[((size_t)l * 2 + 0) * 4 + ci], st));
     return LAFS_OK;
   };
   // One forked section = the tail of layer l2 (part2) and the head of layer l1 = l2 - 1 (part1) for every row range: with two
@@ -476,12 +419,12 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
   auto section = [&](int l2, int l1) -> int {
     if (n_rr > 1) {
       FORKED(stream, n_rr, for (int i = 0; i < n_rr; ++i) {
-        if (l2 >= 0) TRY_F(part2(l2, rr[i].r0, rr[i].R, rr[i].st));
-        if (l1 >= 0) TRY_F(part1(l1, rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
+        if (l2 >= 0) TRY_F(part2(l2, i, rr[i].r0, rr[i].R, rr[i].st));
+        if (l1 >= 0) TRY_F(part1(l1, i, rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false));
       });
     } else {
-      if (l2 >= 0) RUN(part2(l2, 0, T, stream));
-      if (l1 >= 0) RUN(part1(l1, 0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
+      if (l2 >= 0) RUN(part2(l2, 0, 0, T, stream));
+      if (l1 >= 0) RUN(part1(l1, 0, 0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
     }
     return LAFS_OK;
   };
@@ -505,6 +448,23 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const int l1 = (l - 1 >= layer_lo) ? l - 1 : -1;
     RUN(section(l, l1));
     if (l1 >= 0) RUN(wgrad(l1));
+  }
+  // LayerNorm parameter gradients of the layers just walked: the row chains' per-workgroup sums, added in a fixed order (one
+  // launch for the whole range; every chain has joined `stream` by now)
+  {
+    std::vector<lafs_ln_fold_item> items;
+    for (int l = layer_hi - 1; l >= layer_lo; --l)
+      for (int k = 0; k < 2; ++k) {
+        const lafs_block_offsets& o = d->blocks[l];
+        lafs_ln_fold_item it = {};
+        for (int i = 0; i < n_rr; ++i) {
+          it.part[i] = c.ln_part[((size_t)l * 2 + k) * 4 + i];
+          it.n_parts[i] = lafs_layernorm_bwd_parts(rr[i].R, D);
+        }
+        it.dgamma = gr + (k == 0 ? o.ln1_g : o.ln2_g); it.dbeta = gr + (k == 0 ? o.ln1_b : o.ln2_b);
+        items.push_back(it);
+      }
+    RUN(lafs_layernorm_bwd_fold(items.data(), (int)items.size(), D, stream));
   }
   if (two && hipStreamWaitEvent(stream, done[layer_lo], 0) != hipSuccess) ev_failed = true;      // join (s2 is in-order)
   LAFS_CHECK_ARG(!ev_failed, "a HIP event call of the weight-gradient stream protocol failed");

@@ -261,51 +261,73 @@ __global__ __launch_bounds__(64) void gather_bwd_kernel(const float* __restrict_
 }
 
 // ---- class-sharded margin softmax (PartialFC): three row passes with the cross-rank statistics exchanged in between ----
-// y[b] = local index of the row's target class inside this shard, or -1 when another rank owns it.
+// y[b] = local index of the row's target class inside this shard, or -1 when another rank owns it.  Soft (mixup) targets as the
+// reference feeds them to its margin head (dense lam e_y1 + (1 - lam) e_y2 entering the margin itself, ViT_face.py:69-73): y2[b] =
+// local index of the partner's class (or -1), lam[b] = the row's lambda; y2 == nullptr: hard labels.
+struct ShardLabel {
+  int t1, t2; float w1, w2;
+  __device__ __forceinline__ float operator()(int k) const { return (k == t1 ? w1 : 0.f) + (k == t2 ? w2 : 0.f); }
+};
+__device__ __forceinline__ ShardLabel shard_label(const int* y, const int* y2, const float* lam, int b) {
+  ShardLabel L;
+  L.t1 = y[b]; L.t2 = -1; L.w1 = 1.f; L.w2 = 0.f;
+  if (y2 != nullptr) {
+    const float l = lam != nullptr ? lam[b] : 1.f;
+    L.w1 = l; L.w2 = 1.f - l; L.t2 = y2[b];
+    if (L.t2 == L.t1) { L.w1 = (L.t1 >= 0) ? 1.f : 0.f; L.t2 = -1; L.w2 = 0.f; }      // both labels on the same class
+  }
+  return L;
+}
 __global__ __launch_bounds__(256) void shard_rowmax_kernel(const float* __restrict__ cosv, int ld, int S, const int* __restrict__ y,
+                                                          const int* __restrict__ y2, const float* __restrict__ lam,
                                                           float s, float m, int type, float* __restrict__ rowmax) {
   __shared__ float red[4];
   const int b = blockIdx.x;
   const float* row = cosv + (size_t)b * ld;
-  const int t = y[b];
+  const ShardLabel L = shard_label(y, y2, lam, b);
   float mx = -INFINITY;
-  for (int k = threadIdx.x; k < S; k += 256) mx = fmaxf(mx, margin_logit(row[k], k == t ? 1.f : 0.f, s, m, type));
+  for (int k = threadIdx.x; k < S; k += 256) mx = fmaxf(mx, margin_logit(row[k], L(k), s, m, type));
   mx = wave_max(mx);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
   if (threadIdx.x == 0) rowmax[b] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-// rowsum[b] = sum_k exp(z_k - gmax[b]);  tgt[b] = z_target (0 when the target lives on another rank)
+// rowsum[b] = sum_k exp(z_k - gmax[b]);  tgt[b] = sum_k y_k z_k over the targets this rank owns (0 when they live elsewhere)
 __global__ __launch_bounds__(256) void shard_rowsum_kernel(const float* __restrict__ cosv, int ld, int S, const int* __restrict__ y,
+                                                          const int* __restrict__ y2, const float* __restrict__ lam,
                                                           float s, float m, int type, const float* __restrict__ gmax,
                                                           float* __restrict__ rowsum, float* __restrict__ tgt) {
   __shared__ float red[4];
   const int b = blockIdx.x;
   const float* row = cosv + (size_t)b * ld;
-  const int t = y[b];
+  const ShardLabel L = shard_label(y, y2, lam, b);
   const float g = gmax[b];
   float acc = 0.f;
-  for (int k = threadIdx.x; k < S; k += 256) acc += __expf(margin_logit(row[k], k == t ? 1.f : 0.f, s, m, type) - g);
+  for (int k = threadIdx.x; k < S; k += 256) acc += __expf(margin_logit(row[k], L(k), s, m, type) - g);
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     rowsum[b] = red[0] + red[1] + red[2] + red[3];
-    tgt[b] = (t >= 0) ? margin_logit(row[t], 1.f, s, m, type) : 0.f;
+    float t = 0.f;
+    if (L.t1 >= 0) t += L.w1 * margin_logit(row[L.t1], L(L.t1), s, m, type);
+    if (L.t2 >= 0) t += L.w2 * margin_logit(row[L.t2], L(L.t2), s, m, type);
+    tgt[b] = t;
   }
 }
 
-// in place: cos -> dL/dcos = gscale * (exp(z - gmax)/Z - onehot) * dz/dcos
-__global__ __launch_bounds__(256) void shard_grad_kernel(float* __restrict__ cosv, int ld, int S, const int* __restrict__ y, float s,
+// in place: cos -> dL/dcos = gscale * (exp(z - gmax)/Z - y) * dz/dcos
+__global__ __launch_bounds__(256) void shard_grad_kernel(float* __restrict__ cosv, int ld, int S, const int* __restrict__ y,
+                                                        const int* __restrict__ y2, const float* __restrict__ lam, float s,
                                                         float m, int type, const float* __restrict__ gmax,
                                                         const float* __restrict__ Z, float gscale) {
   const int b = blockIdx.x;
   float* row = cosv + (size_t)b * ld;
-  const int t = y[b];
+  const ShardLabel L = shard_label(y, y2, lam, b);
   const float g = gmax[b], iz = 1.0f / Z[b];
   for (int k = threadIdx.x; k < S; k += 256) {
-    const float c = row[k], yk = (k == t) ? 1.f : 0.f;
+    const float c = row[k], yk = L(k);
     const float z = margin_logit(c, yk, s, m, type);
     row[k] = gscale * (__expf(z - g) * iz - yk) * margin_dlogit(c, yk, s, m, type);
   }
@@ -422,31 +444,36 @@ extern "C" int lafs_patch_gather_bwd(const float* img, const float* theta, const
   return LAFS_OK;
 }
 
-extern "C" int lafs_shard_margin_rowmax(const float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
-                                        int margin_type, float* rowmax, hipStream_t stream) {
+extern "C" int lafs_shard_margin_rowmax(const float* cos, int ld, int B, int S, const int32_t* y_local, const int32_t* y2_local,
+                                        const float* lam, float s, float m, int margin_type, float* rowmax, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(cos && y_local && rowmax && B > 0 && S > 0 && ld >= S, "bad operand");
-  hipLaunchKernelGGL(shard_rowmax_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, s, m, margin_type, rowmax);
+  LAFS_CHECK_ARG(y2_local == nullptr || margin_type == 0, "soft (mixup) targets: CosFace margin only (ArcFace takes hard labels)");
+  hipLaunchKernelGGL(shard_rowmax_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, y2_local, lam, s, m, margin_type, rowmax);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
 
-extern "C" int lafs_shard_margin_rowsum(const float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
-                                        int margin_type, const float* gmax, float* rowsum, float* target_logit,
-                                        hipStream_t stream) {
+extern "C" int lafs_shard_margin_rowsum(const float* cos, int ld, int B, int S, const int32_t* y_local, const int32_t* y2_local,
+                                        const float* lam, float s, float m, int margin_type, const float* gmax, float* rowsum,
+                                        float* target_logit, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(cos && y_local && gmax && rowsum && target_logit && B > 0 && S > 0 && ld >= S, "bad operand");
-  hipLaunchKernelGGL(shard_rowsum_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, s, m, margin_type, gmax, rowsum,
-                     target_logit);
+  LAFS_CHECK_ARG(y2_local == nullptr || margin_type == 0, "soft (mixup) targets: CosFace margin only (ArcFace takes hard labels)");
+  hipLaunchKernelGGL(shard_rowsum_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, y2_local, lam, s, m, margin_type, gmax,
+                     rowsum, target_logit);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
 
-extern "C" int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_local, float s, float m,
-                                      int margin_type, const float* gmax, const float* Z, float grad_scale, hipStream_t stream) {
+extern "C" int lafs_shard_margin_grad(float* cos, int ld, int B, int S, const int32_t* y_local, const int32_t* y2_local,
+                                      const float* lam, float s, float m, int margin_type, const float* gmax, const float* Z,
+                                      float grad_scale, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(cos && y_local && gmax && Z && B > 0 && S > 0 && ld >= S, "bad operand");
-  hipLaunchKernelGGL(shard_grad_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, s, m, margin_type, gmax, Z, grad_scale);
+  LAFS_CHECK_ARG(y2_local == nullptr || margin_type == 0, "soft (mixup) targets: CosFace margin only (ArcFace takes hard labels)");
+  hipLaunchKernelGGL(shard_grad_kernel, dim3(B), dim3(256), 0, stream, cos, ld, S, y_local, y2_local, lam, s, m, margin_type, gmax, Z,
+                     grad_scale);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

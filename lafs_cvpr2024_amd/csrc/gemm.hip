@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "lafs_hip.h"
 #include "gemm_kres.hpp"
+#include "ctx.hpp"
 
 // Timing ablations that change RESULTS (no stores / no MFMA / ...) exist only in the -DLAFS_ABLATE build (make ablate ->
 // liblafs_hip_ablate.so, used by tools/bench_kernels.py): in the product library the branches below are compiled out, so no
@@ -58,8 +59,6 @@ struct NTArgs {
   const bf16_t* aux; int ldaux;
   const float* pos; int npatch;
   int f16;                          // operands / 16-bit outputs are fp16 (lafs_gemm_nt_args::operand_f16)
-  const float* ln_g; const float* ln_b; float ln_eps;      // RESID_F32 on the 128x384 tile: LayerNorm of the output rows fused in
-  bf16_t* ln_h; int ldh; float* ln_stats;                   // (ln_h == nullptr: off) -> h = LN(C) as bf16, stats {mean, rstd} per row
   int dbg;                          // timing ablations (lafs_debug_set): 16 = no epilogue stores, 32 = no MFMA/ds_read
   DropCfg drop;                     // element dropout on the linear's output (RESID_F32) / on GELU(u) (BF16_GELU, DGELU_BF16)
   int act;                          // BF16_ACT: LAFS_ACT_*
@@ -506,10 +505,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
           for (int e = 0; e < VPL; ++e) if (full || n + e < p.N) w[e] += ps[e];
         }
-        if constexpr (EPI == EPI_RESID_F32 && WN == 6) {       // the fused LayerNorm below reads the finished rows from the accumulators
-#pragma unroll
-          for (int e = 0; e < VPL; ++e) acc[q][i][e] = w[e];
-        }
         // F32 with the K axis split over blockIdx.z: every slice stores its own [M][ldc] image (lafs_sum_slices folds them)
         float* c = reinterpret_cast<float*>(p.C) + (EPI == EPI_F32 ? (size_t)blockIdx.z * p.M * p.ldc : 0) + orow * p.ldc + n;
         if (full) {
@@ -523,65 +518,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
   }
   };
   epilogue();
-  // ---- fused LayerNorm of the rows just written (128x384 tile = whole rows of a 384-wide residual stream): the next block's
-  // norm1 / this block's norm2 (vision_transformer.py:99,103,107-113) without a second pass over x.  Same arithmetic as
-  // ln_fwd_kernel (two passes: mean, then centred squares); a row's 384 values sit in 6 waves x 4 lanes x 16 registers.
-  if constexpr (EPI == EPI_RESID_F32 && WN == 6) {
-    if (p.ln_h != nullptr) {
-      float* red = reinterpret_cast<float*>(smem);          // [128 rows][8] partials (6 used), twice
-      const float invn = 1.0f / (float)p.N;
-      float mean[4], rstd[4];
-      __syncthreads();                                      // every wave is out of the operand ring
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sum += (acc[j][i][0] + acc[j][i][1]) + (acc[j][i][2] + acc[j][i][3]);
-        sum += __shfl_xor(sum, 16, 64); sum += __shfl_xor(sum, 32, 64);
-        if (fq == 0) red[(wr * RW + i * 16 + frow) * 8 + wc] = sum;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        const float* r8 = red + (wr * RW + i * 16 + frow) * 8;
-        mean[i] = (((r8[0] + r8[1]) + (r8[2] + r8[3])) + (r8[4] + r8[5])) * invn;
-        float sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const float dlt = acc[j][i][r] - mean[i]; sq = fmaf(dlt, dlt, sq); }
-        sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 32, 64);
-        if (fq == 0) red[1024 + (wr * RW + i * 16 + frow) * 8 + wc] = sq;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        const float* r8 = red + 1024 + (wr * RW + i * 16 + frow) * 8;
-        rstd[i] = rsqrtf((((r8[0] + r8[1]) + (r8[2] + r8[3])) + (r8[4] + r8[5])) * invn + p.ln_eps);
-      }
-      const int nc = n0 + wc * 64 + fq * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 g4 = *reinterpret_cast<const float4*>(p.ln_g + nc + j * 16);
-        const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b + nc + j * 16);
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-          const int m = m0 + wr * RW + i * 16 + frow;
-          if (m >= p.M) continue;
-          const float o0 = (acc[j][i][0] - mean[i]) * rstd[i] * g4.x + b4.x, o1 = (acc[j][i][1] - mean[i]) * rstd[i] * g4.y + b4.y;
-          const float o2 = (acc[j][i][2] - mean[i]) * rstd[i] * g4.z + b4.z, o3 = (acc[j][i][3] - mean[i]) * rstd[i] * g4.w + b4.w;
-          *reinterpret_cast<uint2*>(p.ln_h + (size_t)m * p.ldh + nc + j * 16) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
-        }
-      }
-      if (wc == 0 && fq == 0 && p.ln_stats != nullptr) {
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-          const int m = m0 + wr * RW + i * 16 + frow;
-          if (m < p.M) { p.ln_stats[2 * (size_t)m] = mean[i]; p.ln_stats[2 * (size_t)m + 1] = rstd[i]; }
-        }
-      }
-    }
-  }
 #ifdef LAFS_ABLATE
   STAMP(2);
   if (p.stamps && !PERSIST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -793,23 +729,21 @@ int g_debug_flags = 0;
 // CU, so a launch costs whole rounds of 512 tiles: tools/lab/t_quant.py measures the staircase (fc1 input gradient of ViT-S, N = 384,
 // K = 1536: 1023 tiles 50.8 us, 1035 tiles 63.4 us; Part-fViT N = 768, K = 2048: 2046 tiles 122 us, 2052 tiles 135 us).  A 160-row
 // tile costs ~1.2x a 128-row one (1.25x the MFMAs, 1.125x the staging): taken when rounds(160) x 1.2 < rounds(128).
-// LAFS_NT_TALL=0 switches it off (A/B).
-bool tall_tile_shape(int M, int N, int splits) {
-  static const bool tall_on = [] { const char* v = getenv("LAFS_NT_TALL"); return v == nullptr || v[0] != '0'; }();
-  if (!tall_on || splits != 1) return false;
+// LAFS_OPT_NT_TALL = 0 switches it off (A/B).
+bool tall_tile_shape(const lafs_ctx* cx, int M, int N, int splits) {
+  if (!lafs_ctx_opt(cx, LAFS_OPT_NT_TALL) || splits != 1) return false;
   const long tn = ceil_div(N, 128);
   const long r128 = ceil_div((long)ceil_div(M, 128) * tn, 512L), r160 = ceil_div((long)ceil_div(M, 160) * tn, 512L);
   return 6 * r160 < 5 * r128;
 }
 
-bool wide_tile_shape(int M, int N, int splits) {
-  static const bool wide_on = [] { const char* v = getenv("LAFS_NT_WIDE"); return v == nullptr || v[0] != '0'; }();
+bool wide_tile_shape(const lafs_ctx* cx, int M, int N, int splits) {
   const int mt = ceil_div(M, 128);
-  return wide_on && splits == 1 && N % 384 == 0 && mt * (N / 384) >= 160 && mt * (N / 384) <= 256;
+  return lafs_ctx_opt(cx, LAFS_OPT_NT_WIDE) && splits == 1 && N % 384 == 0 && mt * (N / 384) >= 160 && mt * (N / 384) <= 256;
 }
 
 template <int EPI>
-int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
+int launch_nt(const NTArgs& a, int splits, const lafs_ctx* cx, hipStream_t s) {
   // Shape heuristics from tools/bench_kernels.py on MI355X (ViT-S/B shapes):
   //  * wide outputs (N >= 1024) on many rows: 256x128 tiles (less L2->LDS traffic per flop, 16 resident waves/CU);
   //  * long reductions (K >= 640): 64-deep stages (full 128-byte lines per row piece) in a 2-stage ring, 128x128 tiles.
@@ -869,25 +803,17 @@ int launch_nt(const NTArgs& a, int splits, hipStream_t s) {
   // 32 MFMAs (the staging cost is issue time in the wave)
   // ... when its tiles fit ONE round of one workgroup per CU: 197 tiles (teacher, M = 25216) run 12-17 % faster than on the
   // 128x128 kernel; 345 tiles (student: a second round of 89) are slower, and so is a split into whole rounds here + the rest on
-  // the 128x128 kernel (fc2 forward 92-98 against 83-86 us; tools/lab/nt_variants.py).  LAFS_NT_WIDE=0 switches it off (A/B).
-  if constexpr (EPI == EPI_RESID_F32) {
-    if (a.ln_h != nullptr) {                            // fused LayerNorm: the tile has to own whole rows
-      LAFS_CHECK_ARG(a.N == 384 && a.klen % 64 == 0 && splits == 1, "the fused LayerNorm needs N == 384, K % 64 == 0 and no K split (128x384 tiles)");
-      hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 6>), dim3((unsigned)ceil_div(a.M, 128), 1, 1), dim3(768), 0, s, a);
-      LAFS_LAUNCH_CHECK();
-      return LAFS_OK;
-    }
-  }
+  // the 128x128 kernel (fc2 forward 92-98 against 83-86 us; tools/lab/nt_variants.py).  LAFS_OPT_NT_WIDE = 0 switches it off (A/B).
   if constexpr (EPI == EPI_BF16 || EPI == EPI_RESID_F32) {
     const int mt = ceil_div(a.M, 128);
-    if (bk64 && wide_tile_shape(a.M, a.N, splits)) {
+    if (bk64 && wide_tile_shape(cx, a.M, a.N, splits)) {
       hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 6>), dim3((unsigned)(mt * (a.N / 384)), 1, 1), dim3(768), 0, s, a);
       LAFS_LAUNCH_CHECK();
       return LAFS_OK;
     }
   }
   if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_GELU || EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16) {
-    if (bk64 && wm == 2 && tall_tile_shape(a.M, a.N, splits)) {
+    if (bk64 && wm == 2 && tall_tile_shape(cx, a.M, a.N, splits)) {
       hipLaunchKernelGGL((gemm_nt_kernel<EPI, 2, 64, 2, false, false, 5>), dim3((unsigned)(ceil_div(a.M, 160) * tn), 1, 1), dim3(256), 0, s, a);
       LAFS_LAUNCH_CHECK();
       return LAFS_OK;
@@ -920,14 +846,15 @@ extern "C" int lafs_gemm_nt_slices(int K, int splits) { return K >= 32 ? ceil_di
 
 extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) {
   if (g == nullptr) return 0;
-  if (g->ln_out != nullptr) return 3;
-  if (lafs_kres_eligible(g)) return lafs_kpp_selected(g) ? 2 : 1;
+  if (lafs_kres_eligible(g)) return 1;
+  if (g->operand_f16) return 0;                     // fp16 operands (landmark CNN plan): launch_nt takes the 128x128 fp16 kernel first
+  const int splits = (g->epilogue == LAFS_EPI_ATOMIC_F32 || g->epilogue == LAFS_EPI_F32) && g->splits > 1 ? g->splits : 1;
   // the tiled kernel's 128x384 form (launch_nt): plain / residual epilogue, 64-deep stages (K % 64 == 0, K >= 640), no K split
   const bool bk64 = g->K % 64 == 0 && g->K >= 640 && !(g_debug_flags & 2);
-  if ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_RESID_F32) && bk64 && wide_tile_shape(g->M, g->N, g->splits <= 1 ? 1 : g->splits)) return 3;
-  // ... and its 160-row form where that saves a round of workgroup slots (bf16 operands; plain, GELU, residual and GELU' epilogues)
+  if ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_RESID_F32) && bk64 && wide_tile_shape(g->ctx, g->M, g->N, splits)) return 3;
+  // ... and its 160-row form where that saves a round of workgroup slots (plain, GELU, residual and GELU' epilogues)
   if ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_BF16_GELU || g->epilogue == LAFS_EPI_RESID_F32 || g->epilogue == LAFS_EPI_DGELU_BF16) &&
-      bk64 && !g->operand_f16 && tall_tile_shape(g->M, g->N, g->splits <= 1 ? 1 : g->splits))
+      bk64 && tall_tile_shape(g->ctx, g->M, g->N, splits))
     return 4;
   return 0;
 }
@@ -950,17 +877,13 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
 #endif
   a.drop = make_drop(g->drop_p, g->drop_seed, g->drop_step, (unsigned)g->drop_row0 * (unsigned)g->N);
   a.act = g->act;
-  a.ln_g = g->ln_gamma; a.ln_b = g->ln_beta; a.ln_eps = g->ln_eps; a.ln_h = (bf16_t*)g->ln_out; a.ldh = g->ld_ln_out; a.ln_stats = g->ln_stats;
-  LAFS_CHECK_ARG(a.ln_h == nullptr || (g->epilogue == LAFS_EPI_RESID_F32 && a.ln_g && a.ln_b && a.ldh % 4 == 0 && a.ldh >= g->N && g->drop_p == 0.f),
-                 "ln_out: residual epilogue with gamma / beta, ld_ln_out % 4 == 0, no element dropout");
   a.f16 = g->operand_f16 ? 1 : 0;
   LAFS_CHECK_ARG(!a.f16 || ((g->epilogue == LAFS_EPI_BF16 || g->epilogue == LAFS_EPI_BF16_ACT || g->epilogue == LAFS_EPI_F32) && g->splits <= 1),
                  "fp16 operands: plain / activation / fp32 epilogue, no K split");
   LAFS_CHECK_ARG(g->drop_p >= 0.f && g->drop_p < 1.f, "drop_p must be in [0, 1)");
   LAFS_CHECK_ARG(!(g->drop_p > 0.f) || ((long)g->M + g->drop_row0) * g->N < 4294967296L, "dropout needs (row0 + M) * N < 2^32");
   LAFS_CHECK_ARG(g->drop_row0 >= 0, "drop_row0 must be >= 0");
-  if (lafs_kres_eligible(g))                                       // K = 384 streaming shapes of the ViT-S trunk (gemm_kres.hip / gemm_kpp.hip)
-    return lafs_kpp_selected(g) ? lafs_kpp_launch(g, stream) : lafs_kres_launch(g, stream);
+  if (lafs_kres_eligible(g)) return lafs_kres_launch(g, stream);   // K = 384 streaming shapes of the ViT-S trunk (gemm_kres.hip)
   int splits = 1;
   a.klen = g->K;
   if (g->epilogue == LAFS_EPI_ATOMIC_F32 || (g->epilogue == LAFS_EPI_F32 && g->splits > 1)) {
@@ -971,25 +894,25 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   const bool vec_ok = (g->ldc % 8 == 0) || g->C == nullptr;
   LAFS_CHECK_ARG(vec_ok, "ldc must be a multiple of 8 elements");
   switch (g->epilogue) {
-    case LAFS_EPI_BF16: return launch_nt<EPI_BF16>(a, 1, stream);
+    case LAFS_EPI_BF16: return launch_nt<EPI_BF16>(a, 1, g->ctx, stream);
     case LAFS_EPI_BF16_GELU:
       LAFS_CHECK_ARG(g->C2 != nullptr && g->ldc2 % 8 == 0, "GELU epilogue needs C2");
-      return launch_nt<EPI_BF16_GELU>(a, 1, stream);
+      return launch_nt<EPI_BF16_GELU>(a, 1, g->ctx, stream);
     case LAFS_EPI_RESID_F32:
       LAFS_CHECK_ARG(g->resid != nullptr && g->ldr % 4 == 0, "residual epilogue needs resid");
       LAFS_CHECK_ARG(g->seq_scale == nullptr || g->row2seq != nullptr, "seq_scale needs row2seq");
-      return launch_nt<EPI_RESID_F32>(a, 1, stream);
-    case LAFS_EPI_F32: return launch_nt<EPI_F32>(a, splits, stream);
+      return launch_nt<EPI_RESID_F32>(a, 1, g->ctx, stream);
+    case LAFS_EPI_F32: return launch_nt<EPI_F32>(a, splits, g->ctx, stream);
     case LAFS_EPI_DGELU_BF16:
       LAFS_CHECK_ARG(g->aux != nullptr, "dGELU epilogue needs aux (pre-activation)");
-      return launch_nt<EPI_DGELU_BF16>(a, 1, stream);
-    case LAFS_EPI_ATOMIC_F32: return launch_nt<EPI_ATOMIC_F32>(a, splits, stream);
+      return launch_nt<EPI_DGELU_BF16>(a, 1, g->ctx, stream);
+    case LAFS_EPI_ATOMIC_F32: return launch_nt<EPI_ATOMIC_F32>(a, splits, g->ctx, stream);
     case LAFS_EPI_BF16_ACT:
       LAFS_CHECK_ARG(g->act >= 0 && g->act <= LAFS_ACT_HSIGMOID, "unknown activation");
-      return launch_nt<EPI_BF16_ACT>(a, 1, stream);
+      return launch_nt<EPI_BF16_ACT>(a, 1, g->ctx, stream);
     case LAFS_EPI_EMBED_F32:
       LAFS_CHECK_ARG(g->pos != nullptr && g->npatch > 0 && g->M % g->npatch == 0, "embed epilogue needs pos/npatch");
-      return launch_nt<EPI_EMBED_F32>(a, 1, stream);
+      return launch_nt<EPI_EMBED_F32>(a, 1, g->ctx, stream);
     default:
       lafs_set_error("lafs_gemm_nt: unknown epilogue %d", g->epilogue);
       return LAFS_EINVAL;

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include "common.hpp"
 #include "gemm_kres.hpp"
+#include "ctx.hpp"
 
 namespace {
 
@@ -443,13 +444,13 @@ int launch(const KArgs& a, int grid, hipStream_t s) {
 }  // namespace
 
 bool lafs_kres_eligible(const lafs_gemm_nt_args* g) {
-  // LAFS_KRES = bit mask of the epilogues routed here (1 plain, 2 GELU, 4 residual, 8 GELU'); 0 = tiled kernel everywhere.
+  // LAFS_OPT_KRES_MASK = bit mask of the epilogues routed here (1 plain, 2 GELU, 4 residual, 8 GELU'); 0 = tiled kernel everywhere.
   // Default 15 (whole step, one box, tools/lab/ab_env.sh: 16.95 ms against 17.22 with mask 7 and 17.57 with 0).
-  static const int mask = [] { const char* v = getenv("LAFS_KRES"); return v != nullptr ? atoi(v) : 15; }();
+  const int mask = lafs_ctx_opt(g->ctx, LAFS_OPT_KRES_MASK);
   const int e = g->epilogue;
   const int bit = e == LAFS_EPI_BF16 ? 1 : (e == LAFS_EPI_BF16_GELU ? 2 : (e == LAFS_EPI_RESID_F32 ? 4 : (e == LAFS_EPI_DGELU_BF16 ? 8 : 0)));
   if (!(mask & bit)) return false;
-  if (g->splits > 1 || g->operand_f16 || g->ln_out != nullptr) return false;      // (fused LayerNorm: the 128x384 tiled kernel owns whole rows)
+  if (g->splits > 1 || g->operand_f16) return false;
   if (g->K != KK || g->N % 64 != 0 || g->N > MAXN || g->N < 64 || g->M < 2048) return false;
   if (!(e == LAFS_EPI_BF16 || e == LAFS_EPI_BF16_GELU || e == LAFS_EPI_RESID_F32 || e == LAFS_EPI_DGELU_BF16)) return false;
   if (g->drop_p > 0.f) return false;
@@ -459,12 +460,6 @@ bool lafs_kres_eligible(const lafs_gemm_nt_args* g) {
   if (e == LAFS_EPI_DGELU_BF16 && (g->aux == nullptr || g->ldaux % 8 != 0)) return false;
   if (e != LAFS_EPI_BF16_GELU && g->C == nullptr) return false;
   return true;
-}
-
-static int g_comm_cus = 0;
-extern "C" int lafs_set_comm_cus(int cus) {
-  g_comm_cus = cus < 0 ? 0 : (cus > 192 ? 192 : cus);
-  return g_comm_cus;
 }
 
 namespace {
@@ -485,10 +480,11 @@ int kres_launch(const lafs_gemm_nt_args* g, hipStream_t stream, int grid_overrid
   a.items = mus * a.cbn;
   // two 4-wave workgroups per CU: one residency wave of equal item runs (at least ~4 items each, or the reload of the
   // resident operand per run stops being amortised)
-  static const int min_items = [] { const char* v = getenv("LAFS_KRES_MIN_ITEMS"); return v != nullptr ? atoi(v) : 4; }();   // lab knob
+  const int min_items = lafs_ctx_opt(g->ctx, LAFS_OPT_KRES_MIN_ITEMS);      // lab knob
+  const int g_comm_cus = lafs_ctx_opt(g->ctx, LAFS_OPT_COMM_CUS);
   int grid = 512;
   while (grid > 8 && a.items / grid < min_items) grid >>= 1;
-  if (g_comm_cus > 0 && grid > 2 * (256 - g_comm_cus)) grid = (2 * (256 - g_comm_cus)) & ~7;     // CUs left to RCCL (lafs_set_comm_cus)
+  if (g_comm_cus > 0 && grid > 2 * (256 - g_comm_cus)) grid = (2 * (256 - g_comm_cus)) & ~7;     // CUs left to RCCL (LAFS_OPT_COMM_CUS)
   if (grid_override > 0) grid = grid_override;
   switch (e) {
     case LAFS_EPI_BF16: return launch<LAFS_EPI_BF16, true, ABL>(a, grid, stream);

@@ -20,6 +20,7 @@
 // BatchNorm sums are accumulated in fp64 (per-block fp32 partials, one fp64 atomic each): mean and E[x^2] - mean^2 are formed in
 // double, so neither the cancellation nor the order of the atomics reaches the fp32 statistics.
 // (The containers keep the names bf16_t / uint4 of the other files: raw 16-bit lanes.)
+#include <algorithm>
 #include "common.hpp"
 #include "lafs_hip.h"
 
@@ -599,20 +600,53 @@ __global__ __launch_bounds__(256) void theta_bwd_kernel(const float* __restrict_
   }
 }
 
-// ---- gradient scale: scale[0] = target / max |g| (1 when the gradient is all zero or not finite), scale[1] = 1 / scale[0]; one
-// workgroup (the gradient of the raw regressor output is a few thousand floats)
-__global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ g, long n, float target, float* __restrict__ scale) {
+// ---- gradient scale + overflow guard (the reference's torch.cuda.amp.GradScaler, train_largescale.py:739, 867-880, on the device).
+// state(f32)[8] = {scale, 1 / scale, target, found_inf, skipped backwards, clean backwards in a row, -, -}:
+//   grad_scale  (start of a backward)  scale = the power of two that brings max |g| to ~target (target = state[2], or the argument
+//               while state[2] <= 0), clamped to [2^-24, 2^24]; found_inf = 1 when g itself is not finite (fmaxf would skip a NaN);
+//   grad_check  (end of a backward)    found_inf |= any non-finite entry of the CNN's gradient range of the arena;
+//   grad_guard                         found_inf: the range is zeroed (this window's CNN update is dropped: the moments and weights stay
+//               finite), target /= 2 (>= 1), skipped += 1; else after 2000 clean backwards in a row target *= 2 (<= target_max).
+// one workgroup (the gradient of the raw regressor output is a few thousand floats)
+__global__ __launch_bounds__(256) void grad_scale_kernel(const float* __restrict__ g, long n, float target, float* __restrict__ scale,
+                                                        int has_state) {
   __shared__ float red[4];
+  __shared__ int bad[4];
   float m = 0.f;
-  for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(g[i]));
+  int b = 0;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    const float v = fabsf(g[i]);
+    if (!(v < 3.0e38f)) b = 1;                                         // inf or NaN
+    else m = fmaxf(m, v);
+  }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  b = __any(b) ? 1 : 0;
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = m; bad[threadIdx.x >> 6] = b; }
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    float s = (m > 0.f && m < 3.0e38f) ? target / m : 1.f;
+    if (has_state && scale[2] > 0.f) target = scale[2];
+    float s = (m > 0.f) ? target / m : 1.f;
+    s = fminf(fmaxf(s, 5.9604645e-8f), 16777216.0f);                   // [2^-24, 2^24]: finite, and 1 / s is finite
     s = exp2f(floorf(log2f(s)));                                       // a power of two: scaling and un-scaling are exact
     scale[0] = s; scale[1] = 1.0f / s;
+    if (has_state) scale[3] = (bad[0] | bad[1] | bad[2] | bad[3]) ? 1.f : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void grad_check_kernel(const float* __restrict__ g, long n, float* __restrict__ state) {
+  int b = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) b |= !(fabsf(g[i]) < 3.0e38f);
+  if (__any(b) && (threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(state + 3), 0x3f800000u);   // 1.0f
+}
+__global__ __launch_bounds__(256) void grad_guard_kernel(float* __restrict__ g, long n, float* __restrict__ state, float target_max) {
+  const bool found = state[3] != 0.f;
+  if (found)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {                          // (state[3] itself is reset by the next grad_scale)
+    float t = state[2] > 0.f ? state[2] : target_max;
+    if (found) { t = fmaxf(t * 0.5f, 1.f); state[4] += 1.f; state[5] = 0.f; }
+    else if ((state[5] += 1.f) >= 2000.f) { t = fminf(t * 2.f, target_max); state[5] = 0.f; }
+    state[2] = t;
   }
 }
 // dst(fp16)[r, c] = src(f32)[r, c] * scale[0] for c < cols, 0 for cols <= c < ld   (scale == nullptr: 1)
@@ -808,14 +842,22 @@ extern "C" int lafs_cnn_unpad_add_table(const float* padded, float* grad, const 
   return LAFS_OK;
 }
 
-extern "C" int lafs_cnn_grad_scale(const float* g, int64_t n, float target, float* scale, hipStream_t stream) {
+extern "C" int lafs_cnn_grad_scale(const float* g, int64_t n, float target, float* scale, int has_state, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g && scale && n > 0 && target > 0.f, "bad operand");
-  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(256), 0, stream, g, (long)n, target, scale);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(256), 0, stream, g, (long)n, target, scale, has_state);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
-
+extern "C" int lafs_cnn_grad_guard(float* grad, int64_t n, float* state, float target_max, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(grad && state && n > 0 && target_max >= 1.f, "bad operand");
+  const unsigned blocks = (unsigned)std::min<long>((n + 255) / 256, 1024);
+  hipLaunchKernelGGL(grad_check_kernel, dim3(blocks), dim3(256), 0, stream, grad, (long)n, state);
+  hipLaunchKernelGGL(grad_guard_kernel, dim3(blocks), dim3(256), 0, stream, grad, (long)n, state, target_max);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
 extern "C" int lafs_cnn_cast_pad_f16(const float* src, int rows, int cols, void* dst, int ld, const float* scale, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld >= cols, "bad operand");

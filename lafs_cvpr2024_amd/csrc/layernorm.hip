@@ -126,7 +126,8 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
                                                     float* __restrict__ g_io, int ldg, int accumulate,
                                                     bf16_t* __restrict__ gb, int ldgb, const float* __restrict__ seq_scale,
                                                     const int* __restrict__ row2seq, float* __restrict__ dgamma,
-                                                    float* __restrict__ dbeta, int rows, int D, DropCfg drop_in) {
+                                                    float* __restrict__ dbeta, float* __restrict__ part_out, int rows, int D,
+                                                    DropCfg drop_in) {
   const DropCfg drop = drop_resolve(drop_in);
   __shared__ float red[NW][NI * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -217,7 +218,10 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
       float sg = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) sg += red[w][c];
-      atomicAdd((pass ? dbeta : dgamma) + c, sg);
+      // part_out: this workgroup's sums go to a slot of their own ([workgroup][gamma | beta][D]) and lafs_layernorm_bwd_fold adds
+      // the slots in a fixed order -- run-to-run deterministic parameter gradients (one fp32 atomic per column and workgroup otherwise)
+      if (part_out != nullptr) part_out[((size_t)blockIdx.x * 2 + pass) * D + c] = sg;
+      else atomicAdd((pass ? dbeta : dgamma) + c, sg);
     }
   }
 }
@@ -271,6 +275,38 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   if (wave == 0 && n < N) atomicAdd(out + n, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
+
+// dgamma[c] += sum over the partial slots of every listed launch (row chains), slot by slot in ascending order; dbeta likewise.
+// One workgroup of 1024 threads per (item, 64-column group of the 2 D sums): wave w adds slots w, w + 16, ... of its 64 columns,
+// the 16 wave sums are added in wave order through LDS -- the same order on every run.
+struct LnFoldArgs { lafs_ln_fold_item it[LAFS_LN_FOLD_MAX]; int n_items, D, groups; };
+__global__ __launch_bounds__(1024) void ln_fold_kernel(LnFoldArgs p) {
+  __shared__ float red[16][64];
+  const int item = blockIdx.x / p.groups, grp = blockIdx.x % p.groups;
+  const lafs_ln_fold_item& it = p.it[item];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = grp * 64 + lane;                      // column of the [gamma | beta] image: 0 .. 2 D - 1
+  float acc = 0.f;
+  if (col < 2 * p.D) {
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      const float* part = it.part[ch];
+      const int n = it.n_parts[ch];
+      if (part == nullptr) continue;
+      for (int b = wave; b < n; b += 16) acc += part[(size_t)b * 2 * p.D + col];
+    }
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && col < 2 * p.D) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    float* dst = (col < p.D) ? it.dgamma + col : it.dbeta + (col - p.D);
+    *dst += s;
+  }
+}
+
 }  // namespace
 
 #define LN_DISPATCH(NI_, KERNEL, ...)                                                             \
@@ -298,8 +334,7 @@ extern "C" int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, c
   LAFS_CHECK_ARG(x && gamma && beta && stats && (y_bf16 || y_f32), "null operand");
   LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
   LAFS_CHECK_ARG(ldx % 4 == 0 && ldy % 4 == 0 && ldyf % 4 == 0, "row strides must be multiples of 4");
-  static const bool two_rows = [] { const char* v = getenv("LAFS_LN_FWD2"); return v == nullptr || v[0] != '0'; }();
-  if (two_rows && D % 128 == 0 && D <= 512 && rows >= 4096) {      // two rows per wave, grid-stride (see ln_fwd2_kernel)
+  if (D % 128 == 0 && D <= 512 && rows >= 4096) {      // two rows per wave, grid-stride (see ln_fwd2_kernel)
     const dim3 grid2(std::min(1024, ceil_div(rows, 8)));
     switch (D / 128) {
       case 1: hipLaunchKernelGGL(ln_fwd2_kernel<1>, grid2, dim3(256), 0, stream, x, ldx, gamma, beta, eps, (bf16_t*)y_bf16, ldy, y_f32, ldyf, stats, rows); break;
@@ -317,27 +352,49 @@ extern "C" int lafs_layernorm_fwd(const float* x, int ldx, const float* gamma, c
   return LAFS_OK;
 }
 
-extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf, const float* x, int ldx,
-                                  const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
-                                  void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
-                                  float* dgamma, float* dbeta, int rows, int D, float drop_p, uint32_t drop_seed,
-                                  const float* drop_step, int drop_row0, hipStream_t stream) {
-  LAFS_CLEAR_ERROR();
-  LAFS_CHECK_ARG((dy_bf16 || dy_f32) && x && stats && gamma && g_io && dgamma && dbeta, "null operand");
-  LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
-  LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
+extern "C" int lafs_layernorm_bwd_parts(int rows, int D) {
+  if (rows <= 0 || D <= 0) return 0;
   const int ni = ceil_div(D, 256);
   const int nw = ni <= 2 ? 16 : (ni <= 4 ? 8 : 4);          // 32 KB of LDS per workgroup in every case
   int blocks = ceil_div(rows, nw);
   if (blocks > 4096 / nw) blocks = 4096 / nw;
-  const dim3 grid(blocks);
+  return blocks;
+}
+
+extern "C" int lafs_layernorm_bwd_fold(const lafs_ln_fold_item* items, int n_items, int D, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(items != nullptr && n_items > 0 && D > 0, "bad operand");
+  for (int i0 = 0; i0 < n_items; i0 += LAFS_LN_FOLD_MAX) {
+    LnFoldArgs a;
+    a.n_items = std::min(LAFS_LN_FOLD_MAX, n_items - i0); a.D = D; a.groups = ceil_div(2 * D, 64);
+    for (int i = 0; i < a.n_items; ++i) {
+      a.it[i] = items[i0 + i];
+      LAFS_CHECK_ARG(a.it[i].dgamma && a.it[i].dbeta, "null gradient");
+    }
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(a.n_items * a.groups), dim3(1024), 0, stream, a);
+  }
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy_f32, int lddyf, const float* x, int ldx,
+                                  const float* stats, const float* gamma, float* g_io, int ldg, int accumulate,
+                                  void* gb_out, int ldgb, const float* seq_scale, const int32_t* row2seq,
+                                  float* dgamma, float* dbeta, int rows, int D, float drop_p, uint32_t drop_seed,
+                                  const float* drop_step, int drop_row0, float* part_out, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG((dy_bf16 || dy_f32) && x && stats && gamma && g_io && ((dgamma && dbeta) || part_out), "null operand");
+  LAFS_CHECK_ARG(rows > 0 && D > 0 && D % 4 == 0 && D <= 256 * MAXI, "D must be a multiple of 4 and <= 2048");
+  LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
+  const int ni = ceil_div(D, 256);
+  const dim3 grid(lafs_layernorm_bwd_parts(rows, D));
   if (dy_f32 != nullptr) {
     LN_BWD_DISPATCH(ni, true, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
-                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D,
+                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, part_out, rows, D,
                     make_drop(drop_p, drop_seed, drop_step, (unsigned)drop_row0 * (unsigned)D));
   } else {
     LN_BWD_DISPATCH(ni, false, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
-                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, rows, D,
+                    (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, part_out, rows, D,
                     make_drop(drop_p, drop_seed, drop_step, (unsigned)drop_row0 * (unsigned)D));
   }
   LAFS_LAUNCH_CHECK();

@@ -31,6 +31,7 @@ struct WgItem {
   const bf16_t* A; const bf16_t* B;
   float* out;                 // slices > 1: scratch [slices][N1][N2]; slices == 1: C itself
   float* colsum;
+  float* cs_part;             // bias-gradient partials [slices][tiles_n2][2 wave columns][N1] (folded in a fixed order by wgrad_fold_kernel)
   long ldo, slice_stride;     // row stride of `out`, distance between slice images
   int N1, N2, lda, ldb;
   int tile0, tiles_n2;        // first tile of this GEMM in the launch's tile list; tiles along N2
@@ -333,21 +334,40 @@ __global__ __launch_bounds__(64 * WM * WN, OCC * (WM * WN) / 4) void wgrad_kerne
       }
   }
   if (do_colsum) {                                    // lanes l and l + 32 hold the two k-halves of column l & 31
+    // every (slice, tile of the row, wave column) stores its share -- possibly 0 -- into a slot of its own; wgrad_fold_kernel adds
+    // the slots in a fixed order: the bias gradient is run-to-run deterministic (fp32 atomics before round 5)
+    float* part = g_.cs_part + ((size_t)(slice * g_.tiles_n2 + tile % g_.tiles_n2) * 2 + wn) * N1;
 #pragma unroll
     for (int a = 0; a < FA; ++a) {
       const float v = cs[a] + __shfl_xor(cs[a], 32, 64);
       const int n1 = n1_0 + (wm * FA + a) * 32 + (lane & 31);
-      if (h == 0 && n1 < N1) atomicAdd(colsum + n1, v);
+      if (h == 0 && n1 < N1) part[n1] = v;
     }
   }
 }
 
-// C_g[r, c] = (accumulate_g ? C_g : 0) + sum_s part_g[s][r][c] for every GEMM g of the group (part rows are dense: N2 floats)
-struct FoldItem { const float* part; float* C; long slice_stride, n4_begin, ldc; int n2_4, accumulate; };
-struct FoldArgs { FoldItem it[MAXG]; int n_items, slices; long n4_total; };
+// C_g[r, c] = (accumulate_g ? C_g : 0) + sum_s part_g[s][r][c] for every GEMM g of the group (part rows are dense: N2 floats);
+// behind the matrix elements: colsum_g[n] += sum over the (slice, tile, wave column) slots of the bias-gradient partials, in slot order
+struct FoldItem { const float* part; float* C; long slice_stride, n4_begin, ldc; int n2_4, accumulate;
+                  const float* cs_part; float* colsum; long cs_begin; int cs_slots, N1; };
+struct FoldArgs { FoldItem it[MAXG]; int n_items, slices; long n4_total, cs_total; };
 __global__ __launch_bounds__(256) void wgrad_fold_kernel(FoldArgs p) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.n4_total) return;
+  if (i >= p.n4_total) {
+    const long c = i - p.n4_total;
+    if (c >= p.cs_total) return;
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < MAXG; ++k)
+      if (k < p.n_items && c >= p.it[k].cs_begin) gi = k;
+    const FoldItem g = p.it[gi];
+    const long n = c - g.cs_begin;
+    if (g.colsum == nullptr || n >= g.N1) return;
+    float acc = 0.f;
+    for (int s = 0; s < g.cs_slots; ++s) acc += g.cs_part[(size_t)s * g.N1 + n];
+    g.colsum[n] += acc;
+    return;
+  }
   int gi = 0;
 #pragma unroll
   for (int k = 1; k < MAXG; ++k)
@@ -408,10 +428,14 @@ Plan make_plan(const lafs_wgrad_item* items, int n, int M, int max_wg) {
   return best;
 }
 
+// bias-gradient partials of GEMM g: one slot of N1 floats per (slice, tile along N2, wave column)
+inline int64_t cs_slots(const Plan& pl, int g) { return (int64_t)pl.slices * pl.tiles_n2[g] * 2; }
 int64_t plan_bytes(const Plan& pl, const lafs_wgrad_item* items, int n) {
-  if (pl.slices <= 1) return 0;
   int64_t b = 0;
-  for (int g = 0; g < n; ++g) b += (int64_t)pl.slices * items[g].N1 * items[g].N2 * 4;
+  for (int g = 0; g < n; ++g) {
+    if (pl.slices > 1) b += (int64_t)pl.slices * items[g].N1 * items[g].N2 * 4;
+    b += cs_slots(pl, g) * items[g].N1 * 4;            // (sized whether or not the caller passes colsum_a: the size query has no pointers)
+  }
   return b;
 }
 
@@ -427,6 +451,7 @@ int launch(const WgArgs& a, hipStream_t s) {
     }
   }
 #endif
+#ifdef LAFS_LAB_WGRAD_OCC2
   if constexpr (FA * FB <= 9 && (ABL & ~WG_F16) != 0) {          // lab: a sixth ring stage (3 x 3 blocks: 6 x 24 KiB)
     static const bool ns6 = getenv("LAFS_WGRAD_NS6") != nullptr;
     if (ns6) {
@@ -435,6 +460,7 @@ int launch(const WgArgs& a, hipStream_t s) {
       return LAFS_OK;
     }
   }
+#endif
   hipLaunchKernelGGL((wgrad_kernel<2, 2, FA, FB, NS, 1, ABL>), dim3(a.nblk), dim3(256), 0, s, a);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
@@ -455,11 +481,12 @@ int group_impl(const lafs_wgrad_item* items, int n_items, int M, int max_workgro
   }
   const Plan pl = make_plan(items, n_items, M, max_workgroups);
   const int64_t need = plan_bytes(pl, items, n_items);
-  LAFS_CHECK_ARG(need == 0 || (workspace != nullptr && workspace_bytes >= need), "workspace too small (lafs_wgrad_group_workspace_bytes)");
+  LAFS_CHECK_ARG(workspace != nullptr && workspace_bytes >= need, "workspace too small (lafs_wgrad_group_workspace_bytes)");
   WgArgs a = {};
   FoldArgs f = {};
   float* ws = (float*)workspace;
-  long n4 = 0;
+  long n4 = 0, ncs = 0;
+  bool any_cs = false;
   for (int g = 0; g < n_items; ++g) {
     const lafs_wgrad_item& it = items[g];
     WgItem& w = a.it[g];
@@ -471,8 +498,11 @@ int group_impl(const lafs_wgrad_item* items, int n_items, int M, int max_workgro
     FoldItem& fi = f.it[g];
     fi.part = ws; fi.C = it.C; fi.slice_stride = (long)it.N1 * it.N2; fi.n4_begin = n4; fi.ldc = it.ldc;
     fi.n2_4 = it.N2 / 4; fi.accumulate = it.accumulate;
-    n4 += (long)it.N1 * it.N2 / 4;
-    if (pl.slices > 1) ws += (size_t)pl.slices * it.N1 * it.N2;
+    if (pl.slices > 1) { n4 += (long)it.N1 * it.N2 / 4; ws += (size_t)pl.slices * it.N1 * it.N2; }
+    w.cs_part = ws; fi.cs_part = ws; fi.colsum = it.colsum_a; fi.cs_begin = ncs; fi.cs_slots = (int)cs_slots(pl, g); fi.N1 = it.N1;
+    ws += (size_t)cs_slots(pl, g) * it.N1;
+    if (it.colsum_a != nullptr) any_cs = true;
+    ncs += it.N1;
   }
   a.n_items = n_items; a.M = M; a.mlen = pl.mlen; a.slices = pl.slices; a.tiles = pl.tiles;
   a.nblk = (pl.slices * pl.tiles + 7) & ~7;
@@ -482,9 +512,9 @@ int group_impl(const lafs_wgrad_item* items, int n_items, int M, int max_workgro
   else if (pl.fa == 3 && pl.fb == 3) rc = launch<3, 3, ABL>(a, stream);
   else rc = launch<2, 2, ABL>(a, stream);
   if (rc != LAFS_OK) return rc;
-  if (pl.slices > 1) {
-    f.n_items = n_items; f.slices = pl.slices; f.n4_total = n4;
-    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, f);
+  if (pl.slices > 1 || any_cs) {
+    f.n_items = n_items; f.slices = pl.slices; f.n4_total = n4; f.cs_total = any_cs ? ncs : 0;
+    hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((n4 + f.cs_total + 255) / 256)), dim3(256), 0, stream, f);
     LAFS_LAUNCH_CHECK();
   }
   return LAFS_OK;

@@ -62,7 +62,9 @@ class LafsPretrainEngine:
         if self.partfvit and (vit_s.with_land or vit_t.with_land):
             raise _lib.LafsHipError("LAFS pre-training uses with_land=False backbones (the landmark CNN is the frozen front-end)")
         self.sa = attach_arena(student, self.device)
-        _lib.lib().lafs_trunk_streams_init()             # side streams / events exist before anything is captured
+        # the library's side streams / events / kernel options of THIS engine (created now: nothing is created inside a capture;
+        # two engines share no stream or event).  The environment's A/B switches are read by _lib.Ctx, not by the library.
+        self.ctx = _lib.Ctx(self.device)
         self.ta = getattr(teacher, "_lafs_arena", None)
         if self.ta is None:
             for p in teacher.parameters():
@@ -74,6 +76,7 @@ class LafsPretrainEngine:
                     m._bind_arena(self.ta, name + "." if name else "")
         if self.sa.names != self.ta.names or self.sa.size != self.ta.size:
             raise _lib.LafsHipError("student and teacher must have identical parameter layouts")
+        self.sa.ctx = self.ta.ctx = self.ctx
         dino_loss.to(self.device)
         if self.world > 1:                       # DDP's initial parameter broadcast (reference lafs_train.py:375)
             for t in (self.sa.master, self.ta.master, dino_loss.center):
@@ -157,7 +160,7 @@ class LafsPretrainEngine:
             # LAFS_COMM_CUS=n (opt-in, default 0) shrinks the K-resident GEMM's grid by 2 n workgroups while gradients are on the
             # wire.  It does not reserve CUs (the dispatcher still spreads the remaining workgroups over the chip) and has never been
             # A/B-measured beside RCCL kernels, so it stays off until a multi-GPU box shows a gain.
-            _lib.lib().lafs_set_comm_cus(int(os.environ.get("LAFS_COMM_CUS", "0")))
+            self.ctx.set(_lib.OPT_COMM_CUS, int(os.environ.get("LAFS_COMM_CUS", "0")))
         # Update pieces: ranges of the arena in the order their gradients become final -- the DINO head (31 of 53 M parameters at C2)
         # after the head backward, then each run of blocks after its segment of the trunk backward.  A piece's per-tensor norms,
         # clip + AdamW + teacher EMA + shadow refresh run on a stream of their own at the START of a later segment, beside that

@@ -7,8 +7,7 @@
 Round 4: every per-step tensor is allocated once, no ATen kernel is left in a micro-step (labels, DropPath masks, operand
 transposes, the image gradient re-indexing and the gradient zeroing are lafs_* launches), the mixup lambda / step counter are read
 from device memory, and the whole micro-step is ONE hipGraph (two captured variants: the first micro-step of an accumulation
-window WRITES the block and class-table weight gradients instead of accumulating into a zeroed 1 GB arena).  The block weight
-gradients can run on a second stream inside the graph (LAFS_FT_WGRAD_STREAM=1; measured neutral, off by default).  Data-parallel
+window WRITES the block and class-table weight gradients instead of accumulating into a zeroed 1 GB arena).  Data-parallel
 runs and the class-sharded head keep the eager form (their collectives sit between the kernels).
 """
 import os
@@ -43,7 +42,7 @@ class FinetuneEngine:
     def __init__(self, backbone: ViT_face_landmark_patch8, batch_size, acc_step=3, mixup_alpha=0.2, mixup_prob=0.1,
                  s=64.0, m=0.4, margin_type=0, image_size=112, device=None, sharded_head=None, use_graph=None):
         """margin_type 0 = CosFace (the reference), 1 = ArcFace (parity unpinned), on the dense `backbone.loss.weight` head;
-        `sharded_head` (a partial_fc.PartialFC) replaces it by the class-sharded head (hard labels: mixup is off).
+        `sharded_head` (a partial_fc.PartialFC) replaces it by the class-sharded head (CosFace: mixup targets as on the dense head).
         use_graph: None = capture the micro-step whenever it is capturable (single rank, dense head; LAFS_FT_GRAPH=0 disables)."""
         if not isinstance(backbone, ViT_face_landmark_patch8) or (sharded_head is None and not hasattr(backbone, "loss")):
             raise _lib.LafsHipError("FinetuneEngine drives ViT_face_landmark_patch8(loss_type='CosFace') or a sharded head")
@@ -56,7 +55,8 @@ class FinetuneEngine:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.arena = attach_arena(backbone, self.device)
         self.arena.set_decay_groups(finetune_decay_group)
-        _lib.lib().lafs_trunk_streams_init()
+        self.ctx = _lib.Ctx(self.device)                 # this engine's side streams / events / kernel options (lafs_ctx)
+        self.arena.ctx = self.ctx
         self.head = sharded_head
         self.C = backbone.loss.out_features if sharded_head is None else 8
         self.Cpad = (self.C + 127) // 128 * 128
@@ -139,18 +139,15 @@ class FinetuneEngine:
             self.cnn.step_dev = self.hyper[_lib.HP_STEP:]
             m.register_state_dict_pre_hook(lambda *a_, **k_: self.cnn.flush_batches_tracked())
         # streams / graphs
-        # LAFS_FT_WGRAD_STREAM=1: the blocks' weight-gradient GEMMs on a second stream (inside the graph).  Measured at C4 on one box:
-        # 27.24 ms with it, 27.03 without (eager 27.35) -- like the LAFS step, the kernels beside each other slow down by what the
-        # overlap saves -- so it is off by default; tests/test_gpu_finetune.py holds the two-stream step against the one-stream one.
-        single = os.environ.get("LAFS_SINGLE_STREAM") == "1" or os.environ.get("LAFS_FT_WGRAD_STREAM", "0") != "1"
-        self.side_stream = None if single else torch.cuda.Stream(device=dev)
-        self.wgrad_workgroups = int(os.environ.get("LAFS_FT_WGRAD_WG", "0"))
+        # (The blocks' weight gradients on a second stream INSIDE the chain were measured neutral at C4 -- 27.24 ms with, 27.03 without --
+        # and removed in round 5: tools/lab/NOTES.md.  What pays is deferring them beside the landmark CNN's backward, below.)
+        self.wgrad_workgroups = 0
         # Deferred weight gradients (single GPU, HIP landmark plan): the trunk backward launches only its input-gradient chain and keeps
         # every block's dY operands; the twelve grouped weight-gradient launches then run on a second stream BESIDE the landmark
         # CNN's backward -- ~300 small launch-latency-sized kernels that leave most of the chip idle -- capped to
         # LAFS_FT_DEFER_WG workgroups so that the CNN's kernels find free CUs.  Measured at C4 (tools/lab/NOTES.md): the same launches
         # cost 4.5 ms in front of the CNN backward and 2.75 ms beside it.  LAFS_FT_WGRAD_DEFER=0 restores the immediate form.
-        self.defer = (self.cnn is not None and self.world == 1 and sharded_head is None and self.side_stream is None
+        self.defer = (self.cnn is not None and self.world == 1 and sharded_head is None
                       and os.environ.get("LAFS_SINGLE_STREAM") != "1" and os.environ.get("LAFS_FT_WGRAD_DEFER", "1") != "0")
         self.defer_stream = torch.cuda.Stream(device=dev) if self.defer else None
         if self.defer:
@@ -193,15 +190,19 @@ class FinetuneEngine:
         return self.use_graph and (not m.with_land or (self.cnn is not None and m.training))
 
     def micro_step(self, inputs_u8, labels, lam=None):
-        """One forward/backward on a uint8 NCHW batch.  Gradients accumulate in the arena (loss pre-divided by acc_step)."""
+        """One forward/backward on a uint8 NCHW batch.  Gradients accumulate in the arena (loss pre-divided by acc_step).
+        The FIRST micro-step after an optimizer step overwrites / zeroes the gradients itself: between optimizer_step and the next
+        micro_step, arena.grad and p.grad hold the previous window's (stale) gradients unless `zero_after_step` is set."""
         a, m = self.arena, self.model
         a.ensure_fresh()
         lam = self.draw_lambda() if lam is None else float(lam)
-        if self.head is not None:
-            lam = 1.0                                    # the sharded head takes hard labels
+        if self.head is not None and self.head.margin_type != 0:
+            lam = 1.0                                    # ArcFace on the sharded head takes hard labels (parity unpinned either way)
+        self._lam = lam
         self._stage(inputs_u8, labels)
         self._labels = labels
-        self._upload_hyper({_lib.HP_MIX_LAM: lam, _lib.HP_STEP: float(self.micro + 1)})
+        # (the counter seeds the DropPath / dropout / CNN-dropout masks; fp32 holds integers exactly below 2^24: wrap like the LAFS engine)
+        self._upload_hyper({_lib.HP_MIX_LAM: lam, _lib.HP_STEP: float((self.micro + 1) % (1 << 24))})
         first = (self._since_opt == 0)                   # first micro-step since the last optimizer step: gradients are written, not accumulated
         if self._capturable():
             key = (first, bool(m.training))
@@ -210,13 +211,43 @@ class FinetuneEngine:
                 g = self._capture(first)
                 self._graphs[key] = g
             g.replay()
+            if self._cnn_hip:                            # nn.BatchNorm2d.num_batches_tracked: one training forward of the landmark CNN per replay
+                self.cnn.n_forward += 1
         else:
             self._body(first)
         self.micro += 1
         self._since_opt += 1
         return self.loss
 
+    def _warmup(self, first):
+        """One eager micro-step body on a side stream BEFORE the first capture (as LafsPretrainEngine._capture does): code objects
+        are loaded, kernel attributes set and the per-step workspaces (`_ws`, `dth`) allocated by the ordinary allocator instead of
+        from inside a stream capture / the graph's private pool.  The state the body mutates -- gradients, the loss, the landmark
+        CNN's BatchNorm running statistics and loss-scale state -- is snapshotted and put back."""
+        a, cnn = self.arena, self.cnn
+        bn = []
+        if cnn is not None:
+            bn = [t for s in [cnn.stem["bn"]] + [L[k] for L in cnn.blocks for k in ("bn1", "bn2", "bn3")] for t in (s["rm"], s["rv"]) if t is not None]
+            bn.append(cnn.gscale)
+        saved = [t.clone() for t in [a.grad, self.loss] + bn]
+        n_fwd = cnn.n_forward if cnn is not None else 0
+        cur = torch.cuda.current_stream()
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            self._body(first)
+        cur.wait_stream(s)
+        torch.cuda.synchronize()
+        for dst, src in zip([a.grad, self.loss] + bn, saved):
+            dst.copy_(src)
+        if cnn is not None:
+            cnn.n_forward = n_fwd
+            cnn.step = max(cnn.step - 1, 0)
+        self._warm = True
+
     def _capture(self, first):
+        if not getattr(self, "_warm", False):
+            self._warmup(first)
         if self.cnn is not None:
             self.cnn.mark_stale()                        # the operand refresh becomes part of the graph: every replay sees fresh weights
         g = torch.cuda.CUDAGraph()
@@ -255,12 +286,16 @@ class FinetuneEngine:
             self._ws = Fn.trunk_workspace(probe, True, dev)
         emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [self.pos_rows], drop, save=True, dropout=dropout, ws=self._ws,
                                     x_in=self.x_in, x_out=self.x_out, wgrad_overwrite=first,
-                                    wgrad_workgroups=self.wgrad_workgroups if (self.side_stream is not None or self.defer) else 0,
+                                    wgrad_workgroups=self.wgrad_workgroups if self.defer else 0,
                                     wgrad_defer=self.defer)
         if self.head is not None:
             # class-sharded head: all-gather embeddings, local logits, exchanged softmax statistics, reduce-scatter of dE.
             # demb is the gradient of the GLOBAL-batch mean loss, so the later all-reduce of the backbone gradients is a SUM.
-            loss, demb = self.head.forward_backward(emb, self._labels, grad_scale=1.0 / self.acc_step)
+            # soft (mixup) targets as the reference's margin head always gets them (train_largescale.py:802): the partner of row b is
+            # row B-1-b of this rank's batch (util/mixup_my.py:189-200), its weight 1 - lambda
+            soft = self._lam != 1.0
+            loss, demb = self.head.forward_backward(emb, self._labels, grad_scale=1.0 / self.acc_step,
+                                                    labels2=self._labels.flip(0) if soft else None, lam=self._lam)
             self.loss.copy_(loss.detach().view(1))
             self._backward_trunk(st, demb, th, theta)
             return
@@ -311,13 +346,13 @@ class FinetuneEngine:
         g = Fn.vit_backward_begin(a, m._spec, st, demb, g_buf=self.g_buf)
         depth = m.depth
         if not self._reduce_now():
-            Fn.vit_backward_layers(st, g, depth, 0, wgrad_stream=self.side_stream)
+            Fn.vit_backward_layers(st, g, depth, 0)
             return g
         ns = max(1, min(self.grad_slices, depth))
         cuts = [depth - (depth * k) // ns for k in range(ns + 1)]
         hi = self.head_off
         for k in range(ns):
-            Fn.vit_backward_layers(st, g, cuts[k], cuts[k + 1], wgrad_stream=self.side_stream)
+            Fn.vit_backward_layers(st, g, cuts[k], cuts[k + 1])
             lo = self.block_off[cuts[k + 1]]
             if cuts[k + 1] > 0:                                  # the range below block 0 still waits for the embedding / CNN gradients
                 self.reducer.launch(a.grad[lo:hi])

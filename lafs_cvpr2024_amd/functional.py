@@ -108,7 +108,9 @@ def make_trunk_desc(arena, spec: TrunkSpec, geom: PackedGeometry, drop_scales=No
         d.n_groups = len(geom.groups)
         for gi, (n_img, side) in enumerate(geom.groups):
             d.group_n_seq[gi], d.group_max_len[gi] = n_img, (side // geom.patch) ** 2 + 1
-    d._keep = (blocks, drop_scales, geom, arena, dropout_step)
+    ctx = getattr(arena, "ctx", None) or _lib.default_ctx(arena.master.device)
+    d.ctx = ctx.handle
+    d._keep = (blocks, drop_scales, geom, arena, dropout_step, ctx)
     return d
 
 

@@ -157,7 +157,15 @@ class HipLandmarkTrainer:
         self.wbf = torch.zeros(T.cast_size, device=dev, dtype=h16)
         self.gpad = torch.zeros(T.grad_size, device=dev, dtype=f32)
         self.bn_ws = torch.zeros(sums[0], device=dev, dtype=torch.float64)     # BatchNorm sums: fp64 (exact enough to be order-independent)
-        self.gscale = torch.ones(2, device=dev, dtype=f32)                       # {scale, 1 / scale} of this backward's gradients (device)
+        # device state of the loss scaling: {scale, 1 / scale, target, found_inf, skipped backwards, clean backwards in a row, -, -}
+        # (lafs_cnn_grad_scale / lafs_cnn_grad_guard: the reference's GradScaler, train_largescale.py:739, 867-880, without a host sync)
+        self.gscale = torch.tensor([1.0, 1.0, GRAD_TARGET, 0.0, 0.0, 0.0, 0.0, 0.0], device=dev, dtype=f32)
+        # the CNN's gradient range of the arena (stn.* and output_layer.*): what the overflow guard checks and, on inf / NaN, zeroes
+        cnn = [i for i, n in enumerate(arena.names) if n.startswith(("stn.", "output_layer."))]
+        assert cnn == list(range(cnn[0], cnn[-1] + 1)), "the landmark CNN's tensors must be contiguous in the arena"
+        self.grad_lo = arena.offsets[arena.names[cnn[0]]]
+        last = arena.names[cnn[-1]]
+        self.grad_hi = arena.offsets[last] + (arena.numels[last] + _lib.CHUNK - 1) // _lib.CHUNK * _lib.CHUNK
         self._versions = None
         self.step = 0
         self.seed = 0x1A2D
@@ -309,7 +317,9 @@ class HipLandmarkTrainer:
                     bias=a.view(a.master, "output_layer.1.bias"), out=B["t"])
         n_full = self.n_out // 2
         call("lafs_landmark_theta", _p(B["t"]), N, n_full, _p(B["zero_noise"]), 0.0, None, n_full, _p(B["theta"]))
-        self.n_forward += 1
+        if not torch.cuda.is_current_stream_capturing():
+            # (a captured forward is counted per REPLAY by its owner, FinetuneEngine.micro_step: this Python code runs only at capture)
+            self.n_forward += 1
         return B["theta"]
 
     def _dropout(self, buf):
@@ -341,7 +351,7 @@ class HipLandmarkTrainer:
         # loss scaling (the reference's GradScaler, train_largescale.py:803-867): the gradient enters the fp16 backward multiplied by
         # the power of two that brings its largest entry to ~GRAD_TARGET, chosen on the device; it is divided out where gradients
         # leave the 16-bit domain (BatchNorm affine gradients, the fold of the padded weight gradients)
-        call("lafs_cnn_grad_scale", _p(B["dt"]), B["dt"].numel(), GRAD_TARGET, _p(self.gscale))
+        call("lafs_cnn_grad_scale", _p(B["dt"]), B["dt"].numel(), GRAD_TARGET, _p(self.gscale), 1)
         call("lafs_cnn_cast_pad_f16", _p(B["dt"]), N, self.n_out, _p(B["dt_bf"]), self.p_out, _p(self.gscale))
         # head: dW, db, d(feature)
         hd = self.head
@@ -425,6 +435,14 @@ class HipLandmarkTrainer:
         # fold every padded weight gradient into the arena
         call("lafs_cnn_unpad_add_table", _p(self.gpad), _p(a.grad), _p(self.fold_table), _p(self.fold_starts), self.n_fold, self.fold_nblk,
              _p(self.gscale))
+        # overflow guard: an inf / NaN that the 16-bit backward produced (BatchNorm rstd ~31 at eps 1e-3, squeeze-excite / depthwise
+        # fan-in) must not reach AdamW -- the CNN's gradient range is checked and, if poisoned, zeroed; the scale target backs off
+        call("lafs_cnn_grad_guard", self._g(self.grad_lo), self.grad_hi - self.grad_lo, _p(self.gscale), GRAD_TARGET)
+
+    def overflow_state(self):
+        """(current scale target, backwards dropped because of inf / NaN so far) -- one host sync; diagnostics and tests."""
+        st = self.gscale.cpu().tolist()
+        return st[2], int(st[4])
 
     def mark_stale(self):
         """The optimizer changed the master weights in place (no torch version bump): refresh the operand images next forward."""

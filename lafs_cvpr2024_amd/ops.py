@@ -45,7 +45,7 @@ def zeros(*shape, device, dtype=torch.float32):
 
 def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=None, seq_scale=None, row2seq=None,
             aux=None, pos=None, npatch=0, splits=1, n_cols=None, out_rows=None, drop_p=0.0, drop_seed=0, act=0, skip_pre=False, drop_step=None, drop_row0=0,
-            route_only=False, ln=None):
+            route_only=False, ctx=None):
     """out[M,N] = A[M,K] @ B[N,K]^T with a fused epilogue (see lafs_hip.h LAFS_EPI_*).  skip_pre (BF16_GELU): write only
     GELU(u), as the forward-only teacher pass does; route_only: return lafs_gemm_nt_route for this request instead of running it."""
     # 16-bit operand format: bf16 everywhere except the trainable landmark CNN's plan, which runs on fp16 (operand_f16)
@@ -84,11 +84,7 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     if pos is not None:
         _chk(pos, torch.float32, "pos"); a.pos, a.npatch = pos.data_ptr(), npatch
     a.splits = splits
-    if ln is not None:                 # (gamma f32 [N], beta f32 [N], eps, out bf16 [M, N], stats f32 [M, 2] or None): LayerNorm(C) fused in
-        g_, b_, eps_, h_, st_ = ln
-        _chk(g_, torch.float32, "ln gamma"); _chk(b_, torch.float32, "ln beta"); _chk(h_, bf16, "ln out")
-        a.ln_gamma, a.ln_beta, a.ln_eps, a.ln_out, a.ld_ln_out = g_.data_ptr(), b_.data_ptr(), float(eps_), h_.data_ptr(), _ld(h_)
-        a.ln_stats = st_.data_ptr() if st_ is not None else None
+    a.ctx = (ctx or _lib.default_ctx(A.device)).handle
     if skip_pre and epilogue == _lib.EPI_BF16_GELU:
         a.C = None
     if route_only:
@@ -182,14 +178,21 @@ def layernorm_fwd(x, gamma, beta, eps, want_bf16=True, want_f32=False):
 
 def layernorm_bwd(dy, x, stats, gamma, g_io, dgamma, dbeta, accumulate=True, gb_out=None, seq_scale=None, row2seq=None,
                   drop_p=0.0, drop_seed=0, drop_step=None, drop_row0=0):
-    """dy: bf16 or f32 [rows, D].  g_io (f32) receives (accumulates) dx; returns g_io."""
+    """dy: bf16 or f32 [rows, D].  g_io (f32) receives (accumulates) dx; returns g_io.  dgamma / dbeta += the parameter gradients,
+    deterministically: the launch stores per-workgroup sums (part_out) and lafs_layernorm_bwd_fold adds them in a fixed order."""
     rows, D = x.shape
     dy_b = dy if dy.dtype == bf16 else None
     dy_f = dy if dy.dtype == torch.float32 else None
+    n_parts = int(_lib.lib().lafs_layernorm_bwd_parts(rows, D))
+    part = torch.empty(n_parts * 2 * D, device=x.device, dtype=torch.float32)
     call("lafs_layernorm_bwd", _p(dy_b), D if dy_b is None else _ld(dy_b), _p(dy_f), D if dy_f is None else _ld(dy_f),
          _p(x), _ld(x), _p(stats), _p(gamma), _p(g_io), _ld(g_io), 1 if accumulate else 0,
          _p(gb_out), D if gb_out is None else _ld(gb_out), _p(seq_scale), _p(row2seq), _p(dgamma), _p(dbeta), rows, D,
-         float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(drop_step), int(drop_row0))
+         float(drop_p), int(drop_seed) & 0xFFFFFFFF, _p(drop_step), int(drop_row0), _p(part))
+    item = (_lib.LnFoldItem * 1)()
+    item[0].part[0], item[0].n_parts[0] = part.data_ptr(), n_parts
+    item[0].dgamma, item[0].dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+    call("lafs_layernorm_bwd_fold", item, 1, D)
     return g_io
 
 

@@ -52,28 +52,34 @@ def shard_range(num_classes, rank, world):
     return start, n
 
 
-def sample_classes(labels, class_start, num_local, num_sample, generator=None):
+def sample_classes(labels, class_start, num_local, num_sample, generator=None, labels2=None):
     """Pick the class centres this rank scores the batch against.
 
     Returns (index [S] sorted local class ids, y_local [N] int32 position of each row's target inside `index`, -1 if the
-    target belongs to another rank).  All positives present in `labels` are kept; negatives are drawn uniformly without
-    replacement until `num_sample` (partial_fc_v2.sample)."""
+    target belongs to another rank) -- and, with `labels2` (the mixup partners' classes), y2_local likewise.  All positives present
+    in `labels` (and `labels2`) are kept; negatives are drawn uniformly without replacement until `num_sample` (partial_fc_v2.sample)."""
     labels = labels.long()
-    own = (labels >= class_start) & (labels < class_start + num_local)
-    local = labels - class_start
+    pos_src = labels if labels2 is None else torch.cat([labels, labels2.long()])
+    own_p = (pos_src >= class_start) & (pos_src < class_start + num_local)
     if num_sample >= num_local:
         index = torch.arange(num_local, device=labels.device)
     else:
-        positive = torch.unique(local[own], sorted=True)
+        positive = torch.unique((pos_src - class_start)[own_p], sorted=True)
         if num_sample > positive.numel():
             perm = torch.rand(num_local, device=labels.device, generator=generator)
             perm[positive] = 2.0
             index = torch.topk(perm, k=num_sample)[1].sort()[0]
         else:
             index = positive
-    y = torch.full_like(labels, -1)
-    y[own] = torch.searchsorted(index, local[own])
-    return index, y.to(torch.int32)
+
+    def local_pos(lab):
+        own = (lab >= class_start) & (lab < class_start + num_local)
+        y = torch.full_like(lab, -1)
+        y[own] = torch.searchsorted(index, (lab - class_start)[own])
+        return y.to(torch.int32)
+    if labels2 is None:
+        return index, local_pos(labels)
+    return index, local_pos(labels), local_pos(labels2.long())
 
 
 class _Centres(torch.nn.Module):
@@ -106,7 +112,8 @@ class PartialFC:
         # there are more of them than num_sample (small shards, low sample rates, large global batches); at most N distinct
         # labels exist, so this bound holds on every rank and no buffer can overflow on one rank while the others wait in a
         # collective
-        self.Spad = (max(self.num_sample, min(self.num_local, N)) + 127) // 128 * 128
+        # (mixup: up to 2 N distinct classes -- the rows' own and their partners')
+        self.Spad = (max(self.num_sample, min(self.num_local, 2 * N)) + 127) // 128 * 128
         self.ones = torch.ones(self.Spad, device=dev, dtype=f32)
         self.cos = torch.empty(N, self.Spad, device=dev, dtype=f32)
         self.dcos = torch.zeros(N, self.Spad, device=dev, dtype=bf16)
@@ -120,19 +127,34 @@ class PartialFC:
     def weight(self):
         return self.centres.weight
 
-    def forward_backward(self, emb, labels, grad_scale=1.0):
-        """emb f32 [B, D] (this rank's embeddings), labels [B] global class ids.
+    def forward_backward(self, emb, labels, grad_scale=1.0, labels2=None, lam=1.0):
+        """emb f32 [B, D] (this rank's embeddings), labels [B] global class ids.  Soft (mixup) targets as the reference's margin head
+        takes them (train_largescale.py:802, ViT_face.py:69-73): labels2 [B] = the mixup partners' classes, lam = this rank's lambda
+        (target lam e_labels + (1 - lam) e_labels2, entering the CosFace margin itself); labels2 None = hard labels.
         Returns (loss = mean CE over the GLOBAL batch, d loss/d emb [B, D] * grad_scale); the class-centre gradient
         accumulates in this rank's arena."""
         dev, D, B, N, W = self.device, self.D, self.B, self.N, self.world
         a = self.arena
         emb = emb.contiguous()
         labels = labels.to(dev, torch.int64).contiguous()
+        soft = labels2 is not None
+        if soft:
+            if self.margin_type != 0:
+                raise _lib.LafsHipError("soft (mixup) targets need the CosFace margin (ArcFace takes hard labels)")
+            labels2 = labels2.to(dev, torch.int64).contiguous()
+            lam_rows = torch.full((B,), float(lam), device=dev, dtype=f32)
         if W > 1:
             E, L = _gather_rows(emb, W), _gather_rows(labels, W)
+            if soft:
+                L2, lam_rows = _gather_rows(labels2, W), _gather_rows(lam_rows, W)      # every rank draws its own lambda
         else:
             E, L = emb, labels
-        index, y = sample_classes(L, self.class_start, self.num_local, self.num_sample, self.gen)
+            L2 = labels2 if soft else None
+        if soft:
+            index, y, y2 = sample_classes(L, self.class_start, self.num_local, self.num_sample, self.gen, labels2=L2)
+        else:
+            index, y = sample_classes(L, self.class_start, self.num_local, self.num_sample, self.gen)
+            y2, lam_rows = None, None
         S = index.numel()
         full = S == self.num_local
         v = a.view(a.master, "weight", (self.num_local, D))
@@ -142,14 +164,14 @@ class PartialFC:
         call("lafs_weightnorm_fwd", _p(v_s), _p(self.ones), S, self.Spad, D, _p(self.wn), None, self.Spad, _p(self.inv_w))
         ops.gemm_nt(en, self.wn, _lib.EPI_F32, out=self.cos, n_cols=self.Spad)
         rowmax, rowsum, tgt = self.stats[0], self.stats[1], self.stats[2]
-        call("lafs_shard_margin_rowmax", _p(self.cos), self.Spad, N, S, _p(y), self.s, self.m, self.margin_type, _p(rowmax))
+        call("lafs_shard_margin_rowmax", _p(self.cos), self.Spad, N, S, _p(y), _p(y2), _p(lam_rows), self.s, self.m, self.margin_type, _p(rowmax))
         if W > 1:
             dist.all_reduce(rowmax, op=dist.ReduceOp.MAX)
-        call("lafs_shard_margin_rowsum", _p(self.cos), self.Spad, N, S, _p(y), self.s, self.m, self.margin_type, _p(rowmax),
+        call("lafs_shard_margin_rowsum", _p(self.cos), self.Spad, N, S, _p(y), _p(y2), _p(lam_rows), self.s, self.m, self.margin_type, _p(rowmax),
              _p(rowsum), _p(tgt))
         if W > 1:
             dist.all_reduce(self.stats[1:3])
-        call("lafs_shard_margin_grad", _p(self.cos), self.Spad, N, S, _p(y), self.s, self.m, self.margin_type, _p(rowmax),
+        call("lafs_shard_margin_grad", _p(self.cos), self.Spad, N, S, _p(y), _p(y2), _p(lam_rows), self.s, self.m, self.margin_type, _p(rowmax),
              _p(rowsum), grad_scale / N)
         loss = (torch.log(rowsum) + rowmax - tgt).mean()
         ops.scale_cast_bf16(self.cos, out=self.dcos)

@@ -64,12 +64,15 @@ def partial_fc_reference(emb, weight, labels, s=64.0, m=0.4):
 
 
 def partial_fc_sharded(emb_local, labels_local, weight_shard, class_start, s=64.0, m=0.4,
-                       all_gather=None, all_reduce_max=None, all_reduce_sum=None):
+                       all_gather=None, all_reduce_max=None, all_reduce_sum=None, labels2_local=None, lam_local=None):
     """Class-sharded CosFace + CE with the distributed softmax of InsightFace partial_fc_v2
     (DistCrossEntropy), sample_rate = 1.  PARITY UNPINNED (see partial_fc_reference).
     The three callables perform the cross-rank exchange (identity when None).  Returns the
     mean loss over the GLOBAL batch and d loss / d emb restricted to this shard's classes for
-    ALL rows (the caller reduce-scatters it)."""
+    ALL rows (the caller reduce-scatters it).  labels2_local / lam_local: the mixup partners'
+    classes and this rank's lambda -- the dense soft target lam e_y1 + (1-lam) e_y2 of
+    util/mixup_my.py:18-24 entering the margin as CosFace.forward's soft branch does
+    (ViT_face.py:69-73), loss = soft-target CE."""
     ident = lambda t: t
     all_gather = all_gather or ident
     all_reduce_max = all_reduce_max or ident
@@ -78,9 +81,17 @@ def partial_fc_sharded(emb_local, labels_local, weight_shard, class_start, s=64.
     L = all_gather(labels_local).long()
     n_local = weight_shard.shape[0]
     cos = F.linear(F.normalize(E), F.normalize(weight_shard))
-    own = (L >= class_start) & (L < class_start + n_local)
-    y = torch.zeros_like(cos)
-    y[own, (L - class_start)[own]] = 1.0
+
+    def onehot(lab):
+        own = (lab >= class_start) & (lab < class_start + n_local)
+        y = torch.zeros_like(cos)
+        y[own, (lab - class_start)[own]] = 1.0
+        return y
+    y = onehot(L)
+    if labels2_local is not None:
+        L2 = all_gather(labels2_local).long()
+        lam = all_gather(torch.full((emb_local.shape[0],), float(lam_local)))
+        y = lam[:, None] * y + (1.0 - lam)[:, None] * onehot(L2)
     z = s * (cos - m * y)
     gmax = all_reduce_max(z.detach().max(dim=1).values)
     ez = torch.exp(z - gmax[:, None])

@@ -60,6 +60,9 @@ def test_two_rank_step_equals_single_process_full_batch(tmp_path):
     assert float(errs.median()) < 1e-7 and float((errs > 1e-5).float().mean()) < 0.02 and float(errs.max()) < 2.5e-3
 
 
+_PFC_LAMS = (0.3, 0.85)
+
+
 def _pfc_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -88,13 +91,19 @@ def _pfc_worker(rank, world, port, out):
                                          all_gather=gather, all_reduce_max=rmax, all_reduce_sum=rsum)
     dist.all_reduce(dE)                       # gloo has no reduce_scatter: all-reduce and slice (same sum)
     mine = dE[rank * B:(rank + 1) * B]
-    torch.save({"loss": loss, "demb": mine}, out + f".{rank}")
+    # soft (mixup) targets: every rank mixes its own batch with its flip and draws its own lambda (util/mixup_my.py:189-200)
+    lab_r = lab[rank * B:(rank + 1) * B]
+    loss_s, dE_s = margin.partial_fc_sharded(emb[rank * B:(rank + 1) * B], lab_r, Wfull[start:start + n], start, all_gather=gather,
+                                             all_reduce_max=rmax, all_reduce_sum=rsum, labels2_local=lab_r.flip(0), lam_local=_PFC_LAMS[rank])
+    dist.all_reduce(dE_s)
+    torch.save({"loss": loss, "demb": mine, "loss_soft": loss_s, "demb_soft": dE_s[rank * B:(rank + 1) * B]}, out + f".{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_partial_fc_two_shards_equal_unsharded(tmp_path):
-    """The class-sharded softmax exchange (MAX, SUM, SUM; reduce-scatter of dE) reproduces the unsharded CosFace + CE."""
+    """The class-sharded softmax exchange (MAX, SUM, SUM; reduce-scatter of dE) reproduces the unsharded CosFace + CE -- with hard
+    labels and with the reference's soft (mixup) targets (two (class, weight) pairs per row, a lambda per rank)."""
     from oracle import margin
     out = str(tmp_path / "pfc")
     import socket
@@ -108,7 +117,14 @@ def test_partial_fc_two_shards_equal_unsharded(tmp_path):
     lab = torch.randint(0, C, (2 * B,), generator=g)
     ref = margin.partial_fc_reference(emb, Wfull, lab)
     ref.backward()
+    # the reference's own loss on the same data: dense soft target through CosFace's soft branch (F10-pinned) + soft-target CE
+    emb2 = emb.detach().clone().requires_grad_(True)
+    tgt = torch.cat([margin.mixup_batch(torch.zeros(B, 1), lab[r * B:(r + 1) * B], C, _PFC_LAMS[r])[1] for r in range(2)])
+    ref_s = margin.soft_target_cross_entropy(margin.cosface_logits(emb2, Wfull, tgt), tgt)
+    ref_s.backward()
     for r in range(2):
         got = torch.load(out + f".{r}", weights_only=False)
         torch.testing.assert_close(got["loss"], ref.detach(), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(got["demb"], emb.grad[r * B:(r + 1) * B], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(got["loss_soft"], ref_s.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got["demb_soft"], emb2.grad[r * B:(r + 1) * B], rtol=1e-4, atol=1e-6)

@@ -112,8 +112,8 @@ def test_capture_friendly_margin_kernel_equals_the_in_place_one(margin_type, m, 
 
 @pytest.mark.parametrize("with_land", [False, True])
 def test_captured_finetune_step_equals_the_eager_single_stream_step(with_land, monkeypatch):
-    """The fine-tune micro-step as hipGraphs with the block weight gradients on a second stream (the default) against the same engine
-    run eagerly on ONE stream: three accumulation windows of two micro-steps with live dropout / DropPath / mixup.  Without the
+    """The fine-tune micro-step as hipGraphs (the default; with the landmark branch: weight gradients deferred onto a second stream
+    beside the CNN's backward) against the same engine run eagerly: three accumulation windows of two micro-steps with live dropout / DropPath / mixup.  Without the
     landmark branch the two must agree to fp32 round-off (a buffer reused while the second stream still reads it -- the hazard round
     3's side-stream experiment ran into -- shows up at the percent level).  With the trainable landmark branch the losses before
     the first update agree as tightly (its BatchNorm sums are fp64 since round 4: the forward is deterministic); after updates the
@@ -131,9 +131,7 @@ def test_captured_finetune_step_equals_the_eager_single_stream_step(with_land, m
         if with_land:
             det_fill_random(model.stn); det_fill_random(model.output_layer)
         model.train()
-        monkeypatch.setenv("LAFS_FT_WGRAD_STREAM", "1" if mode == "graph" else "0")
         eng = FinetuneEngine(model, B, acc_step=2, device=DEV, use_graph=(mode == "graph"))
-        assert (eng.side_stream is not None) == (mode == "graph")
         g = torch.Generator(device=DEV).manual_seed(9)
         losses = []
         for it in range(6):
@@ -175,7 +173,6 @@ def test_deferred_block_weight_gradients_equal_the_immediate_ones(monkeypatch):
                                          heads=2, mlp_dim=256, dropout=0.1, emb_dropout=0.1, with_land=True, drop_path_rate=0.1)
         det_fill_random(model.stn); det_fill_random(model.output_layer)
         model.train()
-        monkeypatch.setenv("LAFS_FT_WGRAD_STREAM", "0")
         monkeypatch.setenv("LAFS_FT_WGRAD_DEFER", defer)
         monkeypatch.setenv("LAFS_FT_DEFER_WG", "0")     # (a workgroup cap changes the number of token slices = the fp32 summation order)
         eng = FinetuneEngine(model, B, acc_step=2, device=DEV, use_graph=True)
@@ -237,6 +234,78 @@ def test_finetune_micro_step_against_oracle(lam):
     d = (named["patch_to_embedding.weight"].detach() - w0).abs().max().item()
     assert 0.5e-3 < d < 2.5e-3, d
     assert float(eng.arena.grad.abs().max()) == 0.0
+
+
+def test_finetune_accumulation_window_and_adamw_against_oracle():
+    """An accumulation WINDOW of the fine-tune step held against the oracle (reference train_largescale.py:842-843, 870-891,
+    122-173): acc_step = 3 micro-steps on different batches (two mixed, one plain), each loss divided by 3, gradients accumulated
+    -- the first micro-step of a window WRITES the block / class-table gradients, the later ones accumulate (the two captured
+    variants) --, then ONE AdamW step with param_groups_lrd's decay classes (F12: matrices 1e-1, 1-D tensors 0; the `stn*` class is
+    pinned on the device by test_f12_arena_applies_the_reference_weight_decay_groups).  Checked: the three losses, the accumulated
+    gradient of every tensor (relative L2), and the post-step weights in units of the learning rate as F5 does -- first against
+    the oracle's window (gradients differ at the bf16 level, Adam's first step is lr * sign(g): distributional), then EXACTLY
+    (fp32 round-off) against the oracle's AdamW applied to the engine's own accumulated gradients, which is what a wrong decay
+    class, a wrong 1/acc_step or a lost micro-step cannot pass."""
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    from oracle import margin, optim, partfvit
+    torch.manual_seed(7)
+    B, C, ACC = 8, 1000, 3
+    lr, wd = 1e-3, 0.1
+    model = ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=C, image_size=112, patch_size=8, dim=128, depth=2,
+                                     heads=3, mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=False, drop_path_rate=0.0)
+    P = {k: v.clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    init = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randint(0, 256, (B, 3, 112, 112), dtype=torch.uint8, generator=g), torch.randint(0, C, (B,), generator=g), lam)
+               for lam in (0.3, 1.0, 0.8)]
+    eng = FinetuneEngine(model, B, acc_step=ACC, device=DEV)
+    losses = [float(eng.micro_step(u8.to(DEV), y.to(DEV), lam=lam).item()) for u8, y, lam in batches]
+    torch.cuda.synchronize()
+    assert eng._since_opt == ACC and (not eng.use_graph or len(eng._graphs) == 2)
+    named = dict(model.named_parameters())
+    g_eng = {k: p.grad.detach().cpu().clone() for k, p in named.items()}
+    # ---- oracle window: loss / acc_step, gradients summed over the three micro-steps
+    cfg = partfvit.PartFViTConfig(patch_size=8, dim=128, depth=2, heads=3, mlp_dim=256, num_patches=196)
+    ref_losses = []
+    for u8, y, lam in batches:
+        x = u8.float() / 255 * 2 - 1
+        x, tgt = margin.mixup_batch(x, y, C, lam)
+        emb = partfvit.forward_embedding(P, x, cfg)
+        loss = margin.soft_target_cross_entropy(margin.cosface_logits(emb, P["loss.weight"], tgt), tgt) / ACC
+        loss.backward()
+        ref_losses.append(float(loss))
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) / b < 5e-3, (losses, ref_losses)          # the engine's loss is already divided by acc_step
+    errs = {k: rel_l2(g_eng[k], P[k].grad) for k in named if P[k].grad is not None and float(P[k].grad.abs().max()) > 0}
+    assert len(errs) >= 30
+    gate_errors("fine-tune accumulation window vs oracle", errs, GATE_FT)
+    # ---- one AdamW step (torch.optim.AdamW semantics, param_groups_lrd decay classes)
+    eng.optimizer_step(lr=lr, weight_decay=wd)
+    torch.cuda.synchronize()
+    after = {k: p.detach().cpu().clone() for k, p in named.items()}
+
+    def oracle_step(grads):
+        out = {}
+        for k in named:
+            p = init[k].clone()
+            optim.adamw_step_(p, grads[k].clone(), torch.zeros_like(p), torch.zeros_like(p), 1, lr,
+                              optim.finetune_weight_decay(k, tuple(p.shape), wd))
+            out[k] = p
+        return out
+    own = oracle_step(g_eng)                       # the engine's own accumulated gradients through the oracle's optimizer: exact
+    for k in named:
+        d = float((after[k] - own[k]).abs().max())
+        # fp32 round-off of m / (sqrt(v) + eps) (|update| <= lr) and of p (1 - lr wd)
+        assert d <= 2e-3 * lr + 2e-7 * float(init[k].abs().max()), (k, d)
+    ref = oracle_step({k: (P[k].grad if P[k].grad is not None else torch.zeros_like(init[k])) for k in named})
+    e = torch.cat([(after[k].double() - ref[k].double()).abs().flatten() for k in named]).numpy()
+    assert np.median(e) < 0.05 * lr, np.median(e)                  # Adam's first step is lr * sign(g): bf16 noise flips round-off-sized gradients
+    assert np.quantile(e, 0.9) < 0.6 * lr, np.quantile(e, 0.9)
+    assert e.max() < 2.2 * lr, e.max()
+    # the window is closed: the next micro-step is a "first" one again and overwrites the gradients
+    assert eng._since_opt == 0
+    loss2 = float(eng.micro_step(batches[0][0].to(DEV), batches[0][1].to(DEV), lam=batches[0][2]).item())
+    assert abs(loss2 - losses[0]) / losses[0] < 5e-2 and abs(loss2 - losses[0]) > 0     # same batch, updated weights
 
 
 def test_f9_landmark_cnn_wrapper_matches_reference():
@@ -303,6 +372,50 @@ def test_partial_fc_single_rank_matches_unsharded_oracle(margin_type, m, rate):
     w0 = pfc.weight.detach().clone()
     pfc.optimizer_step(lr=1e-3)
     assert float((pfc.weight.detach() - w0).abs().max()) > 0 and float(pfc.arena.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rate", [1.0, 0.25])
+def test_partial_fc_soft_mixup_targets_match_the_unsharded_cosface_soft_oracle(rate):
+    """The class-sharded head with the targets the reference ALWAYS feeds its margin head (train_largescale.py:802: Mixup's dense
+    lam e_y + (1 - lam) e_flip(y), entering the margin itself, ViT_face.py:69-73 -- the unsharded form is pinned by F10): two (class,
+    weight) pairs per row in lafs_shard_margin_*.  At sample_rate 1 loss and both gradients equal CosFace(soft) + SoftTargetCE over
+    all classes; at rate < 1 the same loss restricted to the sampled centres (both labels' classes always kept).  Rows whose partner
+    carries the same class (the middle of an odd flip, repeated ids) collapse to a hard label."""
+    from lafs_cvpr2024_amd.partial_fc import PartialFC, sample_classes
+    from oracle import margin
+    torch.manual_seed(1)
+    C, D, B, lam = 1000, 64, 16, 0.3
+    pfc = PartialFC(D, C, B, sample_rate=rate, s=64.0, m=0.4, margin_type=0, device="cuda", seed=0)
+    emb = torch.randn(B, D, device="cuda")
+    lab = torch.randint(0, C, (B,), device="cuda")
+    lab[5] = lab[B - 1 - 5]                                            # a row mixed with its own class
+    lab2 = lab.flip(0)
+    state = pfc.gen.get_state()
+    loss, demb = pfc.forward_backward(emb, lab, labels2=lab2, lam=lam)
+    pfc.gen.set_state(state)
+    index, y, y2 = sample_classes(lab, 0, C, pfc.num_sample, pfc.gen, labels2=lab2)
+    idx = index.cpu()
+    Wc = pfc.weight.detach().cpu().clone().requires_grad_(True)
+    e = emb.cpu().clone().requires_grad_(True)
+    tgt = torch.zeros(B, idx.numel())
+    tgt[torch.arange(B), y.cpu().long()] += lam
+    tgt[torch.arange(B), y2.cpu().long()] += 1.0 - lam
+    assert float(tgt.sum(1).min()) == pytest.approx(1.0) and float(tgt[5].max()) == pytest.approx(1.0)
+    ref = margin.soft_target_cross_entropy(margin.cosface_logits(e, Wc[idx], tgt, 64.0, 0.4), tgt)
+    ref.backward()
+    assert abs(float(loss) - float(ref)) < 2e-2 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    assert float((demb.cpu() - e.grad).abs().max()) < 3e-2 * float(e.grad.abs().max())
+    gw = pfc.arena.view(pfc.arena.grad, "weight", (C, D)).cpu()
+    assert float((gw - Wc.grad).abs().max()) < 3e-2 * float(Wc.grad.abs().max())
+    # hard labels are the lam = 1 special case of the same kernels
+    pfc.arena.zero_grad()
+    pfc.gen.set_state(state)
+    l1, d1 = pfc.forward_backward(emb, lab, labels2=lab2, lam=1.0)
+    pfc.arena.zero_grad()
+    pfc.gen.set_state(state)
+    l0, d0 = pfc.forward_backward(emb, lab)
+    if rate == 1.0:                                                    # (at rate < 1 the partners' classes change the sampled set)
+        assert abs(float(l1) - float(l0)) < 1e-6 * abs(float(l0)) and torch.equal(d1, d0)
 
 
 def test_f13_partfvit_with_trainable_landmark_branch():
@@ -1001,3 +1114,59 @@ def test_f18_hip_training_plan_of_the_landmark_cnn_against_the_reference():
         torch.testing.assert_close(m.state_dict()[k + ".running_mean"].cpu(), fx["rm." + k], rtol=5e-2, atol=2e-2)
         torch.testing.assert_close(m.state_dict()[k + ".running_var"].cpu(), fx["rv." + k], rtol=1e-1, atol=2e-2)
     assert int(m.state_dict()["stn.features.0.1.num_batches_tracked"]) == int(fx["nbt"]) == 1
+
+
+def test_captured_finetune_steps_count_batchnorm_forwards_and_survive_a_gradient_overflow():
+    """Two state-keeping duties of the trainable landmark branch inside the CAPTURED fine-tune step (round-4 advisor findings):
+    (1) nn.BatchNorm2d.num_batches_tracked advances by one per micro-step although the CNN's Python forward only runs at capture time
+        (the reference increments it every training forward; a checkpoint after N replays must say N);
+    (2) the reference wraps the step in torch.cuda.amp.GradScaler (train_largescale.py:739, 867-880): an inf / NaN in the 16-bit backward
+        skips the update and backs the scale off.  Here: the loss-scale target is forced up to 2^40 (every fp16 activation gradient
+        overflows), the device-side guard must zero the CNN's gradient range, halve the target and count the dropped backward; the
+        AdamW step that follows must leave every weight finite, and the next windows -- target backing off by itself -- train again."""
+    from conftest import det_fill_random
+    from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
+    torch.manual_seed(3)
+    B, C = 16, 500
+    model = ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=C, image_size=112, patch_size=8, dim=128, depth=2,
+                                     heads=2, mlp_dim=256, dropout=0.1, emb_dropout=0.1, with_land=True, drop_path_rate=0.1)
+    det_fill_random(model.stn); det_fill_random(model.output_layer)
+    model.train()
+    eng = FinetuneEngine(model, B, acc_step=1, device=DEV, use_graph=True)
+    assert eng.cnn is not None
+    g = torch.Generator(device=DEV).manual_seed(5)
+    batch = lambda: (torch.randint(0, 256, (B, 3, 112, 112), device=DEV, dtype=torch.uint8, generator=g),
+                     torch.randint(0, C, (B,), device=DEV, generator=g))
+    rv0 = model.stn.features[0][1].running_var.clone()
+    for _ in range(3):
+        eng.micro_step(*batch(), lam=1.0)
+        eng.optimizer_step(lr=1e-3)
+    torch.cuda.synchronize()
+    assert len(eng._graphs) == 1 and eng._warm
+    assert int(model.state_dict()["stn.features.0.1.num_batches_tracked"]) == 3          # (the warm-up run before the capture is not counted,
+    assert not torch.equal(model.stn.features[0][1].running_var, rv0)                     #  and its running-statistics update was undone: three momentum steps)
+    target0, skipped0 = eng.cnn.overflow_state()
+    assert target0 == 1024.0 and skipped0 == 0
+    lo, hi = eng.cnn.grad_lo, eng.cnn.grad_hi
+    w_stn = eng.arena.master[lo:hi].clone()
+    # ---- force an overflow
+    eng.cnn.gscale[2] = float(2 ** 40)
+    eng.micro_step(*batch(), lam=1.0)
+    torch.cuda.synchronize()
+    target1, skipped1 = eng.cnn.overflow_state()
+    assert skipped1 == 1 and target1 == float(2 ** 39), (target1, skipped1)
+    assert float(eng.arena.grad[lo:hi].abs().max()) == 0.0, "the poisoned CNN gradients must have been zeroed"
+    assert bool(torch.isfinite(eng.arena.grad).all())
+    eng.optimizer_step(lr=1e-3)
+    assert bool(torch.isfinite(eng.arena.master).all()) and bool(torch.isfinite(eng.arena.exp_avg_sq).all())
+    # (zero gradient: the CNN's weights only see their decoupled decay and the decaying first moment)
+    assert float((eng.arena.master[lo:hi] - w_stn).abs().max()) < 3e-3
+    # ---- the target backs off by itself until the backward fits fp16 again
+    for _ in range(40):
+        eng.micro_step(*batch(), lam=1.0)
+        eng.optimizer_step(lr=1e-3)
+        if float(eng.arena.grad[lo:hi].abs().max()) > 0:
+            break
+    target2, skipped2 = eng.cnn.overflow_state()
+    assert target2 < target1 and skipped2 > skipped1 and float(eng.arena.grad[lo:hi].abs().max()) > 0, (target2, skipped2)
+    assert bool(torch.isfinite(eng.arena.master).all())

@@ -282,6 +282,30 @@ def test_bench_owns_its_launch_two_ranks_on_one_gpu():
     assert r.returncode != 0 and "debug flags" in r.stderr
 
 
+def test_bench_eight_rank_launch_is_ready_for_an_eight_gpu_node():
+    """The launch the driver uses on an 8-GPU node -- `bench.py --gpus 8` -- at toy dimensions with all eight ranks on the one GPU over
+    gloo (LAFS_BENCH_SHARE_GPU=1; RCCL wants one device per rank): eight rank processes, segmented graphs with the gradient / center
+    all-reduces between them, barrier + max-over-ranks timing, ONE JSON line from rank 0 that reports what the communication backend
+    really saw.  No 1 -> 8 scaling curve has been measured on hardware (README); this pins the launch structure, not a rate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    small = ["--steps", "2", "--warmup", "1", "--batch", "2", "--arch", "vit_tiny", "--out-dim", "1024", "--local-crops", "2", "--no-cpu-baseline",
+             "--no-roofline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LAFS_DEBUG_FLAGS")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"] + small, env=dict(env, LAFS_BENCH_SHARE_GPU="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["comm"]["ranks_seen"] == 8 and line["comm"]["backend"] == "gloo"
+    assert line["config"]["parallelism"] == "dp8" and line["config"]["global_batch"] == 16 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 8 * 2 * 4 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]      # whole-job crops/s
+
+
 # ------------------------------------------------------------------------------------------------ Part-fViT as the LAFS pair
 def _build_partfvit(fx, use_graph, dropout=0.0, drop_path=0.0):
     from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8
@@ -585,3 +609,71 @@ def test_row_chains_equal_the_single_chain(tmp_path):
             dw = (out["2"][name][k].float() - v.float()).abs()
             assert float(dw.max()) <= 4 * 2 * 1e-3 + 1e-6, (name, k)    # at most every step's update flipped: 4 steps x 2 lr
             assert float(dw.median()) <= 2e-5 * (1.0 + float(v.float().abs().max())), (name, k)
+
+
+def test_two_engines_on_two_contexts_and_two_caller_streams_equal_the_single_engine_runs():
+    """The boundary's own claim (include/lafs_hip.h: "calls that share no context and no buffer are independent"): two LAFS engines in
+    one process, each with its own lafs_ctx (side streams, fork / join events, event pool), each with TWO row chains (two crop-
+    resolution groups of >= 4096 rows), stepped eagerly from two host threads on two caller streams at the same time -- against the
+    same two runs made one after the other.  Before round 5 the side streams and events were process-wide statics of the library:
+    two engines issued from two threads would have recorded / waited on the same `fork` / `join` events."""
+    import ctypes as C
+    import threading
+    from lafs_cvpr2024_amd import _lib
+    B, K, nl = 14, 512, 8
+
+    def build(seed):
+        torch.manual_seed(0)
+        mk = lambda: vits.VisionTransformer(img_size=[112], patch_size=8, embed_dim=128, depth=2, num_heads=2, qkv_bias=True, norm_layer=LN6)
+        student = MultiCropWrapper(mk(), vits.DINOHead(128, K, hidden_dim=128, bottleneck_dim=64))
+        teacher = MultiCropWrapper(mk(), vits.DINOHead(128, K, hidden_dim=128, bottleneck_dim=64))
+        teacher.load_state_dict(student.state_dict())
+        crit = DINOLoss(K, 2 + nl, 0.07, 0.04, 3, 10)
+        eng = LafsPretrainEngine(student, teacher, crit, B, n_local=nl, use_graph=False, device=DEV)
+        g = torch.Generator().manual_seed(seed)
+        crops = [torch.randn(B, 3, 112, 112, generator=g).clamp(-1, 1).to(DEV) for _ in range(2)] + \
+                [torch.randn(B, 3, 48, 48, generator=g).clamp(-1, 1).to(DEV) for _ in range(nl)]
+        return eng, teacher, crops
+
+    def run(eng, crops, stream, out):
+        with torch.cuda.stream(stream):
+            out["losses"] = [eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1) for _ in range(3)]
+        stream.synchronize()
+        out["losses"] = [float(x.item()) for x in out["losses"]]
+
+    # reference: the two runs one after the other
+    ref = {}
+    for seed in (1, 2):
+        eng, teacher, crops = build(seed)
+        assert _lib.lib().lafs_trunk_row_ranges(C.byref(Fn_desc(eng))) == 2
+        o = {}
+        run(eng, crops, torch.cuda.Stream(), o)
+        ref[seed] = (o["losses"], eng.ta.master.clone(), eng.sa.master.clone())
+    # concurrent: two engines, two contexts, two threads, two streams
+    pair = {seed: build(seed) for seed in (1, 2)}
+    assert pair[1][0].ctx.handle != pair[2][0].ctx.handle
+    outs, threads = {1: {}, 2: {}}, []
+    streams = {1: torch.cuda.Stream(), 2: torch.cuda.Stream()}
+    torch.cuda.synchronize()
+    for seed in (1, 2):
+        t = threading.Thread(target=run, args=(pair[seed][0], pair[seed][2], streams[seed], outs[seed]))
+        t.start(); threads.append(t)
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for seed in (1, 2):
+        l_ref, t_ref, s_ref = ref[seed]
+        l = outs[seed]["losses"]
+        assert abs(l[0] - l_ref[0]) <= 1e-6 * abs(l_ref[0]), (seed, l, l_ref)              # same weights, same arithmetic
+        for a, b in zip(l[1:], l_ref[1:]):
+            assert abs(a - b) <= 5e-3 * abs(b), (seed, l, l_ref)                            # (position-table gradient atomics through Adam's first steps)
+        eng = pair[seed][0]
+        for mine, want in ((eng.ta.master, t_ref), (eng.sa.master, s_ref)):
+            d = (mine - want).abs()
+            assert float(d.max()) <= 3 * 2.1e-3 and float((d > 1e-5).float().mean()) < 2e-2, (seed, float(d.max()))
+
+
+def Fn_desc(eng):
+    """The student trunk's C descriptor as the engine builds it (for lafs_trunk_row_ranges)."""
+    from lafs_cvpr2024_amd import functional as Fn
+    return Fn.make_trunk_desc(eng.sa, eng.spec_s.trunk, eng.geom_s, None, with_grad=True)

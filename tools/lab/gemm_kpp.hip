@@ -22,6 +22,9 @@
 #include <stdlib.h>
 #include "common.hpp"
 #include "gemm_kres.hpp"
+// (round 5: moved out of the product library -- measured level with gemm_kres.hip, tools/lab/NOTES.md; lab record only)
+bool lafs_kpp_selected(const lafs_gemm_nt_args* g);
+int lafs_kpp_launch(const lafs_gemm_nt_args* g, hipStream_t stream);
 
 namespace kpp {
 

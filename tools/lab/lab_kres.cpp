@@ -8,6 +8,8 @@
 #define LAFS_KRES_LAB
 #include "../../lafs_cvpr2024_amd/csrc/gemm_kres.hip"
 
+#include "../../lafs_cvpr2024_amd/csrc/ctx.hpp"
+int lafs_ctx_opt(const lafs_ctx*, int o) { static const int d[LAFS_OPT_COUNT] = {0, 2, 15, 4, 1, 1, 0, 1}; return d[o]; }
 extern "C" void lafs_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 
 struct Bufs { bf16_t *A, *W, *C, *C2, *aux; float *bias, *resid, *Cf; };
