@@ -193,6 +193,8 @@ def lib():
         path = LIB_PATH
         if os.environ.get("LAFS_USE_ABLATE_LIB") == "1":          # tools/bench_kernels.py ablate: result-changing timing flags
             path = os.path.join(_HERE, "liblafs_hip_ablate.so")
+        elif os.environ.get("LAFS_LIB_VARIANT"):                  # lab: an A/B build of the same sources (csrc/Makefile `variant`)
+            path = os.path.join(_HERE, "liblafs_hip_%s.so" % os.environ["LAFS_LIB_VARIANT"])
         if not os.path.isfile(path):
             raise LafsHipError(f"{path} not found: the HIP extension is not built (run __graft_entry__.build()); "
                                "there is no CPU fallback")

@@ -18,6 +18,7 @@
 #include "common.hpp"
 #include "lafs_hip.h"
 #include "gemm_kres.hpp"
+#include "gemm_big.hpp"
 #include "ctx.hpp"
 
 // Timing ablations that change RESULTS (no stores / no MFMA / ...) exist only in the -DLAFS_ABLATE build (make ablate ->
@@ -847,6 +848,7 @@ extern "C" int lafs_gemm_nt_slices(int K, int splits) { return K >= 32 ? ceil_di
 extern "C" int lafs_gemm_nt_route(const lafs_gemm_nt_args* g) {
   if (g == nullptr) return 0;
   if (lafs_kres_eligible(g)) return 1;
+  if (lafs_big_eligible(g)) return 5;               // wide long-K shapes: 192x256 tiles, one persistent workgroup per CU (gemm_big.hip)
   if (g->operand_f16) return 0;                     // fp16 operands (landmark CNN plan): launch_nt takes the 128x128 fp16 kernel first
   const int splits = (g->epilogue == LAFS_EPI_ATOMIC_F32 || g->epilogue == LAFS_EPI_F32) && g->splits > 1 ? g->splits : 1;
   // the tiled kernel's 128x384 form (launch_nt): plain / residual epilogue, 64-deep stages (K % 64 == 0, K >= 640), no K split
@@ -884,6 +886,10 @@ extern "C" int lafs_gemm_nt(const lafs_gemm_nt_args* g, hipStream_t stream) {
   LAFS_CHECK_ARG(!(g->drop_p > 0.f) || ((long)g->M + g->drop_row0) * g->N < 4294967296L, "dropout needs (row0 + M) * N < 2^32");
   LAFS_CHECK_ARG(g->drop_row0 >= 0, "drop_row0 must be >= 0");
   if (lafs_kres_eligible(g)) return lafs_kres_launch(g, stream);   // K = 384 streaming shapes of the ViT-S trunk (gemm_kres.hip)
+  if (lafs_big_eligible(g)) {                                      // wide long-K shapes of the Part-fViT trunk (gemm_big.hip)
+    LAFS_CHECK_ARG(g->epilogue != LAFS_EPI_RESID_F32 || g->seq_scale == nullptr || g->row2seq != nullptr, "seq_scale needs row2seq");
+    return lafs_big_launch(g, stream);
+  }
   int splits = 1;
   a.klen = g->K;
   if (g->epilogue == LAFS_EPI_ATOMIC_F32 || (g->epilogue == LAFS_EPI_F32 && g->splits > 1)) {

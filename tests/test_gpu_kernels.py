@@ -176,6 +176,75 @@ def test_gemm_nt_k_resident_kernel(M, N):
     assert ops.gemm_nt(Ad, Bd, _lib.EPI_F32, splits=2, route_only=True) == 0
 
 
+@pytest.mark.parametrize("geo", [2, 3])
+@pytest.mark.parametrize("M,N,K", [(192 * 75 + 37, 768, 2048), (192 * 54 + 5, 2112, 768), (192 * 80 + 37, 704, 768), (12288, 2048, 512)])
+def test_gemm_nt_big_tiles_equal_the_tiled_kernel_bit_for_bit(M, N, K, geo):
+    """The wide long-K linears of the Part-fViT trunk (FeedForward 768 <-> 2048, to_qkv 2112, to_out 704; face_pre_pro/ViT_face.py:
+    126-149) on the 192x256 one-workgroup-per-CU kernel (gemm_big.hip, route 5) against the 128x128 tiled kernel selected through a
+    context with LAFS_OPT_NT_BIG = 0: the same MFMA, the same k order per output element, the same epilogue arithmetic -- plain,
+    GELU pair (both first-tensor forms, forward-only form), residual + DropPath scale, GELU', each with and without element dropout --
+    must agree BIT FOR BIT; against fp32 torch within the bf16 tolerances; ragged last row tile (rows past M untouched), ragged last
+    column tile (N = 704, 2112), many tiles per persistent workgroup (the operand ring runs across tile boundaries)."""
+    A, B = rnd_bf(M, K, seed=31), rnd_bf(N, K, scale=0.05, seed=32)
+    g = torch.Generator().manual_seed(33)
+    bias = torch.randn(N, generator=g)
+    ref = A.float() @ B.float().t() + bias
+    Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
+    tiled = _lib.Ctx(DEV, options={_lib.OPT_NT_BIG: 0}, from_env=False)
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 5, "expected the 192x256 route (plain epilogue, full rounds)"
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True, ctx=tiled) in (0, 3, 4)     # (any tile form of gemm.hip: same k order)
+    big = _lib.Ctx(DEV, options={_lib.OPT_NT_BIG: geo}, from_env=False)      # every epilogue forced onto the kernel (default: plain only)
+    guard = 7.0
+    nseq = 13
+    row2seq = (torch.arange(M) * nseq // M).int().to(DEV)
+    sc = torch.tensor([0.0 if i % 5 == 2 else 1.0 / 0.9 for i in range(nseq)]).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    aux = rnd_bf(M, N, seed=35).to(DEV)
+
+    def run(epi, ctx, **kw):
+        f32 = epi == _lib.EPI_RESID_F32
+        out = torch.full((M + 200, N), guard, device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+        res = ops.gemm_nt(Ad, Bd, epi, out=out[:M], ctx=ctx, **kw)
+        assert float((out[M:].float() - guard).abs().max()) == 0.0, "rows past M were written"
+        return res
+    for p_drop in (0.0, 0.1):
+        dk = dict(drop_p=p_drop, drop_seed=91)
+        # plain
+        if p_drop == 0.0:
+            a, b = run(_lib.EPI_BF16, big, bias=bd), run(_lib.EPI_BF16, tiled, bias=bd)
+            assert torch.equal(a, b) and relerr(a.float(), ref) < 1e-2
+        # GELU pair: u / gelu'(u) as first tensor, and the forward-only form
+        for act in (0, 1):
+            o2a = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); o2b = torch.empty_like(o2a)
+            ua = run(_lib.EPI_BF16_GELU, big, bias=bd, out2=o2a, act=act, **dk)[0]
+            ub = run(_lib.EPI_BF16_GELU, tiled, bias=bd, out2=o2b, act=act, **dk)[0]
+            assert torch.equal(ua, ub) and torch.equal(o2a, o2b)
+            if p_drop == 0.0:
+                assert relerr(o2a.float(), F.gelu(ref)) < 1e-2
+                if act == 0:
+                    assert relerr(ua.float(), ref) < 1e-2
+        o2a = torch.empty(M, N, device=DEV, dtype=torch.bfloat16); o2b = torch.empty_like(o2a)
+        ops.gemm_nt(Ad, Bd, _lib.EPI_BF16_GELU, bias=bd, out2=o2a, skip_pre=True, ctx=big, **dk)
+        ops.gemm_nt(Ad, Bd, _lib.EPI_BF16_GELU, bias=bd, out2=o2b, skip_pre=True, ctx=tiled, **dk)
+        assert torch.equal(o2a, o2b)
+        # residual + DropPath scale (+ element dropout on the branch output), out of place and in place
+        kw = dict(bias=bd, resid=resid, seq_scale=sc, row2seq=row2seq, **dk)
+        a, b = run(_lib.EPI_RESID_F32, big, **kw), run(_lib.EPI_RESID_F32, tiled, **kw)
+        assert torch.equal(a, b)
+        if p_drop == 0.0:
+            assert relerr(a, resid.cpu() + sc.cpu()[row2seq.cpu().long()].unsqueeze(1) * ref) < 2e-4
+            inplace = resid.clone()
+            ops.gemm_nt(Ad, Bd, _lib.EPI_RESID_F32, bias=bd, resid=inplace, seq_scale=sc, row2seq=row2seq, out=inplace, ctx=big)
+            assert torch.equal(inplace, a), "in-place residual"
+        # GELU' input gradient: saved gelu'(u) multiplied in / derivative evaluated from u
+        for act in (0, 1):
+            a, b = run(_lib.EPI_DGELU_BF16, big, aux=aux, act=act, **dk), run(_lib.EPI_DGELU_BF16, tiled, aux=aux, act=act, **dk)
+            assert torch.equal(a, b)
+    x = aux.float().cpu().requires_grad_(True)
+    F.gelu(x).sum().backward()
+    assert relerr(run(_lib.EPI_DGELU_BF16, big, aux=aux).float(), (A.float() @ B.float().t()) * x.grad) < 1e-2
+
+
 _TILED_SNIPPET = """
 import torch, torch.nn.functional as F
 from lafs_cvpr2024_amd import _lib, ops

@@ -637,7 +637,7 @@ def test_two_engines_on_two_contexts_and_two_caller_streams_equal_the_single_eng
 
     def run(eng, crops, stream, out):
         with torch.cuda.stream(stream):
-            out["losses"] = [eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1) for _ in range(3)]
+            out["losses"] = [eng.step(crops, lr=1e-3, wd=0.04, momentum=0.9, teacher_temp=0.05, epoch=1).clone() for _ in range(3)]
         stream.synchronize()
         out["losses"] = [float(x.item()) for x in out["losses"]]
 

@@ -174,7 +174,8 @@ def test_mynet_optimizer_index_order_is_the_reference_adamw_order():
 def test_gemm_route_selection_on_the_benchmark_shapes():
     """lafs_gemm_nt_route is host logic (no launch): which kernel form every long GEMM of the three measured workloads takes.
     0 = 128x128 tiles, 1 = K-resident, 3 = 128x384 wide tile (its tiles fit one round of the chip), 4 = 160-row tiles (one round of
-    the 512 workgroup slots less than 128-row tiles would need)."""
+    the 512 workgroup slots less than 128-row tiles would need), 5 = 192x256 tiles on one persistent workgroup per CU (plain epilogue,
+    wide long-K shapes whose tiles fill whole rounds of the 256 CUs)."""
     import ctypes as C
     from lafs_cvpr2024_amd import _lib
     try:
@@ -198,6 +199,8 @@ def test_gemm_route_selection_on_the_benchmark_shapes():
     # Part-fViT (ViT-B: C4 fine-tune at 25 216 rows, the mynet pair's chains)
     for epi, N, K in ((B16, 768, 2048), (B16, 768, 2112), (B16, 704, 768), (RES, 768, 2048), (RES, 768, 704), (GELU, 2048, 768), (DG, 2048, 768)):
         assert route(25216, N, K, epi) == 4, (N, K, epi)                                              # 3 -> 2 / 7 -> 5 rounds
-    assert route(25216, 2112, 768, B16) == 0                                                          # 17 column tiles: 7 rounds either way
+    assert route(25216, 2112, 768, B16) == 5                                                          # 132 x 9 tiles of 192x256 = 4.6 rounds, 93 % full
+    assert route(44160, 768, 2048, B16) == 5 and route(44160, 2112, 768, B16) == 5                    # merged rows: 690 / 2070 tiles, 90 % full
+    assert route(44160, 768, 2048, RES) != 5 and route(44160, 2048, 768, GELU) != 5                   # (heavy epilogues stay on the tiled kernel)
     assert route(18944, 768, 2048, B16) == 0                                                          # 888 tiles: 2 rounds either way
     assert route(1024, 768, 2048, B16) == 0
