@@ -198,20 +198,35 @@ def roofline_fc2(device, iters=200):
 ROOFLINE_KERNELS = {"wgrad_kernel": roofline_wgrad_group, "gemm_nt_kernel": roofline_fc2, "gemm_kres_kernel": roofline_fc1}
 
 
-def dominant_kernel_name():
-    """The kernel with the largest per-step total in the newest committed serialised profile of the step
-    (profiles/round<N>_serial_kernel_stats.csv, rocprofv3 --kernel-trace --stats); falls back to the weight-gradient kernel."""
+def kernel_families():
+    """{family: ms per step} from the newest committed SERIALISED profile of the step (profiles/round<N>_serial_kernel_stats.csv:
+    rocprofv3 --kernel-trace --stats with LAFS_SINGLE_STREAM=1 --no-graph, exclusive times).  A family = every template instantiation
+    of one kernel (the name up to '<'): the K = 384 GEMMs are five instantiations of gemm_kres_kernel and lead the step as a set
+    although no single one of them does."""
     import csv
     import glob
     import re
+    fam = {}
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_serial_kernel_stats.csv")),
+               key=lambda x: int(re.search(r"round(\d+)_", os.path.basename(x)).group(1)))[-1]
+    rows = list(csv.DictReader(open(f)))
+    # steps in the trace: the per-step zeroing kernel runs once per step
+    steps = max([int(r["Calls"]) for r in rows if "zero_chunks_kernel" in r["Name"]] or [1])
+    for r in rows:
+        name = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        key = name.split("<")[0].split("(")[0].strip()
+        fam[key] = fam.get(key, 0.0) + float(r["TotalDurationNs"]) / 1e6 / steps
+    return fam, os.path.relpath(f, ROOT)
+
+
+def dominant_kernel_name():
+    """The kernel FAMILY with the largest per-step total in the newest committed serialised profile of the step (all instantiations
+    of a template summed); its heaviest launch is the one timed live.  Falls back to the weight-gradient kernel."""
     try:
-        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_serial_kernel_stats.csv")),
-                   key=lambda x: int(re.search(r"round(\d+)_", os.path.basename(x)).group(1)))[-1]
-        rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs"]))
-        for r in rows:
-            for key in ROOFLINE_KERNELS:
-                if key in r["Name"]:
-                    return key
+        fam, _ = kernel_families()
+        for key, _ms in sorted(fam.items(), key=lambda kv: -kv[1]):
+            if key in ROOFLINE_KERNELS:
+                return key
     except Exception:
         pass
     return "wgrad_kernel"
@@ -220,6 +235,13 @@ def dominant_kernel_name():
 def dominant_kernel_roofline(device, iters=200):
     dom = dominant_kernel_name()
     out = ROOFLINE_KERNELS[dom](device, iters)
+    try:                                             # how the families rank in that profile (ms of exclusive kernel time per step)
+        fam, src = kernel_families()
+        out["family"] = dom
+        out["family_ms_per_step"] = {k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:6]}
+        out["family_profile"] = src
+    except Exception:
+        pass
     out["others"] = [fn(device, iters) for k, fn in ROOFLINE_KERNELS.items() if k != dom]
     return out
 
@@ -284,17 +306,20 @@ def partfvit_pass_flops(n_seq, n_tok_seq, dim=768, heads=11, mlp=2048, depth=12)
 
 
 def roofline_partfvit_dgrad(device, M, iters=100):
-    """Dominant kernel of both Part-fViT workloads in the serialised profiles (profiles/round4_finetune_kernel_table.txt,
-    round4_mynet_kernel_table.txt): gemm_nt_kernel<BF16,2,64> -- the plain input-gradient GEMMs; its largest instance is the fc1
-    input gradient dH2 = dU W1 (M tokens, N = 768, K = 2048).  Algorithmic bytes: dU and W1^T (bf16) read once, dH2 (bf16) written."""
+    """Dominant kernel family of both Part-fViT workloads in the serialised profiles (profiles/round*_finetune_kernel_table.txt,
+    round*_mynet_kernel_table.txt): the plain input-gradient GEMMs; the largest instance is the fc1 input gradient dH2 = dU W1
+    (M tokens, N = 768, K = 2048), on whichever kernel lafs_gemm_nt routes it to (named in the line).  Algorithmic bytes: dU and
+    W1^T (bf16) read once, dH2 (bf16) written."""
     from lafs_cvpr2024_amd import _lib, ops
     N, K = 768, 2048
     A = torch.randn(M, K, device=device).to(torch.bfloat16)
     W = (torch.randn(N, K, device=device) * 0.02).to(torch.bfloat16)
     out = torch.empty(M, N, device=device, dtype=torch.bfloat16)
     dur = _time_on_stream(lambda: ops.gemm_nt(A, W, _lib.EPI_BF16, out=out), iters)
-    return _roof(f"gemm_nt_kernel<BF16,2,64> M={M} N=768 K=2048 (Part-fViT fc1 input gradient, tiled LDS-DMA kernel)", dur,
-                 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0)
+    route = ops.gemm_nt(A, W, _lib.EPI_BF16, out=out, route_only=True)
+    kern = {5: "gemm_big_kernel<BF16> 192x256 tiles, one persistent workgroup per CU", 4: "gemm_nt_kernel<BF16,2,64,MB=5> 160x128 tiles",
+            3: "gemm_nt_kernel<BF16,2,64,6> 128x384 tiles"}.get(route, "gemm_nt_kernel<BF16,2,64> 128x128 tiles")
+    return _roof(f"{kern} M={M} N=768 K=2048 (Part-fViT fc1 input gradient)", dur, 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0)
 
 
 EXTRA_ROOFLINE = True            # --no-roofline: the extras' kernel tables under rocprofv3 must not contain the roofline loops
