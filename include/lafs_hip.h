@@ -304,6 +304,18 @@ int lafs_dino_loss_fwd_bwd(const float* student, const float* teacher, int ld, c
                            int B, int K, float student_temp, float teacher_temp, float* loss_out,
                            void* grad, int ldg, int grad_is_bf16, float grad_scale, float* workspace,
                            const float* dev_temps, hipStream_t stream);
+/* DINOHead's last layer of BOTH networks + DINOLoss.forward + the row sums of update_center in one piece (vision_transformer.py:
+ * 295-301, lafs_train.py:643-679): the [ncrops B + 2 B, K] logits are formed twice on the MFMA (a K = 256 contraction per class) and
+ * never stored.  zn_*: bf16 [rows, 256] L2-normalised bottleneck rows (student: ncrops B rows in crop-major order, teacher: 2 B),
+ * wn_*: bf16 [Kpad, 256] weight-normalised last-layer rows (pad rows zero), center f32 [K].  Outputs: loss_out f32 [1];
+ * grad_bf16 [ncrops B, ldg] = grad_scale * dL/d(student logits) (pad columns K..Kpad zero); colsum_out f32 [K] (optional) =
+ * sum over the teacher rows of the raw teacher logits.  Same closed form as lafs_dino_loss_fwd_bwd; no atomics: deterministic.
+ * dim must be 256, B <= 64, Kpad % 8 == 0.  workspace f32: lafs_dino_head_loss_workspace(ncrops, B, K) floats. */
+int64_t lafs_dino_head_loss_workspace(int ncrops, int B, int K);
+int lafs_dino_head_loss(const void* zn_student, const void* zn_teacher, const void* wn_student, const void* wn_teacher, int dim,
+                        const float* center, int ncrops, int B, int K, int Kpad, float student_temp, float teacher_temp,
+                        const float* dev_temps, float* loss_out, void* grad_bf16, int ldg, float grad_scale, float* colsum_out,
+                        float* workspace, hipStream_t stream);
 /* colsum(f32)[k] = sum_rows teacher[r, k]   (lafs_train.py:674; all-reduced by the caller) */
 int lafs_colsum_f32(const float* x, int ld, int rows, int K, float* out, hipStream_t stream);
 /* center = center*m + colsum/(rows_total) * (1-m)   (lafs_train.py:676-679) */

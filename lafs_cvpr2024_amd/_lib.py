@@ -154,6 +154,7 @@ _PROTOS = {
     "lafs_mixup_normalize": [vp, vp, i32, i32, f32, vp],
     "lafs_margin_softmax_ce_bf16": [vp, i32, i32, i32, vp, vp, f32, vp, f32, f32, i32, f32, vp, i32, vp, vp, vp],
     "lafs_cast_i64_i32": [vp, vp, i32],
+    "lafs_dino_head_loss": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, i32, f32, vp, vp],
     "lafs_transpose_bf16": [vp, i32, i32, i32, vp, i32],
     "lafs_unpatchify_f32": [vp, i32, i32, i32, vp],
     "lafs_patch_gather_fwd": [vp, vp, i32, i32, i32, vp],
@@ -172,6 +173,7 @@ _NO_STREAM = {
     "lafs_ablation_build": ([], i32),
     "lafs_last_error": ([], C.c_char_p),
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
+    "lafs_dino_head_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),
     "lafs_trunk_row_ranges": ([C.POINTER(TrunkDesc)], i32),
     "lafs_layernorm_bwd_parts": ([i32, i32], i32),

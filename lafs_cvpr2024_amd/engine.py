@@ -111,8 +111,17 @@ class LafsPretrainEngine:
         self.hyper_ring = PinnedRing((_lib.HP_COUNT,), f32)   # the host runs steps ahead of the GPU: never reuse a pinned
         self.temps = torch.zeros(2, device=dev, dtype=f32)    # staging buffer whose copy may still be pending
         self.temps_ring = PinnedRing((2,), f32)
-        self.logits_s = torch.zeros(self.ncrops * B, self.Kpad, device=dev, dtype=f32)
-        self.logits_t = torch.zeros(2 * B, self.Kpad, device=dev, dtype=f32)
+        # The last layer of both heads + the DINO loss + the centre sums as ONE fused group of launches (csrc/dino_head_loss.hip): the
+        # logits are formed twice on the MFMA instead of written once and read twice (0.9 GB and ~0.2 ms per step at C2).  Needs the
+        # DINOHead's default bottleneck (256) and at most 64 images per rank; LAFS_FUSED_HEAD=0 keeps the unfused kernels (A/B runs,
+        # and what the tests that look at the logits themselves use: `logits_s` / `logits_t` only exist there).
+        bott = student.head.last_layer.weight_v.shape[1]
+        self.fused_head = (bott == 256 and 2 * B <= 128 and os.environ.get("LAFS_FUSED_HEAD", "1") != "0")
+        self._logits_s = None if self.fused_head else torch.zeros(self.ncrops * B, self.Kpad, device=dev, dtype=f32)
+        self._logits_t = None if self.fused_head else torch.zeros(2 * B, self.Kpad, device=dev, dtype=f32)
+        self._head_states = None
+        self.head_ws = (torch.empty(_lib.lib().lafs_dino_head_loss_workspace(self.ncrops, B, self.K), device=dev, dtype=f32)
+                        if self.fused_head else None)
         self.dlogits = torch.zeros(self.ncrops * B, self.Kpad, device=dev, dtype=bf16)
         self.loss = torch.zeros(1, device=dev, dtype=f32)
         self.loss_ws = torch.empty(_lib.lib().lafs_dino_loss_workspace(self.ncrops, B, self.K), device=dev, dtype=f32)
@@ -193,6 +202,19 @@ class LafsPretrainEngine:
         self._st = {}
         self.step_count = 0
 
+    def _logits(self, which):
+        """The last step's logits [rows, Kpad] (f32).  With the fused head they are never stored: formed here on demand from the
+        last layer's saved operands (tests / diagnostics only)."""
+        if not self.fused_head:
+            return self._logits_s if which == 0 else self._logits_t
+        if self._head_states is None:
+            raise _lib.LafsHipError("no step has run yet")
+        st = self._head_states[which]
+        return ops.gemm_nt(st.zn, st.wn, _lib.EPI_F32, n_cols=st.Kpad)
+
+    logits_s = property(lambda self: self._logits(0))
+    logits_t = property(lambda self: self._logits(1))
+
     # ------------------------------------------------------------------ pieces (all capturable)
     def _pos_tokens(self, arena, spec, bufs):
         pe = arena.view(arena.master, spec.prefix + spec.pos).view(-1, spec.trunk.dim)
@@ -248,7 +270,7 @@ class LafsPretrainEngine:
             drop_t = self._drop_scales(self.keep_t, self.drop_t, 1) if vit_t.training else None   # rate 0 for the DINO ViT teacher
             dd_t = self._dropout_cfg(vit_t, self.dropout_seed_t)
             feat_t, _, _ = Fn.vit_forward(ta, self.spec_t, self.geom_t, [self.in_global_all], pos_t, drop_t, save=False, dropout=dd_t)
-            Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self.logits_t)
+            _, st_ht = Fn.head_forward(ta, self.head_prefix_t, feat_t, self.K, save=False, logits=self._logits_t, skip_logits=self.fused_head)
         # student: all views in one packed pass
         vit = self.student.backbone
         drop = self._drop_scales(self.keep_s, self.drop_s, 0) if vit.training else None
@@ -257,16 +279,23 @@ class LafsPretrainEngine:
         feat_s, st_v, _ = Fn.vit_forward(sa, self.spec_s, self.geom_s, imgs, self._pos_tokens(sa, self.spec_s, self.pos_s), drop,
                                          save=True, dropout=dd_s, wgrad_overwrite=True,
                                          wgrad_workgroups=int(os.environ.get("LAFS_WGRAD_WG", 200)) if self.side_stream is not None else 0)
-        _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self.logits_s)
+        _, st_h = Fn.head_forward(sa, self.head_prefix_s, feat_s, self.K, save=True, logits=self._logits_s, skip_logits=self.fused_head)
         cur.wait_stream(side)
-        # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
-        ops.dino_loss_fwd_bwd(self.logits_s, self.logits_t, self.dino_loss.center.view(-1), self.ncrops,
-                              float(self.dino_loss.student_temp), 0.04, K=self.K, grad=self.dlogits, ws=self.loss_ws,
-                              loss=self.loss, dev_temps=self.temps)
-        call("lafs_colsum_f32", _p(self.logits_t), self.Kpad, 2 * B, self.K, _p(self.colsum))
+        if self.fused_head:
+            # last layer of both heads + loss forward + dL/dlogits + center column sums, the logits never stored
+            ops.dino_head_loss(st_h.zn, st_ht.zn, st_h.wn, st_ht.wn, self.dino_loss.center.view(-1), self.ncrops, self.K,
+                               float(self.dino_loss.student_temp), 0.04, grad=self.dlogits, loss=self.loss, colsum=self.colsum,
+                               ws=self.head_ws, dev_temps=self.temps)
+        else:
+            # loss forward + dL/dlogits in the same two passes; center column sums of the raw teacher logits
+            ops.dino_loss_fwd_bwd(self._logits_s, self._logits_t, self.dino_loss.center.view(-1), self.ncrops,
+                                  float(self.dino_loss.student_temp), 0.04, K=self.K, grad=self.dlogits, ws=self.loss_ws,
+                                  loss=self.loss, dev_temps=self.temps)
+            call("lafs_colsum_f32", _p(self._logits_t), self.Kpad, 2 * B, self.K, _p(self.colsum))
         train_g = self.student.head.last_layer.weight_g.requires_grad
         dfeat = Fn.head_backward(sa, self.head_prefix_s, st_h, self.dlogits, train_g=train_g, overwrite_last=True)
         self._st = dict(vit=st_v, dfeat=dfeat)
+        self._head_states = (st_h, st_ht)
 
     def _seg_trunk_backward(self, k):
         """Run k of the trunk backward: blocks cuts[k]-1 .. cuts[k+1]; run 0 starts with the final norm, the last run ends with

@@ -280,8 +280,9 @@ class HeadState:
     __slots__ = ("x_bf", "u1", "a1", "u2", "a2", "z", "zn", "inv_z", "wn", "wn_t", "inv_v", "logits", "K", "Kpad")
 
 
-def head_forward(arena, prefix, x, K, save=True, logits=None):
-    """DINOHead: x f32 [n, in_dim] -> logits f32 [n, Kpad] (columns >= K are zero)."""
+def head_forward(arena, prefix, x, K, save=True, logits=None, skip_logits=False):
+    """DINOHead: x f32 [n, in_dim] -> logits f32 [n, Kpad] (columns >= K are zero).  skip_logits: stop in front of the last GEMM
+    (st.zn / st.wn are its operands): the training engine forms the logits inside the fused loss (ops.dino_head_loss)."""
     n = x.shape[0]
     dev = x.device
     st = HeadState()
@@ -300,6 +301,9 @@ def head_forward(arena, prefix, x, K, save=True, logits=None):
     st.inv_v = torch.empty(K, device=dev, dtype=f32)
     call("lafs_weightnorm_fwd", _p(m("last_layer.weight_v")), _p(m("last_layer.weight_g")), K, st.Kpad, Db, _p(st.wn),
          _p(st.wn_t), st.Kpad, _p(st.inv_v))
+    if skip_logits:
+        st.logits = None
+        return None, st
     if logits is None:
         logits = torch.empty(n, st.Kpad, device=dev, dtype=f32)
     ops.gemm_nt(st.zn, st.wn, _lib.EPI_F32, out=logits, n_cols=st.Kpad)

@@ -239,6 +239,25 @@ def patchify(img, order=_lib.PATCH_ORDER_CHW):
     return out
 
 
+def dino_head_loss(zn_s, zn_t, wn_s, wn_t, center, ncrops, K, student_temp, teacher_temp, grad, loss=None, colsum=None, ws=None,
+                   dev_temps=None, grad_scale=1.0):
+    """DINOHead's last layer of both networks + DINO loss + centre row sums with the logits never stored (csrc/dino_head_loss.hip).
+    zn_*: bf16 [rows, 256], wn_*: bf16 [Kpad, 256]; grad: bf16 [ncrops B, >= Kpad] (written); returns (loss[1], grad)."""
+    for t, n in ((zn_s, "zn_s"), (zn_t, "zn_t"), (wn_s, "wn_s"), (wn_t, "wn_t"), (grad, "grad")):
+        _chk(t, bf16, n)
+    rows, B = zn_s.shape[0], zn_t.shape[0] // 2
+    if rows != ncrops * B or zn_s.shape[1] != zn_t.shape[1] or wn_s.shape != wn_t.shape or not zn_s.is_contiguous() or not wn_s.is_contiguous() \
+            or not zn_t.is_contiguous() or not wn_t.is_contiguous():
+        raise _lib.LafsHipError("dino_head_loss: student rows = ncrops * B, teacher rows = 2 * B, contiguous operands of equal widths")
+    if ws is None:
+        ws = torch.empty(_lib.lib().lafs_dino_head_loss_workspace(ncrops, B, K), device=zn_s.device, dtype=torch.float32)
+    if loss is None:
+        loss = torch.empty(1, device=zn_s.device, dtype=torch.float32)
+    call("lafs_dino_head_loss", _p(zn_s), _p(zn_t), _p(wn_s), _p(wn_t), zn_s.shape[1], _p(center), ncrops, B, K, wn_s.shape[0],
+         student_temp, teacher_temp, _p(dev_temps), _p(loss), _p(grad), _ld(grad), grad_scale, _p(colsum), _p(ws))
+    return loss, grad
+
+
 def dino_loss_fwd_bwd(student, teacher, center, ncrops, student_temp, teacher_temp, K=None, grad=None, grad_bf16=True,
                       grad_scale=1.0, ws=None, loss=None, dev_temps=None):
     """Returns (loss[1] f32, grad [rows, ld] bf16|f32).  student/teacher may be padded (ld >= K)."""

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from lafs_cvpr2024_amd import _lib, ops  # noqa: E402
+from lafs_cvpr2024_amd.ops import _p, call  # noqa: E402
 
 DEV = "cuda"
 bf16 = torch.bfloat16
@@ -652,3 +653,49 @@ def test_wgrad_group_under_the_engines_workgroup_caps_at_block_shapes(name, M, d
             for c, r, s, sr in zip(Cs, refs, cs, cref):
                 assert float(((c - (0.5 if acc else 0.0)) - r).norm() / r.norm()) < 1e-4, (name, cap, acc, tuple(c.shape))
                 assert float((s - sr).norm() / sr.norm()) < 1e-4, (name, cap, acc, "colsum")
+
+
+@pytest.mark.parametrize("ncrops,B,K", [(4, 4, 1000), (10, 3, 8192), (10, 64, 100000)])
+def test_fused_head_and_dino_loss_equal_the_unfused_kernels(ncrops, B, K):
+    """lafs_dino_head_loss (the last layer of both DINO heads + DINOLoss.forward + the centre's row sums with the logits formed twice
+    on the MFMA and never stored; vision_transformer.py:295-301, lafs_train.py:643-679) against the unfused kernels it replaces in
+    the training step -- lafs_gemm_nt(F32) -> lafs_dino_loss_fwd_bwd + lafs_colsum_f32, themselves pinned by F4 -- on the same
+    operands: loss to 1e-6 relative, dL/dlogits equal up to single bf16 roundings (the exponentials are evaluated in another order),
+    pad columns exactly zero, centre sums to fp32 round-off; class counts that are no multiple of the 64-class block, a temperature
+    read from device memory; and twice in a row bit for bit (no atomics anywhere)."""
+    g = torch.Generator().manual_seed(40 + ncrops)
+    Kpad = (K + 127) // 128 * 128
+    nrm = lambda t: torch.nn.functional.normalize(t, dim=1)
+    zs, zt = nrm(torch.randn(ncrops * B, 256, generator=g)).to(bf16).to(DEV), nrm(torch.randn(2 * B, 256, generator=g)).to(bf16).to(DEV)
+    ws, wt = torch.zeros(Kpad, 256, dtype=bf16), torch.zeros(Kpad, 256, dtype=bf16)
+    ws[:K] = nrm(torch.randn(K, 256, generator=g)).to(bf16); wt[:K] = nrm(torch.randn(K, 256, generator=g)).to(bf16)
+    ws, wt = ws.to(DEV), wt.to(DEV)
+    center = (0.05 * torch.randn(K, generator=g)).to(DEV)
+    temps = torch.tensor([0.1, 0.055], device=DEV)
+    # unfused
+    ls = ops.gemm_nt(zs, ws, _lib.EPI_F32, n_cols=Kpad); lt = ops.gemm_nt(zt, wt, _lib.EPI_F32, n_cols=Kpad)
+    loss_ref, grad_ref = ops.dino_loss_fwd_bwd(ls, lt, center, ncrops, 0.1, 0.04, K=K, dev_temps=temps)
+    col_ref = torch.empty(K, device=DEV)
+    call("lafs_colsum_f32", _p(lt), Kpad, 2 * B, K, _p(col_ref))
+    # fused
+    guard = 3.0
+    grad = torch.full((ncrops * B + 8, Kpad), guard, device=DEV, dtype=bf16)
+    col = torch.full((K + 8,), guard, device=DEV)
+    loss, _ = ops.dino_head_loss(zs, zt, ws, wt, center, ncrops, K, 0.1, 0.04, grad=grad[:ncrops * B], colsum=col, dev_temps=temps)
+    assert abs(float(loss) - float(loss_ref)) <= 2e-6 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    assert float(loss) == pytest.approx(math.log(K), rel=0.2)
+    gf, gr = grad[:ncrops * B].float(), grad_ref.float()
+    scale = float(gr.abs().max())
+    assert float((gf - gr).abs().max()) <= 2.0 ** -7 * scale and relerr(gf, gr) < 1e-2
+    assert float((gf != gr).float().mean()) < 0.05, "more than single roundings apart"
+    assert float(gf[:, K:].abs().max()) == 0.0 if Kpad > K else True
+    assert torch.all(grad[ncrops * B:] == guard) and torch.all(col[K:] == guard), "wrote past the end"
+    torch.testing.assert_close(col[:K], col_ref, rtol=1e-5, atol=1e-5)
+    grad2 = torch.empty_like(grad[:ncrops * B]); col2 = torch.empty(K, device=DEV)
+    loss2, _ = ops.dino_head_loss(zs, zt, ws, wt, center, ncrops, K, 0.1, 0.04, grad=grad2, colsum=col2, dev_temps=temps)
+    assert torch.equal(loss2, loss) and torch.equal(grad2, grad[:ncrops * B]) and torch.equal(col2, col[:K])
+    # host temperatures (no device override) give the same as the device pair holding the same values
+    temps2 = torch.tensor([0.1, 0.04], device=DEV)
+    la, ga = ops.dino_head_loss(zs, zt, ws, wt, center, ncrops, K, 0.1, 0.04, grad=torch.empty_like(grad2))
+    lb, gb = ops.dino_head_loss(zs, zt, ws, wt, center, ncrops, K, 0.1, 0.04, grad=torch.empty_like(grad2), dev_temps=temps2)
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb)) and relerr(ga.float(), gb.float()) < 1e-2
