@@ -36,6 +36,10 @@ from .vision_transformer import DINOHead
 __all__ = ["DINOLoss", "get_args_parser", "train_lafs", "train_one_epoch", "SyntheticCrops"]
 
 
+# torch.cuda.amp.GradScaler().state_dict() of an unused scaler (its documented defaults): see the checkpoint's 'fp16_scaler' entry
+FP16_SCALER_STATE = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "_growth_tracker": 0}
+
+
 def get_args_parser():
     p = argparse.ArgumentParser('LAFS', add_help=False)
     p.add_argument('--arch', default='mynet', type=str, choices=['mynet', 'vit_tiny', 'vit_small', 'vit_base'])
@@ -285,6 +289,10 @@ def train_lafs(args, dataset=None):
             'epoch': epoch + 1,
             'args': args,
             'dino_loss': dino_loss.state_dict(),
+            # the reference stores its GradScaler's state under this key when it trains in fp16 (lafs_train.py:451-460) and hands the
+            # key to restart_from_checkpoint(fp16_scaler=...).  This path computes in bf16 (fp32 range: nothing to scale), so the entry
+            # is a fresh torch.cuda.amp.GradScaler's state_dict: a reference-side resume finds the key and loads a valid state
+            'fp16_scaler': FP16_SCALER_STATE,
         }
         utils.save_on_master(save_dict, ckpt)
         if args.saveckp_freq and epoch % args.saveckp_freq == 0:

@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """LAFS_TEST_SHUFFLE=<seed>: run the collected tests in a seeded random order (no plugin needed) -- the suite must not depend on
+    the alphabetical order the driver happens to use (round 4's order-dependent hipGraphLaunch crash: DESIGN.md section 7)."""
+    seed = os.environ.get("LAFS_TEST_SHUFFLE")
+    if seed:
+        import random
+        random.Random(int(seed)).shuffle(items)
+
+
 @pytest.fixture(autouse=True)
 def _release_gpu_memory_between_tests(request):
     """GPU tests build whole engines (hipGraph pools of several GB each): drop what a test leaves behind before the next one starts, so
