@@ -68,7 +68,7 @@ enum {
   LAFS_OPT_NT_WIDE = 4,        /* tiled GEMM: 128x384 tiles where they fit one round of the chip (default 1) */
   LAFS_OPT_NT_TALL = 5,        /* tiled GEMM: 160-row tiles where they save a round of workgroup slots (default 1) */
   LAFS_OPT_COMM_CUS = 6,       /* data-parallel runs: CUs left to the collective library's kernels by the K-resident GEMM (default 0) */
-  LAFS_OPT_NT_BIG = 7,         /* tiled GEMM: 256x256 one-workgroup-per-CU tiles for the wide long-K shapes (default 1) */
+  LAFS_OPT_NT_BIG = 7,         /* tiled GEMM: one-workgroup-per-CU 192x256 / 176x256 tiles for the wide long-K shapes (default 1; 2-4 force a geometry) */
   LAFS_OPT_COUNT = 8
 };
 lafs_ctx* lafs_ctx_create(int device);

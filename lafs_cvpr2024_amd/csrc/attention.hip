@@ -474,6 +474,269 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, long sequences
+// The same two phases for sequences of >= 10 tiles, re-cut for what bounds them (tools/lab/NOTES.md, round 5): with two waves per
+// SIMD and two tiles per wave item the loops were LDS-issue and VALU bound, 7 items fell on 8 waves, and the ~5 us of staging of
+// each of a CU's three pairs were exposed.  Here ONE 4-wave workgroup per CU walks over the pairs: a wave owns a SIMD and its whole
+// register file, takes T = NT/4 (+1) CONSECUTIVE tiles per phase (every LDS fragment feeds T x as many MFMAs: half the LDS
+// traffic of the two-tile form at T = 4; the T independent MFMA / exp2 chains are the wave's own latency hiding), and the next
+// pair's operands are requested into registers when phase A ends, so that they arrive behind phase B.
+template <int NT, int T>
+__device__ __forceinline__ void bwd_keys_item(const unsigned char* QsF, int k0, int len, bf16_t* drow, int ld, int inner, int lane,
+                                              float c2, float scale) {
+  constexpr int NTE = (NT + 1) & ~1, TILE = NTE * 16 * 128;   // tiles come in pairs: an odd NT has one more tile of zero rows
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool swp = (lds_f(c16) & 1) != 0;
+  const unsigned char* DsF = QsF + TILE;
+  const unsigned char* KsF = QsF + 2 * TILE;
+  const unsigned char* VsR = QsF + 3 * TILE;
+  const float* lsd = reinterpret_cast<const float*>(QsF + 4 * TILE);
+  bf16x8_t kf[T][2], vf[T][2];
+  f32x4_t dk[T][4], dv[T][4];
+#pragma unroll
+  for (int x = 0; x < T; ++x) {
+    const int key = (k0 + x) * 16 + c16;
+    kf[x][0] = rfrag_f(KsF, key, g, swp); kf[x][1] = rfrag_f(KsF, key, 4 + g, swp);
+    vf[x][0] = rfrag(VsR, key, g); vf[x][1] = rfrag(VsR, key, 4 + g);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[x][dt] = dk[x][dt]; }
+  }
+#pragma unroll 1
+  for (int u = 0; u < (NT + 1) / 2; ++u) {
+    float pv[T][8], ds[T][8];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int qt = 2 * u + tt;
+      const int qrow = qt * 16 + c16;
+      const bf16x8_t qa0 = rfrag_f(QsF, qrow, g, swp), qa1 = rfrag_f(QsF, qrow, 4 + g, swp);
+      const bf16x8_t da0 = rfrag_f(DsF, qrow, g, swp), da1 = rfrag_f(DsF, qrow, 4 + g, swp);
+      const float4 l4 = *reinterpret_cast<const float4*>(lsd + qt * 16 + g * 4);
+      const float4 d4 = *reinterpret_cast<const float4*>(lsd + NTE * 16 + qt * 16 + g * 4);
+      const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int x = 0; x < T; ++x) {
+        f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sx = mfma16(qa0, kf[x][0], sx);
+        sx = mfma16(qa1, kf[x][1], sx);
+        dp = mfma16(da0, vf[x][0], dp);
+        dp = mfma16(da1, vf[x][1], dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, lq[r]));
+          pv[x][tt * 4 + r] = p;
+          ds[x][tt * 4 + r] = p * fmaf(dp[r], scale, dq4[r]);
+        }
+      }
+    }
+    bf16x8_t pf[T], dsf[T];
+#pragma unroll
+    for (int x = 0; x < T; ++x) { pf[x] = pack_frag(pv[x]); dsf[x] = pack_frag(ds[x]); }
+    const int t0 = 2 * u, t1 = 2 * u + 1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16x8_t td = tfrag_f(DsF, t0, t1, dt, lane), tq = tfrag_f(QsF, t0, t1, dt, lane);
+#pragma unroll
+      for (int x = 0; x < T; ++x) {
+        dv[x][dt] = mfma16(td, pf[x], dv[x][dt]);
+        dk[x][dt] = mfma16(tq, dsf[x], dk[x][dt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < T; ++x) {
+    const int key = (k0 + x) * 16 + c16;
+    if (key < len) {
+      uint32_t w[8];
+      bf16_t* op = drow + (size_t)key * ld + inner + g * 16;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        w[2 * dt] = pack_bf2(dk[x][dt][0], dk[x][dt][1]);
+        w[2 * dt + 1] = pack_bf2(dk[x][dt][2], dk[x][dt][3]);
+      }
+      reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        w[2 * dt] = pack_bf2(dv[x][dt][0], dv[x][dt][1]);
+        w[2 * dt + 1] = pack_bf2(dv[x][dt][2], dv[x][dt][3]);
+      }
+      reinterpret_cast<uint4*>(op + inner)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      reinterpret_cast<uint4*>(op + inner)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+}
+
+template <int NT, int T>
+__device__ __forceinline__ void bwd_queries_item(const unsigned char* QsF, int q0, int len, bf16_t* drow, int ld, int lane, float c2,
+                                                 float scale) {
+  constexpr int NTE = (NT + 1) & ~1, TILE = NTE * 16 * 128;   // tiles come in pairs: an odd NT has one more tile of zero rows
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool swp = (lds_f(c16) & 1) != 0;
+  const unsigned char* DsF = QsF + TILE;
+  const unsigned char* KsF = QsF + 2 * TILE;
+  const unsigned char* VsR = QsF + 3 * TILE;
+  const float* lsd = reinterpret_cast<const float*>(QsF + 4 * TILE);
+  bf16x8_t qf[T][2], df[T][2];
+  float nlse_q[T], ndel_q[T];
+  f32x4_t dq[T][4];
+#pragma unroll
+  for (int x = 0; x < T; ++x) {
+    const int q = (q0 + x) * 16 + c16;
+    qf[x][0] = rfrag_f(QsF, q, g, swp); qf[x][1] = rfrag_f(QsF, q, 4 + g, swp);
+    df[x][0] = rfrag_f(DsF, q, g, swp); df[x][1] = rfrag_f(DsF, q, 4 + g, swp);
+    nlse_q[x] = lsd[q]; ndel_q[x] = lsd[NTE * 16 + q];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll 1
+  for (int u = 0; u < (NT + 1) / 2; ++u) {
+    float ds[T][8];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * u + tt;
+      const int krow = t * 16 + c16;
+      const bf16x8_t ka0 = rfrag_f(KsF, krow, g, swp), ka1 = rfrag_f(KsF, krow, 4 + g, swp);
+      const bf16x8_t va0 = rfrag(VsR, krow, g), va1 = rfrag(VsR, krow, 4 + g);
+#pragma unroll
+      for (int x = 0; x < T; ++x) {
+        f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        sx = mfma16(ka0, qf[x][0], sx);
+        sx = mfma16(ka1, qf[x][1], sx);
+        dp = mfma16(va0, df[x][0], dp);
+        dp = mfma16(va1, df[x][1], dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ds[x][tt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, nlse_q[x])) * fmaf(dp[r], scale, ndel_q[x]);
+        }
+      }
+    }
+    bf16x8_t dsf[T];
+#pragma unroll
+    for (int x = 0; x < T; ++x) dsf[x] = pack_frag(ds[x]);
+    const int t0 = 2 * u, t1 = 2 * u + 1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16x8_t tk = tfrag_f(KsF, t0, t1, dt, lane);
+#pragma unroll
+      for (int x = 0; x < T; ++x) dq[x][dt] = mfma16(tk, dsf[x], dq[x][dt]);
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < T; ++x) {
+    const int q = (q0 + x) * 16 + c16;
+    if (q < len) {
+      uint32_t w[8];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        w[2 * dt] = pack_bf2(dq[x][dt][0], dq[x][dt][1]);
+        w[2 * dt + 1] = pack_bf2(dq[x][dt][2], dq[x][dt][3]);
+      }
+      bf16_t* op = drow + (size_t)q * ld + g * 16;
+      reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+}
+
+template <int IT>
+struct BwdRegs { uint4 q[IT], d[IT], k[IT], v[IT], o[IT]; float l[IT]; };
+
+template <int NT, int IT>
+__device__ __forceinline__ void bwd_request(const AttnArgs& a, int pair, int tid, BwdRegs<IT>& R) {
+  constexpr int ROWS = ((NT + 1) & ~1) * 16;
+  const int inner = a.heads * 64;
+  const int seq = pair / a.heads, h = pair % a.heads;
+  const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
+  const bf16_t* qb = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
+  const bf16_t* db = a.dout + (size_t)tok0 * a.lddo + h * 64;
+  const bf16_t* ob = a.out + (size_t)tok0 * a.ldo + h * 64;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+    R.q[i] = make_uint4(0, 0, 0, 0); R.d[i] = R.q[i]; R.k[i] = R.q[i]; R.v[i] = R.q[i]; R.o[i] = R.q[i]; R.l[i] = 0.f;
+    if (idx < ROWS * 8 && row < len) {
+      const bf16_t* qr = qb + (size_t)row * a.ldqkv + ch * 8;
+      R.q[i] = *reinterpret_cast<const uint4*>(qr);
+      R.k[i] = *reinterpret_cast<const uint4*>(qr + inner);
+      R.v[i] = *reinterpret_cast<const uint4*>(qr + 2 * inner);
+      R.d[i] = *reinterpret_cast<const uint4*>(db + (size_t)row * a.lddo + ch * 8);
+      R.o[i] = *reinterpret_cast<const uint4*>(ob + (size_t)row * a.ldo + ch * 8);
+      if (ch == 0) R.l[i] = a.lse[(size_t)(tok0 + row) * a.heads + h];
+    }
+  }
+}
+
+template <int NT, int IT>
+__device__ __forceinline__ void bwd_deposit(unsigned char* s0, float scale, int tid, const BwdRegs<IT>& R) {
+  constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, TILE = NTE * 16 * 128;
+  float* lsd = reinterpret_cast<float*>(s0 + 4 * TILE);
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
+    const uint4 x = R.o[i], y = R.d[i];
+    float d = bf_lo(x.x) * bf_lo(y.x) + bf_hi(x.x) * bf_hi(y.x) + bf_lo(x.y) * bf_lo(y.y) + bf_hi(x.y) * bf_hi(y.y) +
+              bf_lo(x.z) * bf_lo(y.z) + bf_hi(x.z) * bf_hi(y.z) + bf_lo(x.w) * bf_lo(y.w) + bf_hi(x.w) * bf_hi(y.w);
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    if (idx < ROWS * 8) {
+      lds_put<2>(s0, row, ch, R.q[i]); lds_put<2>(s0 + TILE, row, ch, R.d[i]);
+      lds_put<2>(s0 + 2 * TILE, row, ch, R.k[i]); lds_put<0>(s0 + 3 * TILE, row, ch, R.v[i]);
+      if (ch == 0) {                                       // negated and pre-scaled, as in attn_bwd_fused_kernel; rows past the
+        lsd[row] = -1.4426950408889634f * R.l[i];          // sequence carry 0 (their probabilities only have to stay finite)
+        lsd[ROWS + row] = -scale * d;
+      }
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn_bwd_long_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int ROWS = ((NT + 1) & ~1) * 16;
+  constexpr int IT = (ROWS * 8 + 255) / 256;
+  constexpr int BASE = NT / 4, REM = NT % 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int inner = a.heads * 64;
+  const int n_pairs = a.n_seq * a.heads;
+  const float c2 = a.scale * 1.4426950408889634f;
+  BwdRegs<IT> R;
+  int pair = blockIdx.x;
+#ifndef LAFS_LAB_ATTN_NOPF
+  bwd_request<NT, IT>(a, pair, tid, R);
+#endif
+  for (;;) {
+#ifdef LAFS_LAB_ATTN_NOPF
+    bwd_request<NT, IT>(a, pair, tid, R);
+#endif
+    bwd_deposit<NT, IT>(smem, a.scale, tid, R);
+    __syncthreads();
+    const int seq = pair / a.heads, h = pair % a.heads;
+    const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
+    bf16_t* drow = a.dqkv + (size_t)tok0 * a.lddqkv + h * 64;
+    {                                                      // phase A: wave w takes key tiles [w*BASE + min(w, REM), +BASE (+1))
+      const int k0 = wave * BASE + min(wave, REM);
+      if (k0 * 16 < len) {
+        if (REM != 0 && wave < REM) bwd_keys_item<NT, BASE + 1>(smem, k0, len, drow, a.lddqkv, inner, lane, c2, a.scale);
+        else bwd_keys_item<NT, BASE>(smem, k0, len, drow, a.lddqkv, inner, lane, c2, a.scale);
+      }
+    }
+    const int next = pair + gridDim.x;
+#ifndef LAFS_LAB_ATTN_NOPF
+    if (next < n_pairs) bwd_request<NT, IT>(a, next, tid, R);
+#endif
+    {                                                      // phase B: the query tiles, dealt from the other end
+      const int w = 3 - wave;
+      const int q0 = w * BASE + min(w, REM);
+      if (q0 * 16 < len) {
+        if (REM != 0 && w < REM) bwd_queries_item<NT, BASE + 1>(smem, q0, len, drow, a.lddqkv, lane, c2, a.scale);
+        else bwd_queries_item<NT, BASE>(smem, q0, len, drow, a.lddqkv, lane, c2, a.scale);
+      }
+    }
+    if (next >= n_pairs) break;
+    pair = next;
+    __syncthreads();
+  }
+}
+
 template <typename K>
 int launch_attn(K kernel, int n_pairs, int ppb, int threads, size_t lds, const AttnArgs& a, hipStream_t s) {
   // raise the dynamic-LDS limit once per kernel instantiation (not a stream operation; kept out of graph capture)
@@ -508,6 +771,13 @@ int dispatch(int which, const AttnArgs& a, hipStream_t s) {
   // the former delta + dQ + dK/dV kernels; short ones two pairs per 4-wave workgroup, one tile per item: 512 x 37 in 32 us
   // against 42.
   const size_t pair_bytes = 4 * tile + 2 * NT * 16 * 4;
+#ifndef LAFS_LAB_ATTN_BWD_OLD
+  if constexpr (NT >= 10) {
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
+    constexpr int NTE = (NT + 1) & ~1;
+    return launch_attn(attn_bwd_long_kernel<NT>, min(n_pairs, n_cu), 1, 256, (size_t)NTE * 16 * (4 * 128 + 8), a, s);
+  }
+#endif
   if constexpr (NT >= 7) return launch_attn(attn_bwd_fused_kernel<NT, 1, 8, 2>, n_pairs, 1, 512, pair_bytes, a, s);
   else return launch_attn(attn_bwd_fused_kernel<NT, 2, 4, 1>, n_pairs, 2, 256, 2 * pair_bytes, a, s);
 }

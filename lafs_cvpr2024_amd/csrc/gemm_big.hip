@@ -46,13 +46,17 @@ template <int MBW_, int NBW_, int NWM_, int NWN_> struct Geo {
   static constexpr int MBW = MBW_, NBW = NBW_, NWM = NWM_, NWN = NWN_;
   static constexpr int NTH = 64 * NWM * NWN;
   static constexpr int BTM = 16 * MBW * NWM, BTN = 16 * NBW * NWN;       // tile rows / columns
-  static constexpr int STAGE = (BTM + BTN) * ROWB;
   static constexpr int RPP = NTH / 8;                                     // LDS rows one LDS-DMA instruction of the workgroup covers
-  static constexpr int NPA = BTM / RPP, NPIECE = NPA + BTN / RPP;        // LDS-DMA instructions per thread and stage: A rows, all
+  // LDS-DMA instructions per thread and stage.  The stage's LDS rows are the tile's A rows, then its B rows, then (BTM + BTN not
+  // a multiple of RPP: the 176-row tile) rows nobody reads: the last piece's idle waves fetch the last B row again, so that every
+  // wave issues the same count of pieces (s_waitcnt vmcnt is a count).  A piece may straddle the A / B boundary: a wave covers 8
+  // rows and BTM % 8 == 0, so which operand a wave's lanes address is wave-uniform.
+  static constexpr int NPIECE = (BTM + BTN + RPP - 1) / RPP;
+  static constexpr int STAGE = NPIECE * RPP * ROWB;
   static constexpr int NMF = MBW * NBW;                                   // MFMAs of a half stage per wave
   static constexpr int NFR = MBW + NBW;                                   // fragment reads of a half stage per wave
   static constexpr int DSTEP = NMF / NPIECE;                              // one LDS-DMA piece per DSTEP MFMAs of a half stage
-  static_assert(BTM % RPP == 0 && BTN % RPP == 0 && NBW % 4 == 0 && DSTEP >= 1 && 2 * STAGE <= 160 * 1024, "geometry");
+  static_assert(BTM % 16 == 0 && BTN % 64 == 0 && NBW % 4 == 0 && DSTEP >= 1 && 2 * STAGE <= 160 * 1024, "geometry");
 };
 
 struct BArgs {
@@ -87,7 +91,7 @@ template <int VPL> __device__ __forceinline__ int big_perm(int rho) {
 // TWO (BF16_GELU only): both tensors are written (C = u or gelu'(u), C2 = gelu(u)); otherwise only C2
 template <int EPI, bool TWO, typename G>
 __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
-  constexpr int MBW = G::MBW, NBW = G::NBW, BTM = G::BTM, BT = G::BTN, STAGE = G::STAGE, NPA = G::NPA, NPIECE = G::NPIECE, RPP = G::RPP;
+  constexpr int MBW = G::MBW, NBW = G::NBW, BTM = G::BTM, BT = G::BTN, STAGE = G::STAGE, NPIECE = G::NPIECE, RPP = G::RPP;
   constexpr bool F32 = (EPI == LAFS_EPI_RESID_F32);
   constexpr int VPL = F32 ? 4 : 8;
   constexpr int ESTORES = (F32 ? 4 : (TWO ? 4 : 2)) * MBW * (NBW / 4);          // stores of one tile's epilogue per wave
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
   const int total = my_tiles * nk;                          // stages this workgroup consumes
   if (total == 0) return;
 
-  // ---- LDS-DMA producer.  Piece i of a stage covers LDS rows RPP i + (tid >> 3) (i < NPA: A rows, else B rows RPP (i - NPA) + ...);
+  // ---- LDS-DMA producer.  Piece i of a stage covers LDS rows RPP i + (tid >> 3) (rows < BTM: A rows, then the B rows);
   // this thread's 16 bytes are chunk position tid & 7 of its row = source chunk (tid & 7) ^ (row & 7) = (tid & 7) ^ ((tid >> 3) & 7).
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(smem)) + wave * 1024;
   unsigned voff[NPIECE];                                   // byte offset of this thread's piece i from the tile's A / B origin
@@ -123,13 +127,15 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
     const unsigned dk2 = (unsigned)(((t_ & 7) ^ (drow & 7)) * 16);               // source byte offset inside the 128-byte k slice
 #pragma unroll
     for (int i = 0; i < NPIECE; ++i) {
-      if (i < NPA) voff[i] = (unsigned)min(RPP * i + drow, p.M - 1 - m0) * (unsigned)p.lda * 2u + dk2;
-      else voff[i] = (unsigned)min(big_perm<VPL>(RPP * (i - NPA) + drow), p.N - 1 - n0) * (unsigned)p.ldb * 2u + dk2;
+      const int lrow = RPP * i + drow;                       // LDS row of the stage
+      if (RPP * (i + 1) <= BTM || (RPP * i < BTM && lrow < BTM)) voff[i] = (unsigned)min(lrow, p.M - 1 - m0) * (unsigned)p.lda * 2u + dk2;
+      else voff[i] = (unsigned)min(big_perm<VPL>(min(lrow - BTM, BT - 1)), p.N - 1 - n0) * (unsigned)p.ldb * 2u + dk2;
     }
   };
   // piece i of the producer's current stage into ring buffer `buf`
   auto dma_piece = [&](int i, int buf) __attribute__((always_inline)) {
-    lds_dma16_m0_s(i < NPA ? (const void*)gA : (const void*)gB, voff[i], lds0 + buf * STAGE + i * (G::NTH * 16));
+    const bool from_a = RPP * (i + 1) <= BTM || (RPP * i < BTM && RPP * i + 8 * wave < BTM);          // wave-uniform
+    lds_dma16_m0_s(from_a ? (const void*)gA : (const void*)gB, voff[i], lds0 + buf * STAGE + i * (G::NTH * 16));
   };
   // (behind the last stage the cursor stays where it is: the steady-state loop keeps issuing -- the last stage again, into a
   // buffer nobody reads any more -- instead of carrying a branch between its MFMAs)
@@ -322,6 +328,8 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
 
 using GeoOne = Geo<6, 8, 2, 2>;            // 192 x 256, one wave per SIMD
 using GeoTwo = Geo<8, 4, 2, 4>;            // 256 x 256, two waves per SIMD
+using GeoFive = Geo<5, 8, 2, 2>;           // 160 x 256, one wave per SIMD: 158 row tiles of the fine-tune step's 25 216 rows (474 tiles = 1.85 rounds)
+using GeoSlim = Geo<11, 4, 1, 4>;          // 176 x 256, one wave per SIMD, a wave owns 176 x 64: 251 row tiles of the 44 160-row batches
 
 template <int EPI, bool TWO, typename G>
 int launch(BArgs a, hipStream_t s) {
@@ -342,15 +350,26 @@ inline long fill_permille(int M, int N, int btm, int btn) {
 
 }  // namespace
 
-// LAFS_OPT_NT_BIG: 0 off, 1 = where it wins (default), 2 / 3 = force the one- / two-waves-per-SIMD geometry on every shape and
+// LAFS_OPT_NT_BIG: 0 off, 1 = where it wins (default), 2 / 3 / 4 / 5 = force the 192 x 256 / 256 x 256 / 176 x 256 / 160 x 256 geometry on every shape and
 // epilogue the kernel covers (tests, A/B runs).  Measured on one MI355X against the 128x128 tiled kernel, interleaved
 // (tools/lab/t_big_ab.py, M = 44 160): PLAIN epilogue, one wave per SIMD: qkv forward 163.0 -> 149.0 us, fc1 input gradient 131.5 ->
 // 122.1 (1138 TFLOP/s), qkv input gradient 139.0 -> 130.1, projection input gradient 56.5 -> 55.4; the GELU pair / residual / GELU'
 // epilogues LOSE 5-13 % (one workgroup per CU: nothing covers an epilogue that reads operands and writes 2-4x the bytes), the
 // two-waves-per-SIMD geometry loses everywhere on these shapes (519 tiles = 2.03 rounds of 256), and so does a launch whose last
 // round is emptier than ~15 % (M = 25 216, N = 768: 1.55 rounds).  Only the winning combination is routed here by default.
+// geometry of a request: 1 = 192 x 256, 2 = 256 x 256 (two waves per SIMD), 3 = 176 x 256, 4 = 160 x 256.  Unforced, the one-wave-per-SIMD tile
+// whose rounds of one tile per CU are fuller (44 160 x 768: 690 tiles of 192 rows = 2.70 rounds, 753 of 176 rows = 2.94)
+static long geo_fill(const lafs_gemm_nt_args* g, int geo) {
+  return geo == 4 ? fill_permille(g->M, g->N, GeoFive::BTM, GeoFive::BTN) : geo == 3 ? fill_permille(g->M, g->N, GeoSlim::BTM, GeoSlim::BTN)
+       : geo == 2 ? fill_permille(g->M, g->N, GeoTwo::BTM, GeoTwo::BTN) : fill_permille(g->M, g->N, GeoOne::BTM, GeoOne::BTN);
+}
 static int big_geometry(const lafs_gemm_nt_args* g) {
-  return lafs_ctx_opt(g->ctx, LAFS_OPT_NT_BIG) == 3 ? 2 : 1;
+  const int o = lafs_ctx_opt(g->ctx, LAFS_OPT_NT_BIG);
+  if (o >= 2) return o <= 5 ? o - 1 : 1;
+  int best = 1;                                             // (a taller tile wins a tie: fewer operand bytes per MFMA)
+  if (geo_fill(g, 3) > geo_fill(g, best) + 30) best = 3;
+  if (geo_fill(g, 4) > geo_fill(g, best) + 30) best = 4;
+  return best;
 }
 
 bool lafs_big_eligible(const lafs_gemm_nt_args* g) {
@@ -367,7 +386,7 @@ bool lafs_big_eligible(const lafs_gemm_nt_args* g) {
   if ((long)g->M * g->lda * 2 >= (1L << 32) || (long)g->N * g->ldb * 2 >= (1L << 32)) return false;     // 32-bit operand offsets
   if (lafs_ctx_opt(g->ctx, LAFS_OPT_NT_BIG) >= 2) return true;
   // plain epilogue, and at most ~15 % of the slots of the launch's rounds of one tile per CU empty
-  return e == LAFS_EPI_BF16 && fill_permille(g->M, g->N, GeoOne::BTM, GeoOne::BTN) >= 850;
+  return e == LAFS_EPI_BF16 && geo_fill(g, big_geometry(g)) >= 850;
 }
 
 template <typename G>
@@ -389,5 +408,7 @@ int lafs_big_launch(const lafs_gemm_nt_args* g, hipStream_t stream) {
   a.aux = (const bf16_t*)g->aux; a.ldaux = g->ldaux;
   a.drop = make_drop(g->drop_p, g->drop_seed, g->drop_step, (unsigned)g->drop_row0 * (unsigned)g->N);
   a.act = g->act;
-  return big_geometry(g) == 2 ? big_launch_geo<GeoTwo>(g, a, stream) : big_launch_geo<GeoOne>(g, a, stream);
+  const int geo = big_geometry(g);
+  return geo == 2 ? big_launch_geo<GeoTwo>(g, a, stream) : geo == 3 ? big_launch_geo<GeoSlim>(g, a, stream)
+       : geo == 4 ? big_launch_geo<GeoFive>(g, a, stream) : big_launch_geo<GeoOne>(g, a, stream);
 }

@@ -426,7 +426,8 @@ def test_partial_fc_soft_mixup_targets_match_the_unsharded_cosface_soft_oracle(r
     pfc.gen.set_state(state)
     l0, d0 = pfc.forward_backward(emb, lab)
     if rate == 1.0:                                                    # (at rate < 1 the partners' classes change the sampled set)
-        assert abs(float(l1) - float(l0)) < 1e-6 * abs(float(l0)) and torch.equal(d1, d0)
+        assert abs(float(l1) - float(l0)) < 1e-6 * abs(float(l0))
+        assert float((d1 - d0).abs().max()) <= 1e-5 * float(d0.abs().max())      # (dE_n is a split-K sum with fp32 atomics: not bitwise)
 
 
 def test_f13_partfvit_with_trainable_landmark_branch():

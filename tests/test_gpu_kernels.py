@@ -177,7 +177,7 @@ def test_gemm_nt_k_resident_kernel(M, N):
     assert ops.gemm_nt(Ad, Bd, _lib.EPI_F32, splits=2, route_only=True) == 0
 
 
-@pytest.mark.parametrize("geo", [2, 3])
+@pytest.mark.parametrize("geo", [2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(192 * 75 + 37, 768, 2048), (192 * 54 + 5, 2112, 768), (192 * 80 + 37, 704, 768), (12288, 2048, 512)])
 def test_gemm_nt_big_tiles_equal_the_tiled_kernel_bit_for_bit(M, N, K, geo):
     """The wide long-K linears of the Part-fViT trunk (FeedForward 768 <-> 2048, to_qkv 2112, to_out 704; face_pre_pro/ViT_face.py:
@@ -390,7 +390,7 @@ def _attn_ref(qkv, cu, heads, scale):
 
 
 @pytest.mark.parametrize("lens,heads", [([197, 197], 2), ([37] * 5, 3), ([16, 1, 37, 48, 33], 1), ([100, 77], 2),
-                                        ([197, 150], 6), ([256, 200], 1)])
+                                        ([197, 150], 6), ([256, 200], 1), ([160, 130, 9], 3), ([197] * 90, 3)])
 def test_attention_fwd_bwd(lens, heads):
     cu = [0]
     for n in lens:

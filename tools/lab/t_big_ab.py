@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from lafs_cvpr2024_amd import _lib, ops
 dev = "cuda"; torch.manual_seed(0)
-ctxs = {k: _lib.Ctx(dev, options={_lib.OPT_NT_BIG: v}, from_env=False) for k, v in (("tiled", 0), ("big1", 2), ("big2", 3))}
+ctxs = {k: _lib.Ctx(dev, options={_lib.OPT_NT_BIG: v}, from_env=False) for k, v in (("tiled", 0), ("big1", 2), ("big2", 3), ("slim", 4), ("five", 5), ("auto", 1))}
 def timeit(fn, n=60):
     for _ in range(n): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
