@@ -363,6 +363,10 @@ static long geo_fill(const lafs_gemm_nt_args* g, int geo) {
   return geo == 4 ? fill_permille(g->M, g->N, GeoFive::BTM, GeoFive::BTN) : geo == 3 ? fill_permille(g->M, g->N, GeoSlim::BTM, GeoSlim::BTN)
        : geo == 2 ? fill_permille(g->M, g->N, GeoTwo::BTM, GeoTwo::BTN) : fill_permille(g->M, g->N, GeoOne::BTM, GeoOne::BTN);
 }
+static long geo_tiles(const lafs_gemm_nt_args* g, int geo) {
+  const int btm = geo == 4 ? GeoFive::BTM : geo == 3 ? GeoSlim::BTM : geo == 2 ? GeoTwo::BTM : GeoOne::BTM;
+  return (long)ceil_div(g->M, btm) * ceil_div(g->N, 256);
+}
 static int big_geometry(const lafs_gemm_nt_args* g) {
   const int o = lafs_ctx_opt(g->ctx, LAFS_OPT_NT_BIG);
   if (o >= 2) return o <= 5 ? o - 1 : 1;
@@ -386,7 +390,12 @@ bool lafs_big_eligible(const lafs_gemm_nt_args* g) {
   if ((long)g->M * g->lda * 2 >= (1L << 32) || (long)g->N * g->ldb * 2 >= (1L << 32)) return false;     // 32-bit operand offsets
   if (lafs_ctx_opt(g->ctx, LAFS_OPT_NT_BIG) >= 2) return true;
   // plain epilogue, and at most ~15 % of the slots of the launch's rounds of one tile per CU empty
-  return e == LAFS_EPI_BF16 && geo_fill(g, big_geometry(g)) >= 850;
+  // (12-stage tiles -- K = 768 -- expose the ring's fill and the epilogue at every tile change: they need fuller or more rounds;
+  // 25 216 x 704 x 768: 33.5-33.9 us against 31.9 tiled, 25 216 x 2112 x 768 in 5 rounds: 84.7 against 94.0)
+  const int geo = big_geometry(g);
+  const long fill = geo_fill(g, geo);
+  const long rounds = (geo_tiles(g, geo) + 255) / 256;
+  return e == LAFS_EPI_BF16 && fill >= 850 && (g->K >= 1024 || rounds >= 4 || fill >= 950);
 }
 
 template <typename G>
