@@ -119,7 +119,7 @@ __device__ __forceinline__ bf16x8_t tfrag_f(const unsigned char* tile, int ta, i
 
 struct AttnArgs {
   const bf16_t* qkv; int ldqkv;
-  const int* cu; int n_seq, heads; float scale;
+  const int* __restrict__ cu; int n_seq, heads; float scale;
   bf16_t* out; int ldo; float* lse;
   const bf16_t* dout; int lddo; bf16_t* dqkv; int lddqkv;
 };
@@ -231,9 +231,195 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnArgs a) {
 // Q (F), dO (F), K (F) and V (R) of a (sequence, head) pair are staged ONCE; delta = rowsum(O * dO) is formed while staging
 // (the 8 threads that carry a row's eight 16-byte chunks reduce their partial dot products with three shuffles).  Phase A is
 // the dK/dV loop (one wave per 16-key tile, streams the query tiles), phase B the dQ loop (one wave per 16-query tile,
-// streams the key tiles); both only read LDS, so no barrier separates them.  Against the three-kernel form (delta, dQ,
-// dK/dV) the pair's operands cross HBM once instead of 2-3 times: 4.4 -> 3.1 bytes per token-channel.
-// LDS per pair: Q | dO | K | V tiles, then lse[NT*16] and delta[NT*16] (f32).
+// streams the key tiles); both only read LDS.  Against the three-kernel form (delta, dQ, dK/dV) the pair's operands cross HBM
+// once instead of 2-3 times: 4.4 -> 3.1 bytes per token-channel.
+//
+// No masks in either phase: rows beyond the sequence are ZERO in all four tiles, so an out-of-range query contributes
+// dO = 0 / Q = 0 to dV / dK, an out-of-range key contributes K = 0 to dQ, and out-of-range outputs are never stored; the
+// probabilities of padded positions only have to stay finite (their lse entry is 0).
+// Each wave item covers TPI consecutive 16-row tiles, so every LDS fragment (the MFMA A operand) feeds TPI MFMAs: with one
+// tile per item the loops ask the LDS for 256 B/clk/CU at MFMA rate -- twice what it delivers -- and sit in LDS issue stalls.
+
+// phase A item `it`: dK, dV of key tiles it*TPI .. +TPI-1 (their K / V row fragments in kf / vf: a tile index past NT only occurs
+// in the last item, its results are dropped); streams the query tiles of Q (F) / dO (F); lsd = -log2(e) lse | -scale delta
+// the thread id as a value the compiler cannot trace: per-thread offsets derived from it are recomputed where they are used instead of
+// being hoisted out of the pair loop, kept live across the MFMA loops and spilled (their scratch reloads wait on vmcnt, i.e. on every
+// request in flight)
+__device__ __forceinline__ int opaque_tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+// a wave-uniform read of read-only memory through the scalar cache (a plain load of `cu` becomes a vector load + s_waitcnt vmcnt(0):
+// in the pair loop that drains every request and store in flight)
+__device__ __forceinline__ int load_const(const int* p) {
+  typedef const __attribute__((address_space(4))) int* cptr_t;
+  return *(cptr_t)(unsigned long long)p;
+}
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// (`hook(u)` runs in front of step u of the unrolled loop: the streaming kernel hangs its staging there)
+template <int NT, int TPI, typename H = NoHook>
+__device__ __forceinline__ void bwd_phase_keys(const unsigned char* QsF, const unsigned char* DsF, const float* lsd,
+                                               const bf16x8_t (&kf)[TPI][2], const bf16x8_t (&vf)[TPI][2], int it, int len, bf16_t* drow,
+                                               int ld, int inner, int lane, float c2, float scale, const H& hook = H()) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool swp = (lds_f(c16) & 1) != 0;
+  f32x4_t dk[TPI][4], dv[TPI][4];
+#pragma unroll
+  for (int x = 0; x < TPI; ++x)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[x][dt] = dk[x][dt]; }
+#pragma unroll
+  for (int u = 0; u < (NT + 1) / 2; ++u) {
+    hook(u);
+    float pv[TPI][8], ds[TPI][8];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int qt = 2 * u + tt;
+      if (qt < NT) {
+        const int qrow = qt * 16 + c16;
+        const bf16x8_t qa0 = rfrag_f(QsF, qrow, g, swp), qa1 = rfrag_f(QsF, qrow, 4 + g, swp);
+        const bf16x8_t da0 = rfrag_f(DsF, qrow, g, swp), da1 = rfrag_f(DsF, qrow, 4 + g, swp);
+        const float4 l4 = *reinterpret_cast<const float4*>(lsd + qt * 16 + g * 4);
+        const float4 d4 = *reinterpret_cast<const float4*>(lsd + NT * 16 + qt * 16 + g * 4);
+        const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int x = 0; x < TPI; ++x) {
+          f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sx = mfma16(qa0, kf[x][0], sx);
+          sx = mfma16(qa1, kf[x][1], sx);
+          dp = mfma16(da0, vf[x][0], dp);
+          dp = mfma16(da1, vf[x][1], dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, lq[r]));
+            pv[x][tt * 4 + r] = p;
+            ds[x][tt * 4 + r] = p * fmaf(dp[r], scale, dq4[r]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < TPI; ++x)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pv[x][tt * 4 + r] = 0.f; ds[x][tt * 4 + r] = 0.f; }
+      }
+    }
+    bf16x8_t pf[TPI], dsf[TPI];
+#pragma unroll
+    for (int x = 0; x < TPI; ++x) { pf[x] = pack_frag(pv[x]); dsf[x] = pack_frag(ds[x]); }
+    const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16x8_t td = tfrag_f(DsF, t0, t1, dt, lane), tq = tfrag_f(QsF, t0, t1, dt, lane);
+#pragma unroll
+      for (int x = 0; x < TPI; ++x) {
+        dv[x][dt] = mfma16(td, pf[x], dv[x][dt]);
+        dk[x][dt] = mfma16(tq, dsf[x], dk[x][dt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < TPI; ++x) {
+    const int key = (it * TPI + x) * 16 + c16;
+    if (it * TPI + x < NT && key < len) {
+      uint32_t w[8];
+      bf16_t* op = drow + (size_t)key * ld + inner + g * 16;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        w[2 * dt] = pack_bf2(dk[x][dt][0], dk[x][dt][1]);
+        w[2 * dt + 1] = pack_bf2(dk[x][dt][2], dk[x][dt][3]);
+      }
+      reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        w[2 * dt] = pack_bf2(dv[x][dt][0], dv[x][dt][1]);
+        w[2 * dt + 1] = pack_bf2(dv[x][dt][2], dv[x][dt][3]);
+      }
+      reinterpret_cast<uint4*>(op + inner)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      reinterpret_cast<uint4*>(op + inner)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+}
+
+// phase B item `it`: dQ of query tiles it*TPI .. +TPI-1 (their own Q / dO fragments from the F tiles); streams K (F) / V (R)
+template <int NT, int TPI, typename H = NoHook>
+__device__ __forceinline__ void bwd_phase_queries(const unsigned char* QsF, const unsigned char* DsF, const unsigned char* KsF,
+                                                  const unsigned char* VsR, const float* lsd, int it, int len, bf16_t* drow, int ld,
+                                                  int lane, float c2, float scale, const H& hook = H()) {
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool swp = (lds_f(c16) & 1) != 0;
+  bf16x8_t qf[TPI][2], df[TPI][2];
+  float nlse_q[TPI], ndel_q[TPI];
+  f32x4_t dq[TPI][4];
+#pragma unroll
+  for (int x = 0; x < TPI; ++x) {
+    const int q = min(it * TPI + x, NT - 1) * 16 + c16;
+    qf[x][0] = rfrag_f(QsF, q, g, swp); qf[x][1] = rfrag_f(QsF, q, 4 + g, swp);
+    df[x][0] = rfrag_f(DsF, q, g, swp); df[x][1] = rfrag_f(DsF, q, 4 + g, swp);
+    nlse_q[x] = lsd[q]; ndel_q[x] = lsd[NT * 16 + q];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int u = 0; u < (NT + 1) / 2; ++u) {
+    hook(u);
+    float ds[TPI][8];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * u + tt;
+      if (t < NT) {
+        const int krow = t * 16 + c16;
+        const bf16x8_t ka0 = rfrag_f(KsF, krow, g, swp), ka1 = rfrag_f(KsF, krow, 4 + g, swp);
+        const bf16x8_t va0 = rfrag(VsR, krow, g), va1 = rfrag(VsR, krow, 4 + g);
+#pragma unroll
+        for (int x = 0; x < TPI; ++x) {
+          f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          sx = mfma16(ka0, qf[x][0], sx);
+          sx = mfma16(ka1, qf[x][1], sx);
+          dp = mfma16(va0, df[x][0], dp);
+          dp = mfma16(va1, df[x][1], dp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            ds[x][tt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, nlse_q[x])) * fmaf(dp[r], scale, ndel_q[x]);
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < TPI; ++x)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[x][tt * 4 + r] = 0.f;
+      }
+    }
+    bf16x8_t dsf[TPI];
+#pragma unroll
+    for (int x = 0; x < TPI; ++x) dsf[x] = pack_frag(ds[x]);
+    const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const bf16x8_t tk = tfrag_f(KsF, t0, t1, dt, lane);
+#pragma unroll
+      for (int x = 0; x < TPI; ++x) dq[x][dt] = mfma16(tk, dsf[x], dq[x][dt]);
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < TPI; ++x) {
+    const int q = (it * TPI + x) * 16 + c16;
+    if (it * TPI + x < NT && q < len) {
+      uint32_t w[8];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        w[2 * dt] = pack_bf2(dq[x][dt][0], dq[x][dt][1]);
+        w[2 * dt + 1] = pack_bf2(dq[x][dt][2], dq[x][dt][3]);
+      }
+      bf16_t* op = drow + (size_t)q * ld + g * 16;
+      reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+}
+
+// LDS per pair: Q | dO | K | V tiles, then lse[NT*16] and delta[NT*16] (f32).  PPB pairs per workgroup, NW waves, no barrier between
+// the phases (both only read LDS).
 template <int NT, int PPB, int NW, int TPI>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -292,11 +478,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs a) {
   __syncthreads();
   const bool swp = (lds_f(c16) & 1) != 0;
   const float c2 = a.scale * 1.4426950408889634f;      // softmax scale folded with log2(e): p = exp2(s * c2 - lse * log2(e))
-  // No masks in either phase: rows beyond the sequence are ZERO in all four tiles, so an out-of-range query contributes
-  // dO = 0 / Q = 0 to dV / dK, an out-of-range key contributes K = 0 to dQ, and out-of-range outputs are never stored; the
-  // probabilities of padded positions only have to stay finite (their lse entry is 0).
-  // Each wave item covers TPI consecutive 16-row tiles, so every LDS fragment (the MFMA A operand) feeds TPI MFMAs: with one
-  // tile per item the loops ask the LDS for 256 B/clk/CU at MFMA rate -- twice what it delivers -- and sit in LDS issue stalls.
   constexpr int NI = (NT + TPI - 1) / TPI;              // items per pair and phase
   // ---- phase A: dK, dV
   for (int item = wave; item < PPB * NI; item += NW) {
@@ -307,90 +488,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs a) {
     const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
     if (it * TPI * 16 >= len) continue;
     const unsigned char* QsF = smem + pl * PAIR_BYTES;
-    const unsigned char* DsF = QsF + TILE;
     const unsigned char* KsF = QsF + 2 * TILE;
     const unsigned char* VsR = QsF + 3 * TILE;
-    const float* lsd = reinterpret_cast<const float*>(QsF + 4 * TILE);
     bf16x8_t kf[TPI][2], vf[TPI][2];
-    f32x4_t dk[TPI][4], dv[TPI][4];
 #pragma unroll
     for (int x = 0; x < TPI; ++x) {
-      const int key = min(it * TPI + x, NT - 1) * 16 + c16;      // a tile index past NT only occurs in the last item: its results are dropped
+      const int key = min(it * TPI + x, NT - 1) * 16 + c16;
       kf[x][0] = rfrag_f(KsF, key, g, swp); kf[x][1] = rfrag_f(KsF, key, 4 + g, swp);
       vf[x][0] = rfrag(VsR, key, g); vf[x][1] = rfrag(VsR, key, 4 + g);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) { dk[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[x][dt] = dk[x][dt]; }
     }
-#pragma unroll
-    for (int u = 0; u < (NT + 1) / 2; ++u) {
-      float pv[TPI][8], ds[TPI][8];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int qt = 2 * u + tt;
-        if (qt < NT) {
-          const int qrow = qt * 16 + c16;
-          const bf16x8_t qa0 = rfrag_f(QsF, qrow, g, swp), qa1 = rfrag_f(QsF, qrow, 4 + g, swp);
-          const bf16x8_t da0 = rfrag_f(DsF, qrow, g, swp), da1 = rfrag_f(DsF, qrow, 4 + g, swp);
-          const float4 l4 = *reinterpret_cast<const float4*>(lsd + qt * 16 + g * 4);
-          const float4 d4 = *reinterpret_cast<const float4*>(lsd + NT * 16 + qt * 16 + g * 4);
-          const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-          for (int x = 0; x < TPI; ++x) {
-            f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            sx = mfma16(qa0, kf[x][0], sx);
-            sx = mfma16(qa1, kf[x][1], sx);
-            dp = mfma16(da0, vf[x][0], dp);
-            dp = mfma16(da1, vf[x][1], dp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float p = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, lq[r]));
-              pv[x][tt * 4 + r] = p;
-              ds[x][tt * 4 + r] = p * fmaf(dp[r], a.scale, dq4[r]);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int x = 0; x < TPI; ++x)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { pv[x][tt * 4 + r] = 0.f; ds[x][tt * 4 + r] = 0.f; }
-        }
-      }
-      bf16x8_t pf[TPI], dsf[TPI];
-#pragma unroll
-      for (int x = 0; x < TPI; ++x) { pf[x] = pack_frag(pv[x]); dsf[x] = pack_frag(ds[x]); }
-      const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t td = tfrag_f(DsF, t0, t1, dt, lane), tq = tfrag_f(QsF, t0, t1, dt, lane);
-#pragma unroll
-        for (int x = 0; x < TPI; ++x) {
-          dv[x][dt] = mfma16(td, pf[x], dv[x][dt]);
-          dk[x][dt] = mfma16(tq, dsf[x], dk[x][dt]);
-        }
-      }
-    }
-#pragma unroll
-    for (int x = 0; x < TPI; ++x) {
-      const int key = (it * TPI + x) * 16 + c16;
-      if (it * TPI + x < NT && key < len) {
-        uint32_t w[8];
-        bf16_t* op = a.dqkv + (size_t)(tok0 + key) * a.lddqkv + inner + h * 64 + g * 16;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          w[2 * dt] = pack_bf2(dk[x][dt][0], dk[x][dt][1]);
-          w[2 * dt + 1] = pack_bf2(dk[x][dt][2], dk[x][dt][3]);
-        }
-        reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          w[2 * dt] = pack_bf2(dv[x][dt][0], dv[x][dt][1]);
-          w[2 * dt + 1] = pack_bf2(dv[x][dt][2], dv[x][dt][3]);
-        }
-        reinterpret_cast<uint4*>(op + inner)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        reinterpret_cast<uint4*>(op + inner)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-      }
-    }
+    bwd_phase_keys<NT, TPI>(QsF, QsF + TILE, reinterpret_cast<const float*>(QsF + 4 * TILE), kf, vf, it, len,
+                            a.dqkv + (size_t)tok0 * a.lddqkv + h * 64, a.lddqkv, inner, lane, c2, a.scale);
   }
   // ---- phase B: dQ (waves take the items in the opposite order, which evens out the two phases' remainders)
   for (int item = NW - 1 - wave; item < PPB * NI; item += NW) {
@@ -401,339 +509,160 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs a) {
     const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
     if (it * TPI * 16 >= len) continue;
     const unsigned char* QsF = smem + pl * PAIR_BYTES;
-    const unsigned char* DsF = QsF + TILE;
-    const unsigned char* KsF = QsF + 2 * TILE;
-    const unsigned char* VsR = QsF + 3 * TILE;
-    const float* lsd = reinterpret_cast<const float*>(QsF + 4 * TILE);
-    bf16x8_t qf[TPI][2], df[TPI][2];
-    float nlse_q[TPI], ndel_q[TPI];
-    f32x4_t dq[TPI][4];
-#pragma unroll
-    for (int x = 0; x < TPI; ++x) {
-      const int q = min(it * TPI + x, NT - 1) * 16 + c16;
-      qf[x][0] = rfrag_f(QsF, q, g, swp); qf[x][1] = rfrag_f(QsF, q, 4 + g, swp);
-      df[x][0] = rfrag_f(DsF, q, g, swp); df[x][1] = rfrag_f(DsF, q, 4 + g, swp);
-      nlse_q[x] = lsd[q]; ndel_q[x] = lsd[NT * 16 + q];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) dq[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < (NT + 1) / 2; ++u) {
-      float ds[TPI][8];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        const int t = 2 * u + tt;
-        if (t < NT) {
-          const int krow = t * 16 + c16;
-          const bf16x8_t ka0 = rfrag_f(KsF, krow, g, swp), ka1 = rfrag_f(KsF, krow, 4 + g, swp);
-          const bf16x8_t va0 = rfrag(VsR, krow, g), va1 = rfrag(VsR, krow, 4 + g);
-#pragma unroll
-          for (int x = 0; x < TPI; ++x) {
-            f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-            sx = mfma16(ka0, qf[x][0], sx);
-            sx = mfma16(ka1, qf[x][1], sx);
-            dp = mfma16(va0, df[x][0], dp);
-            dp = mfma16(va1, df[x][1], dp);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              ds[x][tt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, nlse_q[x])) * fmaf(dp[r], a.scale, ndel_q[x]);
-          }
-        } else {
-#pragma unroll
-          for (int x = 0; x < TPI; ++x)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ds[x][tt * 4 + r] = 0.f;
-        }
-      }
-      bf16x8_t dsf[TPI];
-#pragma unroll
-      for (int x = 0; x < TPI; ++x) dsf[x] = pack_frag(ds[x]);
-      const int t0 = 2 * u, t1 = (2 * u + 1 < NT) ? 2 * u + 1 : 2 * u;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16x8_t tk = tfrag_f(KsF, t0, t1, dt, lane);
-#pragma unroll
-        for (int x = 0; x < TPI; ++x) dq[x][dt] = mfma16(tk, dsf[x], dq[x][dt]);
-      }
-    }
-#pragma unroll
-    for (int x = 0; x < TPI; ++x) {
-      const int q = (it * TPI + x) * 16 + c16;
-      if (it * TPI + x < NT && q < len) {
-        uint32_t w[8];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          w[2 * dt] = pack_bf2(dq[x][dt][0], dq[x][dt][1]);
-          w[2 * dt + 1] = pack_bf2(dq[x][dt][2], dq[x][dt][3]);
-        }
-        bf16_t* op = a.dqkv + (size_t)(tok0 + q) * a.lddqkv + h * 64 + g * 16;
-        reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-        reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-      }
-    }
+    bwd_phase_queries<NT, TPI>(QsF, QsF + TILE, QsF + 2 * TILE, QsF + 3 * TILE, reinterpret_cast<const float*>(QsF + 4 * TILE), it, len,
+                               a.dqkv + (size_t)tok0 * a.lddqkv + h * 64, a.lddqkv, lane, c2, a.scale);
   }
 }
 
 // ------------------------------------------------------------------------------------------------ backward, long sequences
-// The same two phases for sequences of >= 10 tiles, re-cut for what bounds them (tools/lab/NOTES.md, round 5): with two waves per
-// SIMD and two tiles per wave item the loops were LDS-issue and VALU bound, 7 items fell on 8 waves, and the ~5 us of staging of
-// each of a CU's three pairs were exposed.  Here ONE 4-wave workgroup per CU walks over the pairs: a wave owns a SIMD and its whole
-// register file, takes T = NT/4 (+1) CONSECUTIVE tiles per phase (every LDS fragment feeds T x as many MFMAs: half the LDS
-// traffic of the two-tile form at T = 4; the T independent MFMA / exp2 chains are the wave's own latency hiding), and the next
-// pair's operands are requested into registers when phase A ends, so that they arrive behind phase B.
-template <int NT, int T>
-__device__ __forceinline__ void bwd_keys_item(const unsigned char* QsF, int k0, int len, bf16_t* drow, int ld, int inner, int lane,
-                                              float c2, float scale) {
-  constexpr int NTE = (NT + 1) & ~1, TILE = NTE * 16 * 128;   // tiles come in pairs: an odd NT has one more tile of zero rows
-  const int g = lane >> 4, c16 = lane & 15;
-  const bool swp = (lds_f(c16) & 1) != 0;
-  const unsigned char* DsF = QsF + TILE;
-  const unsigned char* KsF = QsF + 2 * TILE;
-  const unsigned char* VsR = QsF + 3 * TILE;
-  const float* lsd = reinterpret_cast<const float*>(QsF + 4 * TILE);
-  bf16x8_t kf[T][2], vf[T][2];
-  f32x4_t dk[T][4], dv[T][4];
-#pragma unroll
-  for (int x = 0; x < T; ++x) {
-    const int key = (k0 + x) * 16 + c16;
-    kf[x][0] = rfrag_f(KsF, key, g, swp); kf[x][1] = rfrag_f(KsF, key, 4 + g, swp);
-    vf[x][0] = rfrag(VsR, key, g); vf[x][1] = rfrag(VsR, key, 4 + g);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dk[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[x][dt] = dk[x][dt]; }
-  }
-#pragma unroll 1
-  for (int u = 0; u < (NT + 1) / 2; ++u) {
-    float pv[T][8], ds[T][8];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int qt = 2 * u + tt;
-      const int qrow = qt * 16 + c16;
-      const bf16x8_t qa0 = rfrag_f(QsF, qrow, g, swp), qa1 = rfrag_f(QsF, qrow, 4 + g, swp);
-      const bf16x8_t da0 = rfrag_f(DsF, qrow, g, swp), da1 = rfrag_f(DsF, qrow, 4 + g, swp);
-      const float4 l4 = *reinterpret_cast<const float4*>(lsd + qt * 16 + g * 4);
-      const float4 d4 = *reinterpret_cast<const float4*>(lsd + NTE * 16 + qt * 16 + g * 4);
-      const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-      for (int x = 0; x < T; ++x) {
-        f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sx = mfma16(qa0, kf[x][0], sx);
-        sx = mfma16(qa1, kf[x][1], sx);
-        dp = mfma16(da0, vf[x][0], dp);
-        dp = mfma16(da1, vf[x][1], dp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, lq[r]));
-          pv[x][tt * 4 + r] = p;
-          ds[x][tt * 4 + r] = p * fmaf(dp[r], scale, dq4[r]);
-        }
-      }
-    }
-    bf16x8_t pf[T], dsf[T];
-#pragma unroll
-    for (int x = 0; x < T; ++x) { pf[x] = pack_frag(pv[x]); dsf[x] = pack_frag(ds[x]); }
-    const int t0 = 2 * u, t1 = 2 * u + 1;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const bf16x8_t td = tfrag_f(DsF, t0, t1, dt, lane), tq = tfrag_f(QsF, t0, t1, dt, lane);
-#pragma unroll
-      for (int x = 0; x < T; ++x) {
-        dv[x][dt] = mfma16(td, pf[x], dv[x][dt]);
-        dk[x][dt] = mfma16(tq, dsf[x], dk[x][dt]);
-      }
-    }
-  }
-#pragma unroll
-  for (int x = 0; x < T; ++x) {
-    const int key = (k0 + x) * 16 + c16;
-    if (key < len) {
-      uint32_t w[8];
-      bf16_t* op = drow + (size_t)key * ld + inner + g * 16;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        w[2 * dt] = pack_bf2(dk[x][dt][0], dk[x][dt][1]);
-        w[2 * dt + 1] = pack_bf2(dk[x][dt][2], dk[x][dt][3]);
-      }
-      reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        w[2 * dt] = pack_bf2(dv[x][dt][0], dv[x][dt][1]);
-        w[2 * dt + 1] = pack_bf2(dv[x][dt][2], dv[x][dt][3]);
-      }
-      reinterpret_cast<uint4*>(op + inner)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      reinterpret_cast<uint4*>(op + inner)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    }
-  }
-}
-
-template <int NT, int T>
-__device__ __forceinline__ void bwd_queries_item(const unsigned char* QsF, int q0, int len, bf16_t* drow, int ld, int lane, float c2,
-                                                 float scale) {
-  constexpr int NTE = (NT + 1) & ~1, TILE = NTE * 16 * 128;   // tiles come in pairs: an odd NT has one more tile of zero rows
-  const int g = lane >> 4, c16 = lane & 15;
-  const bool swp = (lds_f(c16) & 1) != 0;
-  const unsigned char* DsF = QsF + TILE;
-  const unsigned char* KsF = QsF + 2 * TILE;
-  const unsigned char* VsR = QsF + 3 * TILE;
-  const float* lsd = reinterpret_cast<const float*>(QsF + 4 * TILE);
-  bf16x8_t qf[T][2], df[T][2];
-  float nlse_q[T], ndel_q[T];
-  f32x4_t dq[T][4];
-#pragma unroll
-  for (int x = 0; x < T; ++x) {
-    const int q = (q0 + x) * 16 + c16;
-    qf[x][0] = rfrag_f(QsF, q, g, swp); qf[x][1] = rfrag_f(QsF, q, 4 + g, swp);
-    df[x][0] = rfrag_f(DsF, q, g, swp); df[x][1] = rfrag_f(DsF, q, 4 + g, swp);
-    nlse_q[x] = lsd[q]; ndel_q[x] = lsd[NTE * 16 + q];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[x][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll 1
-  for (int u = 0; u < (NT + 1) / 2; ++u) {
-    float ds[T][8];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t = 2 * u + tt;
-      const int krow = t * 16 + c16;
-      const bf16x8_t ka0 = rfrag_f(KsF, krow, g, swp), ka1 = rfrag_f(KsF, krow, 4 + g, swp);
-      const bf16x8_t va0 = rfrag(VsR, krow, g), va1 = rfrag(VsR, krow, 4 + g);
-#pragma unroll
-      for (int x = 0; x < T; ++x) {
-        f32x4_t sx = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        sx = mfma16(ka0, qf[x][0], sx);
-        sx = mfma16(ka1, qf[x][1], sx);
-        dp = mfma16(va0, df[x][0], dp);
-        dp = mfma16(va1, df[x][1], dp);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ds[x][tt * 4 + r] = __builtin_amdgcn_exp2f(fmaf(sx[r], c2, nlse_q[x])) * fmaf(dp[r], scale, ndel_q[x]);
-        }
-      }
-    }
-    bf16x8_t dsf[T];
-#pragma unroll
-    for (int x = 0; x < T; ++x) dsf[x] = pack_frag(ds[x]);
-    const int t0 = 2 * u, t1 = 2 * u + 1;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const bf16x8_t tk = tfrag_f(KsF, t0, t1, dt, lane);
-#pragma unroll
-      for (int x = 0; x < T; ++x) dq[x][dt] = mfma16(tk, dsf[x], dq[x][dt]);
-    }
-  }
-#pragma unroll
-  for (int x = 0; x < T; ++x) {
-    const int q = (q0 + x) * 16 + c16;
-    if (q < len) {
-      uint32_t w[8];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        w[2 * dt] = pack_bf2(dq[x][dt][0], dq[x][dt][1]);
-        w[2 * dt + 1] = pack_bf2(dq[x][dt][2], dq[x][dt][3]);
-      }
-      bf16_t* op = drow + (size_t)q * ld + g * 16;
-      reinterpret_cast<uint4*>(op)[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      reinterpret_cast<uint4*>(op)[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    }
-  }
-}
-
-template <int IT>
-struct BwdRegs { uint4 q[IT], d[IT], k[IT], v[IT], o[IT]; float l[IT]; };
-
-template <int NT, int IT>
-__device__ __forceinline__ void bwd_request(const AttnArgs& a, int pair, int tid, BwdRegs<IT>& R) {
-  constexpr int ROWS = ((NT + 1) & ~1) * 16;
-  const int inner = a.heads * 64;
-  const int seq = pair / a.heads, h = pair % a.heads;
-  const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
-  const bf16_t* qb = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
-  const bf16_t* db = a.dout + (size_t)tok0 * a.lddo + h * 64;
-  const bf16_t* ob = a.out + (size_t)tok0 * a.ldo + h * 64;
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
-    R.q[i] = make_uint4(0, 0, 0, 0); R.d[i] = R.q[i]; R.k[i] = R.q[i]; R.v[i] = R.q[i]; R.o[i] = R.q[i]; R.l[i] = 0.f;
-    if (idx < ROWS * 8 && row < len) {
-      const bf16_t* qr = qb + (size_t)row * a.ldqkv + ch * 8;
-      R.q[i] = *reinterpret_cast<const uint4*>(qr);
-      R.k[i] = *reinterpret_cast<const uint4*>(qr + inner);
-      R.v[i] = *reinterpret_cast<const uint4*>(qr + 2 * inner);
-      R.d[i] = *reinterpret_cast<const uint4*>(db + (size_t)row * a.lddo + ch * 8);
-      R.o[i] = *reinterpret_cast<const uint4*>(ob + (size_t)row * a.ldo + ch * 8);
-      if (ch == 0) R.l[i] = a.lse[(size_t)(tok0 + row) * a.heads + h];
-    }
-  }
-}
-
-template <int NT, int IT>
-__device__ __forceinline__ void bwd_deposit(unsigned char* s0, float scale, int tid, const BwdRegs<IT>& R) {
-  constexpr int NTE = (NT + 1) & ~1, ROWS = NTE * 16, TILE = NTE * 16 * 128;
-  float* lsd = reinterpret_cast<float*>(s0 + 4 * TILE);
-#pragma unroll
-  for (int i = 0; i < IT; ++i) {
-    const int idx = tid + i * 256, row = idx >> 3, ch = idx & 7;
-    const uint4 x = R.o[i], y = R.d[i];
-    float d = bf_lo(x.x) * bf_lo(y.x) + bf_hi(x.x) * bf_hi(y.x) + bf_lo(x.y) * bf_lo(y.y) + bf_hi(x.y) * bf_hi(y.y) +
-              bf_lo(x.z) * bf_lo(y.z) + bf_hi(x.z) * bf_hi(y.z) + bf_lo(x.w) * bf_lo(y.w) + bf_hi(x.w) * bf_hi(y.w);
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-    if (idx < ROWS * 8) {
-      lds_put<2>(s0, row, ch, R.q[i]); lds_put<2>(s0 + TILE, row, ch, R.d[i]);
-      lds_put<2>(s0 + 2 * TILE, row, ch, R.k[i]); lds_put<0>(s0 + 3 * TILE, row, ch, R.v[i]);
-      if (ch == 0) {                                       // negated and pre-scaled, as in attn_bwd_fused_kernel; rows past the
-        lsd[row] = -1.4426950408889634f * R.l[i];          // sequence carry 0 (their probabilities only have to stay finite)
-        lsd[ROWS + row] = -scale * d;
-      }
-    }
-  }
-}
-
+// Sequences of 10-13 tiles (the 197-token crops): 108 KB of LDS per pair leave ONE 8-wave workgroup per CU, so the time a pair's
+// operands take to arrive (a third of the kernel: the same loops on resident operands run 37 us, the staging alone 19, the
+// one-pair-per-workgroup kernel 73) was exposed three times per CU.  The dQ phase only streams K / V and the dK/dV phase only
+// Q / dO; the other pair of matrices is read once, as each wave's own row fragments, when the phase starts.  So the LDS holds
+// Q | dO twice and K | V once (6 tiles + 2 x lse / delta = 159.3 of 160 KiB at 13 tiles) and ONE workgroup per CU walks over the
+// pairs b, b + grid, ..., dQ phase first:
+//   loop top : barrier (Q | dO and K | V of the pair are in place)
+//   dQ       : streams K | V; in front of its steps 0 / H2: request | deposit the NEXT pair's Q and lse into the other Q | dO buffer
+//   between  : every wave reads its own K / V fragments of the dK/dV phase; barrier (nobody reads K | V any more)
+//   dK, dV   : streams Q | dO; stops 0 / H2 / H3: request the next pair's K, V | deposit them (F / R), request dO, O | deposit dO and
+//              delta = rowsum(O * dO)
+// Every matrix crosses HBM once, a tile or two at a time on the phases' unrolled loops (16-32 registers per thread in flight), and
+// only the first pair's staging and two barriers per pair are outside the MFMA loops.
 template <int NT>
-__global__ __launch_bounds__(256) void attn_bwd_long_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int ROWS = ((NT + 1) & ~1) * 16;
-  constexpr int IT = (ROWS * 8 + 255) / 256;
-  constexpr int BASE = NT / 4, REM = NT % 4;
+  constexpr int TILE = NT * 16 * 128, ROWS = NT * 16, TPI = 2;
+  constexpr int IT = (ROWS * 8 + 511) / 512;
+  constexpr int NI = (NT + TPI - 1) / TPI, U = (NT + 1) / 2, H2 = U / 3, H3 = 2 * U / 3 + 1;
+  static_assert(NI <= 8 && 6 * TILE + 4 * ROWS * 4 <= 160 * 1024 && H2 >= 1 && H3 > H2 && H3 < U, "one item per wave and phase; LDS; stops");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const bool swp = (lds_f(c16) & 1) != 0;
   const int inner = a.heads * 64;
   const int n_pairs = a.n_seq * a.heads;
   const float c2 = a.scale * 1.4426950408889634f;
-  BwdRegs<IT> R;
-  int pair = blockIdx.x;
-#ifndef LAFS_LAB_ATTN_NOPF
-  bwd_request<NT, IT>(a, pair, tid, R);
-#endif
-  for (;;) {
-#ifdef LAFS_LAB_ATTN_NOPF
-    bwd_request<NT, IT>(a, pair, tid, R);
-#endif
-    bwd_deposit<NT, IT>(smem, a.scale, tid, R);
-    __syncthreads();
+  unsigned char* const KV = smem + 4 * TILE;               // K (F) | V (R)
+  float* const lsd_base = reinterpret_cast<float*>(smem + 6 * TILE);
+  const int itB = wave, itA = 7 - wave;                     // this wave's item of the dQ / the dK,dV phase (idle when >= NI)
+  uint4 r0[IT], r1[IT]; float rl[IT];                      // a tile (or two) on its way to the LDS (thread: row idx >> 3, chunk idx & 7)
+  // staging context: the pair whose operands are being fetched, and where its Q | dO go
+  const bf16_t* s_q = nullptr; const bf16_t* s_d = nullptr; const bf16_t* s_o = nullptr; const float* s_l = nullptr;
+  int s_len = 0; unsigned char* s_x = nullptr; float* s_lsd = nullptr;
+  auto stage_pair = [&](int pair, int buf) __attribute__((always_inline)) {
     const int seq = pair / a.heads, h = pair % a.heads;
-    const int tok0 = a.cu[seq], len = a.cu[seq + 1] - tok0;
-    bf16_t* drow = a.dqkv + (size_t)tok0 * a.lddqkv + h * 64;
-    {                                                      // phase A: wave w takes key tiles [w*BASE + min(w, REM), +BASE (+1))
-      const int k0 = wave * BASE + min(wave, REM);
-      if (k0 * 16 < len) {
-        if (REM != 0 && wave < REM) bwd_keys_item<NT, BASE + 1>(smem, k0, len, drow, a.lddqkv, inner, lane, c2, a.scale);
-        else bwd_keys_item<NT, BASE>(smem, k0, len, drow, a.lddqkv, inner, lane, c2, a.scale);
+    const int tok0 = load_const(a.cu + seq);
+    s_len = load_const(a.cu + seq + 1) - tok0;
+    s_q = a.qkv + (size_t)tok0 * a.ldqkv + h * 64;
+    s_d = a.dout + (size_t)tok0 * a.lddo + h * 64;
+    s_o = a.out + (size_t)tok0 * a.ldo + h * 64;
+    s_l = a.lse + (size_t)tok0 * a.heads + h;
+    s_x = smem + buf * 2 * TILE; s_lsd = lsd_base + buf * 2 * ROWS;
+  };
+  // one matrix of the staged pair -> r: rows of `src` (row stride ld), zero past the sequence
+  auto request = [&](uint4 (&r)[IT], const bf16_t* src, int ld) __attribute__((always_inline)) {
+    const int t_ = opaque_tid();
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int idx = t_ + i * 512, row = idx >> 3, ch = idx & 7;
+      r[i] = make_uint4(0, 0, 0, 0);
+      if (idx < ROWS * 8 && row < s_len) r[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
+    }
+  };
+  auto request_lse = [&]() __attribute__((always_inline)) {
+    const int t_ = opaque_tid();
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int idx = t_ + i * 512, row = idx >> 3, ch = idx & 7;
+      rl[i] = 0.f;
+      if (ch == 0 && idx < ROWS * 8 && row < s_len) rl[i] = s_l[(size_t)row * a.heads];
+    }
+  };
+  auto deposit_f = [&](unsigned char* dst, const uint4 (&r)[IT]) __attribute__((always_inline)) {
+    const int t_ = opaque_tid();
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int idx = t_ + i * 512, row = idx >> 3, ch = idx & 7;
+      if (idx < ROWS * 8) lds_put<2>(dst, row, ch, r[i]);
+    }
+  };
+  auto deposit_r = [&](unsigned char* dst, const uint4 (&r)[IT]) __attribute__((always_inline)) {
+    const int t_ = opaque_tid();
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int idx = t_ + i * 512, row = idx >> 3, ch = idx & 7;
+      if (idx < ROWS * 8) lds_put<0>(dst, row, ch, r[i]);
+    }
+  };
+  auto deposit_lse = [&]() __attribute__((always_inline)) {
+    const int t_ = opaque_tid();
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int idx = t_ + i * 512, row = idx >> 3, ch = idx & 7;
+      if (ch == 0 && idx < ROWS * 8) s_lsd[row] = -1.4426950408889634f * rl[i];       // negated and pre-scaled: FMA addends
+    }
+  };
+  // dO in r0, O in r1: dO -> LDS (F), delta = rowsum(O * dO) -> lsd
+  auto deposit_do_delta = [&]() __attribute__((always_inline)) {
+    const int t_ = opaque_tid();
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int idx = t_ + i * 512, row = idx >> 3, ch = idx & 7;
+      const uint4 x = r1[i], y = r0[i];
+      float d = bf_lo(x.x) * bf_lo(y.x) + bf_hi(x.x) * bf_hi(y.x) + bf_lo(x.y) * bf_lo(y.y) + bf_hi(x.y) * bf_hi(y.y) +
+                bf_lo(x.z) * bf_lo(y.z) + bf_hi(x.z) * bf_hi(y.z) + bf_lo(x.w) * bf_lo(y.w) + bf_hi(x.w) * bf_hi(y.w);
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+      if (idx < ROWS * 8) {
+        lds_put<2>(s_x + TILE, row, ch, r0[i]);
+        if (ch == 0) s_lsd[ROWS + row] = -a.scale * d;
       }
     }
-    const int next = pair + gridDim.x;
-#ifndef LAFS_LAB_ATTN_NOPF
-    if (next < n_pairs) bwd_request<NT, IT>(a, next, tid, R);
+  };
+#ifndef LAFS_LAB_ATTN_ABL
+#define LAFS_LAB_ATTN_ABL 0
 #endif
-    {                                                      // phase B: the query tiles, dealt from the other end
-      const int w = 3 - wave;
-      const int q0 = w * BASE + min(w, REM);
-      if (q0 * 16 < len) {
-        if (REM != 0 && w < REM) bwd_queries_item<NT, BASE + 1>(smem, q0, len, drow, a.lddqkv, lane, c2, a.scale);
-        else bwd_queries_item<NT, BASE>(smem, q0, len, drow, a.lddqkv, lane, c2, a.scale);
-      }
-    }
-    if (next >= n_pairs) break;
-    pair = next;
+  bool more = true;
+  // the stops of the dQ phase (the next pair's Q, lse) and of the dK/dV phase (its K, V, dO, delta)
+  auto stop_q = [&](int u) __attribute__((always_inline)) {
+    if (!more || (LAFS_LAB_ATTN_ABL & 2)) return;
+    if (u == 0) { request(r0, s_q, a.ldqkv); request_lse(); }
+    else if (u == H2) { deposit_f(s_x, r0); deposit_lse(); }
+  };
+  auto stop_k = [&](int u) __attribute__((always_inline)) {
+    if (!more || (LAFS_LAB_ATTN_ABL & 1)) return;
+    if (u == 0) { request(r0, s_q + inner, a.ldqkv); request(r1, s_q + 2 * inner, a.ldqkv); }
+    else if (u == H2) { deposit_f(KV, r0); deposit_r(KV + TILE, r1); request(r0, s_d, a.lddo); request(r1, s_o, a.ldo); }
+    else if (u == H3) deposit_do_delta();
+  };
+
+  int pair = blockIdx.x, cur = 0;
+  stage_pair(pair, 0);                                      // the first pair: nothing to hide behind
+  stop_q(0); stop_q(H2); stop_k(0); stop_k(H2); stop_k(H3);
+  for (;;) {
+    const int seq = pair / a.heads, h = pair % a.heads;
+    const int tok0 = load_const(a.cu + seq), len = load_const(a.cu + seq + 1) - tok0;
+    bf16_t* drow = a.dqkv + (size_t)tok0 * a.lddqkv + h * 64;
+    const int next = pair + gridDim.x;
+    more = next < n_pairs;
+    if (more) stage_pair(next, cur ^ 1);
     __syncthreads();
+    const unsigned char* QsF = smem + cur * 2 * TILE;
+    const float* lsd = lsd_base + cur * 2 * ROWS;
+    if (itB < NI && itB * TPI * 16 < len && !(LAFS_LAB_ATTN_ABL & 8))
+      bwd_phase_queries<NT, TPI>(QsF, QsF + TILE, KV, KV + TILE, lsd, itB, len, drow, a.lddqkv, lane, c2, a.scale, stop_q);
+    else { stop_q(0); stop_q(H2); }
+    bf16x8_t kf[TPI][2], vf[TPI][2];
+#pragma unroll
+    for (int x = 0; x < TPI; ++x) {
+      const int key = min(itA * TPI + x, NT - 1) * 16 + c16;
+      kf[x][0] = rfrag_f(KV, key, g, swp); kf[x][1] = rfrag_f(KV, key, 4 + g, swp);
+      vf[x][0] = rfrag(KV + TILE, key, g); vf[x][1] = rfrag(KV + TILE, key, 4 + g);
+    }
+    __syncthreads();
+    if (itA < NI && itA * TPI * 16 < len && !(LAFS_LAB_ATTN_ABL & 4))
+      bwd_phase_keys<NT, TPI>(QsF, QsF + TILE, lsd, kf, vf, itA, len, drow, a.lddqkv, inner, lane, c2, a.scale, stop_k);
+    else { stop_k(0); stop_k(H2); stop_k(H3); }
+    if (!more) break;
+    pair = next; cur ^= 1;
   }
 }
 
@@ -772,10 +701,13 @@ int dispatch(int which, const AttnArgs& a, hipStream_t s) {
   // against 42.
   const size_t pair_bytes = 4 * tile + 2 * NT * 16 * 4;
 #ifndef LAFS_LAB_ATTN_BWD_OLD
-  if constexpr (NT >= 10) {
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n; }();
-    constexpr int NTE = (NT + 1) & ~1;
-    return launch_attn(attn_bwd_long_kernel<NT>, min(n_pairs, n_cu), 1, 256, (size_t)NTE * 16 * (4 * 128 + 8), a, s);
+  if constexpr (NT >= 10 && NT <= 13) {
+    static const int n_cu = [] {
+      int dev = 0, n = 256;
+      (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n;
+    }();
+    return launch_attn(attn_bwd_stream_kernel<NT>, min(n_pairs, n_cu), 1, 512, 6 * tile + 4 * NT * 16 * 4, a, s);
   }
 #endif
   if constexpr (NT >= 7) return launch_attn(attn_bwd_fused_kernel<NT, 1, 8, 2>, n_pairs, 1, 512, pair_bytes, a, s);
