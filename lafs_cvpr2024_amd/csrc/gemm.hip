@@ -384,6 +384,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
     // 128-byte line leave the CU back to back and merge into full-line writes (fc1 at C2: 150 -> ~125 us; debug flag 32768
     // restores the piece-by-piece order for A/B runs)
     constexpr int NPASS = (EPI == EPI_BF16_GELU) ? 2 : 1;
+    uint4 gpk[NG];                                        // (BF16_GELU saving gelu'(u): gelu(u) of the row's pieces, packed)
+#pragma unroll
+    for (int q = 0; q < NG; ++q) gpk[q] = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass)
 #pragma unroll
@@ -445,8 +448,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
           // forward-only pass (teacher): the pre-activation is not needed, only GELU(u) is written; second pass: already stored
         } else if (EPI == EPI_BF16_GELU && p.act == LAFS_GELU_SAVE_GRAD) {        // the first tensor is gelu'(u), not u
           if (full) {
-            st16(c, pack_bf2(gelu_grad_f(w[0]), gelu_grad_f(w[1])), pack_bf2(gelu_grad_f(w[2]), gelu_grad_f(w[3])),
-                 pack_bf2(gelu_grad_f(w[4]), gelu_grad_f(w[5])), pack_bf2(gelu_grad_f(w[6]), gelu_grad_f(w[7])), ntst);
+            // gelu'(u) and gelu(u) from ONE v_rcp + v_exp (gelu_both_f: bit-identical to gelu_grad_f / gelu_f evaluated apart, half the
+            // quarter-rate instructions of this VALU-bound epilogue); gelu(u), with its dropout mask, waits packed for the second pass
+            float d[VPL], g[VPL];
+#pragma unroll
+            for (int e = 0; e < VPL; ++e) {
+              gelu_both_f(w[e], g[e], d[e]);
+              if (drop.thresh) g[e] *= drop_mult(drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
+            }
+            st16(c, pack_bf2(d[0], d[1]), pack_bf2(d[2], d[3]), pack_bf2(d[4], d[5]), pack_bf2(d[6], d[7]), ntst);
+            gpk[q] = make_uint4(pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]), pack_bf2(g[4], g[5]), pack_bf2(g[6], g[7]));
           } else {
 #pragma unroll
             for (int e = 0; e < VPL; ++e) if (n + e < p.N) c[e] = f2bf(gelu_grad_f(w[e]));
@@ -465,6 +476,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
           if DBG(p, 16384) c2 = c + 32;
           if (full && DBG(p, 128)) {
             *reinterpret_cast<uint4*>(c2) = make_uint4(pack_bf2(w[0], w[1]), pack_bf2(w[2], w[3]), pack_bf2(w[4], w[5]), pack_bf2(w[6], w[7]));
+          } else if (full && p.C != nullptr && p.act == LAFS_GELU_SAVE_GRAD) {          // evaluated with gelu'(u) in the first pass
+            st16(c2, gpk[q].x, gpk[q].y, gpk[q].z, gpk[q].w, ntst);
           } else if (drop.thresh && full) {              // dropout(gelu(u)): one 16-byte store like the plain form
             float g[VPL];
 #pragma unroll

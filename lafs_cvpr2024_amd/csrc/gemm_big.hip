@@ -248,9 +248,9 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
               float g[8];
               if (TWO) {
                 float d[8];
-                if (p.act == LAFS_GELU_SAVE_GRAD) {         // (gelu_f / gelu_grad_f as the tiled kernel evaluates them: bit-identical routes)
+                if (p.act == LAFS_GELU_SAVE_GRAD) {         // (as the tiled kernel evaluates them: bit-identical routes)
 #pragma unroll
-                  for (int e = 0; e < 8; ++e) { d[e] = gelu_grad_f(w[e]); g[e] = gelu_f(w[e]); }
+                  for (int e = 0; e < 8; ++e) gelu_both_f(w[e], g[e], d[e]);
                 } else {
 #pragma unroll
                   for (int e = 0; e < 8; ++e) { d[e] = w[e]; g[e] = gelu_f(w[e]); }
@@ -342,10 +342,12 @@ int launch(BArgs a, hipStream_t s) {
   return LAFS_OK;
 }
 
-// tiles of the launch / slots of its rounds of one tile per CU, for a tile shape
+// useful outputs of the launch / outputs its rounds of one tile per CU could hold, for a tile shape (partial edge tiles count as
+// what they are: 640 columns fill 2.5 of 3 column tiles)
 inline long fill_permille(int M, int N, int btm, int btn) {
   const long tiles = (long)ceil_div(M, btm) * ceil_div(N, btn);
-  return tiles * 1000 / (ceil_div(tiles, 256L) * 256);
+  const long slots = ceil_div(tiles, 256L) * 256;
+  return (long)((double)M * N * 1000.0 / ((double)slots * btm * btn));
 }
 
 }  // namespace
@@ -389,13 +391,16 @@ bool lafs_big_eligible(const lafs_gemm_nt_args* g) {
   if (e == LAFS_EPI_BF16 && g->C == nullptr) return false;
   if ((long)g->M * g->lda * 2 >= (1L << 32) || (long)g->N * g->ldb * 2 >= (1L << 32)) return false;     // 32-bit operand offsets
   if (lafs_ctx_opt(g->ctx, LAFS_OPT_NT_BIG) >= 2) return true;
-  // plain epilogue, and at most ~15 % of the slots of the launch's rounds of one tile per CU empty
-  // (12-stage tiles -- K = 768 -- expose the ring's fill and the epilogue at every tile change: they need fuller or more rounds;
-  // 25 216 x 704 x 768: 33.5-33.9 us against 31.9 tiled, 25 216 x 2112 x 768 in 5 rounds: 84.7 against 94.0)
+  // Which epilogues (same box, tools/lab/t_big_ab.py): the plain one, and the GELU pair that saves gelu'(u) (VALU-bound: one
+  // workgroup per CU at 176x256 230 us against 283 tiled at 44 160 x 2048 x 768, 119 against 129 at 25 216 rows); residual and GELU'
+  // epilogues tie or lose.  How full: >= 84 % of the rounds' outputs useful; 12-stage tiles (K = 768) expose the ring's fill and the
+  // epilogue at every tile change and need >= 4 rounds, or 3 that are >= 88 % full (25 216 x 704 x 768 in 2 rounds: 33.5-33.9 us against 31.9 tiled;
+  // 25 216 x 2112 x 768 in 5 rounds: 84.7 against 94.0).
+  const bool epi_ok = e == LAFS_EPI_BF16 || (e == LAFS_EPI_BF16_GELU && g->C != nullptr && g->act == LAFS_GELU_SAVE_GRAD);
   const int geo = big_geometry(g);
   const long fill = geo_fill(g, geo);
   const long rounds = (geo_tiles(g, geo) + 255) / 256;
-  return e == LAFS_EPI_BF16 && fill >= 850 && (g->K >= 1024 || rounds >= 4 || fill >= 950);
+  return epi_ok && fill >= 840 && (g->K >= 1024 || rounds >= 4 || (rounds >= 3 && fill >= 880));
 }
 
 template <typename G>

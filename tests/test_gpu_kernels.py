@@ -84,7 +84,8 @@ def test_gemm_nt_tall_tiles(M, N, K):
     ref = A.float() @ B.float().t() + bias
     Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
     Ms = 2048 + 5
-    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 4, "expected the 160-row tile route"
+    want = (4, 5) if (M, N, K) == (25216, 768, 2048) else (4,)         # (the plain epilogue of that shape: 160x256 persistent tiles since round 5)
+    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) in want, "expected the 160-row tile route"
     assert ops.gemm_nt(Ad[:Ms], Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 0
     guard = 7.0
 

@@ -183,10 +183,11 @@ def test_gemm_route_selection_on_the_benchmark_shapes():
     except Exception as e:                                  # pragma: no cover
         pytest.skip(f"library not built: {e}")
 
-    def route(M, N, K, epi):
+    def route(M, N, K, epi, act=0):
         a = _lib.GemmNTArgs()
         a.M, a.N, a.K, a.epilogue, a.splits = M, N, K, epi, 1
         a.lda, a.ldb, a.ldc, a.ldc2, a.ldr, a.ldaux = K, K, N, N, N, N
+        a.act = act
         a.A = a.B = a.C = a.C2 = a.resid = a.aux = 1 << 20          # (never dereferenced: the route is a function of shapes and presence)
         return int(h.lafs_gemm_nt_route(C.byref(a)))
 
@@ -203,6 +204,7 @@ def test_gemm_route_selection_on_the_benchmark_shapes():
     assert route(25216, 2112, 768, B16) == 5                                                          # 132 x 9 tiles of 192x256 = 4.6 rounds, 93 % full
     assert route(44160, 768, 2048, B16) == 5 and route(44160, 2112, 768, B16) == 5                    # merged rows: 753 / 2259 tiles of 176x256, 98 % full
     assert route(44160, 704, 768, B16) == 5
-    assert route(44160, 768, 2048, RES) != 5 and route(44160, 2048, 768, GELU) != 5                   # (heavy epilogues stay on the tiled kernel)
+    assert route(44160, 768, 2048, RES) != 5 and route(44160, 2048, 768, GELU) != 5 and route(44160, 2048, 768, DG) != 5   # (these stay tiled)
+    assert route(44160, 2048, 768, GELU, act=1) == 5 and route(25216, 2048, 768, GELU, act=1) == 5    # gelu'(u) + gelu(u): VALU-bound, wins there
     assert route(18944, 768, 2048, B16) == 0                                                          # 888 tiles: 2 rounds either way
     assert route(1024, 768, 2048, B16) == 0
