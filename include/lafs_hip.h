@@ -591,6 +591,14 @@ int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const double* su
 int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
                     const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
                     float* dgamma, float* dbeta, const float* grad_scale, hipStream_t stream);
+/* nn.BatchNorm2d in EVAL mode (a model.eval() forward that is still differentiated, face_pre_pro/ViT_face.py:679-711 under
+ * train_largescale.py's test-time paths): lafs_cnn_bn_eval_sums writes the sums a batch with exactly the running statistics would have
+ * (sums[c] = R mean, sums[C + c] = R (var + mean^2), fp64), so that lafs_cnn_bn_apply (running_mean = NULL: no update) normalises with
+ * them; lafs_cnn_bn_bwd_eval is lafs_cnn_bn_bwd with the statistics as constants: dx = gamma rstd dz, same dgamma / dbeta. */
+int lafs_cnn_bn_eval_sums(const float* running_mean, const float* running_var, int64_t R, int C, double* sums, hipStream_t stream);
+int lafs_cnn_bn_bwd_eval(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
+                    const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
+                    float* dgamma, float* dbeta, const float* grad_scale, hipStream_t stream);
 /* Loss scaling and overflow guard of the fp16 backward -- the reference's torch.cuda.amp.GradScaler (train_largescale.py:739,
  * 803-804, 867-880: scale, skip the step on inf / NaN, back the scale off, grow it again) decided on the device, so that a captured
  * step needs no host round trip.

@@ -133,6 +133,8 @@ _PROTOS = {
     "lafs_cnn_bn_stats": [vp, i32, i64, i32, vp],
     "lafs_cnn_bn_apply": [vp, i32, i64, i32, vp, vp, vp, f32, f32, vp, vp, i32, vp, i32, vp, i32, vp],
     "lafs_cnn_bn_bwd": [vp, i32, vp, i32, i64, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, vp],
+    "lafs_cnn_bn_bwd_eval": [vp, i32, vp, i32, i64, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32, vp, vp, vp],
+    "lafs_cnn_bn_eval_sums": [vp, vp, i64, i32, vp],
     "lafs_cnn_dwconv_train_fwd": [vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "lafs_cnn_dwconv_train_bwd": [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "lafs_cnn_scale_act_out": [vp, vp, i32, i32, i32, i32, i32, vp],

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const float* __restrict__ beta, int act, const bf16_t* __restrict__ add,
                                                            int ldadd, int HW, const double* __restrict__ dsums, bf16_t* __restrict__ dx,
                                                            int lddx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           const float* __restrict__ gscale) {
+                                                           const float* __restrict__ gscale, int frozen) {
   extern __shared__ float sc[];                          // [6 lddx]: mean, rstd, gamma, beta, sum dz / R, sum dz xhat / R
   const int C8 = lddx >> 3;
   const long total = R * C8;
@@ -231,7 +231,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   for (int c = threadIdx.x; c < lddx; c += 256) {
     const bool ok = c < C;
     sc[c] = ok ? stat[c] : 0.f; sc[lddx + c] = ok ? stat[C + c] : 0.f; sc[2 * lddx + c] = ok ? gamma[c] : 0.f;
-    sc[3 * lddx + c] = ok ? beta[c] : 0.f; sc[4 * lddx + c] = ok ? (float)(dsums[c] * invR) : 0.f; sc[5 * lddx + c] = ok ? (float)(dsums[C + c] * invR) : 0.f;
+    sc[3 * lddx + c] = ok ? beta[c] : 0.f;
+    // (frozen statistics -- eval mode -- are constants of the backward: dx = gamma rstd dz, no batch-mean terms)
+    sc[4 * lddx + c] = (ok && !frozen) ? (float)(dsums[c] * invR) : 0.f; sc[5 * lddx + c] = (ok && !frozen) ? (float)(dsums[C + c] * invR) : 0.f;
     if (ok && blockIdx.x == 0 && dgamma != nullptr) {      // the affine gradients leave the scaled 16-bit domain here: x 1 / scale
       const double inv = gscale != nullptr ? (double)gscale[1] : 1.0;
       dgamma[c] += (float)(dsums[C + c] * inv); dbeta[c] += (float)(dsums[c] * inv);
@@ -710,9 +712,9 @@ extern "C" int lafs_cnn_bn_apply(const void* x, int ldx, int64_t R, int C, const
   return LAFS_OK;
 }
 
-extern "C" int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
-                               const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
-                               float* dgamma, float* dbeta, const float* grad_scale, hipStream_t stream) {
+static int bn_bwd_impl(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
+                       const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
+                       float* dgamma, float* dbeta, const float* grad_scale, int frozen, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(dy && x && stat && gamma && beta && dsums && dx && R > 0 && C > 0 && HW > 0, "null operand");
   LAFS_CHECK_ARG(lddy % 8 == 0 && ldx % 8 == 0 && lddx % 8 == 0 && lddx >= C && lddy >= lddx && ldx >= lddx, "bad strides");
@@ -725,7 +727,36 @@ extern "C" int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx,
   long blocks = (R * (lddx / 8) + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 6 * lddx * sizeof(float), stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (long)R,
-                     C, stat, gamma, beta, act, (const bf16_t*)add_nc, ldadd, HW, dsums, (bf16_t*)dx, lddx, dgamma, dbeta, grad_scale);
+                     C, stat, gamma, beta, act, (const bf16_t*)add_nc, ldadd, HW, dsums, (bf16_t*)dx, lddx, dgamma, dbeta, grad_scale, frozen);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+extern "C" int lafs_cnn_bn_bwd(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
+                               const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
+                               float* dgamma, float* dbeta, const float* grad_scale, hipStream_t stream) {
+  return bn_bwd_impl(dy, lddy, x, ldx, R, C, stat, gamma, beta, act, add_nc, ldadd, HW, dsums, dx, lddx, dgamma, dbeta, grad_scale, 0, stream);
+}
+
+extern "C" int lafs_cnn_bn_bwd_eval(const void* dy, int lddy, const void* x, int ldx, int64_t R, int C, const float* stat, const float* gamma,
+                                    const float* beta, int act, const void* add_nc, int ldadd, int HW, double* dsums, void* dx, int lddx,
+                                    float* dgamma, float* dbeta, const float* grad_scale, hipStream_t stream) {
+  return bn_bwd_impl(dy, lddy, x, ldx, R, C, stat, gamma, beta, act, add_nc, ldadd, HW, dsums, dx, lddx, dgamma, dbeta, grad_scale, 1, stream);
+}
+
+// eval-mode BatchNorm through the same apply / backward kernels: the sums a batch with exactly the running statistics would have
+__global__ void bn_eval_sums_kernel(const float* __restrict__ rm, const float* __restrict__ rv, double R, int C, double* __restrict__ sums) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const double m = (double)rm[c], v = (double)rv[c];
+    sums[c] = R * m; sums[C + c] = R * (v + m * m);
+  }
+}
+
+extern "C" int lafs_cnn_bn_eval_sums(const float* running_mean, const float* running_var, int64_t R, int C, double* sums, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(running_mean && running_var && sums && R > 0 && C > 0, "bad operand");
+  hipLaunchKernelGGL(bn_eval_sums_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, running_mean, running_var, (double)R, C, sums);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

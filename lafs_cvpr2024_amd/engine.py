@@ -65,6 +65,11 @@ class LafsPretrainEngine:
         # the library's side streams / events / kernel options of THIS engine (created now: nothing is created inside a capture;
         # two engines share no stream or event).  The environment's A/B switches are read by _lib.Ctx, not by the library.
         self.ctx = _lib.Ctx(self.device)
+        # The row chains (long / short sequences on two streams) pay on the ViT-S trunk, whose K = 384 kernels leave CUs idle; the
+        # Part-fViT trunk's wide GEMMs run on one-workgroup-per-CU persistent tiles (gemm_big.hip) that want the whole chip and the
+        # merged 44 160 rows (753 tiles of 176x256 = 2.94 rounds): `mynet` pair 36.1 ms with two chains, 35.4-35.5 with one.
+        if self.partfvit and "LAFS_ROW_CHAINS" not in os.environ:
+            self.ctx.set(_lib.OPT_ROW_CHAINS, 1)
         self.ta = getattr(teacher, "_lafs_arena", None)
         if self.ta is None:
             for p in teacher.parameters():

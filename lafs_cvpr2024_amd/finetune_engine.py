@@ -129,9 +129,9 @@ class FinetuneEngine:
         # optimizer_step leaves the (dead) gradients in place: the next micro-step zeroes / overwrites them itself.  True restores
         # "gradients are zero after a step" for callers that inspect arena.grad / p.grad afterwards (a 1 GB memset per step at C4)
         self.zero_after_step = False
-        # trainable landmark branch: the HIP training plan (landmark_train.HipLandmarkTrainer) whenever the model is in training mode
-        # (BatchNorm batch statistics, Dropout(0.5)); an eval-mode model -- and LAFS_FT_CNN=torch, for A/B runs -- takes the nn.Module
-        # on torch autograd
+        # trainable landmark branch: the HIP plan (landmark_train.HipLandmarkTrainer) in training mode (BatchNorm batch statistics,
+        # Dropout(0.5)) and in eval mode (running statistics as constants of the backward, no dropout); LAFS_FT_CNN=torch, for A/B
+        # runs, takes the nn.Module on torch autograd
         self.cnn = None
         if m.with_land and os.environ.get("LAFS_FT_CNN", "hip") == "hip":
             from .landmark_train import HipLandmarkTrainer
@@ -187,7 +187,7 @@ class FinetuneEngine:
 
     def _capturable(self):
         m = self.model
-        return self.use_graph and (not m.with_land or (self.cnn is not None and m.training))
+        return self.use_graph and (not m.with_land or self.cnn is not None)
 
     def micro_step(self, inputs_u8, labels, lam=None):
         """One forward/backward on a uint8 NCHW batch.  Gradients accumulate in the arena (loss pre-divided by acc_step).
@@ -211,7 +211,7 @@ class FinetuneEngine:
                 g = self._capture(first)
                 self._graphs[key] = g
             g.replay()
-            if self._cnn_hip:                            # nn.BatchNorm2d.num_batches_tracked: one training forward of the landmark CNN per replay
+            if self._cnn_hip and m.training:             # nn.BatchNorm2d.num_batches_tracked: one training forward of the landmark CNN per replay
                 self.cnn.n_forward += 1
         else:
             self._body(first)
@@ -272,7 +272,7 @@ class FinetuneEngine:
         if m.training and (m.dropout_rate > 0.0 or m.emb_dropout_rate > 0.0):
             dropout = (m.dropout_rate, m.emb_dropout_rate, m._drop_seed0, hp[_lib.HP_STEP:])
         img_in, theta, th = self.x, None, None
-        self._cnn_hip = m.with_land and self.cnn is not None and m.training
+        self._cnn_hip = m.with_land and self.cnn is not None
         if m.with_land:
             # trainable landmark regressor -> one-launch patch gather (ViT_face.py:679-711)
             theta = self.cnn.forward(self.x) if self._cnn_hip else m.landmarks(self.x)

@@ -245,17 +245,21 @@ class HipLandmarkTrainer:
 
     # ------------------------------------------------------------------ BatchNorm wrappers
     def _bn_fwd(self, spec, x, R, act, out, resid=None):
-        call("lafs_cnn_bn_stats", _p(x), x.shape[1], R, spec["C"], self._ws(spec["sums"]))
+        train = self.model.training
+        if train:
+            call("lafs_cnn_bn_stats", _p(x), x.shape[1], R, spec["C"], self._ws(spec["sums"]))
+        else:       # eval mode: the running statistics, as the sums of a batch that has exactly them; no momentum update
+            call("lafs_cnn_bn_eval_sums", _p(spec["rm"]), _p(spec["rv"]), R, spec["C"], self._ws(spec["sums"]))
         if spec["stat"] is None:
             spec["stat"] = torch.empty(2 * spec["C"], device=self.device, dtype=f32)
         call("lafs_cnn_bn_apply", _p(x), x.shape[1], R, spec["C"], self._ws(spec["sums"]), self._m(spec["g"]), self._m(spec["b"]), spec["eps"],
-             spec["mom"], _p(spec["rm"]), _p(spec["rv"]), act, _p(resid), resid.shape[1] if resid is not None else 0, _p(out), out.shape[1],
-             _p(spec["stat"]))
+             spec["mom"], _p(spec["rm"]) if train else None, _p(spec["rv"]) if train else None, act, _p(resid),
+             resid.shape[1] if resid is not None else 0, _p(out), out.shape[1], _p(spec["stat"]))
 
     def _bn_bwd(self, spec, dy, x, R, act, dx, add_nc=None, HW=1):
-        call("lafs_cnn_bn_bwd", _p(dy), dy.shape[1], _p(x), x.shape[1], R, spec["C"], _p(spec["stat"]), self._m(spec["g"]), self._m(spec["b"]), act,
-             _p(add_nc), add_nc.shape[1] if add_nc is not None else 0, HW, self._ws(spec["dsums"]), _p(dx), dx.shape[1], self._g(spec["g"]),
-             self._g(spec["b"]), _p(self.gscale))
+        call("lafs_cnn_bn_bwd" if self.model.training else "lafs_cnn_bn_bwd_eval", _p(dy), dy.shape[1], _p(x), x.shape[1], R, spec["C"],
+             _p(spec["stat"]), self._m(spec["g"]), self._m(spec["b"]), act, _p(add_nc), add_nc.shape[1] if add_nc is not None else 0, HW,
+             self._ws(spec["dsums"]), _p(dx), dx.shape[1], self._g(spec["g"]), self._g(spec["b"]), _p(self.gscale))
 
     def _wgrad(self, dy, x, cs):
         """padded dW [po, pi] = dy^T x into the gradient image of conv spec `cs` (folded into the arena at the end of backward)."""
@@ -317,7 +321,7 @@ class HipLandmarkTrainer:
                     bias=a.view(a.master, "output_layer.1.bias"), out=B["t"])
         n_full = self.n_out // 2
         call("lafs_landmark_theta", _p(B["t"]), N, n_full, _p(B["zero_noise"]), 0.0, None, n_full, _p(B["theta"]))
-        if not torch.cuda.is_current_stream_capturing():
+        if self.model.training and not torch.cuda.is_current_stream_capturing():
             # (a captured forward is counted per REPLAY by its owner, FinetuneEngine.micro_step: this Python code runs only at capture)
             self.n_forward += 1
         return B["theta"]

@@ -193,7 +193,8 @@ def test_gemm_nt_big_tiles_equal_the_tiled_kernel_bit_for_bit(M, N, K, geo):
     ref = A.float() @ B.float().t() + bias
     Ad, Bd, bd = A.to(DEV), B.to(DEV), bias.to(DEV)
     tiled = _lib.Ctx(DEV, options={_lib.OPT_NT_BIG: 0}, from_env=False)
-    assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 5, "expected the 192x256 route (plain epilogue, full rounds)"
+    if K >= 2048:                                                        # (12-stage tiles need more / fuller rounds to be routed there by default)
+        assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True) == 5, "expected the 192x256 route (plain epilogue, full rounds)"
     assert ops.gemm_nt(Ad, Bd, _lib.EPI_BF16, bias=bd, route_only=True, ctx=tiled) in (0, 3, 4)     # (any tile form of gemm.hip: same k order)
     big = _lib.Ctx(DEV, options={_lib.OPT_NT_BIG: geo}, from_env=False)      # every epilogue forced onto the kernel (default: plain only)
     guard = 7.0

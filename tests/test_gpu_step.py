@@ -600,6 +600,7 @@ def test_row_chains_equal_the_single_chain(tmp_path):
         assert r.returncode == 0 and "CHAINS_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         out[mode] = torch.load(f)
     la, lb = out["2"]["losses"], out["0"]["losses"]
+    print("[row-chains] relative loss differences, steps 0-3: " + " ".join(f"{abs(a - b) / abs(b):.2e}" for a, b in zip(la, lb)))
     assert abs(la[0] - lb[0]) < 1e-6 * abs(lb[0]), (la, lb)            # same weights: the forward is the same arithmetic
     assert abs(la[1] - lb[1]) < 2e-4 * abs(lb[1]), (la, lb)            # one update apart: atomics-order noise of the gradients (seen up to ~3e-5)
     for a, b in zip(la[2:], lb[2:]):                                     # then Adam's first steps (lr * sign of a near-zero gradient)

@@ -1,0 +1,4 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/b19; mkdir -p $O; cd $R
+timeout 300 python -m pytest tests/test_gpu_kernels.py -q -x -k "gemm" -p no:cacheprovider 2>&1 | tail -2
+ENVS="LAFS_ROW_CHAINS=2|LAFS_ROW_CHAINS=1|LAFS_ROW_CHAINS=1 LAFS_NT_BIG=0" WHICH=mynet bash tools/lab/ab_env_mynet.sh 2>&1 | tee $O/mynet.txt
