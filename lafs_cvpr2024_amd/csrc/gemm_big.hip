@@ -26,6 +26,7 @@
 //     stores drain under the next tile's MFMAs (counted s_waitcnt vmcnt: the epilogue's stores are a compile-time count);
 //   * C^T blocks (MFMA A-operand = 16 weight rows) with the weight rows of a 64-column group permuted as in gemm.hip, so a lane
 //     ends with 8 (bf16) / 4 (fp32) consecutive output columns and the four lane groups of a row store 64 contiguous bytes.
+#include <type_traits>
 #include "common.hpp"
 #include "ctx.hpp"
 #include "gemm_big.hpp"
@@ -187,7 +188,11 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
   // ---- epilogue of the tile at (m0, n0): lane owns rows m0 + wr*16*MBW + 16 i + t16 and, per row and 64-column group jg, 16 / VPL
   // pieces of VPL consecutive columns: piece qq of group jg starts at n0 + wc*128 + 64 jg + qq*4*VPL + fq*VPL; register
   // e = (j & 3) * 4 + r of the group is element e % VPL of piece e / VPL
-  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+  // (WHOLE: the tile lies inside the matrix -- no guard, hence no branch, around any load or store.  With guards every store sits in
+  // its own basic block, and hipcc opens each block with s_waitcnt vmcnt(0) -- the bias registers came from loads -- which also
+  // sits out the store before it: 22 serialised write round trips per tile in the plain epilogue)
+  auto epilogue_body = [&](int m0, int n0, auto whole_c) __attribute__((always_inline)) {
+    constexpr bool WHOLE = decltype(whole_c)::value;
     constexpr int NG = 16 / VPL;
 #pragma unroll
     for (int jg = 0; jg < NBW / 4; ++jg) {
@@ -199,29 +204,63 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int n = ncol0 + (e / VPL) * 4 * VPL + (e % VPL);
-          if (n < p.N) bias[e] = p.bias[n];
+          if (WHOLE || n < p.N) bias[e] = p.bias[n];
         }
       }
+      // Operand loads of the epilogue (the residual rows, the saved gelu'(u) / u rows, the per-sequence DropPath scale) are requested
+      // for RB rows at once, in front of the arithmetic and the stores of those rows: left inside the per-piece code each load was
+      // followed by its own s_waitcnt vmcnt(0) -- which also sits out every store issued before it -- i.e. 4 x MBW serialised HBM round
+      // trips per tile (~30 us of a 69 us tile of the fc2 forward)
+      constexpr bool PRE = (EPI == LAFS_EPI_RESID_F32 || EPI == LAFS_EPI_DGELU_BF16);
+      constexpr int RB = PRE ? (G::NTH > 256 ? 2 : 4) : 1;      // (two waves per SIMD: half the registers)
 #pragma unroll
-      for (int i = 0; i < MBW; ++i) {
+      for (int i0 = 0; i0 < MBW; i0 += RB) {
+        uint4 pre[RB][NG];
+        float scs[RB];
+        if (PRE) {
+          int sidx[RB];                                       // (index loads first: the scale loads behind the row loads wait on these only)
+#pragma unroll
+          for (int ii = 0; ii < RB; ++ii) {
+            const int m = m0 + wr * (16 * MBW) + min(i0 + ii, MBW - 1) * 16 + t16;
+            sidx[ii] = (EPI == LAFS_EPI_RESID_F32 && p.seq_scale != nullptr) ? p.row2seq[(WHOLE || m < p.M) ? m : p.M - 1] : 0;
+          }
+#pragma unroll
+          for (int ii = 0; ii < RB; ++ii) {
+            const int i = i0 + ii;
+            if (i < MBW) {
+              const int m = m0 + wr * (16 * MBW) + i * 16 + t16;
+              const int mc = (WHOLE || m < p.M) ? m : p.M - 1;
+#pragma unroll
+              for (int qq = 0; qq < NG; ++qq) {
+                const int n = ncol0 + qq * 4 * VPL;
+                const int nc = (WHOLE || n + VPL <= p.N) ? n : 0;
+                if (EPI == LAFS_EPI_RESID_F32) pre[ii][qq] = *reinterpret_cast<const uint4*>(p.resid + (size_t)mc * p.ldr + nc);
+                else pre[ii][qq] = *reinterpret_cast<const uint4*>(p.aux + (size_t)mc * p.ldaux + nc);
+              }
+            }
+          }
+#pragma unroll
+          for (int ii = 0; ii < RB; ++ii) scs[ii] = (EPI == LAFS_EPI_RESID_F32 && p.seq_scale != nullptr) ? p.seq_scale[sidx[ii]] : 1.0f;
+        }
+#pragma unroll
+      for (int ii = 0; ii < RB; ++ii) {
+        const int i = i0 + ii;
+        if (i >= MBW) continue;
         const int m = m0 + wr * (16 * MBW) + i * 16 + t16;
-        const bool rowok = m < p.M;
-        const int mc = rowok ? m : p.M - 1;                 // (operand loads of rows beyond M read the last row: a fixed count of loads)
+        const bool rowok = WHOLE || m < p.M;
         float v[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[j * 4 + r] = acc[jg * 4 + j][i][r] + bias[j * 4 + r];
-        float sc = 1.0f;
-        if (EPI == LAFS_EPI_RESID_F32 && p.seq_scale != nullptr) sc = p.seq_scale[p.row2seq[mc]];
+        const float sc = PRE ? scs[ii] : 1.0f;
 #pragma unroll
         for (int qq = 0; qq < NG; ++qq) {
           const int n = ncol0 + qq * 4 * VPL;
-          const bool ok = rowok && (n + VPL <= p.N);        // (N % 8 == 0: a piece is inside the matrix or outside it)
-          const int nc = (n + VPL <= p.N) ? n : 0;
+          const bool ok = WHOLE || (rowok && (n + VPL <= p.N));        // (N % 8 == 0: a piece is inside the matrix or outside it)
           float* w = v + qq * VPL;
           if (EPI == LAFS_EPI_RESID_F32) {
-            const uint4 r4 = *reinterpret_cast<const uint4*>(p.resid + (size_t)mc * p.ldr + nc);
+            const uint4 r4 = pre[ii][qq];
             if (drop.thresh) {
 #pragma unroll
               for (int e = 0; e < VPL; ++e) w[e] *= drop_mult(drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
@@ -231,7 +270,7 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
             if (ok) st16f(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n, w[0], w[1], w[2], w[3]);
           } else {
             if (EPI == LAFS_EPI_DGELU_BF16) {
-              const uint4 a4 = *reinterpret_cast<const uint4*>(p.aux + (size_t)mc * p.ldaux + nc);
+              const uint4 a4 = pre[ii][qq];
               if (p.act == LAFS_GELU_SAVE_GRAD) {           // aux already holds gelu'(u)
                 w[0] *= bf_lo(a4.x); w[1] *= bf_hi(a4.x); w[2] *= bf_lo(a4.y); w[3] *= bf_hi(a4.y);
                 w[4] *= bf_lo(a4.z); w[5] *= bf_hi(a4.z); w[6] *= bf_lo(a4.w); w[7] *= bf_hi(a4.w);
@@ -274,7 +313,14 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
           }
         }
       }
+      }
     }
+  };
+  auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) {
+    // (the GELU epilogues keep the one guarded form: their stores already issue back to back, and two copies of that much
+    // arithmetic cost the 176x256 geometry 13 spilled registers -- 230 -> 277 us on the fc1 forward)
+    if (EPI != LAFS_EPI_BF16_GELU && m0 + BTM <= p.M && n0 + BT <= p.N) epilogue_body(m0, n0, std::true_type());
+    else epilogue_body(m0, n0, std::false_type());
   };
 
   // ---- prologue: stages 0 and 1 in flight, stage 0's first fragments in registers
@@ -391,15 +437,21 @@ bool lafs_big_eligible(const lafs_gemm_nt_args* g) {
   if (e == LAFS_EPI_BF16 && g->C == nullptr) return false;
   if ((long)g->M * g->lda * 2 >= (1L << 32) || (long)g->N * g->ldb * 2 >= (1L << 32)) return false;     // 32-bit operand offsets
   if (lafs_ctx_opt(g->ctx, LAFS_OPT_NT_BIG) >= 2) return true;
-  // Which epilogues (same box, tools/lab/t_big_ab.py): the plain one, and the GELU pair that saves gelu'(u) (VALU-bound: one
-  // workgroup per CU at 176x256 230 us against 283 tiled at 44 160 x 2048 x 768, 119 against 129 at 25 216 rows); residual and GELU'
-  // epilogues tie or lose.  How full: >= 84 % of the rounds' outputs useful; 12-stage tiles (K = 768) expose the ring's fill and the
-  // epilogue at every tile change and need >= 4 rounds, or 3 that are >= 88 % full (25 216 x 704 x 768 in 2 rounds: 33.5-33.9 us against 31.9 tiled;
-  // 25 216 x 2112 x 768 in 5 rounds: 84.7 against 94.0).
-  const bool epi_ok = e == LAFS_EPI_BF16 || (e == LAFS_EPI_BF16_GELU && g->C != nullptr && g->act == LAFS_GELU_SAVE_GRAD);
+  // Which epilogues (same box, tools/lab/t_big_ab.py, us tiled -> here): the plain one; the GELU pair that saves gelu'(u) (VALU-bound:
+  // 283 -> 230 at 44 160 x 2048 x 768, 129 -> 119 at 25 216 rows); GELU' (224 -> 206-212, 111 -> 104); residual + DropPath scale only
+  // from three rounds on (44 160 rows: fc2 forward 209 -> 173, projection 122 -> 96; a tie at 25 216 rows = 2 rounds).  The GELU pair
+  // that writes u, and the forward-only GELU, stay tiled (not measured).  How full: >= 84 % of the rounds' outputs useful; 12-stage
+  // tiles (K = 768) expose the ring's fill and the epilogue at every tile change and need >= 4 rounds, or 3 that are >= 88 % full
+  // (25 216 x 704 x 768 in 2 rounds: 33.5-33.9 us against 31.9 tiled; 25 216 x 2112 x 768 in 5 rounds: 84.7 against 94.0).
   const int geo = big_geometry(g);
   const long fill = geo_fill(g, geo);
   const long rounds = (geo_tiles(g, geo) + 255) / 256;
+#ifdef LAFS_LAB_BIG_OLDRULE
+  const bool epi_ok = e == LAFS_EPI_BF16 || (e == LAFS_EPI_BF16_GELU && g->C != nullptr && g->act == LAFS_GELU_SAVE_GRAD);
+#else
+  const bool epi_ok = e == LAFS_EPI_BF16 || e == LAFS_EPI_DGELU_BF16 || (e == LAFS_EPI_RESID_F32 && rounds >= 3) ||
+                      (e == LAFS_EPI_BF16_GELU && g->C != nullptr && g->act == LAFS_GELU_SAVE_GRAD);
+#endif
   return epi_ok && fill >= 840 && (g->K >= 1024 || rounds >= 4 || (rounds >= 3 && fill >= 880));
 }
 
