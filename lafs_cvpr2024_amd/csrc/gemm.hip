@@ -15,6 +15,7 @@
 // MFMA row so that every lane ends up with 16 CONTIGUOUS output columns of one row: epilogues read/write
 // 32-64 B per lane (bias, residual, GELU, fp32/bf16 stores) with no LDS transpose.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.hpp"
 #include "lafs_hip.h"
 #include "gemm_kres.hpp"
@@ -306,7 +307,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
   }
 
   STAMP(1);
-  auto epilogue = [&]() {
+  // (WHOLE: the tile lies inside the matrix.  Without guards there are no branches around the epilogue's loads and stores; with
+  // them every guarded piece is its own basic block that hipcc opens with s_waitcnt vmcnt(0) -- the bias / prefetched operand
+  // registers came from loads -- so the one-row-ahead prefetch below was waited for right where it was issued, and every store sat
+  // out the store before it)
+  auto epilogue = [&](auto whole_c) __attribute__((always_inline)) {
+  constexpr bool WHOLE = decltype(whole_c)::value;
   // ---- epilogue: lane owns rows m = m0 + wr*64 + i*16 + (lane&15) and, per row, NG groups of VPL consecutive columns:
   // group q starts at n0 + wc*64 + q*4*VPL + fq*VPL; register e = j*4 + r of the row is element e % VPL of group e / VPL.
   constexpr int VPL = EpiTraits<EPI>::VPL, NG = 16 / VPL;
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int n = ncol0 + (e / VPL) * 4 * VPL + (e % VPL);
-      if (n < p.N) bias[e] = p.bias[n];
+      if (WHOLE || n < p.N) bias[e] = p.bias[n];
     }
   }
   // Operands the epilogue reads per output piece (the fp32 residual of RESID_F32, the pre-activation of DGELU_BF16) are
@@ -336,11 +342,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
   auto prefetch = [&](int i) {
     if (!PRE || i >= MB) return;
     const int mi = m0 + wr * RW + i * 16 + frow;
-    if (mi >= p.M) return;
+    if (!WHOLE && mi >= p.M) return;
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       const int n = ncol0 + q * 4 * VPL;
-      if (n + VPL > p.N) continue;
+      if (!WHOLE && n + VPL > p.N) continue;
       if (EPI == EPI_RESID_F32) pre[q] = *reinterpret_cast<const uint4*>(p.resid + (size_t)mi * p.ldr + n);
       else pre[q] = *reinterpret_cast<const uint4*>(p.aux + (size_t)mi * p.ldaux + n);
     }
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
       const int mi = m0 + wr * RW + i * 16 + frow;
-      if (mi < p.M) scv[i] = p.seq_scale[p.row2seq[mi]];
+      if (WHOLE || mi < p.M) scv[i] = p.seq_scale[p.row2seq[mi]];
     }
   }
 #pragma unroll
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
       for (int q = 0; q < NG; ++q) cur[q] = pre[q];
       prefetch(i + 1);
     }
-    if (m >= p.M) continue;
+    if (!WHOLE && m >= p.M) continue;
     float v[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -392,8 +398,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       const int n = ncol0 + q * 4 * VPL;
-      if (n >= p.N) continue;
-      const bool full = (n + VPL <= p.N);
+      if (!WHOLE && n >= p.N) continue;
+      const bool full = WHOLE || (n + VPL <= p.N);
       float* w = v + q * VPL;
 #ifdef LAFS_ABLATE
       // pacing experiment: (dbg >> 24) & 31 sleeps of 128 clocks before every store group, so that a workgroup's stores enter
@@ -531,7 +537,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
     }
   }
   };
-  epilogue();
+  // (plain / residual / GELU' epilogues only: the others are rare or already store back to back, and two copies of them cost registers)
+  if ((EPI == EPI_BF16 || EPI == EPI_RESID_F32 || EPI == EPI_DGELU_BF16) && m0 + BMT <= p.M && n0 + BN <= p.N) epilogue(std::true_type());
+  else epilogue(std::false_type());
 #ifdef LAFS_ABLATE
   STAMP(2);
   if (p.stamps && !PERSIST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
