@@ -586,8 +586,8 @@ print("CHAINS_DONE")
 def test_row_chains_equal_the_single_chain(tmp_path):
     """The trunk passes as two chains of launches over the row ranges of the two crop-resolution groups (csrc/engine.hip:
     row_ranges; LAFS_ROW_CHAINS, read once per process) against ONE chain over all rows: four captured steps from the same
-    initialisation; the first loss is identical, the later ones and the weights agree up to the order of the fp32 atomics of the LayerNorm
-    parameter gradients as Adam's first steps amplify it."""
+    initialisation; the first loss is identical, the later ones and the weights agree up to the grouping of the LayerNorm / bias
+    gradients' partial sums (per chain, then folded in a fixed order) as Adam's first steps amplify it."""
     import os
     import subprocess
     import sys
@@ -602,7 +602,8 @@ def test_row_chains_equal_the_single_chain(tmp_path):
     la, lb = out["2"]["losses"], out["0"]["losses"]
     print("[row-chains] relative loss differences, steps 0-3: " + " ".join(f"{abs(a - b) / abs(b):.2e}" for a, b in zip(la, lb)))
     assert abs(la[0] - lb[0]) < 1e-6 * abs(lb[0]), (la, lb)            # same weights: the forward is the same arithmetic
-    assert abs(la[1] - lb[1]) < 2e-4 * abs(lb[1]), (la, lb)            # one update apart: atomics-order noise of the gradients (seen up to ~3e-5)
+    assert abs(la[1] - lb[1]) < 2e-5 * abs(lb[1]), (la, lb)            # one update apart: the gradients' column sums are folded in a fixed order per
+                                                                         # configuration since round 5 (no fp32 atomics): observed 2.1e-6 (round 4, atomics: up to 3e-5)
     for a, b in zip(la[2:], lb[2:]):                                     # then Adam's first steps (lr * sign of a near-zero gradient)
         assert abs(a - b) < 5e-3 * abs(b), (la, lb)                      # amplify that noise; a race would be orders above this
     for name in ("teacher", "student"):

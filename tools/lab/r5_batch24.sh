@@ -1,0 +1,5 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/b24; mkdir -p $O; cd $R
+timeout 2400 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $O/full.log 2>&1; echo "full rc=$?"; tail -6 $O/full.log | cut -c1-300
+grep -h "grad-gate\|\[F17\]\|\[F18\]\|\[composition\]\|\[fine-tune window\]\|\[finetune graph\|\[row-chains\]\|\[eval-mode" $O/full.log | cut -c1-400 > $O/gates.txt; wc -l $O/gates.txt
+python __graft_entry__.py smoke 2>&1 | tail -3
