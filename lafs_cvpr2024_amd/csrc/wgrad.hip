@@ -307,32 +307,46 @@ __global__ __launch_bounds__(64 * WM * WN, OCC * (WM * WN) / 4) void wgrad_kerne
   const long ldo = g_.ldo;
   const bool direct_acc = (p.slices == 1) && g_.accumulate;
   const int c2 = n2_0 + wn * FB * 32 + (lane & 31);
-  if (!direct_acc) {
+  // (WHOLE: the tile lies inside the matrix.  A guard around every store makes every store a basic block of its own, which hipcc
+  // opens with s_waitcnt vmcnt(0): FA x FB x 16 = 144 stores per wave each sat out the store before it -- found in round 5 with
+  // tools/lab/scan_waits.py; ViT-S and Part-fViT weights are multiples of the 192 x 192 tile except 704 and 2048)
+  auto store_tile = [&](auto whole_c) __attribute__((always_inline)) {
+    constexpr bool WHOLE = decltype(whole_c)::value;
+    if (!direct_acc) {
 #pragma unroll
-    for (int a = 0; a < FA; ++a)
+      for (int a = 0; a < FA; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n1 = n1_0 + (wm * FA + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float* dst = out + (size_t)n1 * ldo + c2;
+        for (int r = 0; r < 16; ++r) {
+          const int n1 = n1_0 + (wm * FA + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float* dst = out + (size_t)n1 * ldo + c2;
 #pragma unroll
-        for (int b = 0; b < FB; ++b)
-          if (n1 < N1 && c2 + b * 32 < N2) dst[b * 32] = acc[a][b][r];
+          for (int b = 0; b < FB; ++b)
+            if (WHOLE || (n1 < N1 && c2 + b * 32 < N2)) dst[b * 32] = acc[a][b][r];
+        }
+    } else {                                          // a single slice accumulating into C: one writer per element
+#pragma unroll
+      for (int a = 0; a < FA; ++a) {                   // (all 16 x FB old values of a block row requested before the first store: C may
+        float old[16][FB];                             // alias nothing the compiler can prove, so it keeps each load behind the stores before it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n1 = n1_0 + (wm * FA + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float* dst = out + (size_t)n1 * ldo + c2;
+#pragma unroll
+          for (int b = 0; b < FB; ++b) old[r][b] = (WHOLE || (n1 < N1 && c2 + b * 32 < N2)) ? dst[b * 32] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n1 = n1_0 + (wm * FA + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float* dst = out + (size_t)n1 * ldo + c2;
+#pragma unroll
+          for (int b = 0; b < FB; ++b)
+            if (WHOLE || (n1 < N1 && c2 + b * 32 < N2)) dst[b * 32] = old[r][b] + acc[a][b][r];
+        }
       }
-  } else {                                            // a single slice accumulating into C: one writer per element
-#pragma unroll
-    for (int a = 0; a < FA; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n1 = n1_0 + (wm * FA + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float* dst = out + (size_t)n1 * ldo + c2;
-        float old[FB];
-#pragma unroll
-        for (int b = 0; b < FB; ++b) old[b] = (n1 < N1 && c2 + b * 32 < N2) ? dst[b * 32] : 0.f;
-#pragma unroll
-        for (int b = 0; b < FB; ++b)
-          if (n1 < N1 && c2 + b * 32 < N2) dst[b * 32] = old[b] + acc[a][b][r];
-      }
-  }
+    }
+  };
+  if (n1_0 + WM * FA * 32 <= N1 && n2_0 + WN * FB * 32 <= N2) store_tile(std::true_type());
+  else store_tile(std::false_type());
   if (do_colsum) {                                    // lanes l and l + 32 hold the two k-halves of column l & 31
     // every (slice, tile of the row, wave column) stores its share -- possibly 0 -- into a slot of its own; wgrad_fold_kernel adds
     // the slots in a fixed order: the bias gradient is run-to-run deterministic (fp32 atomics before round 5)
