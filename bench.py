@@ -325,6 +325,12 @@ def roofline_partfvit_dgrad(device, M, iters=100):
 EXTRA_ROOFLINE = True            # --no-roofline: the extras' kernel tables under rocprofv3 must not contain the roofline loops
 
 
+def _extras_graph():
+    """The extra workloads run as one hipGraph per step; LAFS_BENCH_EXTRAS_NO_GRAPH=1 (profiling only: tools/profile_extras_r5.sh, with
+    LAFS_SINGLE_STREAM=1) issues them eagerly on one stream so that rocprofv3's per-kernel times are exclusive times."""
+    return os.environ.get("LAFS_BENCH_EXTRAS_NO_GRAPH") != "1"
+
+
 def _extra_evidence(out, flops, dt, device, M):
     out["step_tflops"] = round(flops / dt / 1e12, 1)
     out["step_mfma_frac"] = round(flops / dt / 2.5e15, 4)
@@ -354,7 +360,7 @@ def extra_mynet_pretrain(device, B=64, nl=8, K=100000, steps=12, warmup=4):
     teacher = MultiCropWrapper(tb, vits.DINOHead(dim, K, use_bn=False))
     teacher.load_state_dict(student.state_dict())
     crit = DINOLoss(K, 2 + nl, 0.07, 0.04, 30, 41)
-    eng = LafsPretrainEngine(student, teacher, crit, B, n_local=nl, clip_grad=3.0, freeze_last_layer=1, use_graph=True, device=device)
+    eng = LafsPretrainEngine(student, teacher, crit, B, n_local=nl, clip_grad=3.0, freeze_last_layer=1, use_graph=_extras_graph(), device=device)
     g = torch.Generator(device=device).manual_seed(0)
     eng.in_global_all.copy_(torch.randn(eng.in_global_all.shape, device=device, generator=g).clamp_(-1, 1))
     eng.in_local_all.copy_(torch.randn(eng.in_local_all.shape, device=device, generator=g).clamp_(-1, 1))
@@ -392,7 +398,7 @@ def extra_finetune(device, head="CosFace", with_land=True, dropout=0.1, B=128, C
     if sharded:
         from lafs_cvpr2024_amd.partial_fc import PartialFC
         sh = PartialFC(768, C, B, sample_rate=0.1, device=device)
-    eng = FinetuneEngine(m, B, acc_step=1, device=device, sharded_head=sh)
+    eng = FinetuneEngine(m, B, acc_step=1, device=device, sharded_head=sh, use_graph=_extras_graph())
     m.train()
     x = torch.randint(0, 256, (B, 3, 112, 112), dtype=torch.uint8, device=device)
     y = torch.randint(0, C, (B,), device=device)

@@ -83,6 +83,9 @@ def main():
         src = os.path.join(ROOT, "gpurun_out", log)
         if os.path.isfile(src):
             shutil.copy(src, os.path.join(DST, f"{R}_{name}"))
+    # serialised (one stream, no hipGraph) kernel tables of the extra workloads: tools/profile_extras_r5.sh
+    for tab in glob.glob(os.path.join(ROOT, "gpurun_out", "r5", "*_serial_kernel_table.txt")):
+        shutil.copy(tab, os.path.join(DST, f"{R}_{os.path.basename(tab)}"))
     # the kernels of ONE graph-replayed step (between two optimizer launches of the trace), with counts: shows what is -- and is
     # not (at::native, Tensile) -- inside a step, which the whole-run stats cannot (model construction launches ATen kernels)
     tr = glob.glob(os.path.join(SRC, "step", "**", "*kernel_trace.csv"), recursive=True)
