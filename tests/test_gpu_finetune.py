@@ -644,7 +644,7 @@ def test_finetune_engine_with_sharded_head_single_rank():
     head.arena.refresh_shadows()
     e2 = FinetuneEngine(bare, B, acc_step=1, device=DEV, sharded_head=head)
     e2.zero_after_step = True
-    l2 = float(e2.micro_step(u8, labels).item())
+    l2 = float(e2.micro_step(u8, labels, lam=1.0).item())              # (lam = None would draw the mixup decision from the global RNG: order-dependent)
     assert abs(l1 - l2) < 5e-3 * abs(l1), (l1, l2)
     g1, g2 = dict(dense.named_parameters()), dict(bare.named_parameters())
     for k in ("patch_to_embedding.weight", "transformer.layers.0.0.fn.fn.to_qkv.weight", "transformer.layers.1.1.fn.fn.net.3.weight"):
