@@ -2,6 +2,7 @@
 # usage (on the GPU box): tools/lab/pmc_mem.sh <binary> [args]   -> per-kernel HBM/L2 traffic (FETCH_SIZE x2-corrected, WRITE_SIZE, TCC hit rate)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/labmem; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 BIN=$R/$1; shift
+case "$BIN" in *.py) set -- "$BIN" "$@"; BIN=python3;; esac
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/p1 -o g --output-format csv -- $BIN "$@" > $O/out1.txt 2> $O/err1.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/p2 -o g --output-format csv -- $BIN "$@" > $O/out2.txt 2> $O/err2.txt
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $O/p3 -o g --output-format csv -- $BIN "$@" > $O/out3.txt 2> $O/err3.txt
