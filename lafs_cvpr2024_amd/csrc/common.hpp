@@ -16,7 +16,8 @@ typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 #define LAFS_EINVAL (-1)
 #define LAFS_ESHAPE (-2)
 
-extern "C" void lafs_set_error(const char* fmt, ...);
+// (internal: shared by the translation units of the library, not part of the C ABI)
+extern "C" __attribute__((visibility("hidden"))) void lafs_set_error(const char* fmt, ...);
 #define LAFS_CHECK_ARG(cond, msg)                                                     \
   do {                                                                                \
     if (!(cond)) {                                                                    \

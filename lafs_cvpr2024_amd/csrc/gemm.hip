@@ -84,9 +84,6 @@ __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float 
   else *reinterpret_cast<f32x4v_t*>(p) = v;
 }
 
-constexpr int BM = 128;
-constexpr int NT_BK = 32;                          // k-depth of one pipeline stage
-constexpr int NT_NS = 3;                           // LDS ring depth (stages in flight: NS-1)
 
 // LDS row -> weight row inside the 128-row tile.  MFMA row slot s = (rho & 15) of column-group j = (rho >> 4) & 3 ends
 // up in lane group g = s >> 2, register r = s & 3.  VPL = how many CONSECUTIVE output columns one lane should own so
@@ -456,7 +453,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
           if (full) {
             // gelu'(u) and gelu(u) from ONE v_rcp + v_exp (gelu_both_f: bit-identical to gelu_grad_f / gelu_f evaluated apart, half the
             // quarter-rate instructions of this VALU-bound epilogue); gelu(u), with its dropout mask, waits packed for the second pass
-            float d[VPL], g[VPL];
+            float d[8], g[8];                               // (VPL == 8 whenever this branch is live; fixed size keeps the VPL == 4 instantiations in bounds)
 #pragma unroll
             for (int e = 0; e < VPL; ++e) {
               gelu_both_f(w[e], g[e], d[e]);
@@ -485,7 +482,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WN == 6) ? 3 : ((WN == 4) ? 4 : ((WM
           } else if (full && p.C != nullptr && p.act == LAFS_GELU_SAVE_GRAD) {          // evaluated with gelu'(u) in the first pass
             st16(c2, gpk[q].x, gpk[q].y, gpk[q].z, gpk[q].w, ntst);
           } else if (drop.thresh && full) {              // dropout(gelu(u)): one 16-byte store like the plain form
-            float g[VPL];
+            float g[8];
 #pragma unroll
             for (int e = 0; e < VPL; ++e) g[e] = gelu_f(w[e]) * drop_mult(drop, (unsigned)m * (unsigned)p.N + (unsigned)(n + e));
             st16(c2, pack_bf2(g[0], g[1]), pack_bf2(g[2], g[3]), pack_bf2(g[4], g[5]), pack_bf2(g[6], g[7]), ntst);
@@ -568,7 +565,7 @@ __device__ __forceinline__ int tn_f(int row) { return ((row & 3) | (((row >> 3) 
 // (WM/2 panels of A, WN/2 of B per stage).  The product path uses 2x2 (see launch_tn for the measured comparison).
 // CS = false compiles the bias-gradient (column-sum) accumulators out: 16 registers the 16-wave 256x256 variant needs back.
 template <int WM, int WN, int KB, bool CS = true>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? 3 : (WM * WN == 8 ? 4 : 1)) void gemm_tn_kernel(TNArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4) ? (KB == 64 ? 2 : 3) : (WM * WN == 8 ? 4 : 1)) void gemm_tn_kernel(TNArgs p) {
   constexpr int NTH = 64 * WM * WN;
   constexpr int PA = WM / 2, PB = WN / 2;
   constexpr int TN_BM = KB, TN_PANEL = KB * 256, NS = (KB == 32) ? 3 : 2;
