@@ -69,7 +69,9 @@ enum {
   LAFS_OPT_NT_TALL = 5,        /* tiled GEMM: 160-row tiles where they save a round of workgroup slots (default 1) */
   LAFS_OPT_COMM_CUS = 6,       /* data-parallel runs: CUs left to the collective library's kernels by the K-resident GEMM (default 0) */
   LAFS_OPT_NT_BIG = 7,         /* tiled GEMM: one-workgroup-per-CU 192x256 / 176x256 tiles for the wide long-K shapes (default 1; 2-4 force a geometry) */
-  LAFS_OPT_COUNT = 8
+  LAFS_OPT_MLP_FUSED = 8,      /* trunk passes: the block's MLP as ONE launch (lafs_mlp_fused) where it applies (dim 384, no element dropout): bit mask
+                                  1 forward-only pass, 2 saving forward, 4 backward input gradients (default 0: step A/B in DESIGN.md section 6) */
+  LAFS_OPT_COUNT = 9
 };
 lafs_ctx* lafs_ctx_create(int device);
 void lafs_ctx_destroy(lafs_ctx* ctx);
@@ -140,6 +142,41 @@ int lafs_gemm_nt(const lafs_gemm_nt_args* args, hipStream_t stream);
  * round of the 512 workgroup slots than 160-row ones need), 5 = the 256x256 one-workgroup-per-CU kernel (gemm_big.hip).
  * Mirrors lafs_gemm_nt's own decisions, including its operand-format and validation order. */
 int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused MLP of a ViT-S block (csrc/mlp_fused.hip): two chained GEMMs, the hidden-wide intermediate never leaves the chip.
+ *   vision_transformer.py:59-65 (Mlp.forward: fc1 -> GELU -> fc2) with the residual + DropPath of Block.forward (:112), and the
+ *   input-gradient chain of the same lines in the backward.  Embedding width 384 (compile time), hidden width H % 64 == 0,
+ *   128 <= H <= 1536.  Results are bit-identical to the two lafs_gemm_nt launches each mode replaces.
+ *   LAFS_MLP_FWD       out(f32)[M,384] = resid + seq_scale[row2seq[m]] * (gelu(X Wa^T + bias_a) Wb^T + bias_b)
+ *                      X = LayerNorm-2 output (bf16), Wa = fc1.weight [H,384], Wb = fc2.weight [384,H] (bf16 shadows);
+ *                      replaces lafs_gemm_nt(LAFS_EPI_BF16_GELU, C == NULL) + lafs_gemm_nt(LAFS_EPI_RESID_F32)
+ *   LAFS_MLP_FWD_SAVE  the same, and save_grad(bf16)[M,H] = gelu'(u), save_act(bf16)[M,H] = gelu(u) are written (what the backward
+ *                      and the fc2 weight gradient read): replaces (LAFS_EPI_BF16_GELU, act = LAFS_GELU_SAVE_GRAD) + RESID_F32
+ *   LAFS_MLP_BWD       save_act(bf16)[M,H] = du = (X Wa^T) * save_grad  (written: the fc1 weight gradient's operand),
+ *                      out(bf16)[M,384] = du Wb^T;  X = upstream gradient (bf16), Wa = fc2.weight^T shadow [H,384],
+ *                      Wb = fc1.weight^T shadow [384,H]: replaces (LAFS_EPI_DGELU_BF16, act = LAFS_GELU_SAVE_GRAD) + LAFS_EPI_BF16
+ * One 8-wave workgroup per 128 rows; caller-allocated buffers only; never synchronises. */
+enum { LAFS_MLP_FWD = 0, LAFS_MLP_FWD_SAVE = 1, LAFS_MLP_BWD = 2 };
+typedef struct lafs_mlp_args {
+  const void* X; int ldx;          /* bf16 [M, 384]                                       */
+  const void* Wa; int ldwa;        /* bf16 [H, 384]                                       */
+  const void* Wb; int ldwb;        /* bf16 [384, H]                                       */
+  int M, H;
+  int mode;                        /* LAFS_MLP_*                                          */
+  const float* bias_a;             /* f32 [H]   or NULL (forward modes)                   */
+  const float* bias_b;             /* f32 [384] or NULL (forward modes)                   */
+  const float* resid; int ldr;     /* f32 [M, 384] (forward modes; may alias out)         */
+  const float* seq_scale;          /* f32 [n_seq] or NULL (forward modes: DropPath)       */
+  const int32_t* row2seq;          /* i32 [M]                                             */
+  void* out; int ldo;              /* f32 [M, 384] (forward) / bf16 [M, 384] (backward)   */
+  void* save_grad; int ldsg;       /* bf16 [M, H]: gelu'(u), written by FWD_SAVE, read by BWD */
+  void* save_act; int ldsa;        /* bf16 [M, H]: FWD_SAVE writes gelu(u); BWD writes du */
+  const lafs_ctx* ctx;             /* reserved (NULL = defaults)                          */
+} lafs_mlp_args;
+int lafs_mlp_fused(const lafs_mlp_args* args, hipStream_t stream);
+/* 1 when lafs_mlp_fused takes this geometry (dim == 384, hidden % 64 == 0 in [128, 1536]), else 0. */
+int lafs_mlp_fused_supported(int dim, int hidden, int rows);
 
 /* C[N1,N2] (f32) += A[M,N1]^T * B[M,N2]   (weight gradient dW = dY^T X; reduction over the token axis,
  * split over `splits` workgroups with fp32 atomics; splits <= 0 picks a default).  N1,N2,lda,ldb % 8 == 0.

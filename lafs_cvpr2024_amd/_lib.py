@@ -26,6 +26,14 @@ class GemmNTArgs(C.Structure):
                 ("ctx", C.c_void_p)]
 
 
+class MlpArgs(C.Structure):
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int), ("Wa", C.c_void_p), ("ldwa", C.c_int), ("Wb", C.c_void_p), ("ldwb", C.c_int),
+                ("M", C.c_int), ("H", C.c_int), ("mode", C.c_int), ("bias_a", C.c_void_p), ("bias_b", C.c_void_p),
+                ("resid", C.c_void_p), ("ldr", C.c_int), ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
+                ("out", C.c_void_p), ("ldo", C.c_int), ("save_grad", C.c_void_p), ("ldsg", C.c_int),
+                ("save_act", C.c_void_p), ("ldsa", C.c_int), ("ctx", C.c_void_p)]
+
+
 class WgradItem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int), ("C", C.c_void_p), ("ldc", C.c_int),
                 ("N1", C.c_int), ("N2", C.c_int), ("accumulate", C.c_int), ("colsum_a", C.c_void_p)]
@@ -59,12 +67,13 @@ class TrunkDesc(C.Structure):
 
 EPI_BF16, EPI_BF16_GELU, EPI_RESID_F32, EPI_F32, EPI_DGELU_BF16, EPI_ATOMIC_F32, EPI_EMBED_F32, EPI_BF16_ACT = range(8)
 ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = range(4)
+MLP_FWD, MLP_FWD_SAVE, MLP_BWD = range(3)
 PATCH_ORDER_CHW, PATCH_ORDER_HWC = 0, 1
 CHUNK = 1024
 SEG_DECAY, SEG_LAST_LAYER, SEG_TRAINABLE, SEG_LOW_DECAY, SEG_OVERWRITTEN = 1, 2, 4, 8, 16
 HP_LR, HP_WD, HP_BETA1, HP_BETA2, HP_EPS, HP_CLIP, HP_EMA_M, HP_FREEZE_LAST, HP_GRAD_SCALE, HP_WD_LOW, HP_STEP, HP_MIX_LAM = range(12)
 HP_COUNT = 16
-OPT_SIDE_STREAMS, OPT_ROW_CHAINS, OPT_KRES_MASK, OPT_KRES_MIN_ITEMS, OPT_NT_WIDE, OPT_NT_TALL, OPT_COMM_CUS, OPT_NT_BIG = range(8)
+OPT_SIDE_STREAMS, OPT_ROW_CHAINS, OPT_KRES_MASK, OPT_KRES_MIN_ITEMS, OPT_NT_WIDE, OPT_NT_TALL, OPT_COMM_CUS, OPT_NT_BIG, OPT_MLP_FUSED = range(9)
 
 vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 
@@ -72,6 +81,7 @@ vp, i32, i64, f32, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32
 _PROTOS = {
     "lafs_debug_tr16": [vp, vp],
     "lafs_gemm_nt": [C.POINTER(GemmNTArgs)],
+    "lafs_mlp_fused": [C.POINTER(MlpArgs)],
     "lafs_gemm_tn_acc": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp],
     "lafs_gemm_tn_part": [vp, i32, vp, i32, vp, i32, i64, i32, i32, i32, i32, vp],
     "lafs_reduce_partials": [vp, i64, i32, i64, vp],
@@ -166,6 +176,7 @@ _NO_STREAM = {
     "lafs_version": ([], i32),
     "lafs_gemm_nt_slices": ([i32, i32], i32),
     "lafs_gemm_nt_route": ([C.POINTER(GemmNTArgs)], i32),
+    "lafs_mlp_fused_supported": ([i32, i32, i32], i32),
     "lafs_ctx_create": ([i32], vp),
     "lafs_ctx_destroy": ([vp], None),
     "lafs_ctx_set": ([vp, i32, i32], i32),
@@ -221,7 +232,7 @@ def lib():
 class Ctx:
     """Owner of one lafs_ctx (include/lafs_hip.h): the side streams / events of the trunk passes and the kernel-selection options.
     One per engine; the environment is read HERE, never inside the library: LAFS_SINGLE_STREAM=1 / LAFS_ATTN_STREAM=0 (no side
-    streams), LAFS_ROW_CHAINS, LAFS_KRES, LAFS_KRES_MIN_ITEMS, LAFS_NT_WIDE, LAFS_NT_TALL, LAFS_NT_BIG, LAFS_COMM_CUS."""
+    streams), LAFS_ROW_CHAINS, LAFS_KRES, LAFS_KRES_MIN_ITEMS, LAFS_NT_WIDE, LAFS_NT_TALL, LAFS_NT_BIG, LAFS_MLP_FUSED, LAFS_COMM_CUS."""
 
     def __init__(self, device=None, options=None, from_env=True):
         import torch
@@ -242,7 +253,7 @@ class Ctx:
         if e.get("LAFS_SINGLE_STREAM") == "1" or e.get("LAFS_ATTN_STREAM") == "0":
             o[OPT_SIDE_STREAMS] = 0
         for name, key in (("LAFS_ROW_CHAINS", OPT_ROW_CHAINS), ("LAFS_KRES", OPT_KRES_MASK), ("LAFS_KRES_MIN_ITEMS", OPT_KRES_MIN_ITEMS),
-                          ("LAFS_NT_WIDE", OPT_NT_WIDE), ("LAFS_NT_TALL", OPT_NT_TALL), ("LAFS_NT_BIG", OPT_NT_BIG),
+                          ("LAFS_NT_WIDE", OPT_NT_WIDE), ("LAFS_NT_TALL", OPT_NT_TALL), ("LAFS_NT_BIG", OPT_NT_BIG), ("LAFS_MLP_FUSED", OPT_MLP_FUSED),
                           ("LAFS_COMM_CUS", OPT_COMM_CUS)):
             if e.get(name) not in (None, ""):
                 o[key] = int(e[name])

@@ -135,6 +135,12 @@ int gemm(const lafs_ctx* cx, const void* A, int lda, const void* B, int ldb, int
   return lafs_gemm_nt(&g, s);
 }
 
+// The block's MLP as one launch (csrc/mlp_fused.hip) where the context asks for it and the geometry allows: bit 1 forward-only pass,
+// 2 saving forward, 4 backward input gradients
+bool mlp_fused_on(const lafs_trunk_desc* d, int bit, int rows) {
+  return (lafs_ctx_opt(d->ctx, LAFS_OPT_MLP_FUSED) & bit) != 0 && d->dropout_p == 0.f && lafs_mlp_fused_supported(d->dim, d->mlp, rows) != 0;
+}
+
 }  // namespace
 
 // Side streams for the attention launches of the second and later crop-resolution groups and for the row chains: the 197-token and
@@ -289,10 +295,21 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
       // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
       // becomes one multiply per value
+      if (mlp_fused_on(d, save_for_backward ? 2 : 1, R)) {     // fc1 -> GELU -> fc2 -> residual in one launch, the hidden tile on chip
+        lafs_mlp_args m = {};
+        m.X = b.h2 + rD; m.ldx = D; m.Wa = sh + o.w_fc1; m.ldwa = D; m.Wb = sh + o.w_fc2; m.ldwb = M; m.M = R; m.H = M;
+        m.mode = save_for_backward ? LAFS_MLP_FWD_SAVE : LAFS_MLP_FWD;
+        m.bias_a = d->master + o.b_fc1; m.bias_b = d->master + o.b_fc2; m.resid = b.x1 + rD; m.ldr = D; m.seq_scale = sm; m.row2seq = r2s;
+        m.out = nxt + rD; m.ldo = D;
+        if (save_for_backward) { m.save_grad = b.u + rM; m.ldsg = M; m.save_act = b.a + rM; m.ldsa = M; }
+        m.ctx = cx;
+        RUN(lafs_mlp_fused(&m, st));
+      } else {
       RUN(gemm(cx, b.h2 + rD, D, sh + o.w_fc1, D, R, M, D, LAFS_EPI_BF16_GELU, save_for_backward ? b.u + rM : nullptr, M, d->master + o.b_fc1, st,
                b.a + rM, M, nullptr, 0, nullptr, nullptr, nullptr, 0, dp, ds + 1, LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
       RUN(gemm(cx, b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
                r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
+      }
       cur = nxt;
     }
     return LAFS_OK;
@@ -368,9 +385,17 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
     const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
     // ---- MLP branch ----
+    if (mlp_fused_on(d, 4, R)) {                               // GELU' input gradient -> fc1 input gradient in one launch (du written once)
+      lafs_mlp_args m = {};
+      m.X = s.gbm[p] + rD; m.ldx = D; m.Wa = sht + o.w_fc2_t; m.ldwa = D; m.Wb = sht + o.w_fc1_t; m.ldwb = M; m.M = R; m.H = M;
+      m.mode = LAFS_MLP_BWD; m.out = s.dh + rD; m.ldo = D; m.save_grad = b.u + rM; m.ldsg = M; m.save_act = s.du[p] + rM; m.ldsa = M;
+      m.ctx = cx;
+      RUN(lafs_mlp_fused(&m, st));
+    } else {
     RUN(gemm(cx, s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
              nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
     RUN(gemm(cx, s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
+    }
     RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, b.x1 + rD, D, b.st2 + 2 * (size_t)r0, d->master + o.ln2_g, g + rD, D, 1, s.gba[p] + rD, D,
                            scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), d->dropout_step, r0,
                            c.ln_part[((size_t)l * 2 + 1) * 4 + ci], st));

@@ -1,0 +1,409 @@
+// Fused MLP of a ViT-S block for gfx950: two chained GEMMs with the 1536-wide intermediate kept on chip.
+//
+//   forward  (vision_transformer.py:59-65 Mlp.forward + the residual / DropPath of Block.forward :112):
+//       out(f32)[M,384] = resid + seq_scale[row2seq[m]] * ( gelu(X W1^T + b1) W2^T + b2 )
+//       (saving pass: gelu'(u) and gelu(u) are also written, bf16 [M,H] -- what the backward and the fc2 weight gradient read)
+//   backward (the input-gradient chain of the same lines): du = (dY W2) * gelu'(u)  (written, bf16: the fc1 weight gradient's
+//       operand) ;  dX(bf16)[M,384] = du W1
+//
+// It replaces two launches of lafs_gemm_nt (fc1 + GELU on gemm_kres.hip, fc2 + residual on gemm.hip; in the backward the GELU'
+// input gradient and the fc1 input gradient) whose 1536-wide intermediate made a round trip through HBM: 25 216 teacher rows write
+// and re-read 77 MB of gelu(u) per layer, 44 160 student rows read 135 MB of gelu(u) in fc2 and 135 MB of du in the fc1 input gradient.
+// Both GEMMs of a direction have the SAME shape of dataflow -- [rows, 384] x Wa[H, 384]^T -> [rows, H] -> x Wb[384, H]^T ->
+// [rows, 384] (backward: Wa = fc2.weight^T shadow, Wb = fc1.weight^T shadow) -- so one kernel template serves both.
+//
+// Structure (why: DESIGN.md section 4 "Fused MLP"; what round 2's tools/lab/mlp_fused.hip lacked):
+//   * one 8-wave workgroup per CU = TWO waves per SIMD, each wave owning 16 token rows of a 128-row unit: its 16 x 384 operand
+//     is resident in registers (48), its 16 x 384 result tile of GEMM 2 in accumulators (96), a 16 x 64 tile of GEMM 1 in 16 more.
+//     With one wave per SIMD (32 rows each, round 2) every LDS-DMA issue stall, fragment-read latency and GELU evaluation was
+//     exposed; two waves cover each other's stalls (MFMA and VALU time still add on a SIMD: profiles/lab_mfma_valu_overlap.txt);
+//   * the hidden axis is walked in items of 64 columns: stage A = 64 rows of Wa (64 x 768 B = 48 KiB, whole rows), stage B = the
+//     item's 64-column slice of Wb (384 rows x 128 B = 48 KiB, whole cache lines); a ring of three 48-KiB LDS buffers, filled by
+//     LDS-DMA (global_load_lds_dwordx4) with counted s_waitcnt vmcnt and one s_barrier per stage (48 MFMAs per wave and stage);
+//   * GEMM 1 computes C^T blocks (first MFMA operand = 16 weight rows, second = 16 tokens) with the weight rows of a stage
+//     interleaved so that a lane ends with 8 CONSECUTIVE hidden columns of its token per 32-column slice: after GELU (or the
+//     multiplication by gelu'(u)) and the bf16 rounding those 8 values ARE the lane's B-operand fragment of GEMM 2 -- the
+//     intermediate never leaves the registers, not even for the LDS;
+//   * same MFMA (v_mfma_f32_16x16x32_bf16), same operand roles, same ascending k order, same bias / GELU / residual arithmetic as
+//     the two kernels it replaces: results are BIT-IDENTICAL to the two-launch path (tests/test_gpu_kernels.py).
+#include "common.hpp"
+#include "lafs_hip.h"
+#include "ctx.hpp"
+
+// lab builds only (tools/lab/Makefile: mlp_abl): timing ablations -- 1 no GELU / gelu' arithmetic, 2 no fragment reads, 4 no LDS-DMA
+// after the prologue's stages, 8 no MFMA, 16 no workgroup barriers (racy), 32 / 64 every second fragment read of stage B / A only.
+// 0 in the library.
+#ifndef LAFS_MLP_ABL
+#define LAFS_MLP_ABL 0
+#endif
+#define MABL(bit) ((LAFS_MLP_ABL & (bit)) != 0)
+
+namespace {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4v_t __attribute__((ext_vector_type(4)));
+
+constexpr int D = 384;                       // embedding width: reduction of GEMM 1, output width of GEMM 2 (compile time: sizes the registers)
+constexpr int ROWB = D * 2;                  // bytes of a 384-wide bf16 row
+constexpr int CPR = D / 8;                   // 16-byte chunks per such row (48)
+constexpr int HC = 64;                       // hidden columns per item
+constexpr int STAGE = HC * ROWB;             // 48 KiB: 64 rows x 768 B (Wa rows / token rows) or 384 rows x 128 B (Wb slice)
+constexpr int NSTG = 3;
+constexpr int NTH = 512, NWV = NTH / 64;
+constexpr int NDMA = STAGE / 16 / NTH;       // LDS-DMA instructions per thread and stage (6)
+constexpr int NKK = D / 32;                  // k steps of GEMM 1 (12)
+constexpr int NOB = D / 16;                  // 16-column output blocks of GEMM 2 (24)
+constexpr int UROWS = 16 * NWV;              // token rows per workgroup (128)
+constexpr int MAXH = 1536;
+#ifndef LAFS_MLP_FD
+#define LAFS_MLP_FD 6
+#endif
+constexpr int FD = LAFS_MLP_FD;              // fragment reads in flight ahead of their MFMAs
+static_assert(STAGE % (16 * NTH) == 0 && STAGE == D * 128 && NWV == 8, "stage layout");
+
+struct MArgs {
+  const bf16_t* X; int ldx;
+  const bf16_t* Wa; int ldwa;
+  const bf16_t* Wb; int ldwb;
+  int M, H;
+  const float* bias_a; const float* bias_b;
+  const float* resid; int ldr;
+  const float* seq_scale; const int* row2seq;
+  void* out; int ldo;
+  bf16_t* g; int ldg;                        // gelu'(u): written by the saving forward, read by the backward
+  bf16_t* a; int lda;                        // saving forward: gelu(u) written;  backward: du written
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void st16(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  const u32x4_t v = {a, b, c, d};
+  *reinterpret_cast<u32x4_t*>(p) = v;
+}
+__device__ __forceinline__ void st16f(void* p, float a, float b, float c, float d) {
+  const f32x4v_t v = {a, b, c, d};
+  *reinterpret_cast<f32x4v_t*>(p) = v;
+}
+
+// MODE: LAFS_MLP_FWD (0) forward-only, LAFS_MLP_FWD_SAVE (1) forward saving gelu'(u) and gelu(u), LAFS_MLP_BWD (2) input gradients
+template <int MODE>
+__global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
+  constexpr bool FWD = (MODE != LAFS_MLP_BWD);
+  constexpr int NS = (MODE == LAFS_MLP_FWD_SAVE) ? 4 : (MODE == LAFS_MLP_BWD ? 2 : 0);   // stores of an item's mid-epilogue (active waves)
+  constexpr int NL = (MODE == LAFS_MLP_BWD) ? 2 : 0;                                     // its operand loads (every wave)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
+  __shared__ __attribute__((aligned(16))) float sba[FWD ? MAXH : 4];
+  __shared__ __attribute__((aligned(16))) float sbb[FWD ? D : 4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int t = lane & 15, q = lane >> 4;
+  const int u0 = blockIdx.x * UROWS;                   // first row of this workgroup's unit
+  const int NI = p.H / HC;                             // items (>= 2)
+  const int row = u0 + wave * 16 + t;                  // this lane's token row
+  const bool active = (u0 + wave * 16) < p.M;          // wave-uniform: the wave owns at least one row of the matrix
+  const bool rowok = row < p.M;
+  const int rowc = min(row, p.M - 1);
+
+  if constexpr (FWD) {
+    for (int i = tid; i < p.H; i += NTH) sba[i] = p.bias_a ? p.bias_a[i] : 0.f;
+    for (int i = tid; i < D; i += NTH) sbb[i] = p.bias_b ? p.bias_b[i] : 0.f;
+    __syncthreads();                                   // (also keeps these loads out of the counted waits below)
+  }
+
+  // ---- LDS images.  Stage A (64 rows of 48 chunks): logical chunk c of row rho at position c ^ (rho & 15); MFMA row s of 16-row
+  // group gi (rho = 16 gi + s) lands in lane quarter s >> 2, register s & 3, and carries hidden column 32 (gi >> 1) + 8 (s >> 2) +
+  // 4 (gi & 1) + (s & 3) of the item: groups (2 ks, 2 ks + 1) give a lane 8 consecutive columns of slice ks.  Stage B (384 rows of
+  // 8 chunks): chunk c of row rho at position c ^ (rho & 7); row rho carries output column rho (fp32 results: 4 consecutive columns
+  // = 16 bytes per MFMA) or, for the bf16 result of the backward, column 32 (rho >> 5) + 8 ((rho & 15) >> 2) + 4 ((rho >> 4) & 1) +
+  // (rho & 3): blocks (2 P, 2 P + 1) give a lane 8 consecutive columns.  The images are lane-linear for the DMA, so swizzle and
+  // permutation go on the source address.
+  int doffa[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; ++i) {
+    const int x = i * NTH + tid, rho = x / CPR, cp = x % CPR, c = cp ^ (rho & 15);
+    const int s16 = rho & 15, gi = rho >> 4;
+    const int hrel = 32 * (gi >> 1) + 8 * (s16 >> 2) + 4 * (gi & 1) + (s16 & 3);
+    doffa[i] = (hrel * p.ldwa + c * 8) * 2;            // bytes from the item's first Wa row
+  }
+  int doffb;                                           // piece i adds i * 64 rows: a scalar offset (the row permutation keeps multiples of 32)
+  {
+    const int rho = tid >> 3, cp = tid & 7, c = cp ^ (rho & 7);
+    const int rsrc = FWD ? rho : (32 * (rho >> 5) + 8 * ((rho & 15) >> 2) + 4 * ((rho >> 4) & 1) + (rho & 3));
+    doffb = (rsrc * p.ldwb + c * 8) * 2;
+  }
+  const unsigned lds0 = lds_addr_of(smem);
+  auto issue_a = [&](int item, int buf) {              // Wa rows [64 item, 64 item + 64) -> ring buffer buf
+    const bf16_t* base = p.Wa + (size_t)item * HC * p.ldwa;
+    const unsigned st = lds0 + buf * STAGE + wave * 1024;
+    fence();
+    if (MABL(4) && item >= 2) return;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) lds_dma16_m0_s(base, (unsigned)doffa[i], st + i * (NTH * 16));
+    fence();
+  };
+  auto issue_b = [&](int item, int buf) {              // Wb[:, 64 item .. + 64) -> ring buffer buf
+    const bf16_t* base = p.Wb + (size_t)item * HC;
+    const unsigned st = lds0 + buf * STAGE + wave * 1024;
+    fence();
+    if (MABL(4) && item >= 1) return;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) lds_dma16_m0_s(base + (size_t)i * 64 * p.ldwb, (unsigned)doffb, st + i * (NTH * 16));
+    fence();
+  };
+  auto issue_rows = [&](int half, int buf) {           // token rows [u0 + 64 half, + 64) as a stage-A image (unpermuted)
+    const unsigned st = lds0 + buf * STAGE + wave * 1024;
+    fence();
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int x = i * NTH + tid, rho = x / CPR, cp = x % CPR, c = cp ^ (rho & 15);
+      const int r = min(u0 + 64 * half + rho, p.M - 1);
+      lds_dma16_m0(p.X + (size_t)r * p.ldx + c * 8, st + i * (NTH * 16));
+    }
+    fence();
+  };
+
+  // fragment offsets.  Stage A: row 16 gi + t, chunk (4 kk + q) ^ t (four registers by kk & 3, the rest immediates);
+  // stage B: row 16 ob + t, chunk (4 ks + q) ^ (t & 7)
+  int foff[4], goff[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    foff[i] = t * ROWB + (((4 * i + q) ^ t) << 4);
+    asm volatile("" : "+v"(foff[i]));
+  }
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    goff[ks] = t * 128 + (((4 * ks + q) ^ (t & 7)) << 4);
+    asm volatile("" : "+v"(goff[ks]));
+  }
+
+  // ---- prologue: the unit's 128 token rows through ring buffers 0 and 1 while stage 0 flies into buffer 2
+  issue_rows(0, 0);
+  issue_rows(1, 1);
+  issue_a(0, 2);
+  wait_vm<NDMA>();                                     // this thread's row pieces have landed (stage 0 is younger)
+  __builtin_amdgcn_s_barrier();
+  bf16x8_t areg[NKK];                                  // 16 tokens x 384 k: lane (t, q) holds k = 32 kk + 8 q .. + 7 of token t
+  {
+    const unsigned char* st = smem + (wave >> 2) * STAGE + (wave & 3) * (16 * ROWB);
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) areg[kk] = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                        // buffers 0 and 1 are free again
+  uint4 gp[NL > 0 ? NL : 1];                           // backward: gelu'(u) of the item's two slices (8 bf16 each)
+  auto fetch_g = [&](int item) {                       // exactly NL loads
+    if constexpr (NL > 0) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) gp[ks] = *reinterpret_cast<const uint4*>(p.g + (size_t)rowc * p.ldg + item * HC + 32 * ks + 8 * q);
+      fence();
+    }
+  };
+  fetch_g(0);
+  issue_b(0, 0);                                       // stage 1
+  issue_a(1, 1);                                       // stage 2
+  // in flight, oldest first: stage 0, [gelu' of item 0], stage 1, stage 2
+
+  f32x4_t acc2[NOB];
+#pragma unroll
+  for (int ob = 0; ob < NOB; ++ob) acc2[ob] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc1[4];
+  bf16x8_t gfrag[2];
+  float sc = 1.0f;
+  if constexpr (FWD) {
+    if (p.seq_scale != nullptr) sc = p.seq_scale[p.row2seq[rowc]];     // (two dependent loads, long retired when the waits below count)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // ... made explicit: nothing uncounted stays in the queue
+  }
+  // NOTE: the waits below count THIS wave's vector-memory instructions in issue order (loads, LDS-DMA and stores retire in order
+  // on gfx950); the s_waitcnt vmcnt(0) above drains the prologue's stages once (a few hundred cycles per unit of ~100 k).
+  // After it: nothing in flight.  Re-issue order from here on is what the counts below assume.
+
+  bf16x8_t wprev = areg[0];                            // (lab: ablations 32 / 64)
+  int buf = 2;                                         // ring buffer of the stage consumed next
+  auto next_buf = [&](int b) { return (b + 1 == NSTG) ? 0 : b + 1; };
+  for (int it = 0; it < NI; ++it) {
+    const bool has_next = (it + 1 < NI);
+    // ================= stage A of the item: acc1 = Wa rows x tokens (48 MFMAs)
+    if constexpr (FWD) {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+        acc1[gi] = *reinterpret_cast<const f32x4_t*>(sba + it * HC + 32 * (gi >> 1) + 8 * q + 4 * (gi & 1));
+    } else {
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) acc1[gi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // younger than this stage's DMA: the previous item's mid-epilogue stores, the stage B issued behind it, this item's gelu' loads
+    if (it == 0) wait_vm<0>();
+    else if (active) wait_vm<NS + NDMA + NL>();
+    else wait_vm<NDMA + NL>();
+    if constexpr (!MABL(16)) __builtin_amdgcn_s_barrier();
+    if (it > 0 && has_next) issue_a(it + 1, next_buf(next_buf(buf)));           // stage 2 it + 2 (item 0: issued by the prologue)
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          bf16x8_t w = areg[(kk + 1) % NKK];
+          if constexpr (MABL(64)) { if (gi % 2 == 0) wprev = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256 + gi * (16 * ROWB)); w = wprev; }
+          else if constexpr (!MABL(2)) w = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256 + gi * (16 * ROWB));
+          if constexpr (!MABL(8)) acc1[gi] = mfma16(w, areg[kk], acc1[gi]);
+          else asm volatile("" :: "v"(w));
+        }
+      if constexpr ((LAFS_MLP_ABL & (2 | 8 | 32 | 64)) == 0) {
+      __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);
+#pragma unroll
+      for (int i = 0; i < 4 * NKK - FD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, FD, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    buf = next_buf(buf);
+    // ----------------- mid-epilogue: GELU (forward) / x gelu'(u) (backward), bf16 rounding, hand-over to GEMM 2 in registers
+    fence();
+    if constexpr (MODE == LAFS_MLP_BWD) {              // younger than the gelu' loads: the stage A issued above (item 0: stages 1, 2 -- drained)
+      if (it == 0) wait_vm<0>();
+      else if (has_next) wait_vm<NDMA>();
+      else wait_vm<0>();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[r] = acc1[2 * ks][r]; v[4 + r] = acc1[2 * ks + 1][r]; }
+      const int n = it * HC + 32 * ks + 8 * q;
+      if constexpr (MABL(1)) {
+      } else if constexpr (MODE == LAFS_MLP_FWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+      } else if constexpr (MODE == LAFS_MLP_FWD_SAVE) {
+        float dv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float gv; gelu_both_f(v[e], gv, dv[e]); v[e] = gv; }
+        if (rowok) st16(p.g + (size_t)row * p.ldg + n, pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3]), pack_bf2(dv[4], dv[5]), pack_bf2(dv[6], dv[7]));
+      } else {
+        const uint4 a4 = gp[ks];
+        v[0] *= bf_lo(a4.x); v[1] *= bf_hi(a4.x); v[2] *= bf_lo(a4.y); v[3] *= bf_hi(a4.y);
+        v[4] *= bf_lo(a4.z); v[5] *= bf_hi(a4.z); v[6] *= bf_lo(a4.w); v[7] *= bf_hi(a4.w);
+      }
+      const u32x4_t pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+      gfrag[ks] = __builtin_bit_cast(bf16x8_t, pk);
+      if constexpr (MODE != LAFS_MLP_FWD) {
+        if (rowok) st16(p.a + (size_t)row * p.lda + n, pk[0], pk[1], pk[2], pk[3]);
+      }
+    }
+    fence();
+    // ================= stage B of the item: acc2 += Wb slice rows x intermediate (48 MFMAs)
+    // younger than this stage's DMA: the stage A issued above (if any) and the mid-epilogue's stores
+    if (has_next) { if (active) wait_vm<NDMA + NS>(); else wait_vm<NDMA>(); }
+    else { if (active) wait_vm<NS>(); else wait_vm<0>(); }
+    if constexpr (!MABL(16)) __builtin_amdgcn_s_barrier();
+    if (has_next) {
+      issue_b(it + 1, next_buf(next_buf(buf)));        // stage 2 it + 3
+      fetch_g(it + 1);
+    }
+    {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* st = smem + buf * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) {
+          bf16x8_t w = areg[ob % NKK];
+          if constexpr (MABL(32)) { if (ob % 2 == 0) wprev = *reinterpret_cast<const bf16x8_t*>(st + goff[ks] + ob * 2048); w = wprev; }
+          else if constexpr (!MABL(2)) w = *reinterpret_cast<const bf16x8_t*>(st + goff[ks] + ob * 2048);
+          if constexpr (!MABL(8)) acc2[ob] = mfma16(w, gfrag[ks], acc2[ob]);
+          else asm volatile("" :: "v"(w));
+        }
+      if constexpr ((LAFS_MLP_ABL & (2 | 8 | 32 | 64)) == 0) {
+      __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);
+#pragma unroll
+      for (int i = 0; i < 2 * NOB - FD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, FD, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    buf = next_buf(buf);
+  }
+
+  // ---- final epilogue of the unit: lane (t, q) owns row `row` and, per output block ob, 4 consecutive fp32 columns (forward)
+  // or, per block pair, 8 consecutive bf16 columns (backward)
+  if (!rowok) return;
+  if constexpr (FWD) {
+    const float* rs = p.resid + (size_t)row * p.ldr;
+    float* o = reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo;
+#pragma unroll
+    for (int o0 = 0; o0 < NOB; o0 += 6) {
+      uint4 r4[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) r4[j] = *reinterpret_cast<const uint4*>(rs + 16 * (o0 + j) + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const int n = 16 * (o0 + j) + 4 * q;
+        const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(sbb + n);
+        float w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = acc2[o0 + j][r] + b4[r];
+        w[0] = __uint_as_float(r4[j].x) + sc * w[0]; w[1] = __uint_as_float(r4[j].y) + sc * w[1];
+        w[2] = __uint_as_float(r4[j].z) + sc * w[2]; w[3] = __uint_as_float(r4[j].w) + sc * w[3];
+        st16f(o + n, w[0], w[1], w[2], w[3]);
+      }
+    }
+  } else {
+    bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + (size_t)row * p.ldo;
+#pragma unroll
+    for (int P = 0; P < NOB / 2; ++P) {
+      const f32x4_t x = acc2[2 * P], y = acc2[2 * P + 1];
+      st16(o + 32 * P + 8 * q, pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]));
+    }
+  }
+}
+
+template <int MODE>
+int launch(const MArgs& a, hipStream_t s) {
+  const int units = (a.M + UROWS - 1) / UROWS;
+  hipLaunchKernelGGL((mlp_fused_kernel<MODE>), dim3(units), dim3(NTH), 0, s, a);
+  LAFS_LAUNCH_CHECK();
+  return LAFS_OK;
+}
+
+}  // namespace
+
+extern "C" int lafs_mlp_fused_supported(int dim, int hidden, int rows) {
+  return (dim == D && hidden % HC == 0 && hidden >= 2 * HC && hidden <= MAXH && rows > 0) ? 1 : 0;
+}
+
+extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
+  LAFS_CLEAR_ERROR();
+  LAFS_CHECK_ARG(g != nullptr, "null arguments");
+  LAFS_CHECK_ARG(g->mode == LAFS_MLP_FWD || g->mode == LAFS_MLP_FWD_SAVE || g->mode == LAFS_MLP_BWD, "bad mode");
+  LAFS_CHECK_ARG(lafs_mlp_fused_supported(D, g->H, g->M), "hidden width must be a multiple of 64 in [128, 1536], M > 0 (the embedding width is 384)");
+  LAFS_CHECK_ARG(g->X && g->Wa && g->Wb && g->out, "null operand");
+  LAFS_CHECK_ARG(g->ldx >= D && g->ldx % 8 == 0 && g->ldwa >= D && g->ldwa % 8 == 0 && g->ldwb >= g->H && g->ldwb % 8 == 0, "operand strides: multiples of 8 elements");
+  LAFS_CHECK_ARG(g->ldo >= D && g->ldo % 8 == 0, "output stride: a multiple of 8 elements");
+  const bool fwd = g->mode != LAFS_MLP_BWD;
+  if (fwd) {
+    LAFS_CHECK_ARG(g->resid != nullptr && g->ldr >= D && g->ldr % 4 == 0, "the forward needs the fp32 residual");
+    LAFS_CHECK_ARG(g->seq_scale == nullptr || g->row2seq != nullptr, "seq_scale needs row2seq");
+  }
+  if (g->mode != LAFS_MLP_FWD) {
+    LAFS_CHECK_ARG(g->save_grad != nullptr && g->ldsg >= g->H && g->ldsg % 8 == 0, "gelu'(u) buffer");
+    LAFS_CHECK_ARG(g->save_act != nullptr && g->ldsa >= g->H && g->ldsa % 8 == 0, "gelu(u) / du buffer");
+  }
+  MArgs a;
+  a.X = (const bf16_t*)g->X; a.ldx = g->ldx; a.Wa = (const bf16_t*)g->Wa; a.ldwa = g->ldwa; a.Wb = (const bf16_t*)g->Wb; a.ldwb = g->ldwb;
+  a.M = g->M; a.H = g->H; a.bias_a = fwd ? g->bias_a : nullptr; a.bias_b = fwd ? g->bias_b : nullptr;
+  a.resid = g->resid; a.ldr = g->ldr; a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
+  a.out = g->out; a.ldo = g->ldo; a.g = (bf16_t*)g->save_grad; a.ldg = g->ldsg; a.a = (bf16_t*)g->save_act; a.lda = g->ldsa;
+  switch (g->mode) {
+    case LAFS_MLP_FWD: return launch<LAFS_MLP_FWD>(a, stream);
+    case LAFS_MLP_FWD_SAVE: return launch<LAFS_MLP_FWD_SAVE>(a, stream);
+    default: return launch<LAFS_MLP_BWD>(a, stream);
+  }
+}

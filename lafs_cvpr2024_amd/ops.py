@@ -93,6 +93,41 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     return (out, out2) if epilogue == _lib.EPI_BF16_GELU else out
 
 
+def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=None, row2seq=None, out=None, save_grad=None, save_act=None):
+    """The fused MLP of a ViT-S block (lafs_mlp_fused, csrc/mlp_fused.hip; vision_transformer.py:59-65,112).
+    MLP_FWD / MLP_FWD_SAVE: out(f32) = resid + seq_scale[row2seq] * (gelu(X Wa^T + bias_a) Wb^T + bias_b), the saving form also
+    writes save_grad = gelu'(u) and save_act = gelu(u); MLP_BWD: save_act = du = (X Wa^T) * save_grad, out(bf16) = du Wb^T."""
+    _chk(X, bf16, "X"); _chk(Wa, bf16, "Wa"); _chk(Wb, bf16, "Wb")
+    M, H = X.shape[0], Wa.shape[0]
+    fwd = mode != _lib.MLP_BWD
+    if out is None:
+        out = torch.empty(M, X.shape[1], device=X.device, dtype=torch.float32 if fwd else bf16)
+    _chk(out, torch.float32 if fwd else bf16, "out")
+    if mode == _lib.MLP_FWD_SAVE and save_grad is None:
+        save_grad = torch.empty(M, H, device=X.device, dtype=bf16)
+    if mode != _lib.MLP_FWD and save_act is None:
+        save_act = torch.empty(M, H, device=X.device, dtype=bf16)
+    a = _lib.MlpArgs()
+    a.X, a.ldx, a.Wa, a.ldwa, a.Wb, a.ldwb = X.data_ptr(), _ld(X), Wa.data_ptr(), _ld(Wa), Wb.data_ptr(), _ld(Wb)
+    a.M, a.H, a.mode = M, H, int(mode)
+    if bias_a is not None:
+        _chk(bias_a, torch.float32, "bias_a"); a.bias_a = bias_a.data_ptr()
+    if bias_b is not None:
+        _chk(bias_b, torch.float32, "bias_b"); a.bias_b = bias_b.data_ptr()
+    if resid is not None:
+        _chk(resid, torch.float32, "resid"); a.resid, a.ldr = resid.data_ptr(), _ld(resid)
+    if seq_scale is not None:
+        _chk(seq_scale, torch.float32, "seq_scale"); _chk(row2seq, torch.int32, "row2seq")
+        a.seq_scale, a.row2seq = seq_scale.data_ptr(), row2seq.data_ptr()
+    a.out, a.ldo = out.data_ptr(), _ld(out)
+    if save_grad is not None:
+        _chk(save_grad, bf16, "save_grad"); a.save_grad, a.ldsg = save_grad.data_ptr(), _ld(save_grad)
+    if save_act is not None:
+        _chk(save_act, bf16, "save_act"); a.save_act, a.ldsa = save_act.data_ptr(), _ld(save_act)
+    call("lafs_mlp_fused", C.byref(a))
+    return out, save_grad, save_act
+
+
 def gemm_tn_acc(A, B, Cacc, splits=0, colsum=None):
     """Cacc[N1,N2] (f32) += A[M,N1]^T @ B[M,N2]; optional colsum[N1] (f32) += column sums of A (bias gradient)."""
     _chk(A, bf16, "A"); _chk(B, bf16, "B"); _chk(Cacc, torch.float32, "C")

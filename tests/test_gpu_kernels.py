@@ -701,3 +701,63 @@ def test_fused_head_and_dino_loss_equal_the_unfused_kernels(ncrops, B, K):
     la, ga = ops.dino_head_loss(zs, zt, ws, wt, center, ncrops, K, 0.1, 0.04, grad=torch.empty_like(grad2))
     lb, gb = ops.dino_head_loss(zs, zt, ws, wt, center, ncrops, K, 0.1, 0.04, grad=torch.empty_like(grad2), dev_temps=temps2)
     assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb)) and relerr(ga.float(), gb.float()) < 1e-2
+
+
+@pytest.mark.parametrize("M,H", [(128 * 19, 1536), (128 * 17 + 37, 1536), (128 * 16 + 16 * 5 + 3, 768), (25216, 1536), (100, 128)])
+def test_fused_mlp_equals_the_two_launches_bit_for_bit(M, H):
+    """lafs_mlp_fused (csrc/mlp_fused.hip; Mlp.forward + the residual of Block.forward, vision_transformer.py:59-65,112, and its
+    input-gradient chain) against the two lafs_gemm_nt launches each mode replaces: same MFMA, same operand roles, same ascending k
+    order, same bias / GELU / residual arithmetic -> 0 differing bits in every output (fp32 result, saved gelu'(u) / gelu(u), du,
+    dX); against fp32 torch within the bf16 tolerances; ragged last unit (rows past M untouched), partly and wholly idle waves."""
+    D = 384
+    g = torch.Generator().manual_seed(71)
+    X = rnd_bf(M, D, seed=72).to(DEV)
+    W1, W2 = rnd_bf(H, D, scale=0.05, seed=73).to(DEV), rnd_bf(D, H, scale=0.03, seed=74).to(DEV)
+    b1, b2 = (torch.randn(H, generator=g) * 0.1).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
+    resid = torch.randn(M, D, generator=g).to(DEV)
+    nseq = 11
+    row2seq = (torch.arange(M) * nseq // M).int().to(DEV)
+    sc = torch.tensor([0.0 if i % 4 == 1 else 1.0 / 0.9 for i in range(nseq)]).to(DEV)
+    guard = 5.0
+    # GEMM 1 of either direction accumulates on top of its bias like the K-resident kernel (gemm_kres.hip, rows >= 2048); the tiled
+    # kernel adds the bias to the finished sum, which rounds differently: below 2048 rows the comparison is by tolerance
+    exact = M >= 2048
+    if exact:
+        assert ops.gemm_nt(X, W1, _lib.EPI_BF16_GELU, bias=b1, route_only=True) == 1
+    same = (lambda a, b: torch.equal(a, b)) if exact else (lambda a, b: relerr(a.float(), b.float()) < 8e-3)
+    # ---- two launches (the kernels of the K-resident / tiled routes)
+    a_t = ops.gemm_nt(X, W1, _lib.EPI_BF16_GELU, bias=b1, skip_pre=True)[1]                        # teacher form: gelu(u) only
+    y_t = ops.gemm_nt(a_t, W2, _lib.EPI_RESID_F32, bias=b2, resid=resid, seq_scale=sc, row2seq=row2seq)
+    gs, a_s = ops.gemm_nt(X, W1, _lib.EPI_BF16_GELU, bias=b1, act=1)                               # saving form: gelu'(u), gelu(u)
+    y_s = ops.gemm_nt(a_s, W2, _lib.EPI_RESID_F32, bias=b2, resid=resid, seq_scale=sc, row2seq=row2seq)
+    assert torch.equal(a_t, a_s)
+    # ---- fused forward, both modes
+    out = torch.full((M + 130, D), guard, device=DEV)
+    y = ops.mlp_fused(X, W1, W2, _lib.MLP_FWD, bias_a=b1, bias_b=b2, resid=resid, seq_scale=sc, row2seq=row2seq, out=out[:M])[0]
+    assert float((out[M:] - guard).abs().max()) == 0.0, "rows past M were written"
+    assert same(y, y_t), f"forward-only: {int((y != y_t).sum())} differing values, max {float((y - y_t).abs().max()):.3e}"
+    sg = torch.full((M + 130, H), guard, device=DEV, dtype=bf16); sa = torch.full((M + 130, H), guard, device=DEV, dtype=bf16)
+    y2, g2, a2 = ops.mlp_fused(X, W1, W2, _lib.MLP_FWD_SAVE, bias_a=b1, bias_b=b2, resid=resid, seq_scale=sc, row2seq=row2seq,
+                               save_grad=sg[:M], save_act=sa[:M])
+    assert float((sg[M:].float() - guard).abs().max()) == 0.0 and float((sa[M:].float() - guard).abs().max()) == 0.0
+    assert same(y2, y_s) and same(g2, gs) and same(a2, a_s)
+    # in place on the residual stream (resid aliases out: every lane reads its pieces before it writes them)
+    r2 = resid.clone()
+    ops.mlp_fused(X, W1, W2, _lib.MLP_FWD, bias_a=b1, bias_b=b2, resid=r2, seq_scale=sc, row2seq=row2seq, out=r2)
+    assert same(r2, y_t)
+    # against fp32 math
+    u = X.float() @ W1.float().t() + b1
+    ref = resid + sc[row2seq.long()].unsqueeze(1) * (F.gelu(u).to(bf16).float() @ W2.float().t() + b2)
+    assert relerr(y, ref) < 2e-3
+    # ---- backward: du = (dY W2) * gelu'(u), dX = du W1, on the transposed shadows
+    dY = rnd_bf(M, D, seed=75).to(DEV)
+    W2t, W1t = W2.t().contiguous(), W1.t().contiguous()                                            # [H, D], [D, H]
+    du_ref = ops.gemm_nt(dY, W2t, _lib.EPI_DGELU_BF16, aux=gs, act=1)
+    dx_ref = ops.gemm_nt(du_ref, W1t, _lib.EPI_BF16)
+    dub = torch.full((M + 130, H), guard, device=DEV, dtype=bf16); dxb = torch.full((M + 130, D), guard, device=DEV, dtype=bf16)
+    dx, _, du = ops.mlp_fused(dY, W2t, W1t, _lib.MLP_BWD, out=dxb[:M], save_grad=gs, save_act=dub[:M])
+    assert float((dub[M:].float() - guard).abs().max()) == 0.0 and float((dxb[M:].float() - guard).abs().max()) == 0.0
+    assert same(du, du_ref), f"du: {int((du != du_ref).sum())} differing values"
+    assert same(dx, dx_ref), f"dX: {int((dx != dx_ref).sum())} differing values"
+    dxf = ((dY.float() @ W2.float()) * gs.float()).to(bf16).float() @ W1.float()
+    assert relerr(dx.float(), dxf) < 1e-2
