@@ -70,7 +70,8 @@ enum {
   LAFS_OPT_COMM_CUS = 6,       /* data-parallel runs: CUs left to the collective library's kernels by the K-resident GEMM (default 0) */
   LAFS_OPT_NT_BIG = 7,         /* tiled GEMM: one-workgroup-per-CU 192x256 / 176x256 tiles for the wide long-K shapes (default 1; 2-4 force a geometry) */
   LAFS_OPT_MLP_FUSED = 8,      /* trunk passes: the block's MLP as ONE launch (lafs_mlp_fused) where it applies (dim 384, no element dropout): bit mask
-                                  1 forward-only pass, 2 saving forward, 4 backward input gradients (default 0: step A/B in DESIGN.md section 6) */
+                                  1 forward-only pass, 2 saving forward, 4 backward input gradients, 8 LayerNorm 2 inside the fused forward (default 0: step A/B in
+                                  DESIGN.md section 6) */
   LAFS_OPT_COUNT = 9
 };
 lafs_ctx* lafs_ctx_create(int device);
@@ -156,7 +157,8 @@ int lafs_gemm_nt_route(const lafs_gemm_nt_args* args);
  *   LAFS_MLP_BWD       save_act(bf16)[M,H] = du = (X Wa^T) * save_grad  (written: the fc1 weight gradient's operand),
  *                      out(bf16)[M,384] = du Wb^T;  X = upstream gradient (bf16), Wa = fc2.weight^T shadow [H,384],
  *                      Wb = fc1.weight^T shadow [384,H]: replaces (LAFS_EPI_DGELU_BF16, act = LAFS_GELU_SAVE_GRAD) + LAFS_EPI_BF16
- * One 8-wave workgroup per 128 rows; caller-allocated buffers only; never synchronises. */
+ * One 8-wave workgroup per 128 rows (rows past the last full round of the chip: 64-row units); caller-allocated buffers only;
+ * never synchronises. */
 enum { LAFS_MLP_FWD = 0, LAFS_MLP_FWD_SAVE = 1, LAFS_MLP_BWD = 2 };
 typedef struct lafs_mlp_args {
   const void* X; int ldx;          /* bf16 [M, 384]                                       */
@@ -172,7 +174,13 @@ typedef struct lafs_mlp_args {
   void* out; int ldo;              /* f32 [M, 384] (forward) / bf16 [M, 384] (backward)   */
   void* save_grad; int ldsg;       /* bf16 [M, H]: gelu'(u), written by FWD_SAVE, read by BWD */
   void* save_act; int ldsa;        /* bf16 [M, H]: FWD_SAVE writes gelu(u); BWD writes du */
-  const lafs_ctx* ctx;             /* reserved (NULL = defaults)                          */
+  const lafs_ctx* ctx;             /* rounds of the chip are sized by the context's CU count (NULL: one launch of 128-row units) */
+  /* LayerNorm prologue (forward modes; vision_transformer.py:112 `self.norm2`): with ln_gamma != NULL, X is ignored and the GEMM-1
+   * operand is LayerNorm(resid; ln_gamma, ln_beta, ln_eps) computed inside the kernel, bit-identical to lafs_layernorm_fwd on
+   * >= 4096 rows; ln_stats (f32 [M, 2]: mean, rstd) and ln_out (bf16 [M, 384]: the operand itself -- what the LayerNorm backward
+   * and the fc1 weight gradient read) are written when not NULL. */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  float* ln_stats; void* ln_out; int ldln;
 } lafs_mlp_args;
 int lafs_mlp_fused(const lafs_mlp_args* args, hipStream_t stream);
 /* 1 when lafs_mlp_fused takes this geometry (dim == 384, hidden % 64 == 0 in [128, 1536]), else 0. */

@@ -31,7 +31,9 @@ class MlpArgs(C.Structure):
                 ("M", C.c_int), ("H", C.c_int), ("mode", C.c_int), ("bias_a", C.c_void_p), ("bias_b", C.c_void_p),
                 ("resid", C.c_void_p), ("ldr", C.c_int), ("seq_scale", C.c_void_p), ("row2seq", C.c_void_p),
                 ("out", C.c_void_p), ("ldo", C.c_int), ("save_grad", C.c_void_p), ("ldsg", C.c_int),
-                ("save_act", C.c_void_p), ("ldsa", C.c_int), ("ctx", C.c_void_p)]
+                ("save_act", C.c_void_p), ("ldsa", C.c_int), ("ctx", C.c_void_p),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+                ("ln_stats", C.c_void_p), ("ln_out", C.c_void_p), ("ldln", C.c_int)]
 
 
 class WgradItem(C.Structure):

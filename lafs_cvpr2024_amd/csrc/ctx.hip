@@ -27,6 +27,7 @@ extern "C" lafs_ctx* lafs_ctx_create(int device) {
   c->device = device;
   for (int i = 0; i < LAFS_OPT_COUNT; ++i) c->opt[i] = kDefaults[i];
   bool ok = (device == prev) || hipSetDevice(device) == hipSuccess;
+  if (ok && hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->n_cu = 0;
   // streams and events exist from here on: never created lazily inside a hipGraph capture
   for (int i = 0; ok && i < 3; ++i) {
     ok = hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess &&

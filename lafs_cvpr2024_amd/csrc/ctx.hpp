@@ -8,6 +8,7 @@
 
 struct lafs_ctx {
   int device = 0;
+  int n_cu = 0;                                             // compute units of the device (one-workgroup-per-CU kernels size their rounds by it)
   hipStream_t side[3] = {nullptr, nullptr, nullptr};       // second .. fourth row chain / second attention group
   hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> pool;                             // weight-gradient stream protocol (lafs_trunk_backward)

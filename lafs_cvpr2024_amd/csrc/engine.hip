@@ -290,18 +290,25 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
       RUN(gemm(cx, b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
                r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0));
+      const bool mlp_one = mlp_fused_on(d, save_for_backward ? 2 : 1, R);
+      const bool ln_inside = mlp_one && mlp_fused_on(d, 8, R);          // LayerNorm 2 as the fused kernel's prologue (no launch, no h2 round trip)
+      if (!ln_inside)
       RUN(lafs_layernorm_fwd(b.x1 + rD, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D, nullptr, 0, b.st2 + 2 * (size_t)r0,
                              R, D, st));
       // a forward-only pass (teacher) never reads the pre-activation u: skip its store (77 MB per layer at C2).  A saving pass
       // stores gelu'(u) in its place (LAFS_GELU_SAVE_GRAD): that is all the backward needs of u, and the GELU' input gradient
       // becomes one multiply per value
-      if (mlp_fused_on(d, save_for_backward ? 2 : 1, R)) {     // fc1 -> GELU -> fc2 -> residual in one launch, the hidden tile on chip
+      if (mlp_one) {                                           // fc1 -> GELU -> fc2 -> residual in one launch, the hidden tile on chip
         lafs_mlp_args m = {};
         m.X = b.h2 + rD; m.ldx = D; m.Wa = sh + o.w_fc1; m.ldwa = D; m.Wb = sh + o.w_fc2; m.ldwb = M; m.M = R; m.H = M;
         m.mode = save_for_backward ? LAFS_MLP_FWD_SAVE : LAFS_MLP_FWD;
         m.bias_a = d->master + o.b_fc1; m.bias_b = d->master + o.b_fc2; m.resid = b.x1 + rD; m.ldr = D; m.seq_scale = sm; m.row2seq = r2s;
         m.out = nxt + rD; m.ldo = D;
         if (save_for_backward) { m.save_grad = b.u + rM; m.ldsg = M; m.save_act = b.a + rM; m.ldsa = M; }
+        if (ln_inside) {
+          m.X = nullptr; m.ln_gamma = d->master + o.ln2_g; m.ln_beta = d->master + o.ln2_b; m.ln_eps = d->ln_eps;
+          if (save_for_backward) { m.ln_stats = b.st2 + 2 * (size_t)r0; m.ln_out = b.h2 + rD; m.ldln = D; }
+        }
         m.ctx = cx;
         RUN(lafs_mlp_fused(&m, st));
       } else {

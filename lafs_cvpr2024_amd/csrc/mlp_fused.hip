@@ -72,6 +72,10 @@ struct MArgs {
   void* out; int ldo;
   bf16_t* g; int ldg;                        // gelu'(u): written by the saving forward, read by the backward
   bf16_t* a; int lda;                        // saving forward: gelu(u) written;  backward: du written
+  const float* ln_g; const float* ln_b; float ln_eps;   // LNP: X = LayerNorm(resid) computed in the prologue
+  float* ln_stats; bf16_t* ln_out; int ldln;            //      (mean, rstd) per row and the bf16 operand as by-products (optional)
+  int unit_waves;                            // waves of a workgroup that own rows (8: 128-row units; 4: 64-row units, one computing wave per SIMD)
+  int row0;                                  // first row of this launch's first unit
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -86,7 +90,10 @@ __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float 
 }
 
 // MODE: LAFS_MLP_FWD (0) forward-only, LAFS_MLP_FWD_SAVE (1) forward saving gelu'(u) and gelu(u), LAFS_MLP_BWD (2) input gradients
-template <int MODE>
+// LNP (forward modes): the GEMM-1 operand is LayerNorm(resid) (vision_transformer.py:112 norm2), computed by each wave for its own 16
+// rows with the row arithmetic of ln_fwd2_kernel (layernorm.hip: 32 lanes per row, float4 pieces at columns 4 l + 128 i, the same
+// summation order -> the same bits), written into the ring buffers as the stage-A image the fragments are read from.
+template <int MODE, bool LNP>
 __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   constexpr bool FWD = (MODE != LAFS_MLP_BWD);
   constexpr int NS = (MODE == LAFS_MLP_FWD_SAVE) ? 4 : (MODE == LAFS_MLP_BWD ? 2 : 0);   // stores of an item's mid-epilogue (active waves)
@@ -97,11 +104,11 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15, q = lane >> 4;
-  const int u0 = blockIdx.x * UROWS;                   // first row of this workgroup's unit
+  const int u0 = p.row0 + blockIdx.x * (16 * p.unit_waves);   // first row of this workgroup's unit
   const int NI = p.H / HC;                             // items (>= 2)
   const int row = u0 + wave * 16 + t;                  // this lane's token row
-  const bool active = (u0 + wave * 16) < p.M;          // wave-uniform: the wave owns at least one row of the matrix
-  const bool rowok = row < p.M;
+  const bool active = wave < p.unit_waves && (u0 + wave * 16) < p.M;   // wave-uniform: the wave owns at least one row of the matrix
+  const bool rowok = active && row < p.M;              // (idle waves take part in the LDS-DMA and the barriers only)
   const int rowc = min(row, p.M - 1);
 
   if constexpr (FWD) {
@@ -177,11 +184,64 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   }
 
   // ---- prologue: the unit's 128 token rows through ring buffers 0 and 1 while stage 0 flies into buffer 2
-  issue_rows(0, 0);
-  issue_rows(1, 1);
-  issue_a(0, 2);
-  wait_vm<NDMA>();                                     // this thread's row pieces have landed (stage 0 is younger)
-  __builtin_amdgcn_s_barrier();
+  if constexpr (!LNP) {
+    issue_rows(0, 0);
+    issue_rows(1, 1);
+    issue_a(0, 2);
+    wait_vm<NDMA>();                                   // this thread's row pieces have landed (stage 0 is younger)
+    __builtin_amdgcn_s_barrier();
+  } else {
+    issue_a(0, 2);
+    if (active) {
+      const int l = lane & 31, rsel = lane >> 5;
+      float4 xr[8][3], g4[3], b4[3];                   // the wave's 16 rows as 8 pairs: all loads in flight before the first reduction
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = min(u0 + wave * 16 + 2 * j + rsel, p.M - 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xr[j][i] = *reinterpret_cast<const float4*>(p.resid + (size_t)r * p.ldr + l * 4 + 128 * i);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        g4[i] = *reinterpret_cast<const float4*>(p.ln_g + l * 4 + 128 * i);
+        b4[i] = *reinterpret_cast<const float4*>(p.ln_b + l * 4 + 128 * i);
+      }
+      auto half_sum = [](float v) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+      };
+      unsigned char* img = smem + (wave >> 2) * STAGE;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float4 (&cur)[3] = xr[j];
+        const int r = u0 + wave * 16 + 2 * j + rsel;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s += cur[i].x + cur[i].y + cur[i].z + cur[i].w;
+        const float mean = half_sum(s) / (float)D;
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float a = cur[i].x - mean, b = cur[i].y - mean, c = cur[i].z - mean, d = cur[i].w - mean;
+          qq += a * a + b * b + c * c + d * d;
+        }
+        const float rstd = rsqrtf(half_sum(qq) / (float)D + p.ln_eps);
+        if (p.ln_stats != nullptr && l == 0 && r < p.M) *reinterpret_cast<float2*>(p.ln_stats + 2 * (size_t)r) = make_float2(mean, rstd);
+        const int rho = (wave & 3) * 16 + 2 * j + rsel;                 // row of the stage-A image
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const float o0 = (cur[i].x - mean) * rstd * g4[i].x + b4[i].x, o1 = (cur[i].y - mean) * rstd * g4[i].y + b4[i].y;
+          const float o2 = (cur[i].z - mean) * rstd * g4[i].z + b4[i].z, o3 = (cur[i].w - mean) * rstd * g4[i].w + b4[i].w;
+          const uint2 pk = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
+          const int c = (l >> 1) + 16 * i;                               // 16-byte chunk of columns 4 l + 128 i .. + 3, half l & 1
+          *reinterpret_cast<uint2*>(img + rho * ROWB + ((c ^ (rho & 15)) << 4) + (l & 1) * 8) = pk;
+          if (p.ln_out != nullptr && r < p.M) *reinterpret_cast<uint2*>(p.ln_out + (size_t)r * p.ldln + l * 4 + 128 * i) = pk;
+        }
+      }
+    }
+    // (a wave reads back only its own rows, and the LDS serves a wave's operations in order: no barrier in between)
+  }
   bf16x8_t areg[NKK];                                  // 16 tokens x 384 k: lane (t, q) holds k = 32 kk + 8 q .. + 7 of token t
   {
     const unsigned char* st = smem + (wave >> 2) * STAGE + (wave & 3) * (16 * ROWB);
@@ -237,7 +297,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     else wait_vm<NDMA + NL>();
     if constexpr (!MABL(16)) __builtin_amdgcn_s_barrier();
     if (it > 0 && has_next) issue_a(it + 1, next_buf(next_buf(buf)));           // stage 2 it + 2 (item 0: issued by the prologue)
-    {
+    if (active) {
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* st = smem + buf * STAGE;
 #pragma unroll
@@ -269,6 +329,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
       else if (has_next) wait_vm<NDMA>();
       else wait_vm<0>();
     }
+    if (active) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       float v[8];
@@ -295,6 +356,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
         if (rowok) st16(p.a + (size_t)row * p.lda + n, pk[0], pk[1], pk[2], pk[3]);
       }
     }
+    }
     fence();
     // ================= stage B of the item: acc2 += Wb slice rows x intermediate (48 MFMAs)
     // younger than this stage's DMA: the stage A issued above (if any) and the mid-epilogue's stores
@@ -305,7 +367,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
       issue_b(it + 1, next_buf(next_buf(buf)));        // stage 2 it + 3
       fetch_g(it + 1);
     }
-    {
+    if (active) {
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* st = smem + buf * STAGE;
 #pragma unroll
@@ -365,10 +427,33 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   }
 }
 
-template <int MODE>
-int launch(const MArgs& a, hipStream_t s) {
+#ifndef LAFS_MLP_UW
+#define LAFS_MLP_UW 0
+#endif
+// One workgroup per CU and unit: a launch costs whole rounds of the chip.  Rows beyond the last full round of 128-row units go out as
+// a second launch of 64-row units (one computing wave per SIMD: about 0.6 of a full unit's time, tools/lab/NOTES.md) when they fit one
+// round that way -- 44 160 rows: 256 x 128 + 178 x 64 instead of two rounds of 128.
+template <int MODE, bool LNP>
+int launch(MArgs a, int n_cu, hipStream_t s) {
   const int units = (a.M + UROWS - 1) / UROWS;
-  hipLaunchKernelGGL((mlp_fused_kernel<MODE>), dim3(units), dim3(NTH), 0, s, a);
+  int full = units, half = 0;
+  constexpr int LAB_UW = LAFS_MLP_UW > 0 ? LAFS_MLP_UW : NWV;
+  if (LAFS_MLP_UW > 0) { a.unit_waves = LAB_UW; full = (a.M + 16 * LAB_UW - 1) / (16 * LAB_UW); }      // lab
+  else if (n_cu > 0 && units > n_cu) {
+    const int rounds = units / n_cu, rest = units - rounds * n_cu;          // rest: units of the last, partial round
+    const int rest_rows = a.M - rounds * n_cu * UROWS;
+    const int h = (rest_rows + 63) / 64;
+    if (rest > 0 && h <= n_cu) { full = rounds * n_cu; half = h; }
+  }
+  if (full > 0) {
+    MArgs b = a;
+    if (half > 0) b.M = full * UROWS;                                          // (whole units: nothing ragged in the first launch)
+    hipLaunchKernelGGL((mlp_fused_kernel<MODE, LNP>), dim3(full), dim3(NTH), 0, s, b);
+  }
+  if (half > 0) {
+    a.unit_waves = 4; a.row0 = full * UROWS;
+    hipLaunchKernelGGL((mlp_fused_kernel<MODE, LNP>), dim3(half), dim3(NTH), 0, s, a);
+  }
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }
@@ -384,8 +469,11 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
   LAFS_CHECK_ARG(g != nullptr, "null arguments");
   LAFS_CHECK_ARG(g->mode == LAFS_MLP_FWD || g->mode == LAFS_MLP_FWD_SAVE || g->mode == LAFS_MLP_BWD, "bad mode");
   LAFS_CHECK_ARG(lafs_mlp_fused_supported(D, g->H, g->M), "hidden width must be a multiple of 64 in [128, 1536], M > 0 (the embedding width is 384)");
-  LAFS_CHECK_ARG(g->X && g->Wa && g->Wb && g->out, "null operand");
-  LAFS_CHECK_ARG(g->ldx >= D && g->ldx % 8 == 0 && g->ldwa >= D && g->ldwa % 8 == 0 && g->ldwb >= g->H && g->ldwb % 8 == 0, "operand strides: multiples of 8 elements");
+  const bool has_ln = g->mode != LAFS_MLP_BWD && g->ln_gamma != nullptr;
+  LAFS_CHECK_ARG((has_ln || g->X) && g->Wa && g->Wb && g->out, "null operand");
+  LAFS_CHECK_ARG(!has_ln || (g->ln_beta != nullptr && (g->ln_out == nullptr || (g->ldln >= D && g->ldln % 4 == 0))), "LayerNorm prologue: beta / output stride");
+  LAFS_CHECK_ARG(has_ln || (g->ldx >= D && g->ldx % 8 == 0), "operand strides: multiples of 8 elements");
+  LAFS_CHECK_ARG(g->ldwa >= D && g->ldwa % 8 == 0 && g->ldwb >= g->H && g->ldwb % 8 == 0, "operand strides: multiples of 8 elements");
   LAFS_CHECK_ARG(g->ldo >= D && g->ldo % 8 == 0, "output stride: a multiple of 8 elements");
   const bool fwd = g->mode != LAFS_MLP_BWD;
   if (fwd) {
@@ -401,9 +489,13 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
   a.M = g->M; a.H = g->H; a.bias_a = fwd ? g->bias_a : nullptr; a.bias_b = fwd ? g->bias_b : nullptr;
   a.resid = g->resid; a.ldr = g->ldr; a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
   a.out = g->out; a.ldo = g->ldo; a.g = (bf16_t*)g->save_grad; a.ldg = g->ldsg; a.a = (bf16_t*)g->save_act; a.lda = g->ldsa;
+  a.unit_waves = NWV; a.row0 = 0;
+  const int n_cu = g->ctx != nullptr ? g->ctx->n_cu : 0;                      // (no context: one launch of 128-row units)
+  const bool lnp = fwd && g->ln_gamma != nullptr;
+  a.ln_g = g->ln_gamma; a.ln_b = g->ln_beta; a.ln_eps = g->ln_eps; a.ln_stats = g->ln_stats; a.ln_out = (bf16_t*)g->ln_out; a.ldln = g->ldln;
   switch (g->mode) {
-    case LAFS_MLP_FWD: return launch<LAFS_MLP_FWD>(a, stream);
-    case LAFS_MLP_FWD_SAVE: return launch<LAFS_MLP_FWD_SAVE>(a, stream);
-    default: return launch<LAFS_MLP_BWD>(a, stream);
+    case LAFS_MLP_FWD: return lnp ? launch<LAFS_MLP_FWD, true>(a, n_cu, stream) : launch<LAFS_MLP_FWD, false>(a, n_cu, stream);
+    case LAFS_MLP_FWD_SAVE: return lnp ? launch<LAFS_MLP_FWD_SAVE, true>(a, n_cu, stream) : launch<LAFS_MLP_FWD_SAVE, false>(a, n_cu, stream);
+    default: return launch<LAFS_MLP_BWD, false>(a, n_cu, stream);
   }
 }

@@ -93,11 +93,16 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
     return (out, out2) if epilogue == _lib.EPI_BF16_GELU else out
 
 
-def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=None, row2seq=None, out=None, save_grad=None, save_act=None):
+def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=None, row2seq=None, out=None, save_grad=None, save_act=None, ctx=None,
+              ln=None, ln_stats=None, ln_out=None):
     """The fused MLP of a ViT-S block (lafs_mlp_fused, csrc/mlp_fused.hip; vision_transformer.py:59-65,112).
     MLP_FWD / MLP_FWD_SAVE: out(f32) = resid + seq_scale[row2seq] * (gelu(X Wa^T + bias_a) Wb^T + bias_b), the saving form also
     writes save_grad = gelu'(u) and save_act = gelu(u); MLP_BWD: save_act = du = (X Wa^T) * save_grad, out(bf16) = du Wb^T."""
-    _chk(X, bf16, "X"); _chk(Wa, bf16, "Wa"); _chk(Wb, bf16, "Wb")
+    _chk(Wa, bf16, "Wa"); _chk(Wb, bf16, "Wb")
+    if ln is None:
+        _chk(X, bf16, "X")
+    else:
+        X = resid                                        # ln = (gamma, beta, eps): the operand is LayerNorm(resid), formed in the kernel
     M, H = X.shape[0], Wa.shape[0]
     fwd = mode != _lib.MLP_BWD
     if out is None:
@@ -108,8 +113,15 @@ def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=N
     if mode != _lib.MLP_FWD and save_act is None:
         save_act = torch.empty(M, H, device=X.device, dtype=bf16)
     a = _lib.MlpArgs()
-    a.X, a.ldx, a.Wa, a.ldwa, a.Wb, a.ldwb = X.data_ptr(), _ld(X), Wa.data_ptr(), _ld(Wa), Wb.data_ptr(), _ld(Wb)
+    a.X, a.ldx, a.Wa, a.ldwa, a.Wb, a.ldwb = (X.data_ptr() if ln is None else None), _ld(X), Wa.data_ptr(), _ld(Wa), Wb.data_ptr(), _ld(Wb)
     a.M, a.H, a.mode = M, H, int(mode)
+    if ln is not None:
+        _chk(ln[0], torch.float32, "ln gamma"); _chk(ln[1], torch.float32, "ln beta")
+        a.ln_gamma, a.ln_beta, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+        if ln_stats is not None:
+            _chk(ln_stats, torch.float32, "ln_stats"); a.ln_stats = ln_stats.data_ptr()
+        if ln_out is not None:
+            _chk(ln_out, bf16, "ln_out"); a.ln_out, a.ldln = ln_out.data_ptr(), _ld(ln_out)
     if bias_a is not None:
         _chk(bias_a, torch.float32, "bias_a"); a.bias_a = bias_a.data_ptr()
     if bias_b is not None:
@@ -124,6 +136,7 @@ def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=N
         _chk(save_grad, bf16, "save_grad"); a.save_grad, a.ldsg = save_grad.data_ptr(), _ld(save_grad)
     if save_act is not None:
         _chk(save_act, bf16, "save_act"); a.save_act, a.ldsa = save_act.data_ptr(), _ld(save_act)
+    a.ctx = (ctx or _lib.default_ctx(X.device)).handle
     call("lafs_mlp_fused", C.byref(a))
     return out, save_grad, save_act
 

@@ -761,3 +761,36 @@ def test_fused_mlp_equals_the_two_launches_bit_for_bit(M, H):
     assert same(dx, dx_ref), f"dX: {int((dx != dx_ref).sum())} differing values"
     dxf = ((dY.float() @ W2.float()) * gs.float()).to(bf16).float() @ W1.float()
     assert relerr(dx.float(), dxf) < 1e-2
+
+
+@pytest.mark.parametrize("M", [128 * 40, 128 * 33 + 50, 25216])
+def test_fused_mlp_layernorm_prologue_equals_the_layernorm_launch_bit_for_bit(M):
+    """LayerNorm 2 (vision_transformer.py:112 `self.norm2`, eps 1e-6) computed inside lafs_mlp_fused from the fp32 residual stream:
+    the operand it forms, the (mean, rstd) statistics and every output of the fused kernel equal lafs_layernorm_fwd followed by the
+    fused kernel on its output, bit for bit (>= 4096 rows: the two-rows-per-wave LayerNorm kernel, whose row arithmetic the prologue
+    repeats), forward-only and saving form, ragged last unit."""
+    D, H = 384, 1536
+    g = torch.Generator().manual_seed(81)
+    x = (torch.randn(M, D, generator=g) * 1.7 + 0.3).to(DEV)
+    gam, bet = (1.0 + 0.2 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    W1, W2 = rnd_bf(H, D, scale=0.05, seed=83).to(DEV), rnd_bf(D, H, scale=0.03, seed=84).to(DEV)
+    b1, b2 = (torch.randn(H, generator=g) * 0.1).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
+    nseq = 9
+    row2seq = (torch.arange(M) * nseq // M).int().to(DEV)
+    sc = torch.tensor([0.0 if i % 4 == 1 else 1.0 / 0.9 for i in range(nseq)]).to(DEV)
+    h = torch.empty(M, D, device=DEV, dtype=bf16); st = torch.empty(M, 2, device=DEV)
+    call("lafs_layernorm_fwd", _p(x), D, _p(gam), _p(bet), 1e-6, _p(h), D, None, 0, _p(st), M, D)
+    kw = dict(bias_a=b1, bias_b=b2, resid=x, seq_scale=sc, row2seq=row2seq)
+    y_ref = ops.mlp_fused(h, W1, W2, _lib.MLP_FWD, **kw)[0]
+    y = ops.mlp_fused(None, W1, W2, _lib.MLP_FWD, ln=(gam, bet, 1e-6), **kw)[0]
+    assert torch.equal(y, y_ref), f"{int((y != y_ref).sum())} differing values, max {float((y - y_ref).abs().max()):.3e}"
+    guard = 3.0
+    h2 = torch.full((M + 64, D), guard, device=DEV, dtype=bf16); st2 = torch.full((M + 64, 2), guard, device=DEV)
+    y2, g2, a2 = ops.mlp_fused(None, W1, W2, _lib.MLP_FWD_SAVE, ln=(gam, bet, 1e-6), ln_stats=st2[:M], ln_out=h2[:M], **kw)
+    yr, gr, ar = ops.mlp_fused(h, W1, W2, _lib.MLP_FWD_SAVE, **kw)
+    assert float((h2[M:].float() - guard).abs().max()) == 0.0 and float((st2[M:] - guard).abs().max()) == 0.0, "rows past M were written"
+    assert torch.equal(h2[:M], h), f"operand: {int((h2[:M] != h).sum())} differing values"
+    assert torch.equal(st2[:M], st)
+    assert torch.equal(y2, yr) and torch.equal(g2, gr) and torch.equal(a2, ar)
+    ref = F.layer_norm(x.float().cpu(), (D,), gam.cpu(), bet.cpu(), 1e-6)
+    assert relerr(h.float(), ref) < 8e-3

@@ -97,3 +97,24 @@ for rnd in range(4):                                   # interleaved rounds, min
         best[(n, mode)] = min(best.get((n, mode), 1e9), us)
 for (n, mode), us in best.items():
     print(f"abl {n:4d} ({names.get(n, '?'):24s}) mode {mode}: {us:6.1f} us", flush=True)
+
+# ---- unit sizes: 256 full units (128 rows, 8 computing waves) against 256 units of 64 / 48 / 32 rows (libmlp_uw<N>.so: N computing waves)
+Mbig = 128 * 256
+Xb = torch.randn(Mbig, D, generator=g).to(bf16).to(DEV); rb = torch.randn(Mbig, D, generator=g).to(DEV); ob = torch.empty(Mbig, D, device=DEV)
+gb = torch.empty(Mbig, H, device=DEV, dtype=bf16); ab = torch.empty(Mbig, H, device=DEV, dtype=bf16)
+cases = [(None, 8)] + [(os.path.join(here, "libmlp_uw%d.so" % n), n) for n in (4, 3, 2) if os.path.isfile(os.path.join(here, "libmlp_uw%d.so" % n))]
+for mode in (_lib.MLP_FWD, _lib.MLP_FWD_SAVE, _lib.MLP_BWD):
+    line = []
+    for path, uw in cases:
+        h = _lib.lib() if path is None else C.CDLL(path)
+        fn = h.lafs_mlp_fused
+        fn.argtypes = [C.POINTER(_lib.MlpArgs), C.c_void_p]; fn.restype = C.c_int
+        a = _lib.MlpArgs()
+        a.X, a.ldx, a.Wa, a.ldwa, a.Wb, a.ldwb = Xb.data_ptr(), D, W1.data_ptr(), D, W2.data_ptr(), H
+        a.M, a.H, a.mode = 16 * uw * 256, H, mode
+        a.bias_a, a.bias_b, a.resid, a.ldr = b1.data_ptr(), b2.data_ptr(), rb.data_ptr(), D
+        a.out, a.ldo = (ob.data_ptr() if mode != _lib.MLP_BWD else Xb.data_ptr()), D
+        a.save_grad, a.ldsg, a.save_act, a.ldsa = gb.data_ptr(), H, ab.data_ptr(), H
+        us = min(timeit(lambda: fn(C.byref(a), C.c_void_p(st)), 20) for _ in range(3))
+        line.append(f"{uw} waves x 256 units: {us:6.1f} us")
+    print(f"mode {mode}: " + "   ".join(line), flush=True)
