@@ -70,7 +70,7 @@ enum {
   LAFS_OPT_COMM_CUS = 6,       /* data-parallel runs: CUs left to the collective library's kernels by the K-resident GEMM (default 0) */
   LAFS_OPT_NT_BIG = 7,         /* tiled GEMM: one-workgroup-per-CU 192x256 / 176x256 tiles for the wide long-K shapes (default 1; 2-4 force a geometry) */
   LAFS_OPT_MLP_FUSED = 8,      /* trunk passes: the block's MLP as ONE launch (lafs_mlp_fused) where it applies (dim 384, no element dropout): bit mask
-                                  1 forward-only pass, 2 saving forward, 4 backward input gradients, 8 LayerNorm 2 inside the fused forward (default 0: step A/B in
+                                  1 forward-only pass, 2 saving forward, 4 backward input gradients, 8 LayerNorm 2 inside the fused forward (default 15: step A/B in
                                   DESIGN.md section 6) */
   LAFS_OPT_COUNT = 9
 };
