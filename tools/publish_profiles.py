@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out", "profiles"), os.path.join(ROOT, "profiles")
 R = sys.argv[1] if len(sys.argv) > 1 else "round3"
 DOM = "gemm_kres_kernel<1, true"          # student fc1: BF16_GELU epilogue (pre-activation stored) on the K-resident kernel
+MLP = "mlp_fused_kernel<1, true"          # student saving forward with the LayerNorm prologue (csrc/mlp_fused.hip)
 FC2 = "gemm_nt_kernel<2, 2, 64"           # student fc2: RESID_F32 epilogue, 128x128 tile, 64-deep stages (prefix: further template arguments follow)
 
 
@@ -68,6 +69,9 @@ def main():
                             (M * 384 + 1536 * 384 + 2 * M * 1536) * 2.0, 2.0 * M * 1536 * 384),
         "fc2": kernel_entry("gemm_nt_kernel<RESID_F32, WM=2, BK=64>  M=44160 N=384 K=1536 (student fc2 forward, tiled kernel)", [FC2],
                             (M * 1536 + 384 * 1536) * 2.0 + 2.0 * M * 384 * 4.0, 2.0 * M * 384 * 1536),
+        "mlp_fused": kernel_entry("mlp_fused_kernel<FWD_SAVE, LN prologue>  M=25216 H=1536 (student LayerNorm 2 + MLP + residual, one launch)", [MLP],
+                                  25216 * 384 * 4.0 * 2 + 2 * 1536 * 384 * 2.0 + 2 * 25216 * 1536 * 2.0 + 25216 * 384 * 2.0 + 25216 * 8.0,
+                                  4.0 * 25216 * 384 * 1536),
     }
     json.dump(out, open(os.path.join(DST, f"{R}_kernel_pmc.json"), "w"), indent=1)
     for name, sub in (("serial", "serial"), ("landmark_cnn", "cnn")):
@@ -103,7 +107,7 @@ def main():
             for k, v in cnt.most_common():
                 fo.write(f"{v:5d}  {k}\n")
     print(json.dumps({k: {kk: out[k][kk] for kk in ("launches_averaged", "hbm_bytes_per_launch", "algorithmic_bytes_per_launch")}
-                      for k in ("wgrad_group", "fc1", "fc2")}))
+                      for k in ("wgrad_group", "fc1", "fc2", "mlp_fused")}))
 
 
 if __name__ == "__main__":
