@@ -32,7 +32,7 @@
 
 // lab builds only (tools/lab/Makefile: mlp_abl): timing ablations -- 1 no GELU / gelu' arithmetic, 2 no fragment reads, 4 no LDS-DMA
 // after the prologue's stages, 8 no MFMA, 16 no workgroup barriers (racy), 32 / 64 every second fragment read of stage B / A only.
-// 0 in the library.
+// 128 phase time stamps of wave 0 (s_memtime; lafs_mlp_args::ctx carries the output buffer).  0 in the library.
 #ifndef LAFS_MLP_ABL
 #define LAFS_MLP_ABL 0
 #endif
@@ -76,7 +76,8 @@ struct MArgs {
   float* ln_stats; bf16_t* ln_out; int ldln;            //      (mean, rstd) per row and the bf16 operand as by-products (optional)
   int unit_waves;                            // waves of a workgroup that own rows (8: 128-row units; 4: 64-row units, one computing wave per SIMD)
   int row0;                                  // first row of this launch's first unit
-};
+  unsigned long long* stamps;                // lab (ablation 128): per workgroup, wave 0: cycles in {wait + barrier A, DMA issue A, MFMA A, mid-epilogue,
+};                                           //   wait + barrier B, DMA issue B, MFMA B, prologue, final epilogue, whole kernel}
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
@@ -104,6 +105,8 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15, q = lane >> 4;
+  unsigned long long t_begin = 0;
+  if constexpr (MABL(128)) t_begin = __builtin_amdgcn_s_memtime();
   const int u0 = p.row0 + blockIdx.x * (16 * p.unit_waves);   // first row of this workgroup's unit
   const int NI = p.H / HC;                             // items (>= 2)
   const int row = u0 + wave * 16 + t;                  // this lane's token row
@@ -278,6 +281,15 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   // After it: nothing in flight.  Re-issue order from here on is what the counts below assume.
 
   bf16x8_t wprev = areg[0];                            // (lab: ablations 32 / 64)
+  unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
+  auto lap = [&](int slot) {
+    if constexpr (MABL(128)) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tacc[slot] += now - t_last;
+      t_last = now;
+    }
+  };
+  if constexpr (MABL(128)) { t_last = __builtin_amdgcn_s_memtime(); tacc[7] = t_last - t_begin; }
   int buf = 2;                                         // ring buffer of the stage consumed next
   auto next_buf = [&](int b) { return (b + 1 == NSTG) ? 0 : b + 1; };
   for (int it = 0; it < NI; ++it) {
@@ -296,7 +308,9 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     else if (active) wait_vm<NS + NDMA + NL>();
     else wait_vm<NDMA + NL>();
     if constexpr (!MABL(16)) __builtin_amdgcn_s_barrier();
+    lap(0);
     if (it > 0 && has_next) issue_a(it + 1, next_buf(next_buf(buf)));           // stage 2 it + 2 (item 0: issued by the prologue)
+    lap(1);
     if (active) {
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* st = smem + buf * STAGE;
@@ -322,6 +336,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     buf = next_buf(buf);
+    lap(2);
     // ----------------- mid-epilogue: GELU (forward) / x gelu'(u) (backward), bf16 rounding, hand-over to GEMM 2 in registers
     fence();
     if constexpr (MODE == LAFS_MLP_BWD) {              // younger than the gelu' loads: the stage A issued above (item 0: stages 1, 2 -- drained)
@@ -358,15 +373,18 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     }
     }
     fence();
+    lap(3);
     // ================= stage B of the item: acc2 += Wb slice rows x intermediate (48 MFMAs)
     // younger than this stage's DMA: the stage A issued above (if any) and the mid-epilogue's stores
     if (has_next) { if (active) wait_vm<NDMA + NS>(); else wait_vm<NDMA>(); }
     else { if (active) wait_vm<NS>(); else wait_vm<0>(); }
     if constexpr (!MABL(16)) __builtin_amdgcn_s_barrier();
+    lap(4);
     if (has_next) {
       issue_b(it + 1, next_buf(next_buf(buf)));        // stage 2 it + 3
       fetch_g(it + 1);
     }
+    lap(5);
     if (active) {
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* st = smem + buf * STAGE;
@@ -392,11 +410,22 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
     buf = next_buf(buf);
+    lap(6);
   }
+  auto stamp_out = [&]() {
+    if constexpr (MABL(128)) {
+      if (tid == 0 && p.stamps != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tacc[8] = now - t_last; tacc[9] = now - t_begin;
+        for (int i = 0; i < 10; ++i) p.stamps[(size_t)blockIdx.x * 10 + i] = tacc[i];
+      }
+    }
+  };
 
   // ---- final epilogue of the unit: lane (t, q) owns row `row` and, per output block ob, 4 consecutive fp32 columns (forward)
   // or, per block pair, 8 consecutive bf16 columns (backward)
-  if (!rowok) return;
+  if (!rowok) { stamp_out(); return; }
   if constexpr (FWD) {
     const float* rs = p.resid + (size_t)row * p.ldr;
     float* o = reinterpret_cast<float*>(p.out) + (size_t)row * p.ldo;
@@ -425,6 +454,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
       st16(o + 32 * P + 8 * q, pack_bf2(x[0], x[1]), pack_bf2(x[2], x[3]), pack_bf2(y[0], y[1]), pack_bf2(y[2], y[3]));
     }
   }
+  stamp_out();
 }
 
 #ifndef LAFS_MLP_UW
@@ -490,7 +520,8 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
   a.resid = g->resid; a.ldr = g->ldr; a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
   a.out = g->out; a.ldo = g->ldo; a.g = (bf16_t*)g->save_grad; a.ldg = g->ldsg; a.a = (bf16_t*)g->save_act; a.lda = g->ldsa;
   a.unit_waves = NWV; a.row0 = 0;
-  const int n_cu = g->ctx != nullptr ? g->ctx->n_cu : 0;                      // (no context: one launch of 128-row units)
+  a.stamps = MABL(128) ? (unsigned long long*)g->ctx : nullptr;
+  const int n_cu = (g->ctx != nullptr && !MABL(128)) ? g->ctx->n_cu : 0;                      // (no context: one launch of 128-row units)
   const bool lnp = fwd && g->ln_gamma != nullptr;
   a.ln_g = g->ln_gamma; a.ln_b = g->ln_beta; a.ln_eps = g->ln_eps; a.ln_stats = g->ln_stats; a.ln_out = (bf16_t*)g->ln_out; a.ldln = g->ldln;
   switch (g->mode) {
