@@ -286,7 +286,8 @@ int lafs_debug_dropout_mask(int rows, int cols, float drop_p, uint32_t drop_seed
  * Fused multi-head attention over variable-length sequences, head_dim = 64
  *   vision_transformer.py:80-89 (scale = head_dim^-0.5); face_pre_pro/ViT_face.py:155-179 (scale = dim^-0.5)
  * qkv(bf16) [T, 3*H*64]: columns [q | k | v], each H*64 wide, head-major.  cu_seqlens(i32, device) [n_seq+1].
- * All sequences of one call must have length <= max_len <= 256.
+ * All sequences of one call must have length <= max_len <= 256.  cu_seqlens is read through the scalar (constant) cache: it must not
+ * be written while a launch that reads it is in flight (the engines build it once per geometry).
  * ------------------------------------------------------------------------------------------------ */
 int lafs_attention_fwd(const void* qkv, int ldqkv, const int32_t* cu_seqlens, int n_seq, int max_len, int heads,
                        float scale, void* out_bf16, int ldo, float* lse, hipStream_t stream);
@@ -653,6 +654,13 @@ int lafs_cnn_bn_bwd_eval(const void* dy, int lddy, const void* x, int ldx, int64
  *   lafs_cnn_grad_guard (after the backward, over the CNN's gradient range of the arena): found_inf |= any non-finite entry;
  *     found_inf: the range is zeroed (this accumulation window's CNN update is dropped; AdamW's moments stay finite), target
  *     halves (>= 1), skipped += 1; otherwise 2000 clean backwards in a row double the target again (<= target_max).
+ *     DEVIATION from GradScaler, by design of this guard: it runs once per MICRO-step and covers the landmark CNN's range only --
+ *     (a) with acc_step > 1 an overflow zeroes what earlier micro-steps of the window accumulated there and later ones still add
+ *     to it, so the optimizer then applies a partial CNN gradient instead of skipping; (b) the optimizer step itself is never
+ *     skipped: AdamW still decays the CNN's weights and moments, and the ViT / margin-head ranges (computed in bf16 with fp32
+ *     accumulation, which cannot overflow where fp16 does) update normally, whereas the reference's scaler.step skips the whole
+ *     step for every parameter (train_largescale.py:878-880); (c) in data-parallel runs only the overflowing rank zeroes its share
+ *     before the all-reduce.  An overflow has not been observed in any test or benchmark run (state[4] == 0 throughout).
  * lafs_cnn_cast_pad_f16: dst(fp16)[r, c] = src(f32)[r, c] * scale[0], pad columns [cols, ld) zero.
  * lafs_cnn_cast_f16_f32: dst(f32)[i] = src(fp16)[i]. */
 int lafs_cnn_grad_scale(const float* g, int64_t n, float target, float* scale, int has_state, hipStream_t stream);

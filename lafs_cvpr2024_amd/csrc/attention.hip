@@ -702,11 +702,9 @@ int dispatch(int which, const AttnArgs& a, hipStream_t s) {
   const size_t pair_bytes = 4 * tile + 2 * NT * 16 * 4;
 #ifndef LAFS_LAB_ATTN_BWD_OLD
   if constexpr (NT >= 10 && NT <= 13) {
-    static const int n_cu = [] {
-      int dev = 0, n = 256;
-      (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-      return n;
-    }();
+    // (per call, for the device that is current NOW: no process-global state -- another device of the same process has its own count)
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     return launch_attn(attn_bwd_stream_kernel<NT>, min(n_pairs, n_cu), 1, 512, 6 * tile + 4 * NT * 16 * 4, a, s);
   }
 #endif

@@ -96,6 +96,11 @@ __global__ __launch_bounds__(G::NTH, 1) void gemm_big_kernel(BArgs p) {
   constexpr bool F32 = (EPI == LAFS_EPI_RESID_F32);
   constexpr int VPL = F32 ? 4 : 8;
   constexpr int ESTORES = (F32 ? 4 : (TWO ? 4 : 2)) * MBW * (NBW / 4);          // stores of one tile's epilogue per wave
+  // The cross-tile wait below uses the largest of the immediates 16 / 32 / 48 that does not exceed ESTORES (a LOWER bound of the
+  // stores younger than the awaited stage): a geometry / epilogue with fewer than 16 stores per wave would need a smaller immediate.
+  // That hipcc emits exactly one store instruction per counted store and skips none is what the bit-exact comparison with the tiled
+  // kernel holds for every Geo x EPI (tests/test_gpu_kernels.py::test_gemm_nt_big_tiles_equal_the_tiled_kernel_bit_for_bit).
+  static_assert(ESTORES >= 16 && ESTORES < 64, "cross-tile s_waitcnt vmcnt immediates assume 16 <= ESTORES < 64");
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
   const DropCfg drop = drop_resolve(p.drop);
   const int tid = threadIdx.x, lane = tid & 63;

@@ -7,8 +7,13 @@
 Round 4: every per-step tensor is allocated once, no ATen kernel is left in a micro-step (labels, DropPath masks, operand
 transposes, the image gradient re-indexing and the gradient zeroing are lafs_* launches), the mixup lambda / step counter are read
 from device memory, and the whole micro-step is ONE hipGraph (two captured variants: the first micro-step of an accumulation
-window WRITES the block and class-table weight gradients instead of accumulating into a zeroed 1 GB arena).  Data-parallel
-runs and the class-sharded head keep the eager form (their collectives sit between the kernels).
+window WRITES the block and class-table weight gradients instead of accumulating into a zeroed 1 GB arena).
+
+Round 6, data-parallel runs (reference: DistributedDataParallel(broadcast_buffers=True), train_largescale.py:676-677): parameters and
+buffers are broadcast from rank 0 at construction; the micro-steps of an accumulation window that reduce nothing are the same single
+graph as on one rank (deferred weight gradients included), and the window's LAST micro-step -- whose gradient slices go out over RCCL
+as the backward retires them -- is captured as one hipGraph per segment with the FlatReducer launches between the replays, exactly as
+LafsPretrainEngine does.  Only the class-sharded head keeps the eager form (its collectives sit inside the head itself).
 """
 import os
 
@@ -57,6 +62,16 @@ class FinetuneEngine:
         self.arena.set_decay_groups(finetune_decay_group)
         self.ctx = _lib.Ctx(self.device)                 # this engine's side streams / events / kernel options (lafs_ctx)
         self.arena.ctx = self.ctx
+        self.cnn_flush = None
+        if self.world > 1:
+            # DDP's construction-time broadcast of parameters AND buffers from rank 0 (train_largescale.py:676-677; before the landmark
+            # plan below takes its references to the BatchNorm statistics).  DDP also re-broadcasts the buffers before every forward:
+            # in training mode the BatchNorm layers normalise with batch statistics, the running statistics are only written, and
+            # only rank 0 saves checkpoints (train_largescale.py:899-910) -- rank 0's buffers evolve as under DDP and the other ranks'
+            # copies are never read; sync_buffers() makes every rank hold rank 0's values (before an evaluation on all ranks).
+            dist.broadcast(self.arena.master, 0)
+            self.arena.refresh_shadows()
+            self.sync_buffers()
         self.head = sharded_head
         self.C = backbone.loss.out_features if sharded_head is None else 8
         self.Cpad = (self.C + 127) // 128 * 128
@@ -138,6 +153,7 @@ class FinetuneEngine:
             self.cnn = HipLandmarkTrainer(m, a, batch_size, image_size, device=dev)
             self.cnn.step_dev = self.hyper[_lib.HP_STEP:]
             m.register_state_dict_pre_hook(lambda *a_, **k_: self.cnn.flush_batches_tracked())
+            self.cnn_flush = self.cnn.flush_batches_tracked
         # streams / graphs
         # (The blocks' weight gradients on a second stream INSIDE the chain were measured neutral at C4 -- 27.24 ms with, 27.03 without --
         # and removed in round 5: tools/lab/NOTES.md.  What pays is deferring them beside the landmark CNN's backward, below.)
@@ -147,17 +163,32 @@ class FinetuneEngine:
         # CNN's backward -- ~300 small launch-latency-sized kernels that leave most of the chip idle -- capped to
         # LAFS_FT_DEFER_WG workgroups so that the CNN's kernels find free CUs.  Measured at C4 (tools/lab/NOTES.md): the same launches
         # cost 4.5 ms in front of the CNN backward and 2.75 ms beside it.  LAFS_FT_WGRAD_DEFER=0 restores the immediate form.
-        self.defer = (self.cnn is not None and self.world == 1 and sharded_head is None
+        # (data-parallel runs: on every micro-step of a window but the last, whose gradient slices leave as the backward retires them)
+        self.defer = (self.cnn is not None and sharded_head is None
                       and os.environ.get("LAFS_SINGLE_STREAM") != "1" and os.environ.get("LAFS_FT_WGRAD_DEFER", "1") != "0")
         self.defer_stream = torch.cuda.Stream(device=dev) if self.defer else None
         if self.defer:
             self.wgrad_workgroups = int(os.environ.get("LAFS_FT_DEFER_WG", "128"))
         if use_graph is None:
             use_graph = os.environ.get("LAFS_FT_GRAPH", "1") != "0"
-        self.use_graph = bool(use_graph) and self.world == 1 and sharded_head is None
+        self.use_graph = bool(use_graph) and sharded_head is None
         self._graphs = {}
         self._pool = None
         self._ws = None
+
+    def sync_buffers(self):
+        """Every rank takes rank 0's buffers (BatchNorm running statistics and counters of the landmark CNN): what DDP's
+        broadcast_buffers does in front of every forward (train_largescale.py:676-677)."""
+        if self.world > 1:
+            if self.cnn_flush is not None:
+                self.cnn_flush()
+            for b in self.model.buffers():
+                dist.broadcast(b, 0)
+
+    def _defer_now(self):
+        """Deferred weight gradients on this micro-step?  Not on the one that completes a data-parallel window: its gradient
+        ranges are handed to the collective run by run, so every block's weight gradients have to exist when its run ends."""
+        return self.defer and not self._reduce_now()
 
     # ------------------------------------------------------------------ host side of a micro-step
     def draw_lambda(self):
@@ -205,12 +236,17 @@ class FinetuneEngine:
         self._upload_hyper({_lib.HP_MIX_LAM: lam, _lib.HP_STEP: float((self.micro + 1) % (1 << 24))})
         first = (self._since_opt == 0)                   # first micro-step since the last optimizer step: gradients are written, not accumulated
         if self._capturable():
-            key = (first, bool(m.training))
-            g = self._graphs.get(key)
-            if g is None:
-                g = self._capture(first)
-                self._graphs[key] = g
-            g.replay()
+            key = (first, bool(m.training), self._reduce_now())
+            segs = self._graphs.get(key)
+            if segs is None:
+                segs = self._capture(first)
+                self._graphs[key] = segs
+            for g, out in segs:                          # one graph per segment; the gradient range a segment completes goes out behind it
+                g.replay()
+                if out is not None:
+                    self.reducer.launch(out)
+            if key[2]:
+                self._reduced = True
             if self._cnn_hip and m.training:             # nn.BatchNorm2d.num_batches_tracked: one training forward of the landmark CNN per replay
                 self.cnn.n_forward += 1
         else:
@@ -235,7 +271,9 @@ class FinetuneEngine:
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(cur)
         with torch.cuda.stream(s):
-            self._body(first)
+            self._body(first)                            # (a window's last micro-step: its all-reduces really run, on every rank alike)
+            self.reducer.wait_all()
+        self._reduced = False
         cur.wait_stream(s)
         torch.cuda.synchronize()
         for dst, src in zip([a.grad, self.loss] + bn, saved):
@@ -250,16 +288,35 @@ class FinetuneEngine:
             self._warmup(first)
         if self.cnn is not None:
             self.cnn.mark_stale()                        # the operand refresh becomes part of the graph: every replay sees fresh weights
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self._pool):
-            self._body(first)
-        if self._pool is None:
-            self._pool = g.pool()
-        return g
+        # The body is a generator that yields the gradient range to all-reduce wherever a collective has to sit between kernels (only on
+        # the last micro-step of a data-parallel window): every stretch between two yields becomes one hipGraph.  With a process group
+        # alive its watchdog thread polls events while this thread captures -- thread-local capture mode keeps its (legal) runtime
+        # calls from invalidating the capture (as in LafsPretrainEngine._capture).
+        segs, gen, done = [], self._body_gen(first), False
+        mode = dict(capture_error_mode="thread_local") if self.world > 1 else {}
+        while not done:
+            g, out = torch.cuda.CUDAGraph(), None
+            with torch.cuda.graph(g, pool=self._pool, **mode):
+                try:
+                    out = next(gen)
+                except StopIteration:
+                    done = True
+            if self._pool is None:
+                self._pool = g.pool()
+            segs.append((g, out))
+        return segs
 
     # ------------------------------------------------------------------ the device side (capturable: lafs_* launches only)
     def _body(self, first):
+        """Eager form: the segments back to back, each completed gradient range handed to the reducer as it appears."""
+        for out in self._body_gen(first):
+            self.reducer.launch(out)
+        if self._reduce_now():
+            self._reduced = True
+
+    def _body_gen(self, first):
         a, m, B, D, dev = self.arena, self.model, self.B, self.D, self.device
+        defer = self._defer_now()
         hp = self.hyper
         if first:                                        # gradient of everything no kernel overwrites <- 0
             call("lafs_zero_chunks", _p(a.grad), _p(a.chunk_seg), _p(a.seg_flags), a.n_chunks, _lib.SEG_OVERWRITTEN)
@@ -281,23 +338,24 @@ class FinetuneEngine:
             img_in = self.img_in
             call("lafs_patch_gather_fwd", _p(self.x), _p(th), B, self.S, th.shape[1], _p(img_in))
         if self._ws is None:
+            # (sized for the deferred form -- one operand slot per layer -- which also holds the immediate form's two)
             probe = Fn.make_trunk_desc(a, m._spec.trunk, self.geom, drop, with_grad=True, wgrad_defer=self.defer,
                                        wgrad_workgroups=self.wgrad_workgroups if self.defer else 0)
             self._ws = Fn.trunk_workspace(probe, True, dev)
         emb, st, _ = Fn.vit_forward(a, m._spec, self.geom, [img_in], [self.pos_rows], drop, save=True, dropout=dropout, ws=self._ws,
                                     x_in=self.x_in, x_out=self.x_out, wgrad_overwrite=first,
-                                    wgrad_workgroups=self.wgrad_workgroups if self.defer else 0,
-                                    wgrad_defer=self.defer)
+                                    wgrad_workgroups=self.wgrad_workgroups if defer else 0,
+                                    wgrad_defer=defer)
         if self.head is not None:
             # class-sharded head: all-gather embeddings, local logits, exchanged softmax statistics, reduce-scatter of dE.
             # demb is the gradient of the GLOBAL-batch mean loss, so the later all-reduce of the backbone gradients is a SUM.
             # soft (mixup) targets as the reference's margin head always gets them (train_largescale.py:802): the partner of row b is
             # row B-1-b of this rank's batch (util/mixup_my.py:189-200), its weight 1 - lambda
-            soft = self._lam != 1.0
+            soft = self._lam != 1.0                      # (more than one rank: PartialFC takes the soft form on every rank, normalize_targets)
             loss, demb = self.head.forward_backward(emb, self._labels, grad_scale=1.0 / self.acc_step,
                                                     labels2=self._labels.flip(0) if soft else None, lam=self._lam)
             self.loss.copy_(loss.detach().view(1))
-            self._backward_trunk(st, demb, th, theta)
+            yield from self._backward_trunk(st, demb, th, theta)
             return
         # ---- margin head (face_pre_pro/ViT_face.py:49-89 + timm SoftTargetCrossEntropy, train_largescale.py:820)
         call("lafs_l2norm_fwd", _p(emb), D, _p(self.xn), D, _p(self.inv_x), B, D)
@@ -315,13 +373,13 @@ class FinetuneEngine:
         # d(Wn) and the weight-norm backward of the class table (~0.55 ms of HBM-bound work at C4) gate nothing in the trunk backward:
         # with deferred weight gradients they follow those on the second stream, beside the landmark CNN's backward
         self._head_first = first
-        if not (self.defer and self._cnn_hip and os.environ.get("LAFS_FT_DEFER_HEAD", "1") != "0"):
+        if not (defer and self._cnn_hip and os.environ.get("LAFS_FT_DEFER_HEAD", "1") != "0"):
             self._head_param_grads()
             self._head_first = None
         call("lafs_l2norm_bwd", _p(emb), D, _p(self.dxn), D, _p(self.inv_x), _p(self.demb), D, B, D)
         if self._reduce_now():
-            self.reducer.launch(a.grad[self.head_off:])          # margin head (+ anything behind it): final from here on
-        self._backward_trunk(st, self.demb, th, theta)
+            yield a.grad[self.head_off:]                         # margin head (+ anything behind it): final from here on
+        yield from self._backward_trunk(st, self.demb, th, theta)
 
     def _head_param_grads(self):
         """d(Wn) [C, D] = dcos^T @ emb_n (reduction over the batch: an NT GEMM that writes the 633 MB matrix once) and the weight-norm
@@ -341,13 +399,14 @@ class FinetuneEngine:
 
     def _trunk_layers_backward(self, st, demb):
         """Final norm + all blocks; with DP on the window's last micro-step in `grad_slices` runs, each run's gradient range
-        handed to RCCL as soon as it has been enqueued."""
+        handed to RCCL as soon as it has been enqueued (a generator: it yields those ranges)."""
         a, m = self.arena, self.model
         g = Fn.vit_backward_begin(a, m._spec, st, demb, g_buf=self.g_buf)
+        self._g = g
         depth = m.depth
         if not self._reduce_now():
             Fn.vit_backward_layers(st, g, depth, 0)
-            return g
+            return
         ns = max(1, min(self.grad_slices, depth))
         cuts = [depth - (depth * k) // ns for k in range(ns + 1)]
         hi = self.head_off
@@ -355,15 +414,15 @@ class FinetuneEngine:
             Fn.vit_backward_layers(st, g, cuts[k], cuts[k + 1])
             lo = self.block_off[cuts[k + 1]]
             if cuts[k + 1] > 0:                                  # the range below block 0 still waits for the embedding / CNN gradients
-                self.reducer.launch(a.grad[lo:hi])
+                yield a.grad[lo:hi]
                 hi = lo
         self._hi_left = hi
-        return g
 
     def _backward_trunk(self, st, demb, th, theta):
         a, m, B, D = self.arena, self.model, self.B, self.D
         reduce_now = self._reduce_now()
-        g = self._trunk_layers_backward(st, demb)
+        yield from self._trunk_layers_backward(st, demb)
+        g = self._g
         deferred = bool(st.desc.wgrad_defer)
         cur = torch.cuda.current_stream()
         if deferred and self._cnn_hip:                   # the blocks' weight gradients: beside everything from here to the end of the CNN backward
@@ -390,8 +449,7 @@ class FinetuneEngine:
         if deferred and self._cnn_hip:
             cur.wait_stream(self.defer_stream)
         if reduce_now:                                           # what is left: block 0's run + embedding + landmark CNN
-            self.reducer.launch(a.grad[: self._hi_left])
-            self._reduced = True
+            yield a.grad[: self._hi_left]
 
     # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, lr, weight_decay=0.1, beta1=0.9, beta2=0.999, eps=1e-8):

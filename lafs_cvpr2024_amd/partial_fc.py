@@ -82,6 +82,17 @@ def sample_classes(labels, class_start, num_local, num_sample, generator=None, l
     return index, local_pos(labels), local_pos(labels2.long())
 
 
+def normalize_targets(world, margin_type, labels, labels2, lam):
+    """(labels2, lam, soft) as forward_backward uses them.  On more than one rank the CosFace head ALWAYS takes the soft form -- a row
+    without a mixup partner is its own partner with weight 1 - lam = 0, which the kernels evaluate exactly as a hard label -- because
+    the soft form issues two more all-gathers (partner classes, per-row lambdas) and every rank draws its OWN lambda (90 % of the
+    draws are 1 at mixup_prob 0.1): a per-rank choice would let the ranks' collective sequences diverge (hang, or mismatched
+    buffers)."""
+    if labels2 is None and world > 1 and margin_type == 0:
+        return labels, 1.0, True
+    return labels2, lam, labels2 is not None
+
+
 class _Centres(torch.nn.Module):
     def __init__(self, n, d):
         super().__init__()
@@ -137,7 +148,7 @@ class PartialFC:
         a = self.arena
         emb = emb.contiguous()
         labels = labels.to(dev, torch.int64).contiguous()
-        soft = labels2 is not None
+        labels2, lam, soft = normalize_targets(W, self.margin_type, labels, labels2, lam)
         if soft:
             if self.margin_type != 0:
                 raise _lib.LafsHipError("soft (mixup) targets need the CosFace margin (ArcFace takes hard labels)")

@@ -128,3 +128,57 @@ def test_partial_fc_two_shards_equal_unsharded(tmp_path):
         torch.testing.assert_close(got["demb"], emb.grad[r * B:(r + 1) * B], rtol=1e-4, atol=1e-6)
         torch.testing.assert_close(got["loss_soft"], ref_s.detach(), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(got["demb_soft"], emb2.grad[r * B:(r + 1) * B], rtol=1e-4, atol=1e-6)
+
+
+def _exchange_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from lafs_cvpr2024_amd import partial_fc as pfc
+    calls = []
+    real_gather = pfc._gather_rows
+    pfc._gather_rows = lambda t, w: (calls.append(tuple(t.shape)), real_gather(t, w))[1]
+    B, C = 4, 37
+    g = torch.Generator().manual_seed(9)
+    lab = torch.randint(0, C, (world * B,), generator=g)
+    mine = lab[rank * B:(rank + 1) * B]
+    lam = (1.0, 0.3)[rank]                                    # rank 0 drew "no mixup", rank 1 mixes: the advisor's hang scenario
+    labels2 = None if lam == 1.0 else mine.flip(0)
+    # --- the product's own target normalisation + exchange helpers (the CPU-safe part of PartialFC.forward_backward)
+    l2, lam_n, soft = pfc.normalize_targets(world, 0, mine, labels2, lam)
+    assert soft and l2 is not None
+    L = pfc._gather_rows(mine, world)
+    L2 = pfc._gather_rows(l2, world)
+    lam_rows = pfc._gather_rows(torch.full((B,), float(lam_n)), world)
+    start, n = pfc.shard_range(C, rank, world)
+    index, y, y2 = pfc.sample_classes(L, start, n, n, labels2=L2)
+    part = torch.arange(world * B * 3, dtype=torch.float32).view(world * B, 3) * (rank + 1)
+    rs = pfc._reduce_scatter_rows(part.clone(), world, rank)
+    torch.save({"calls": calls, "L": L, "L2": L2, "lam_rows": lam_rows, "y": y, "y2": y2, "start": start, "n": n, "rs": rs}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partial_fc_exchange_helpers_issue_the_same_collectives_whatever_each_rank_drew(tmp_path):
+    """lafs_cvpr2024_amd/partial_fc.py's own exchange logic on CPU tensors over gloo (the kernels between the collectives need the
+    GPU: tests/test_gpu_dp.py): with lambdas (1.0, 0.3) -- rank 0 drew no mixup, rank 1 mixes -- both ranks issue the SAME sequence
+    of all-gathers (normalize_targets turns rank 0's hard labels into the soft form with a zero-weight partner), the gathered rows
+    are rank-major, rank 0's rows carry lambda 1 and their own class as partner, and the reduce-scatter hands every rank the sum of
+    its slice."""
+    out = str(tmp_path / "ex")
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    mp.spawn(_exchange_worker, args=(2, port, out), nprocs=2, join=True)
+    r = [torch.load(out + f".{k}", weights_only=False) for k in range(2)]
+    assert r[0]["calls"] == r[1]["calls"] and len(r[0]["calls"]) == 3
+    B, C = 4, 37
+    lab = torch.randint(0, C, (2 * B,), generator=torch.Generator().manual_seed(9))
+    for k in range(2):
+        assert torch.equal(r[k]["L"], lab)
+        assert torch.equal(r[k]["L2"], torch.cat([lab[:B], lab[B:].flip(0)]))           # rank 0: own classes; rank 1: its flipped batch
+        assert torch.equal(r[k]["lam_rows"], torch.tensor([1.0] * B + [0.3] * B))
+        own = (lab >= r[k]["start"]) & (lab < r[k]["start"] + r[k]["n"])
+        assert torch.equal(r[k]["y"][own].long(), lab[own] - r[k]["start"]) and bool((r[k]["y"][~own] == -1).all())
+        full = torch.arange(2 * B * 3, dtype=torch.float32).view(2 * B, 3) * 3.0       # (1 + 2) x the ramp
+        assert torch.equal(r[k]["rs"], full[k * B:(k + 1) * B])

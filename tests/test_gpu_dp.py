@@ -179,17 +179,78 @@ def test_partial_fc_two_class_shards_on_one_gpu(tmp_path):
     ref.backward()
     for r in range(2):
         got = torch.load(out + f".{r}", weights_only=False)
-        assert abs(float(got["loss"].detach()) - float(ref)) < 2e-2 * abs(float(ref))
         e = emb.grad[r * B:(r + 1) * B]
-        assert float((got["demb"] - e).abs().max()) < 3e-2 * float(e.abs().max())
         w = Wfull.grad[got["start"]:got["start"] + got["dW"].shape[0]]
-        assert float((got["dW"] - w).abs().max()) < 3e-2 * float(Wfull.grad.abs().max())
+        errs = (abs(float(got["loss"].detach()) - float(ref)) / abs(float(ref)), float((got["demb"] - e).abs().max()) / float(e.abs().max()),
+                float((got["dW"] - w).abs().max()) / float(Wfull.grad.abs().max()))
+        print(f"[pfc] rank {r}: loss / dE / dW errors {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+        assert max(errs) < 1e-2, errs                # (round 5: 2 % / 3 %; the observed values are a few 1e-3: bf16 operands of the logit GEMM)
+
+
+def _pfc_soft_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lafs_cvpr2024_amd.partial_fc import PartialFC, shard_range
+    g = torch.Generator().manual_seed(6)
+    C, D, B = 1000, 64, 8
+    Wfull = torch.randn(C, D, generator=g) * 0.05
+    emb = torch.randn(world * B, D, generator=g)
+    lab = torch.randint(0, C, (world * B,), generator=g)
+    pfc = PartialFC(D, C, B, sample_rate=1.0, device="cuda")
+    start, n = shard_range(C, rank, world)
+    with torch.no_grad():
+        pfc.weight.copy_(Wfull[start:start + n])
+    mine = lab[rank * B:(rank + 1) * B].cuda()
+    lam = _PFC_SOFT_LAMS[rank]                               # rank 0 drew "no mixup" (hard labels), rank 1 mixes with its flipped batch
+    loss, demb = pfc.forward_backward(emb[rank * B:(rank + 1) * B].cuda(), mine, labels2=None if lam == 1.0 else mine.flip(0), lam=lam)
+    torch.cuda.synchronize()
+    torch.save({"loss": loss.detach().cpu(), "demb": demb.cpu(), "dW": pfc.arena.view(pfc.arena.grad, "weight", (n, D)).cpu(), "start": start},
+               out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+_PFC_SOFT_LAMS = (1.0, 0.3)
+
+
+def test_partial_fc_soft_labels_with_a_rank_that_drew_no_mixup(tmp_path):
+    """The product's class-sharded head (partial_fc.PartialFC: HIP kernels + exchange) with the reference's soft mixup targets where
+    the ranks drew DIFFERENT lambdas, one of them 1.0 (90 % of the draws at mixup_prob 0.1, train_largescale.py:389): the ranks'
+    collective sequences must not diverge (round-5 advisor finding: a per-rank soft / hard choice hangs), and loss and gradients
+    equal the unsharded CosFace-soft + soft-target CE of the oracle (F10-pinned) on the global batch."""
+    from oracle import margin
+    out = str(tmp_path / "pfcs")
+    mp.spawn(_pfc_soft_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = torch.Generator().manual_seed(6)
+    C, D, B = 1000, 64, 8
+    Wfull = (torch.randn(C, D, generator=g) * 0.05).requires_grad_(True)
+    emb = torch.randn(2 * B, D, generator=g).requires_grad_(True)
+    lab = torch.randint(0, C, (2 * B,), generator=g)
+    lab2 = torch.cat([lab[:B], lab[B:].flip(0)])
+    lam_rows = torch.tensor([_PFC_SOFT_LAMS[0]] * B + [_PFC_SOFT_LAMS[1]] * B)
+    target = torch.zeros(2 * B, C)
+    target.scatter_add_(1, lab.view(-1, 1), lam_rows.view(-1, 1))
+    target.scatter_add_(1, lab2.view(-1, 1), (1 - lam_rows).view(-1, 1))
+    logits = margin.cosface_logits(emb, Wfull, target)
+    ref = margin.soft_target_cross_entropy(logits, target)
+    ref.backward()
+    worst = 0.0
+    for r in range(2):
+        got = torch.load(out + f".{r}", weights_only=False)
+        e = emb.grad[r * B:(r + 1) * B]
+        w = Wfull.grad[got["start"]:got["start"] + got["dW"].shape[0]]
+        errs = (abs(float(got["loss"]) - float(ref)) / abs(float(ref)), float((got["demb"] - e).abs().max()) / float(e.abs().max()),
+                float((got["dW"] - w).abs().max()) / float(Wfull.grad.abs().max()))
+        print(f"[pfc-soft] rank {r}: loss / dE / dW errors {errs[0]:.2e} {errs[1]:.2e} {errs[2]:.2e}")
+        worst = max(worst, *errs)
+    assert worst < 1.5e-2, worst                       # (observed 8.2e-3: bf16 operands of the logit GEMM; hard labels above: 6.1e-3, gate 1e-2)
 
 
 # ------------------------------------------------------------------------------------------------ dense fine-tune head, DP
-def _ft_model(with_land):
+def _ft_model(with_land, seed=3):
     from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8
-    torch.manual_seed(3)
+    torch.manual_seed(seed)
     return ViT_face_landmark_patch8(loss_type="CosFace", GPU_ID=None, num_class=512, image_size=112, patch_size=8, dim=128, depth=4, heads=3,
                                     mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=with_land, drop_path_rate=0.0)
 
@@ -199,41 +260,56 @@ def _ft_data(B):
     return [(torch.randint(0, 256, (B, 3, 112, 112), dtype=torch.uint8, generator=g), torch.randint(0, 512, (B,), generator=g)) for _ in range(3)]
 
 
-def _ft_worker(rank, world, port, out, with_land):
+def _ft_worker(rank, world, port, out, with_land, use_graph):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
-    model = _ft_model(with_land)
+    # rank 1 starts from ANOTHER initialisation and from perturbed BatchNorm statistics: the engine's construction-time broadcast of
+    # parameters and buffers (DDP, train_largescale.py:676-677) has to override both
+    model = _ft_model(with_land, seed=3 if rank == 0 else 77)
+    if rank == 1:
+        with torch.no_grad():
+            for b in model.buffers():
+                if b.is_floating_point():
+                    b.add_(0.25)
     if with_land:
         model.eval()                                  # BatchNorm batch statistics differ between a half batch and the full one
-    eng = FinetuneEngine(model, 8, acc_step=3, device="cuda")
-    assert eng.world == 2
+    eng = FinetuneEngine(model, 8, acc_step=3, device="cuda", use_graph=use_graph)
+    assert eng.world == 2 and eng.use_graph == use_graph
     w0 = eng.arena.master.clone()
+    bufs = torch.cat([b.detach().float().flatten().cpu() for b in model.buffers()]) if with_land else torch.zeros(1)
     for u8, y in _ft_data(16):                        # this rank's half of every micro-batch
         # batch mixup pairs row i with row B-1-i of the SAME rank's batch: lam = 1 keeps the two decompositions comparable
         loss = eng.micro_step(u8[rank * 8:(rank + 1) * 8].cuda(), y[rank * 8:(rank + 1) * 8].cuda(), lam=1.0)
     assert eng._reduced                               # the slices went out during the third backward, not at the optimizer step
+    if use_graph:                                     # two single-graph micro-steps, then the window's last one as one graph per segment
+        keys = sorted(eng._graphs)
+        assert [len(eng._graphs[k]) for k in keys if not k[2]] == [1, 1] and all(len(eng._graphs[k]) > 2 for k in keys if k[2]), keys
     eng.reducer.wait_all()
     gsum = eng.arena.grad.clone()                     # SUM over ranks of the accumulated local-mean gradients
     eng._reduced = True
     eng.optimizer_step(lr=1e-3, weight_decay=0.1)
     torch.cuda.synchronize()
-    torch.save({"grad": gsum.cpu(), "master": eng.arena.master.cpu(), "moved": float((eng.arena.master - w0).abs().max())}, out + f".{rank}")
+    torch.save({"grad": gsum.cpu(), "master": eng.arena.master.cpu(), "moved": float((eng.arena.master - w0).abs().max()), "w0": w0.cpu(),
+                "bufs": bufs}, out + f".{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("with_land", [False, True])
-def test_dense_finetune_two_ranks_equal_one_rank_on_the_full_batch(tmp_path, with_land):
-    """train_largescale.py under DDP (:676-677, 842-891): two ranks x batch 8, acc_step 3, against one process x batch 16.  The
+@pytest.mark.parametrize("with_land,use_graph", [(False, False), (False, True), (True, True)])
+def test_dense_finetune_two_ranks_equal_one_rank_on_the_full_batch(tmp_path, with_land, use_graph):
+    """train_largescale.py under DDP (:676-677, 842-891): two ranks x batch 8, acc_step 3, against one process x batch 16.  Rank 1
+    is built from another seed and perturbed BatchNorm statistics: the engine's broadcast from rank 0 must override them.  The
     gradient slices are launched as the last backward retires them (head first) and optimizer_step only waits; the summed
-    gradient over 1/world equals the full-batch gradient, the replicas end bit-identical and close to the single-process run."""
+    gradient over 1/world equals the full-batch gradient, the replicas end bit-identical and close to the single-process run --
+    eager, and captured (the window's last micro-step as one hipGraph per segment with the collectives between the replays)."""
     from lafs_cvpr2024_amd.finetune_engine import FinetuneEngine
     out = str(tmp_path / "ft")
     port = _free_port()
-    mp.spawn(_ft_worker, args=(2, port, out, with_land), nprocs=2, join=True)
+    mp.spawn(_ft_worker, args=(2, port, out, with_land, use_graph), nprocs=2, join=True)
     r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    assert torch.equal(r0["w0"], r1["w0"]) and torch.equal(r0["bufs"], r1["bufs"]), "parameters / buffers were not broadcast from rank 0"
     assert torch.equal(r0["grad"], r1["grad"]) and torch.equal(r0["master"], r1["master"]) and r0["moved"] > 1e-4
     model = _ft_model(with_land)
     if with_land:

@@ -1189,12 +1189,17 @@ def test_f18_hip_training_plan_of_the_landmark_cnn_against_the_reference():
     assert float(d.mean()) < 0.5 and float(d.max()) < 6.0, (float(d.mean()), float(d.max()))
     assert max(errs.values()) < 1.3 * max(yard_g.values()) + 0.05, (errs, yard_g)
     assert min(cos.values()) > min(yard_c.values()) - 0.08, (cos, yard_c)
+    # ... and ABSOLUTELY (round-5 review: a gate relative to a yardstick computed in the same test would pass a joint regression of
+    # plan and statement): observed on MI355X 0.31 / 0.95
+    assert max(errs.values()) < 0.35 and min(cos.values()) > 0.93, (max(errs.values()), min(cos.values()))
     # gradient norms of ALL tensors.  (A BatchNorm bias whose output only feeds a 1x1 convolution + batch-statistics BatchNorm has
     # an exactly zero gradient -- the shift is removed again by the next mean subtraction -- which the reference reproduces down to
     # fp32 round-off (1e-4) and any 16-bit evaluation only down to ITS round-off: those tensors are left out of the comparison.)
     ref = dict(zip([str(k) for k in fx["gnorm_keys"]], fx["gnorms"].tolist()))
     floor = 1e-2 * float(np.median(list(ref.values())))
-    off = {k: (float(named[k].grad.norm()), v) for k, v in ref.items() if v > floor and abs(float(named[k].grad.norm()) - v) > 0.5 * v}
+    dev_n = {k: abs(float(named[k].grad.norm()) - v) / v for k, v in ref.items() if v > floor}
+    print(f"[F18] gradient norms: worst relative deviation {max(dev_n.values()):.3f} over {len(dev_n)} tensors")
+    off = {k: (float(named[k].grad.norm()), ref[k]) for k, r_ in dev_n.items() if r_ > 0.25}          # (round 5: 0.5)
     assert not off, off
     assert sum(v > floor for v in ref.values()) >= 130
     tr.flush_batches_tracked()
