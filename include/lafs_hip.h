@@ -70,7 +70,7 @@ enum {
   LAFS_OPT_COMM_CUS = 6,       /* data-parallel runs: CUs left to the collective library's kernels by the K-resident GEMM (default 0) */
   LAFS_OPT_NT_BIG = 7,         /* tiled GEMM: one-workgroup-per-CU 192x256 / 176x256 tiles for the wide long-K shapes (default 1; 2-4 force a geometry) */
   LAFS_OPT_MLP_FUSED = 8,      /* trunk passes: the block's MLP as ONE launch (lafs_mlp_fused) where it applies (dim 384, no element dropout): bit mask
-                                  1 forward-only pass, 2 saving forward, 4 backward input gradients, 8 LayerNorm 2 inside the fused forward (default 15: step A/B in
+                                  1 forward-only pass, 2 saving forward, 4 backward input gradients, 8 LayerNorm 2 inside the fused forward, 16 its backward inside the fused backward (default 15: step A/B in
                                   DESIGN.md section 6) */
   LAFS_OPT_COUNT = 9
 };
@@ -181,8 +181,16 @@ typedef struct lafs_mlp_args {
    * and the fc1 weight gradient read) are written when not NULL. */
   const float* ln_gamma; const float* ln_beta; float ln_eps;
   float* ln_stats; void* ln_out; int ldln;
+  /* LayerNorm backward in the epilogue (LAFS_MLP_BWD with ln_gamma != NULL): out is not written; instead, with x = resid (f32
+   * [M, 384]) and its statistics ln_stats (read), dx = LN'(bf16(dX)) is added into ln_g_io (f32 [M, 384], the residual gradient
+   * stream), ln_gb_out (bf16 [M, 384]) = bf16(seq_scale[row2seq[m]] * ln_g_io) and the launch's gamma / beta sums go to
+   * ln_part_out (f32 [lafs_mlp_fused_ln_parts(M)][2][384], the slot layout of lafs_layernorm_bwd: fold with
+   * lafs_layernorm_bwd_fold) -- what lafs_layernorm_bwd(accumulate = 1) computes from the stored dX, without the launch. */
+  float* ln_g_io; int ldgio; void* ln_gb_out; int ldgb; float* ln_part_out;
 } lafs_mlp_args;
 int lafs_mlp_fused(const lafs_mlp_args* args, hipStream_t stream);
+/* Slots a LAFS_MLP_BWD launch with the LayerNorm epilogue writes for M rows (one per 128-row workgroup). */
+int lafs_mlp_fused_ln_parts(int rows);
 /* 1 when lafs_mlp_fused takes this geometry (dim == 384, hidden % 64 == 0 in [128, 1536]), else 0. */
 int lafs_mlp_fused_supported(int dim, int hidden, int rows);
 

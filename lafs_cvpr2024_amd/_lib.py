@@ -33,7 +33,8 @@ class MlpArgs(C.Structure):
                 ("out", C.c_void_p), ("ldo", C.c_int), ("save_grad", C.c_void_p), ("ldsg", C.c_int),
                 ("save_act", C.c_void_p), ("ldsa", C.c_int), ("ctx", C.c_void_p),
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
-                ("ln_stats", C.c_void_p), ("ln_out", C.c_void_p), ("ldln", C.c_int)]
+                ("ln_stats", C.c_void_p), ("ln_out", C.c_void_p), ("ldln", C.c_int),
+                ("ln_g_io", C.c_void_p), ("ldgio", C.c_int), ("ln_gb_out", C.c_void_p), ("ldgb", C.c_int), ("ln_part_out", C.c_void_p)]
 
 
 class WgradItem(C.Structure):
@@ -179,6 +180,7 @@ _NO_STREAM = {
     "lafs_gemm_nt_slices": ([i32, i32], i32),
     "lafs_gemm_nt_route": ([C.POINTER(GemmNTArgs)], i32),
     "lafs_mlp_fused_supported": ([i32, i32, i32], i32),
+    "lafs_mlp_fused_ln_parts": ([i32], i32),
     "lafs_ctx_create": ([i32], vp),
     "lafs_ctx_destroy": ([vp], None),
     "lafs_ctx_set": ([vp, i32, i32], i32),

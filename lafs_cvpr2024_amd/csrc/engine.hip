@@ -79,7 +79,7 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
     }
     c.s.dh = (bf16_t*)take(T * D * 2);
     c.s.d_o = (bf16_t*)take(T * I * 2);
-    c.ln_part_floats = (size_t)lafs_layernorm_bwd_parts(d->n_tok, d->dim) * 2 * D;
+    c.ln_part_floats = (size_t)std::max(lafs_layernorm_bwd_parts(d->n_tok, d->dim), lafs_mlp_fused_ln_parts(d->n_tok)) * 2 * D;
     c.ln_part.resize((size_t)d->depth * 2 * 4);
     for (auto& q : c.ln_part) q = (float*)take(c.ln_part_floats * 4);
     lafs_wgrad_item it[4];
@@ -392,17 +392,26 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
     const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
     const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
     // ---- MLP branch ----
+    // (LayerNorm 2's backward inside the same launch: its gamma / beta slots are numbered by workgroup, one launch of <= capacity units)
+    const bool ln_inside = mlp_fused_on(d, 4, R) && mlp_fused_on(d, 16, R) &&
+                           (size_t)lafs_mlp_fused_ln_parts(R) * 2 * D <= c.ln_part_floats;
     if (mlp_fused_on(d, 4, R)) {                               // GELU' input gradient -> fc1 input gradient in one launch (du written once)
       lafs_mlp_args m = {};
       m.X = s.gbm[p] + rD; m.ldx = D; m.Wa = sht + o.w_fc2_t; m.ldwa = D; m.Wb = sht + o.w_fc1_t; m.ldwb = M; m.M = R; m.H = M;
       m.mode = LAFS_MLP_BWD; m.out = s.dh + rD; m.ldo = D; m.save_grad = b.u + rM; m.ldsg = M; m.save_act = s.du[p] + rM; m.ldsa = M;
       m.ctx = cx;
+      if (ln_inside) {
+        m.resid = b.x1 + rD; m.ldr = D; m.ln_stats = b.st2 + 2 * (size_t)r0; m.ln_gamma = d->master + o.ln2_g;
+        m.ln_g_io = g + rD; m.ldgio = D; m.ln_gb_out = s.gba[p] + rD; m.ldgb = D; m.seq_scale = scale(l, 0); m.row2seq = r2s;
+        m.ln_part_out = c.ln_part[((size_t)l * 2 + 1) * 4 + ci];
+      }
       RUN(lafs_mlp_fused(&m, st));
     } else {
     RUN(gemm(cx, s.gbm[p] + rD, D, sht + o.w_fc2_t, D, R, M, D, LAFS_EPI_DGELU_BF16, s.du[p] + rM, M, nullptr, st, nullptr, 0, nullptr, 0, nullptr,
              nullptr, b.u + rM, M, dp, dseed(l, 1), LAFS_GELU_SAVE_GRAD, d->dropout_step, r0));
     RUN(gemm(cx, s.du[p] + rM, M, sht + o.w_fc1_t, M, R, D, M, LAFS_EPI_BF16, s.dh + rD, D, nullptr, st));
     }
+    if (!ln_inside)
     RUN(lafs_layernorm_bwd(s.dh + rD, D, nullptr, 0, b.x1 + rD, D, b.st2 + 2 * (size_t)r0, d->master + o.ln2_g, g + rD, D, 1, s.gba[p] + rD, D,
                            scale(l, 0), r2s, gr + o.ln2_g, gr + o.ln2_b, R, D, dp, dseed(l, 0), d->dropout_step, r0,
                            c.ln_part[((size_t)l * 2 + 1) * 4 + ci], st));
@@ -491,7 +500,9 @@ extern "C" int lafs_trunk_backward(const lafs_trunk_desc* d, const float* x_in, 
         lafs_ln_fold_item it = {};
         for (int i = 0; i < n_rr; ++i) {
           it.part[i] = c.ln_part[((size_t)l * 2 + k) * 4 + i];
-          it.n_parts[i] = lafs_layernorm_bwd_parts(rr[i].R, D);
+          const bool fused = k == 1 && mlp_fused_on(d, 4, rr[i].R) && mlp_fused_on(d, 16, rr[i].R) &&
+                             (size_t)lafs_mlp_fused_ln_parts(rr[i].R) * 2 * D <= c.ln_part_floats;      // (the same test as part1's)
+          it.n_parts[i] = fused ? lafs_mlp_fused_ln_parts(rr[i].R) : lafs_layernorm_bwd_parts(rr[i].R, D);
         }
         it.dgamma = gr + (k == 0 ? o.ln1_g : o.ln2_g); it.dbeta = gr + (k == 0 ? o.ln1_b : o.ln2_b);
         items.push_back(it);

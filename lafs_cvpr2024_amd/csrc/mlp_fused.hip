@@ -72,6 +72,10 @@ struct MArgs {
   void* out; int ldo;
   bf16_t* g; int ldg;                        // gelu'(u): written by the saving forward, read by the backward
   bf16_t* a; int lda;                        // saving forward: gelu(u) written;  backward: du written
+  // LNB (backward): LayerNorm-2 backward in the final epilogue -- x (resid), its statistics (ln_stats), gamma (ln_g); the residual
+  // gradient stream g_io (read-modify-write), its DropPath-scaled bf16 copy gb (the projection input gradient's operand), and this
+  // workgroup's gamma / beta sums part[blockIdx][2][384]
+  float* g_io; int ldgio; bf16_t* gb; int ldgb; float* part;
   const float* ln_g; const float* ln_b; float ln_eps;   // LNP: X = LayerNorm(resid) computed in the prologue
   float* ln_stats; bf16_t* ln_out; int ldln;            //      (mean, rstd) per row and the bf16 operand as by-products (optional)
   int unit_waves;                            // waves of a workgroup that own rows (8: 128-row units; 4: 64-row units, one computing wave per SIMD)
@@ -90,7 +94,19 @@ __device__ __forceinline__ void st16f(void* p, float a, float b, float c, float 
   *reinterpret_cast<f32x4v_t*>(p) = v;
 }
 
+// sum over the 16 lanes of a DPP row (every lane ends with it): rotations by 1, 2, 4, 8 inside the row (row_ror)
+template <int CTRL> __device__ __forceinline__ float dpp_rot(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_rot<0x121>(v); v += dpp_rot<0x122>(v); v += dpp_rot<0x124>(v); v += dpp_rot<0x128>(v);
+  return v;
+}
+
 // MODE: LAFS_MLP_FWD (0) forward-only, LAFS_MLP_FWD_SAVE (1) forward saving gelu'(u) and gelu(u), LAFS_MLP_BWD (2) input gradients
+// LNP, backward mode: the LayerNorm backward of norm2 runs in the final epilogue on the finished rows (dX rounded to bf16 as the
+// separate path stores it, then dx = LN'(dX), g += dx, gb = bf16(scale g), per-workgroup gamma / beta sums) -- no dX round trip
+// through HBM and no lafs_layernorm_bwd launch.
 // LNP (forward modes): the GEMM-1 operand is LayerNorm(resid) (vision_transformer.py:112 norm2), computed by each wave for its own 16
 // rows with the row arithmetic of ln_fwd2_kernel (layernorm.hip: 32 lanes per row, float4 pieces at columns 4 l + 128 i, the same
 // summation order -> the same bits), written into the ring buffers as the stage-A image the fragments are read from.
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   constexpr int NL = (MODE == LAFS_MLP_BWD) ? 2 : 0;                                     // its operand loads (every wave)
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
   __shared__ __attribute__((aligned(16))) float sba[FWD ? MAXH : 4];
-  __shared__ __attribute__((aligned(16))) float sbb[FWD ? D : 4];
+  __shared__ __attribute__((aligned(16))) float sbb[(FWD || LNP) ? D : 4];        // forward: fc2 bias; backward + LNP: gamma
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15, q = lane >> 4;
@@ -118,6 +134,9 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     for (int i = tid; i < p.H; i += NTH) sba[i] = p.bias_a ? p.bias_a[i] : 0.f;
     for (int i = tid; i < D; i += NTH) sbb[i] = p.bias_b ? p.bias_b[i] : 0.f;
     __syncthreads();                                   // (also keeps these loads out of the counted waits below)
+  } else if constexpr (LNP) {
+    for (int i = tid; i < D; i += NTH) sbb[i] = p.ln_g[i];
+    __syncthreads();
   }
 
   // ---- LDS images.  Stage A (64 rows of 48 chunks): logical chunk c of row rho at position c ^ (rho & 15); MFMA row s of 16-row
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   }
 
   // ---- prologue: the unit's 128 token rows through ring buffers 0 and 1 while stage 0 flies into buffer 2
-  if constexpr (!LNP) {
+  if constexpr (!(LNP && FWD)) {
     issue_rows(0, 0);
     issue_rows(1, 1);
     issue_a(0, 2);
@@ -425,6 +444,93 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
 
   // ---- final epilogue of the unit: lane (t, q) owns row `row` and, per output block ob, 4 consecutive fp32 columns (forward)
   // or, per block pair, 8 consecutive bf16 columns (backward)
+  if constexpr (!FWD && LNP) {
+    // ------ LayerNorm backward on the wave's 16 finished rows.  Lane (t, q): row t, columns 32 P + 8 q + e (P < 12, e < 8).
+    float xh[NOB][4];                                   // x-hat, same register <-> column map as acc2
+    float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 0.f, scl = 1.0f;
+    if (active) {
+      const float2 ms = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)rowc);
+      mean = ms.x; rstd = ms.y;
+      if (p.seq_scale != nullptr) scl = p.seq_scale[p.row2seq[rowc]];
+      const float* xr = p.resid + (size_t)rowc * p.ldr;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {                // all 24 pieces of the row in flight before the first use
+        const float4 v = *reinterpret_cast<const float4*>(xr + 32 * (ob >> 1) + 8 * q + 4 * (ob & 1));
+        xh[ob][0] = v.x; xh[ob][1] = v.y; xh[ob][2] = v.z; xh[ob][3] = v.w;
+      }
+    }
+    float* red = reinterpret_cast<float*>(smem + 2 * STAGE);      // [wave][gamma 384 | beta 384]: ring buffer 2 holds stage 45, read by all
+    if (active) {
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        const f32x4_t gm = *reinterpret_cast<const f32x4_t*>(sbb + 32 * (ob >> 1) + 8 * q + 4 * (ob & 1));
+        float cg[4], cb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // dX as the separate path hands it over: rounded to bf16; rows past M contribute nothing
+          const float dy = rowok ? bf2f(f2bf(acc2[ob][r])) : 0.f;
+          const float xv = (xh[ob][r] - mean) * rstd;
+          xh[ob][r] = xv;
+          cg[r] = dy * xv; cb[r] = dy;
+          const float d = dy * gm[r];
+          acc2[ob][r] = d;
+          s1 += d; s2 += d * xv;
+        }
+        // column sums over the wave's 16 rows: rotations inside the 16-lane row (DPP row_ror 1, 2, 4, 8)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cg[r] = row16_sum(cg[r]);
+          cb[r] = row16_sum(cb[r]);
+        }
+        if (t == 0) {
+          const int c = 32 * (ob >> 1) + 8 * q + 4 * (ob & 1);
+          st16f(red + wave * (2 * D) + c, cg[0], cg[1], cg[2], cg[3]);
+          st16f(red + wave * (2 * D) + D + c, cb[0], cb[1], cb[2], cb[3]);
+        }
+      }
+      // row sums over the four quarter lanes of the row
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      const float m1 = s1 / (float)D, m2 = s2 / (float)D;
+      if (rowok) {
+        float* gr = p.g_io + (size_t)row * p.ldgio;
+        bf16_t* gbr = p.gb + (size_t)row * p.ldgb;
+#pragma unroll
+        for (int P0 = 0; P0 < NOB / 2; P0 += 3) {
+          float4 old[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) old[j] = *reinterpret_cast<const float4*>(gr + 32 * (P0 + (j >> 1)) + 8 * q + 4 * (j & 1));
+#pragma unroll
+          for (int jp = 0; jp < 3; ++jp) {
+            float o[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int ob = 2 * (P0 + jp) + h;
+              const float4 og = old[2 * jp + h];
+              o[4 * h + 0] = rstd * (acc2[ob][0] - m1 - xh[ob][0] * m2) + og.x;
+              o[4 * h + 1] = rstd * (acc2[ob][1] - m1 - xh[ob][1] * m2) + og.y;
+              o[4 * h + 2] = rstd * (acc2[ob][2] - m1 - xh[ob][2] * m2) + og.z;
+              o[4 * h + 3] = rstd * (acc2[ob][3] - m1 - xh[ob][3] * m2) + og.w;
+              st16f(gr + 32 * (P0 + jp) + 8 * q + 4 * h, o[4 * h], o[4 * h + 1], o[4 * h + 2], o[4 * h + 3]);
+            }
+            st16(gbr + 32 * (P0 + jp) + 8 * q, pack_bf2(scl * o[0], scl * o[1]), pack_bf2(scl * o[2], scl * o[3]),
+                 pack_bf2(scl * o[4], scl * o[5]), pack_bf2(scl * o[6], scl * o[7]));
+          }
+        }
+      }
+    }
+    __syncthreads();                                    // every computing wave's column sums are in the LDS
+    {
+      const int n_act = min(p.unit_waves, (p.M - u0 + 15) / 16);      // waves that own rows (>= 1)
+      for (int c = tid; c < 2 * D; c += NTH) {
+        float sg = 0.f;
+        for (int w = 0; w < n_act; ++w) sg += red[w * (2 * D) + c];
+        p.part[(size_t)blockIdx.x * (2 * D) + c] = sg;               // slot layout of lafs_layernorm_bwd: [workgroup][gamma | beta][D]
+      }
+    }
+    stamp_out();
+    return;
+  }
   if (!rowok) { stamp_out(); return; }
   if constexpr (FWD) {
     const float* rs = p.resid + (size_t)row * p.ldr;
@@ -500,11 +606,18 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
   LAFS_CHECK_ARG(g->mode == LAFS_MLP_FWD || g->mode == LAFS_MLP_FWD_SAVE || g->mode == LAFS_MLP_BWD, "bad mode");
   LAFS_CHECK_ARG(lafs_mlp_fused_supported(D, g->H, g->M), "hidden width must be a multiple of 64 in [128, 1536], M > 0 (the embedding width is 384)");
   const bool has_ln = g->mode != LAFS_MLP_BWD && g->ln_gamma != nullptr;
-  LAFS_CHECK_ARG((has_ln || g->X) && g->Wa && g->Wb && g->out, "null operand");
+  if (g->mode == LAFS_MLP_BWD && g->ln_gamma != nullptr) {
+    LAFS_CHECK_ARG(g->resid != nullptr && g->ldr >= D && g->ldr % 4 == 0 && g->ln_stats != nullptr, "LayerNorm backward: x and its statistics");
+    LAFS_CHECK_ARG(g->ln_g_io != nullptr && g->ldgio >= D && g->ldgio % 4 == 0 && g->ln_gb_out != nullptr && g->ldgb >= D && g->ldgb % 8 == 0 &&
+                   g->ln_part_out != nullptr, "LayerNorm backward: gradient stream, its bf16 copy and the gamma / beta slots");
+    LAFS_CHECK_ARG(g->seq_scale == nullptr || g->row2seq != nullptr, "seq_scale needs row2seq");
+  }
+  LAFS_CHECK_ARG((has_ln || g->X) && g->Wa && g->Wb, "null operand");
   LAFS_CHECK_ARG(!has_ln || (g->ln_beta != nullptr && (g->ln_out == nullptr || (g->ldln >= D && g->ldln % 4 == 0))), "LayerNorm prologue: beta / output stride");
   LAFS_CHECK_ARG(has_ln || (g->ldx >= D && g->ldx % 8 == 0), "operand strides: multiples of 8 elements");
   LAFS_CHECK_ARG(g->ldwa >= D && g->ldwa % 8 == 0 && g->ldwb >= g->H && g->ldwb % 8 == 0, "operand strides: multiples of 8 elements");
-  LAFS_CHECK_ARG(g->ldo >= D && g->ldo % 8 == 0, "output stride: a multiple of 8 elements");
+  LAFS_CHECK_ARG((g->mode == LAFS_MLP_BWD && g->ln_gamma != nullptr) || (g->out != nullptr && g->ldo >= D && g->ldo % 8 == 0),
+                 "output stride: a multiple of 8 elements");
   const bool fwd = g->mode != LAFS_MLP_BWD;
   if (fwd) {
     LAFS_CHECK_ARG(g->resid != nullptr && g->ldr >= D && g->ldr % 4 == 0, "the forward needs the fp32 residual");
@@ -527,6 +640,13 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
   switch (g->mode) {
     case LAFS_MLP_FWD: return lnp ? launch<LAFS_MLP_FWD, true>(a, n_cu, stream) : launch<LAFS_MLP_FWD, false>(a, n_cu, stream);
     case LAFS_MLP_FWD_SAVE: return lnp ? launch<LAFS_MLP_FWD_SAVE, true>(a, n_cu, stream) : launch<LAFS_MLP_FWD_SAVE, false>(a, n_cu, stream);
-    default: return launch<LAFS_MLP_BWD, false>(a, n_cu, stream);
+    default:
+      if (g->ln_gamma != nullptr) {                      // LayerNorm backward in the epilogue: the slots are numbered by workgroup of ONE launch
+        a.g_io = g->ln_g_io; a.ldgio = g->ldgio; a.gb = (bf16_t*)g->ln_gb_out; a.ldgb = g->ldgb; a.part = g->ln_part_out;
+        return launch<LAFS_MLP_BWD, true>(a, 0, stream);
+      }
+      return launch<LAFS_MLP_BWD, false>(a, n_cu, stream);
   }
 }
+
+extern "C" int lafs_mlp_fused_ln_parts(int rows) { return rows > 0 ? (rows + UROWS - 1) / UROWS : 0; }

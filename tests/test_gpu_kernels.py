@@ -794,3 +794,47 @@ def test_fused_mlp_layernorm_prologue_equals_the_layernorm_launch_bit_for_bit(M)
     assert torch.equal(y2, yr) and torch.equal(g2, gr) and torch.equal(a2, ar)
     ref = F.layer_norm(x.float().cpu(), (D,), gam.cpu(), bet.cpu(), 1e-6)
     assert relerr(h.float(), ref) < 8e-3
+
+
+@pytest.mark.parametrize("M", [128 * 35, 128 * 33 + 50])
+def test_fused_mlp_backward_with_the_layernorm_backward_in_its_epilogue(M):
+    """LAFS_MLP_BWD with the LayerNorm-2 backward in the epilogue (vision_transformer.py:112 backward) against the separate path --
+    lafs_mlp_fused(BWD) storing dX, then lafs_layernorm_bwd(accumulate) with its partial slots, then the fold: the residual gradient
+    stream, its DropPath-scaled bf16 copy and dgamma / dbeta agree to fp32 summation order (the epilogue rounds dX to bf16 exactly
+    as the stored tensor is); du is bit-identical; rows past M untouched."""
+    D, H = 384, 1536
+    g = torch.Generator().manual_seed(91)
+    x = (torch.randn(M, D, generator=g) * 1.3 + 0.2).to(DEV)
+    gam = (1.0 + 0.2 * torch.randn(D, generator=g)).to(DEV); bet = torch.zeros(D, device=DEV)
+    h = torch.empty(M, D, device=DEV, dtype=bf16); st = torch.empty(M, 2, device=DEV)
+    call("lafs_layernorm_fwd", _p(x), D, _p(gam), _p(bet), 1e-6, _p(h), D, None, 0, _p(st), M, D)
+    W1t, W2t = rnd_bf(D, H, scale=0.05, seed=93).to(DEV), rnd_bf(H, D, scale=0.03, seed=94).to(DEV)     # fc1.weight^T [D, H], fc2.weight^T [H, D]
+    dY = rnd_bf(M, D, seed=95).to(DEV)
+    gs = (torch.rand(M, H, generator=g) * 1.1).to(bf16).to(DEV)
+    nseq = 7
+    row2seq = (torch.arange(M) * nseq // M).int().to(DEV)
+    sc = torch.tensor([0.0 if i % 3 == 1 else 1.0 / 0.9 for i in range(nseq)]).to(DEV)
+    g0 = torch.randn(M, D, generator=g).to(DEV)
+    # ---- separate path
+    dx, _, du_ref = ops.mlp_fused(dY, W2t, W1t, _lib.MLP_BWD, save_grad=gs)
+    g_ref = g0.clone(); gb_ref = torch.empty(M, D, device=DEV, dtype=bf16)
+    nparts = int(_lib.lib().lafs_layernorm_bwd_parts(M, D))
+    part = torch.zeros(nparts, 2, D, device=DEV)
+    call("lafs_layernorm_bwd", _p(dx), D, None, 0, _p(x), D, _p(st), _p(gam), _p(g_ref), D, 1, _p(gb_ref), D, _p(sc), _p(row2seq),
+         None, None, M, D, 0.0, 0, None, 0, _p(part))
+    dgam_ref, dbet_ref = part[:, 0].double().sum(0), part[:, 1].double().sum(0)
+    # ---- one launch
+    guard = 9.0
+    gio = torch.full((M + 40, D), guard, device=DEV); gio[:M] = g0
+    gb = torch.full((M + 40, D), guard, device=DEV, dtype=bf16)
+    units = int(_lib.lib().lafs_mlp_fused_ln_parts(M))
+    part2 = torch.full((units + 2, 2, D), guard, device=DEV)
+    _, _, du = ops.mlp_fused(dY, W2t, W1t, _lib.MLP_BWD, save_grad=gs, ln_bwd=(x, st, gam, gio[:M], gb[:M], part2), seq_scale=sc, row2seq=row2seq)
+    assert torch.equal(du, du_ref)
+    assert float((gio[M:] - guard).abs().max()) == 0.0 and float((gb[M:].float() - guard).abs().max()) == 0.0 and float((part2[units:] - guard).abs().max()) == 0.0
+    e_g = relerr(gio[:M] - g0, g_ref - g0)
+    e_gb = relerr(gb[:M].float(), gb_ref.float())
+    dgam, dbet = part2[:units, 0].double().sum(0), part2[:units, 1].double().sum(0)
+    e_p = max(relerr(dgam, dgam_ref), relerr(dbet, dbet_ref))
+    print(f"[mlp-bwd + LN] dx {e_g:.2e}, bf16 copy {e_gb:.2e}, gamma / beta sums {e_p:.2e}")
+    assert e_g < 2e-5 and e_gb < 8e-3 and e_p < 2e-5
