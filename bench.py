@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--out-dim", type=int, default=100000)
     ap.add_argument("--local-crops", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--depth", type=int, default=0, help="override the trunk depth (tests of the multi-rank launch structure at toy size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="run only the roofline kernels' loops (for rocprofv3)")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline kernels' loops (profiles of the step alone)")
@@ -342,7 +343,8 @@ def roofline_partfvit_dgrad(device, M, iters=100):
     route = ops.gemm_nt(A, W, _lib.EPI_BF16, out=out, route_only=True)
     kern = {5: "gemm_big_kernel<BF16> 192x256 tiles, one persistent workgroup per CU", 4: "gemm_nt_kernel<BF16,2,64,MB=5> 160x128 tiles",
             3: "gemm_nt_kernel<BF16,2,64,6> 128x384 tiles"}.get(route, "gemm_nt_kernel<BF16,2,64> 128x128 tiles")
-    return _roof(f"{kern} M={M} N=768 K=2048 (Part-fViT fc1 input gradient)", dur, 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0)
+    return _roof(f"{kern} M={M} N=768 K=2048 (Part-fViT fc1 input gradient)", dur, 2.0 * M * N * K, (M * K + N * K + M * N) * 2.0,
+                 _pmc_traffic(f"partfvit_dgrad_{M}"))
 
 
 EXTRA_ROOFLINE = True            # --no-roofline: the extras' kernel tables under rocprofv3 must not contain the roofline loops
@@ -517,7 +519,10 @@ def main():
     from lafs_cvpr2024_amd.utils import MultiCropWrapper, cosine_scheduler
 
     if args.roofline_only:
-        print(json.dumps({"roofline": dominant_kernel_roofline(device, iters=200)}))
+        # (the extras' dominant kernel at both workloads' row counts rides along, so that the PMC passes of tools/collect_profiles_round.sh
+        # cover it: extras.*.roofline.traffic)
+        print(json.dumps({"roofline": dominant_kernel_roofline(device, iters=200),
+                          "extras_roofline": {str(M): roofline_partfvit_dgrad(device, M) for M in (44160, 25216)}}))
         return
     if args.no_roofline:
         global EXTRA_ROOFLINE
@@ -533,9 +538,15 @@ def main():
     dims = {"vit_small": (384, 12, 6), "vit_tiny": (192, 12, 3), "vit_base": (768, 12, 12)}[args.arch]
     torch.manual_seed(0)
     B, K, nl = args.batch, args.out_dim, args.local_crops
-    student = MultiCropWrapper(vits.__dict__[args.arch](patch_size=8, drop_path_rate=0.1),
-                               vits.DINOHead(dims[0], K, use_bn=False, norm_last_layer=True))
-    teacher = MultiCropWrapper(vits.__dict__[args.arch](patch_size=8), vits.DINOHead(dims[0], K, use_bn=False))
+    if args.depth > 0:                               # (tests only: the named architecture cut to --depth blocks)
+        from functools import partial
+        dims = (dims[0], args.depth, dims[2])
+        mk = lambda dpr: vits.VisionTransformer(patch_size=8, embed_dim=dims[0], depth=dims[1], num_heads=dims[2], mlp_ratio=4, qkv_bias=True,
+                                                norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), drop_path_rate=dpr)
+    else:
+        mk = lambda dpr: vits.__dict__[args.arch](patch_size=8, drop_path_rate=dpr)
+    student = MultiCropWrapper(mk(0.1), vits.DINOHead(dims[0], K, use_bn=False, norm_last_layer=True))
+    teacher = MultiCropWrapper(mk(0.0), vits.DINOHead(dims[0], K, use_bn=False))
     teacher.load_state_dict(student.state_dict())
     crit = DINOLoss(K, 2 + nl, 0.07, 0.04, 30, 41)
     eng = LafsPretrainEngine(student, teacher, crit, B, n_local=nl, clip_grad=3.0, freeze_last_layer=1,
@@ -607,7 +618,7 @@ def main():
             "unit": "face-crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.arch}/8 LAFS pretrain step, 2 global 112x112 + {nl} local 48x48 crops, "
+            "config": {"workload": f"{args.arch}/8{' (depth %d)' % args.depth if args.depth > 0 else ''} LAFS pretrain step, 2 global 112x112 + {nl} local 48x48 crops, "
                                    f"batch {B}/GPU, out_dim {K}, drop_path 0.1, dp{world}",
                        "global_batch": B * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                        "landmark_frontend_in_step": bool(args.frontend), "device_augmentation_in_step": bool(args.augment)},

@@ -252,19 +252,34 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
   const int n_rr = row_ranges(d, stream, rr);
   // rows [r0, r0 + R) = the sequences of groups [g_lo, g_hi) (seq_lo = index of their first sequence) on stream st
   // (nseq >= 0: ONE attention launch over nseq sequences of group g_lo -- a row range of a split pass)
-  auto chain = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams) -> int {
+  // residual stream of every layer: input / output buffer (the same for every row range)
+  std::vector<const float*> lay_in(d->depth);
+  std::vector<float*> lay_out(d->depth);
+  {
     const float* cur = x_in;
     for (int l = 0; l < d->depth; ++l) {
+      float* nxt;
+      if (l == d->depth - 1) nxt = x_out;
+      else if (save_for_backward) nxt = c.layers[l + 1].x0;
+      else nxt = (cur == c.xalt) ? x_out : c.xalt;            // ping-pong; never aliases x_in
+      lay_in[l] = cur; lay_out[l] = nxt; cur = nxt;
+    }
+  }
+  // layers [l_lo, l_hi); parts: 1 = the attention branch (LayerNorm 1 .. projection + residual), 2 = the MLP branch
+  auto chain = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams, int l_lo, int l_hi,
+                   int parts) -> int {
+    for (int l = l_lo; l < l_hi; ++l) {
       const lafs_block_offsets& o = d->blocks[l];
       const LayerBuf& b = c.layers[save_for_backward ? l : 0];
       const float* sa = d->drop_scales ? d->drop_scales + ((size_t)l * 2 + 0) * d->n_seq : nullptr;
       const float* sm = d->drop_scales ? d->drop_scales + ((size_t)l * 2 + 1) * d->n_seq : nullptr;
       const int32_t* r2s = d->row2seq ? d->row2seq + r0 : nullptr;
-      float* nxt;
-      if (l == d->depth - 1) nxt = x_out;
-      else if (save_for_backward) nxt = c.layers[l + 1].x0;
-      else nxt = (cur == c.xalt) ? x_out : c.xalt;            // ping-pong; never aliases x_in
+      const float* cur = lay_in[l];
+      float* nxt = lay_out[l];
       const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
+      const float dp = d->dropout_p;
+      const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
+      if (parts & 1) {
       RUN(lafs_layernorm_fwd(cur + rD, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1 + rD, D, nullptr, 0, b.st1 + 2 * (size_t)r0,
                              R, D, st));
       RUN(gemm(cx, b.h1 + rD, D, sh + o.w_qkv, D, R, 3 * I, D, LAFS_EPI_BF16, b.qkv + 3 * rI, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, st));
@@ -286,10 +301,10 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       } else {
         RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, st));
       }
-      const float dp = d->dropout_p;
-      const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
       RUN(gemm(cx, b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
                r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0));
+      }
+      if (!(parts & 2)) continue;
       const bool mlp_one = mlp_fused_on(d, save_for_backward ? 2 : 1, R);
       const bool ln_inside = mlp_one && mlp_fused_on(d, 8, R);          // LayerNorm 2 as the fused kernel's prologue (no launch, no h2 round trip)
       if (!ln_inside)
@@ -317,15 +332,23 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       RUN(gemm(cx, b.a + rM, M, sh + o.w_fc2, M, R, D, M, LAFS_EPI_RESID_F32, nxt + rD, D, d->master + o.b_fc2, st, nullptr, 0, b.x1 + rD, D, sm,
                r2s, nullptr, 0, dp, ds + 2, 0, d->dropout_step, r0));
       }
-      cur = nxt;
     }
     return LAFS_OK;
   };
-  if (n_rr > 1) {                                           // the side streams join behind everything `stream` has enqueued so far
+  // LAFS_OPT_MLP_FUSED bit 32 (lab): the row chains meet in front of every MLP, which then runs as ONE launch over all rows -- whole
+  // rounds of the chip plus a round of 64-row units instead of a round per chain (csrc/mlp_fused.hip)
+  const bool merge_mlp = n_rr > 1 && (lafs_ctx_opt(d->ctx, LAFS_OPT_MLP_FUSED) & 32) != 0 && mlp_fused_on(d, save_for_backward ? 2 : 1, T);
+  if (merge_mlp) {
+    for (int l = 0; l < d->depth; ++l) {
+      FORKED(stream, n_rr, for (int i = 0; i < n_rr; ++i)
+        TRY_F(chain(rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false, l, l + 1, 1)););
+      RUN(chain(0, T, 0, d->n_groups, 0, -1, stream, false, l, l + 1, 2));
+    }
+  } else if (n_rr > 1) {                                    // the side streams join behind everything `stream` has enqueued so far
     FORKED(stream, n_rr, for (int i = 0; i < n_rr; ++i)
-      TRY_F(chain(rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false)););
+      TRY_F(chain(rr[i].r0, rr[i].R, rr[i].gi, rr[i].gi + 1, rr[i].seq_lo, rr[i].nseq, rr[i].st, false, 0, d->depth, 3)););
   } else {
-    RUN(chain(0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1));
+    RUN(chain(0, T, 0, d->n_groups, 0, -1, stream, d->n_groups > 1, 0, d->depth, 3));
   }
   return LAFS_OK;
 }

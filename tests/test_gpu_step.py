@@ -292,8 +292,9 @@ def test_bench_eight_rank_launch_is_ready_for_an_eight_gpu_node():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    small = ["--steps", "2", "--warmup", "1", "--batch", "2", "--arch", "vit_tiny", "--out-dim", "1024", "--local-crops", "2", "--no-cpu-baseline",
-             "--no-roofline"]
+    # (eight processes time-slicing one GPU pay a context switch per kernel: the trunk is cut to 2 blocks -- 250 s at depth 12)
+    small = ["--steps", "2", "--warmup", "1", "--batch", "2", "--arch", "vit_tiny", "--depth", "2", "--out-dim", "1024", "--local-crops", "2",
+             "--no-cpu-baseline", "--no-roofline"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LAFS_DEBUG_FLAGS")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"] + small, env=dict(env, LAFS_BENCH_SHARE_GPU="1"),
                        capture_output=True, text=True, timeout=900)

@@ -47,6 +47,25 @@ def kernel_entry(title, parts, alg_bytes, flops):
                         "wave_active_frac": sq["SQ_ACTIVE_INST_ANY"] / wc, "lds_bank_conflict_cycles": sq["SQ_LDS_BANK_CONFLICT"]}}
 
 
+def big_entry(M, geo):
+    """The Part-fViT fc1 input gradient (M x 768 x 2048) on the persistent-tile kernel: the gemm_big_kernel dispatches whose name carries
+    this geometry (two row counts run in one profile: they differ by their Geo<...>)."""
+    def per_launch(path, counter):
+        tot, n = 0.0, 0
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter and "gemm_big_kernel" in r["Kernel_Name"] and geo in r["Kernel_Name"].replace(" ", ""):
+                tot += float(r["Counter_Value"]); n += 1
+        return (tot / n if n else None), n
+    f, n = per_launch(os.path.join(SRC, "pmc_fetch", "f_counter_collection.csv"), "FETCH_SIZE")
+    w, _ = per_launch(os.path.join(SRC, "pmc_write", "w_counter_collection.csv"), "WRITE_SIZE")
+    if f is None or w is None:
+        return None
+    rd, wr = f * 1024 * 2, w * 1024
+    return {"kernel": f"gemm_big_kernel<BF16, {geo}>  M={M} N=768 K=2048 (Part-fViT fc1 input gradient)", "launches_averaged": n,
+            "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+            "algorithmic_bytes_per_launch": (M * 2048 + 768 * 2048 + M * 768) * 2.0, "flops_per_launch": 2.0 * M * 768 * 2048}
+
+
 def main():
     os.makedirs(DST, exist_ok=True)
     shutil.copy(os.path.join(SRC, "step", "step_kernel_stats.csv"), os.path.join(DST, f"{R}_step_kernel_stats.csv"))
@@ -73,6 +92,13 @@ def main():
                                   25216 * 384 * 4.0 * 2 + 2 * 1536 * 384 * 2.0 + 2 * 25216 * 1536 * 2.0 + 25216 * 384 * 2.0 + 25216 * 8.0,
                                   4.0 * 25216 * 384 * 1536),
     }
+    for M, geo in ((44160, "Geo<11,4,1,4>"), (25216, "Geo<5,8,2,2>")):       # the extras' roofline kernel (bench.py roofline_partfvit_dgrad)
+        try:
+            e = big_entry(M, geo)
+            if e is not None:
+                out[f"partfvit_dgrad_{M}"] = e
+        except Exception as ex:
+            print("big_entry", M, ex)
     json.dump(out, open(os.path.join(DST, f"{R}_kernel_pmc.json"), "w"), indent=1)
     for name, sub in (("serial", "serial"), ("landmark_cnn", "cnn")):
         hits = glob.glob(os.path.join(ROOT, "gpurun_out", sub, "**", "*kernel_stats.csv"), recursive=True)
