@@ -143,6 +143,7 @@ class _PartFViTFunction(torch.autograd.Function):
                                      drop, save=save, dropout=model._next_dropout())
         ctx.model, ctx.st = model, (st if save else None)
         ctx.x_dim = x.dim()
+        model._last_tokens = _.view(n_img, n + 1, -1)[:, 1:] if getattr(model, "_want_tokens", False) else None
         return feat
 
     @staticmethod
@@ -172,8 +173,6 @@ class ViT_face_landmark_patch8(nn.Module):
         super().__init__()
         if patch_size != 8 or channels != 3 or dim_head != 64:
             raise NotImplementedError("HIP kernels are specialised for 3x8x8 patches and head_dim 64")
-        if use_standcoord:
-            raise NotImplementedError("use_standcoord (fixed grid + jitter) is never enabled by the reference's entry points")
         if not (0.0 <= dropout < 1.0 and 0.0 <= emb_dropout < 1.0):
             raise ValueError("dropout rates must be in [0, 1)")
         if pool != 'cls':
@@ -183,6 +182,8 @@ class ViT_face_landmark_patch8(nn.Module):
         self.patch_size, self.fp16, self.num_patches = patch_size, fp16, num_patches
         self.row_num = int(math.sqrt(num_patches))
         self.with_land, self.pool, self.loss_type, self.GPU_ID = with_land, pool, loss_type, GPU_ID
+        self.use_standcoord, self.Random_prob, self.shuffle = use_standcoord, Random_prob, shuffle      # reference :576, 717-742
+        self._want_tokens, self._last_tokens = False, None
         if with_land:                                     # reference :577-602
             from .mobilenet import MobileNetV3_backbone
             self.stn = MobileNetV3_backbone(mode='large')
@@ -265,19 +266,43 @@ class ViT_face_landmark_patch8(nn.Module):
         return ((t - tmin) / (tmax - tmin) * 111).view(-1, self.row_num * self.row_num, 2)
 
     def forward(self, x, label=None, mask=None, visualize=False, save_token=False, opt=None, keep_num=None, glo_diff=False):
-        if mask is not None or save_token:
-            raise NotImplementedError("attention masks / token dumps are not on the training hot path")
+        """(reference :659-795)  `save_token`: also the patch tokens behind the transformer, in front of the head's LayerNorm, detached
+        (an analysis dump in the reference: returns (emb, tokens, theta)); `use_standcoord` (constructor): the patches are gathered at
+        the centres of the regular 8 x 8 grid -- jittered by N(0, 3^2) px with `Random_prob`, re-drawn with replacement with `shuffle`,
+        both from the CPU generator in the reference's order -- and the mosaic is transposed (:717-742).  Attention masks are not
+        supported (never passed by either entry point)."""
+        if mask is not None:
+            raise NotImplementedError("attention masks are not on the training hot path (never passed by either entry point)")
         if self._arena is None:
             attach_arena(self)
+        theta = self.theta
         if self.with_land and x.dim() == 4:
             num_land = keep_num if keep_num is not None else self.row_num * self.row_num
             theta = self.landmarks(x)
             self.theta = theta
             x = extract_patches_pytorch_gridsample(x, theta[:, :num_land], patch_shape=self.patch_shape, num_landm=num_land)
+        if self.use_standcoord and x.dim() == 4:
+            b, side = x.shape[0], x.shape[-1]
+            num_land = (side // self.patch_size) ** 2
+            rc = torch.arange(0, int(math.isqrt(num_land)), dtype=torch.float32) * 8 + 4
+            cx, cy = torch.meshgrid(rc, rc, indexing="ij")
+            theta = torch.stack((cx, cy), 2).view(1, -1, 2).repeat(b, 1, 1)
+            if self.Random_prob:
+                theta = theta + torch.randn(theta.shape) * 3
+            if self.shuffle:
+                ids = torch.randint(0, theta.shape[1], (b, theta.shape[1], 1))
+                theta = torch.gather(theta, 1, ids.repeat(1, 1, 2))
+            theta = theta.to(x.device)
+            x = extract_patches_pytorch_gridsample(x, theta[:, :num_land], patch_shape=self.patch_shape, num_landm=num_land)
+            x = x.permute(0, 1, 3, 2).contiguous()
+        self._want_tokens = bool(save_token)
         emb = self.forward_embedding(x)
+        self._want_tokens = False
+        if save_token:
+            return emb, self._last_tokens, self.theta
         if label is not None:
             return self.loss(emb, label), self.theta
-        return (emb, self.theta) if visualize else emb
+        return (emb, theta) if visualize else emb
 
 
 # ------------------------------------------------------------------------------------------------- landmark CNN wrapper

@@ -96,10 +96,27 @@ def transformer(P, x, cfg, drop_scales=None, masks=None):
     return x
 
 
-def forward_embedding(P, x, cfg, drop_scales=None, masks=None):
+def standard_coords(num_land, noise=None, shuffle_id=None, batch=1):
+    """The `use_standcoord` landmarks of ViT_face_landmark_patch8.forward (ViT_face.py:717-742): the centres of the sqrt(n) x sqrt(n)
+    grid of 8 x 8 cells (meshgrid in 'ij' order, so landmark k = (i, j) carries (x, y) = (8 i + 4, 8 j + 4)), repeated over the
+    batch; `noise` [B, n, 2] = the reference's torch.randn(theta.shape) draw (x 3 px, Random_prob), `shuffle_id` [B, n] = its
+    torch.randint draw (landmarks re-drawn with replacement, shuffle)."""
+    r = int(round(num_land ** 0.5))
+    rc = torch.arange(0, r, dtype=torch.float32) * 8 + 4
+    cx, cy = torch.meshgrid(rc, rc, indexing="ij")
+    theta = torch.stack((cx, cy), 2).view(1, -1, 2).repeat(batch, 1, 1)
+    if noise is not None:
+        theta = theta + noise * 3
+    if shuffle_id is not None:
+        theta = torch.gather(theta, 1, shuffle_id.view(batch, -1, 1).repeat(1, 1, 2))
+    return theta
+
+
+def forward_embedding(P, x, cfg, drop_scales=None, masks=None, return_tokens=False):
     """ViT_face_landmark_patch8.forward without the landmark branch: 4-D image or 3-D [B,n,192]
     patches -> emb [B, dim] (ViT_face.py:759-776).  masks: see transformer(); masks["emb"] [B, n+1, D] is the
-    embedding dropout (:614, 768)."""
+    embedding dropout (:614, 768).  return_tokens: also the patch tokens behind the transformer, in front of the head's
+    LayerNorm (`save_token`, :769-770)."""
     if x.dim() == 4:
         x = patches_from_image(x, cfg.patch_size)
     t = F.linear(x, P["patch_to_embedding.weight"], P["patch_to_embedding.bias"])
@@ -109,4 +126,5 @@ def forward_embedding(P, x, cfg, drop_scales=None, masks=None):
     if masks is not None and "emb" in masks:
         t = t * masks["emb"].view(t.shape)
     t = transformer(P, t, cfg, drop_scales, masks)
-    return F.layer_norm(t[:, 0], (cfg.dim,), P["mlp_head.0.weight"], P["mlp_head.0.bias"], cfg.ln_eps)
+    emb = F.layer_norm(t[:, 0], (cfg.dim,), P["mlp_head.0.weight"], P["mlp_head.0.bias"], cfg.ln_eps)
+    return (emb, t[:, 1:]) if return_tokens else emb

@@ -22,6 +22,29 @@ def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+def test_f20_partfvit_standard_coordinates_and_token_dump():
+    """F20 on the HIP path: `use_standcoord` (regular-grid landmarks, transposed mosaic; with Random_prob + shuffle under the
+    reference's own random draws: the module draws from the CPU generator in the reference's order) and `save_token`
+    (reference ViT_face.py:717-742, 769-770, 778-779)."""
+    from lafs_cvpr2024_amd.face_pre_pro.ViT_face import ViT_face_landmark_patch8
+    fx = load_golden("f20_partfvit_standcoord")
+    m = ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=128, depth=2, heads=3,
+                                 mlp_dim=256, dropout=0.0, emb_dropout=0.0, with_land=False, use_standcoord=True, drop_path_rate=0.0)
+    m.load_state_dict(sub(fx, "p."))
+    m.eval()
+    x = fx["x"].to(DEV)
+    with torch.no_grad():
+        e, tok, _ = m(x, save_token=True)
+        print(f"[F20] emb {rel_l2(e, fx['e_plain']):.2e}, tokens {rel_l2(tok, fx['tok_plain']):.2e}; plain vs jittered + re-drawn in the reference: "
+              f"{rel_l2(fx['e_rand'], fx['e_plain']):.2e}")
+        assert rel_l2(e, fx["e_plain"]) < 2e-2 and rel_l2(tok, fx["tok_plain"]) < 2e-2, (rel_l2(e, fx["e_plain"]), rel_l2(tok, fx["tok_plain"]))
+        m.Random_prob, m.shuffle = True, True
+        torch.manual_seed(2020)                   # the reference's draws: torch.randn(theta.shape), then torch.randint(0, c, (b, c, 1))
+        e2 = m(x)
+        assert rel_l2(e2, fx["e_rand"]) < 2e-2, rel_l2(e2, fx["e_rand"])
+        assert rel_l2(e2, fx["e_plain"]) > 5 * rel_l2(e2, fx["e_rand"])      # (the jittered, re-drawn landmarks give ANOTHER embedding: that one)
+
+
 def test_f7_partfvit_forward_backward():
     fx = load_golden("f7_partfvit")
     m = ViT_face_landmark_patch8(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=128, depth=2,

@@ -220,6 +220,26 @@ def test_f7_partfvit_forward_backward():
         close(P[k].grad, g, 2e-3, 2e-5)
 
 
+def test_f20_partfvit_standard_coordinates_and_token_dump():
+    """F20: ViT_face_landmark_patch8(use_standcoord=True) of the reference (ViT_face.py:717-742) -- patches gathered at the centres of
+    the regular grid, mosaic transposed -- with `save_token` (the patch tokens in front of the head's LayerNorm, :769-770), and the
+    same with Random_prob + shuffle (the reference's own torch.randn / torch.randint draws are in the fixture)."""
+    fx = load_golden("f20_partfvit_standcoord")
+    cfg = partfvit.PartFViTConfig(patch_size=8, dim=128, depth=2, heads=3, mlp_dim=256, num_patches=196)
+    P = sub(fx, "p.")
+    x = fx["x"]
+
+    def run(noise=None, ids=None):
+        th = partfvit.standard_coords(196, noise=noise, shuffle_id=ids, batch=x.shape[0])
+        mosaic = gather.extract_patches(x, th, 8).permute(0, 1, 3, 2)
+        return partfvit.forward_embedding(P, mosaic, cfg, return_tokens=True)
+    e, tok = run()
+    close(e, fx["e_plain"], 1e-4, 1e-5)
+    close(tok, fx["tok_plain"], 1e-4, 1e-5)
+    e2, _ = run(fx["noise"], fx["ids"].view(2, 196))
+    close(e2, fx["e_rand"], 1e-4, 1e-5)
+
+
 @pytest.mark.parametrize("n", [196, 36])
 def test_f8_landmark_patch_gather(n):
     fx = load_golden(f"f8_gather_n{n}")

@@ -416,6 +416,28 @@ def main():
     ((e1 * w1).sum() + (e2 * w2).sum()).backward()
     save("f7_partfvit", ximg=ximg, xpat=xpat, w1=w1, w2=w2, e1=e1, e2=e2, **sd(pv), **grads(pv))
 
+    # ---------------------------------------------------------------- F20 Part-fViT forward options: use_standcoord (+ Random_prob, shuffle), save_token
+    print("F20 part-fvit standcoord / save_token")
+    torch.manual_seed(20)
+    kw = dict(loss_type="None", GPU_ID=None, num_class=10, image_size=112, patch_size=8, dim=128, depth=2, heads=3, mlp_dim=256,
+              dropout=0.0, emb_dropout=0.0, with_land=False, use_standcoord=True)
+    ps = ref_face.ViT_face_landmark_patch8(**kw)
+    for m in ps.modules():
+        if isinstance(m, ref_vit.DropPath):
+            m.drop_prob = 0.0
+    with torch.no_grad():                           # (N(0, 1) position / cls tables would drown the patches: keep the output sensitive to WHERE they are gathered)
+        ps.pos_embedding.mul_(0.05); ps.cls_token.mul_(0.05)
+    ps.eval()
+    xs = torch.randn(2, 3, 112, 112).clamp(-1, 1)
+    with torch.no_grad():
+        e_plain, tok_plain, _ = ps(xs, save_token=True)
+        ps.Random_prob, ps.shuffle = True, True
+        torch.manual_seed(2020)                     # the forward draws torch.randn(theta.shape) and then torch.randint(0, c, (b, c, 1))
+        e_rand = ps(xs)
+        torch.manual_seed(2020)
+        noise = torch.randn(2, 196, 2); ids = torch.randint(0, 196, (2, 196, 1))
+    save("f20_partfvit_standcoord", x=xs, e_plain=e_plain, tok_plain=tok_plain, e_rand=e_rand, noise=noise, ids=ids, **sd(ps))
+
     # ---------------------------------------------------------------- F8 landmark patch gather
     print("F8 gather")
     torch.manual_seed(8)
