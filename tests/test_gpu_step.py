@@ -272,7 +272,7 @@ def test_bench_owns_its_launch_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 4
-    assert line["debug_flags"] == 0 and line["roofline"]["kernel"].startswith(("wgrad_kernel", "gemm_nt_kernel", "gemm_kres_kernel"))
+    assert line["debug_flags"] == 0 and line["roofline"]["kernel"].startswith(("wgrad_kernel", "gemm_nt_kernel", "gemm_kres_kernel", "mlp_fused_kernel"))
     r = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "GPU(s) are visible" in r.stderr                      # a 1-GPU box cannot run 2 RCCL ranks
     r = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),

@@ -19,7 +19,7 @@ S = lambda r: (int(r["Start_Timestamp"]) - t0) / 1e3
 E = lambda r: (int(r["End_Timestamp"]) - t0) / 1e3
 first = lambda pat: next((r for r in step if pat in r["Kernel_Name"]), None)
 last = lambda pat: next((r for r in reversed(step) if pat in r["Kernel_Name"]), None)
-loss0, lossg = first("row_stats"), last("loss_grad")
+loss0 = first("row_stats") or first("head_stats")
 bwd0 = first("scatter_cls")
 upd0 = first("center_ema")
 end = max(E(r) for r in step)
