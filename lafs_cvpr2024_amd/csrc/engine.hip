@@ -80,6 +80,9 @@ Carve carve(const lafs_trunk_desc* d, void* ws, int save) {
     c.s.dh = (bf16_t*)take(T * D * 2);
     c.s.d_o = (bf16_t*)take(T * I * 2);
     c.ln_part_floats = (size_t)std::max(lafs_layernorm_bwd_parts(d->n_tok, d->dim), lafs_mlp_fused_ln_parts(d->n_tok)) * 2 * D;
+    // (four full-size slot buffers per norm whatever the number of row chains in use -- 75 MB of 7.3 GB at C2: the chain count is an
+    // option of the context, which may change on a live engine after its workspace was sized; sizing by the chains in use, as the
+    // round-5 advisor suggested, would make that a silent overflow)
     c.ln_part.resize((size_t)d->depth * 2 * 4);
     for (auto& q : c.ln_part) q = (float*)take(c.ln_part_floats * 4);
     lafs_wgrad_item it[4];
