@@ -129,6 +129,17 @@ __device__ __forceinline__ float act_f(float v, int act) {
   return v;
 }
 
+// ---- LayerNorm row arithmetic shared by ln_fwd2_kernel (layernorm.hip) and the fused MLP's LayerNorm prologue (mlp_fused.hip), which
+// must agree BIT FOR BIT: the multiply-adds are explicit and in a fixed order -- left to -ffp-contract, `a*a + b*b` may become
+// fma(a, a, b*b) in one kernel and fma(b, b, a*a) in another (observed: 2 of 1 966 080 bf16 outputs differed between two
+// instantiations of the same source).
+__device__ __forceinline__ float ln_sum4(float s, const float4& v) { return s + (((v.x + v.y) + v.z) + v.w); }
+__device__ __forceinline__ float ln_sq4(float q, const float4& v, float mean) {
+  const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+  return q + __builtin_fmaf(d, d, __builtin_fmaf(c, c, __builtin_fmaf(b, b, a * a)));
+}
+__device__ __forceinline__ float ln_out1(float x, float mean, float rstd, float g, float b) { return __builtin_fmaf((x - mean) * rstd, g, b); }
+
 // ---- wave reductions (64 lanes) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

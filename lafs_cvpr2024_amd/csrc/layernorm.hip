@@ -87,23 +87,20 @@ __global__ __launch_bounds__(256) void ln_fwd2_kernel(const float* __restrict__ 
   for (; row < rows; row += stride) {
     const bool more = row + stride < rows;
     if (more) load_row(row + stride, nxt);
-    float s = 0.f;
+    float s = 0.f;                                     // (row arithmetic: common.hpp ln_sum4 / ln_sq4 / ln_out1, shared with mlp_fused.hip)
 #pragma unroll
-    for (int i = 0; i < NI; ++i) s += cur[i].x + cur[i].y + cur[i].z + cur[i].w;
+    for (int i = 0; i < NI; ++i) s = ln_sum4(s, cur[i]);
     const float mean = half_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const float a = cur[i].x - mean, b = cur[i].y - mean, c = cur[i].z - mean, d = cur[i].w - mean;
-      q += a * a + b * b + c * c + d * d;
-    }
+    for (int i = 0; i < NI; ++i) q = ln_sq4(q, cur[i], mean);
     const float rstd = rsqrtf(half_sum(q) / (float)D + eps);
     if (l == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)row) = make_float2(mean, rstd);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = l * 4 + 128 * i;
-      const float o0 = (cur[i].x - mean) * rstd * g4[i].x + b4[i].x, o1 = (cur[i].y - mean) * rstd * g4[i].y + b4[i].y;
-      const float o2 = (cur[i].z - mean) * rstd * g4[i].z + b4[i].z, o3 = (cur[i].w - mean) * rstd * g4[i].w + b4[i].w;
+      const float o0 = ln_out1(cur[i].x, mean, rstd, g4[i].x, b4[i].x), o1 = ln_out1(cur[i].y, mean, rstd, g4[i].y, b4[i].y);
+      const float o2 = ln_out1(cur[i].z, mean, rstd, g4[i].z, b4[i].z), o3 = ln_out1(cur[i].w, mean, rstd, g4[i].w, b4[i].w);
       if (y != nullptr) *reinterpret_cast<uint2*>(y + (size_t)row * ldy + c) = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
       if (yf != nullptr) *reinterpret_cast<float4*>(yf + (size_t)row * ldyf + c) = make_float4(o0, o1, o2, o3);
     }

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   const bool rowok = active && row < p.M;              // (idle waves take part in the LDS-DMA and the barriers only)
   const int rowc = min(row, p.M - 1);
 
+  float sc = 1.0f;                                     // DropPath scale of this lane's row (forward)
   if constexpr (FWD) {
+    if (p.seq_scale != nullptr) sc = p.seq_scale[p.row2seq[rowc]];
     for (int i = tid; i < p.H; i += NTH) sba[i] = p.bias_a ? p.bias_a[i] : 0.f;
     for (int i = tid; i < D; i += NTH) sbb[i] = p.bias_b ? p.bias_b[i] : 0.f;
     __syncthreads();                                   // (also keeps these loads out of the counted waits below)
@@ -228,33 +230,44 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
         g4[i] = *reinterpret_cast<const float4*>(p.ln_g + l * 4 + 128 * i);
         b4[i] = *reinterpret_cast<const float4*>(p.ln_b + l * 4 + 128 * i);
       }
-      auto half_sum = [](float v) {
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        return v;
-      };
       unsigned char* img = smem + (wave >> 2) * STAGE;
+      // the 8 row pairs' reductions side by side (8 independent butterflies in flight instead of 8 x 2 dependent chains of 5 cross-lane
+      // exchanges); per row the arithmetic and its order are ln_fwd2_kernel's
+      float mean[8], rstd[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s = ln_sum4(s, xr[j][i]);
+        mean[j] = s;
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mean[j] += __shfl_xor(mean[j], o, 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        mean[j] = mean[j] / (float)D;
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) qq = ln_sq4(qq, xr[j][i], mean[j]);
+        rstd[j] = qq;
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rstd[j] += __shfl_xor(rstd[j], o, 64);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float4 (&cur)[3] = xr[j];
         const int r = u0 + wave * 16 + 2 * j + rsel;
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) s += cur[i].x + cur[i].y + cur[i].z + cur[i].w;
-        const float mean = half_sum(s) / (float)D;
-        float qq = 0.f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          const float a = cur[i].x - mean, b = cur[i].y - mean, c = cur[i].z - mean, d = cur[i].w - mean;
-          qq += a * a + b * b + c * c + d * d;
-        }
-        const float rstd = rsqrtf(half_sum(qq) / (float)D + p.ln_eps);
-        if (p.ln_stats != nullptr && l == 0 && r < p.M) *reinterpret_cast<float2*>(p.ln_stats + 2 * (size_t)r) = make_float2(mean, rstd);
+        const float mn = mean[j], rs = rsqrtf(rstd[j] / (float)D + p.ln_eps);
+        if (p.ln_stats != nullptr && l == 0 && r < p.M) *reinterpret_cast<float2*>(p.ln_stats + 2 * (size_t)r) = make_float2(mn, rs);
         const int rho = (wave & 3) * 16 + 2 * j + rsel;                 // row of the stage-A image
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          const float o0 = (cur[i].x - mean) * rstd * g4[i].x + b4[i].x, o1 = (cur[i].y - mean) * rstd * g4[i].y + b4[i].y;
-          const float o2 = (cur[i].z - mean) * rstd * g4[i].z + b4[i].z, o3 = (cur[i].w - mean) * rstd * g4[i].w + b4[i].w;
+          const float o0 = ln_out1(cur[i].x, mn, rs, g4[i].x, b4[i].x), o1 = ln_out1(cur[i].y, mn, rs, g4[i].y, b4[i].y);
+          const float o2 = ln_out1(cur[i].z, mn, rs, g4[i].z, b4[i].z), o3 = ln_out1(cur[i].w, mn, rs, g4[i].w, b4[i].w);
           const uint2 pk = make_uint2(pack_bf2(o0, o1), pack_bf2(o2, o3));
           const int c = (l >> 1) + 16 * i;                               // 16-byte chunk of columns 4 l + 128 i .. + 3, half l & 1
           *reinterpret_cast<uint2*>(img + rho * ROWB + ((c ^ (rho & 15)) << 4) + (l & 1) * 8) = pk;
@@ -290,14 +303,9 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   for (int ob = 0; ob < NOB; ++ob) acc2[ob] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   f32x4_t acc1[4];
   bf16x8_t gfrag[2];
-  float sc = 1.0f;
-  if constexpr (FWD) {
-    if (p.seq_scale != nullptr) sc = p.seq_scale[p.row2seq[rowc]];     // (two dependent loads, long retired when the waits below count)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // ... made explicit: nothing uncounted stays in the queue
-  }
-  // NOTE: the waits below count THIS wave's vector-memory instructions in issue order (loads, LDS-DMA and stores retire in order
-  // on gfx950); the s_waitcnt vmcnt(0) above drains the prologue's stages once (a few hundred cycles per unit of ~100 k).
-  // After it: nothing in flight.  Re-issue order from here on is what the counts below assume.
+  // NOTE: the waits below count THIS wave's vector-memory instructions in issue order (loads, LDS-DMA and stores retire in order on
+  // gfx950).  In flight here, oldest first: [whatever the prologue stored: LayerNorm by-products], stage 0, [gelu' of item 0], stage 1,
+  // stage 2 -- a wait for "at most the 12 youngest" therefore covers stage 0 and everything older.
 
   bf16x8_t wprev = areg[0];                            // (lab: ablations 32 / 64)
   unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = 0;
@@ -323,7 +331,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
       for (int gi = 0; gi < 4; ++gi) acc1[gi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     // younger than this stage's DMA: the previous item's mid-epilogue stores, the stage B issued behind it, this item's gelu' loads
-    if (it == 0) wait_vm<0>();
+    if (it == 0) wait_vm<2 * NDMA>();                  // younger than stage 0 and the gelu' loads of item 0: stages 1 and 2
     else if (active) wait_vm<NS + NDMA + NL>();
     else wait_vm<NDMA + NL>();
     if constexpr (!MABL(16)) __builtin_amdgcn_s_barrier();
@@ -358,8 +366,8 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     lap(2);
     // ----------------- mid-epilogue: GELU (forward) / x gelu'(u) (backward), bf16 rounding, hand-over to GEMM 2 in registers
     fence();
-    if constexpr (MODE == LAFS_MLP_BWD) {              // younger than the gelu' loads: the stage A issued above (item 0: stages 1, 2 -- drained)
-      if (it == 0) wait_vm<0>();
+    if constexpr (MODE == LAFS_MLP_BWD) {              // younger than the gelu' loads: the stage A issued above (item 0: stages 1 and 2)
+      if (it == 0) wait_vm<2 * NDMA>();
       else if (has_next) wait_vm<NDMA>();
       else wait_vm<0>();
     }
