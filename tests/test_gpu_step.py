@@ -603,8 +603,12 @@ def test_row_chains_equal_the_single_chain(tmp_path):
     la, lb = out["2"]["losses"], out["0"]["losses"]
     print("[row-chains] relative loss differences, steps 0-3: " + " ".join(f"{abs(a - b) / abs(b):.2e}" for a, b in zip(la, lb)))
     assert abs(la[0] - lb[0]) < 1e-6 * abs(lb[0]), (la, lb)            # same weights: the forward is the same arithmetic
-    assert abs(la[1] - lb[1]) < 2e-5 * abs(lb[1]), (la, lb)            # one update apart: the gradients' column sums are folded in a fixed order per
-                                                                         # configuration since round 5 (no fp32 atomics): observed 2.1e-6 (round 4, atomics: up to 3e-5)
+    # one update apart.  The LayerNorm / bias column sums are folded in a fixed order per configuration since round 5, but the step is
+    # not bit-reproducible run to run (the patch embedding's weight gradient still leaves as fp32 atomics, lafs_gemm_tn_acc), and Adam's
+    # FIRST update is lr * sign(g): an entry whose gradient is round-off flips by 2 lr.  Round 6 measured the SAME configuration twice
+    # (tools/lab/chains_probe.sh, 6 runs): step-1 losses 3.7915149 x5 and 3.7904572 x1 (2.8e-4 apart), against 3.7915068 for one chain --
+    # the gate is that run-to-run spread, not the 2.1e-6 a lucky pair shows (round 5's 2e-5 failed 1 run in 6)
+    assert abs(la[1] - lb[1]) < 1e-3 * abs(lb[1]), (la, lb)
     for a, b in zip(la[2:], lb[2:]):                                     # then Adam's first steps (lr * sign of a near-zero gradient)
         assert abs(a - b) < 5e-3 * abs(b), (la, lb)                      # amplify that noise; a race would be orders above this
     for name in ("teacher", "student"):
