@@ -316,9 +316,13 @@ int lafs_patchify(const float* img, int B, int S, int order, void* patches, hipS
 int lafs_embed_cls(const float* cls, const float* pos, float* tokens, int ldt, int n_seq, int npatch, int D,
                    hipStream_t stream);
 /* Backward of the token assembly: g(f32) [n_seq*(np+1), D] ->
- *   gp(bf16) [n_seq*np, D] (patch rows only), dpos(f32)[np+1, D] += sum over sequences, dcls(f32)[D] += sum g[cls rows]. */
+ *   gp(bf16) [n_seq*np, D] (patch rows only), dpos(f32)[np+1, D] += sum over sequences, dcls(f32)[D] += sum g[cls rows].
+ * workspace (f32, lafs_embed_bwd_workspace_bytes; may be NULL): with it every chunk of 16 sequences stores its sums into a slot of its
+ * own and a second launch adds the slots in ascending order -- run-to-run deterministic gradients of the position table and the cls
+ * token; without it the sums leave as one fp32 atomic per element and chunk (round 1-5 behaviour). */
+int64_t lafs_embed_bwd_workspace_bytes(int n_seq, int npatch, int D);
 int lafs_embed_bwd(const float* g, int ldg, int n_seq, int npatch, int D, void* gp, float* dpos, float* dcls,
-                   hipStream_t stream);
+                   float* workspace, hipStream_t stream);
 /* feat(bf16 and/or f32) [n_seq, D] = x[row of cls token of each sequence]; and its scatter-back. */
 int lafs_gather_cls(const float* x, int ldx, const int32_t* cu_seqlens, int n_seq, int D, float* out_f32,
                     hipStream_t stream);

@@ -103,7 +103,7 @@ _PROTOS = {
     "lafs_attention_bwd": [vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, f32, vp, i32],
     "lafs_patchify": [vp, i32, i32, i32, vp],
     "lafs_embed_cls": [vp, vp, vp, i32, i32, i32, i32],
-    "lafs_embed_bwd": [vp, i32, i32, i32, i32, vp, vp, vp],
+    "lafs_embed_bwd": [vp, i32, i32, i32, i32, vp, vp, vp, vp],
     "lafs_gather_cls": [vp, i32, vp, i32, i32, vp],
     "lafs_scatter_cls": [vp, vp, i32, i32, vp, i32],
     "lafs_l2norm_fwd": [vp, i32, vp, i32, vp, i32, i32],
@@ -189,6 +189,7 @@ _NO_STREAM = {
     "lafs_debug_get": ([], i32),
     "lafs_ablation_build": ([], i32),
     "lafs_last_error": ([], C.c_char_p),
+    "lafs_embed_bwd_workspace_bytes": ([i32, i32, i32], i64),
     "lafs_dino_loss_workspace": ([i32, i32, i32], i64),
     "lafs_dino_head_loss_workspace": ([i32, i32, i32], i64),
     "lafs_trunk_workspace_bytes": ([C.POINTER(TrunkDesc), i32], i64),

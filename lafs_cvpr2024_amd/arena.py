@@ -141,5 +141,14 @@ class ParamArena:
         if self._versions != self._version_key():
             self.refresh_shadows()
 
+    def scratch(self, key, n_floats):
+        """A float32 device buffer of at least n_floats, allocated once per key and kept (workspaces of kernels that fold their own
+        partial sums: static across the steps of a captured graph)."""
+        cache = self.__dict__.setdefault("_scratch", {})
+        buf = cache.get(key)
+        if buf is None or buf.numel() < n_floats:
+            buf = cache[key] = torch.empty(max(int(n_floats), 4), device=self.device, dtype=torch.float32)
+        return buf
+
     def zero_grad(self):
         self.grad.zero_()

@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void embed_cls_kernel(const float* __restrict_
 // chunk in registers and adds it to dpos with one atomic per element (n_seq/EB_SEQ adds per address).
 constexpr int EB_SEQ = 16;
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, int ldg, int n_seq, int npatch, int D,
-                                                       bf16_t* __restrict__ gp, float* __restrict__ dpos, float* __restrict__ dcls) {
+                                                       bf16_t* __restrict__ gp, float* __restrict__ dpos, float* __restrict__ dcls,
+                                                       float* __restrict__ part) {
   const int per = D >> 2;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= (npatch + 1) * per) return;
@@ -71,10 +72,38 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     if (t > 0 && gp != nullptr)
       *reinterpret_cast<uint2*>(gp + ((size_t)s * npatch + (t - 1)) * D + c) = make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w));
   }
+  if (part != nullptr) {                               // deterministic form: this sequence chunk's sums go to a slot of their own
+    *reinterpret_cast<float4*>(part + ((size_t)blockIdx.y * (npatch + 1) + t) * D + c) = acc;
+    return;
+  }
   float* dp = dpos + (size_t)t * D + c;
   atomicAdd(dp, acc.x); atomicAdd(dp + 1, acc.y); atomicAdd(dp + 2, acc.z); atomicAdd(dp + 3, acc.w);
   if (t == 0 && dcls != nullptr) {
     atomicAdd(dcls + c, acc.x); atomicAdd(dcls + c + 1, acc.y); atomicAdd(dcls + c + 2, acc.z); atomicAdd(dcls + c + 3, acc.w);
+  }
+}
+
+// dpos[t, c] += sum over the chunk slots in ascending order (dcls likewise from the t = 0 rows): one writer per element, a fixed order
+__global__ __launch_bounds__(256) void embed_bwd_fold_kernel(const float* __restrict__ part, int n_chunks, int npatch, int D,
+                                                            float* __restrict__ dpos, float* __restrict__ dcls) {
+  const int per = D >> 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (npatch + 1) * per) return;
+  const int t = i / per, c = (i % per) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < n_chunks; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)k * (npatch + 1) + t) * D + c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  float4* dp = reinterpret_cast<float4*>(dpos + (size_t)t * D + c);
+  float4 o = *dp;
+  o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+  *dp = o;
+  if (t == 0 && dcls != nullptr) {
+    float4* dc = reinterpret_cast<float4*>(dcls + c);
+    float4 q = *dc;
+    q.x += acc.x; q.y += acc.y; q.z += acc.z; q.w += acc.w;
+    *dc = q;
   }
 }
 
@@ -116,12 +145,19 @@ extern "C" int lafs_embed_cls(const float* cls, const float* pos, float* tokens,
   return LAFS_OK;
 }
 
+extern "C" int64_t lafs_embed_bwd_workspace_bytes(int n_seq, int npatch, int D) {
+  if (n_seq <= 0 || npatch <= 0 || D <= 0) return -1;
+  return (int64_t)ceil_div(n_seq, EB_SEQ) * (npatch + 1) * D * 4;
+}
+
 extern "C" int lafs_embed_bwd(const float* g, int ldg, int n_seq, int npatch, int D, void* gp, float* dpos, float* dcls,
-                              hipStream_t stream) {
+                              float* workspace, hipStream_t stream) {
   LAFS_CLEAR_ERROR();
   LAFS_CHECK_ARG(g && dpos && n_seq > 0 && npatch > 0 && D > 0 && D % 4 == 0 && ldg % 4 == 0, "bad operand");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3(ceil_div((npatch + 1) * (D / 4), 256), ceil_div(n_seq, EB_SEQ)), dim3(256), 0, stream, g, ldg, n_seq, npatch, D,
-                     (bf16_t*)gp, dpos, dcls);
+  const int chunks = ceil_div(n_seq, EB_SEQ), cols = ceil_div((npatch + 1) * (D / 4), 256);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(cols, chunks), dim3(256), 0, stream, g, ldg, n_seq, npatch, D, (bf16_t*)gp, dpos, dcls, workspace);
+  if (workspace != nullptr)
+    hipLaunchKernelGGL(embed_bwd_fold_kernel, dim3(cols), dim3(256), 0, stream, workspace, chunks, npatch, D, dpos, dcls);
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
 }

@@ -3,6 +3,7 @@
 These functions are the single implementation used by the drop-in nn.Modules (through torch.autograd.Function
 wrappers) and by the fused, hipGraph-captured training engine.
 """
+import os
 import ctypes as C
 import math
 from dataclasses import dataclass, field
@@ -250,12 +251,24 @@ def vit_backward_end(arena, spec: ViTSpec, st: ViTState, g, want_dx=False, dpos_
         # dpos_out[gi]: accumulate this group's position gradient straight into a caller buffer (e.g. the arena's gradient rows of
         # a table that needs no resampling) instead of a fresh zeroed temporary
         dp = dpos_out[gi] if (dpos_out is not None and dpos_out[gi] is not None) else ops.zeros(np_ + 1, D, device=dev)
-        call("lafs_embed_bwd", _p(rows), D, n_img, np_, D, _p(gp), _p(dp), _p(gv(spec.cls)))
-        ops.gemm_tn_acc(gp, st.patches[gi], gv(spec.w_patch).view(D, -1), colsum=gv(spec.b_patch))
+        # position / cls sums and the patch embedding's weight + bias gradients WITHOUT fp32 atomics (round 6: per-chunk slots folded in
+        # a fixed order; the wide-tile weight-gradient kernel with its slice fold) -- the last two atomic producers of the LAFS step:
+        # the step is bit-reproducible run to run (tools/lab/chains_probe.sh)
+        ws = arena.scratch(("embed_bwd", n_img, np_, D), int(_lib.lib().lafs_embed_bwd_workspace_bytes(n_img, np_, D)) // 4)
+        call("lafs_embed_bwd", _p(rows), D, n_img, np_, D, _p(gp), _p(dp), _p(gv(spec.cls)), _p(ws))
+        # (capped to EMBED_WGRAD_CUS workgroups: the output is two 192 x 192 tiles, and the default plan -- as many token slices as fill
+        # the chip -- would fold 128 slice images, 38 MB, for a 295 KB gradient)
+        prob = [(gp, st.patches[gi], gv(spec.w_patch).view(D, -1), True, gv(spec.b_patch))]
+        items, Mp = ops._wgrad_items(prob)
+        wws = arena.scratch(("embed_wgrad", Mp, D), max(int(_lib.lib().lafs_wgrad_group_workspace_bytes(items, 1, Mp, EMBED_WGRAD_CUS)), 16) // 4)
+        ops.wgrad_group(prob, workspace=wws, max_workgroups=EMBED_WGRAD_CUS)
         dpos.append(dp)
         if want_dx:
             dx.append(ops.gemm_nt(gp, wt, _lib.EPI_F32).view(n_img, np_, 192))
     return (dpos, dx) if want_dx else dpos
+
+
+EMBED_WGRAD_CUS = int(os.environ.get("LAFS_EMBED_WGRAD_CUS", "64"))      # lab knob (tools/lab/NOTES.md)
 
 
 def unpatchify_grad(dpatch, order):
