@@ -70,8 +70,9 @@ enum {
   LAFS_OPT_COMM_CUS = 6,       /* data-parallel runs: CUs left to the collective library's kernels by the K-resident GEMM (default 0) */
   LAFS_OPT_NT_BIG = 7,         /* tiled GEMM: one-workgroup-per-CU 192x256 / 176x256 tiles for the wide long-K shapes (default 1; 2-4 force a geometry) */
   LAFS_OPT_MLP_FUSED = 8,      /* trunk passes: the block's MLP as ONE launch (lafs_mlp_fused) where it applies (dim 384, no element dropout): bit mask
-                                  1 forward-only pass, 2 saving forward, 4 backward input gradients, 8 LayerNorm 2 inside the fused forward, 16 its backward inside the fused backward (default 15: step A/B in
-                                  DESIGN.md section 6) */
+                                  1 forward-only pass, 2 saving forward, 4 backward input gradients, 8 LayerNorm 2 inside the fused forward, 16 its backward inside the fused backward,
+                                  32 (lab) one MLP launch over all row chains, 64 the NEXT block's LayerNorm 1 in the fused forward's epilogue (bit-identical
+                                  to its launch).  Default 79 = 1 + 2 + 4 + 8 + 64: step A/B in DESIGN.md section 6 */
   LAFS_OPT_COUNT = 9
 };
 lafs_ctx* lafs_ctx_create(int device);
@@ -187,6 +188,12 @@ typedef struct lafs_mlp_args {
    * ln_part_out (f32 [lafs_mlp_fused_ln_parts(M)][2][384], the slot layout of lafs_layernorm_bwd: fold with
    * lafs_layernorm_bwd_fold) -- what lafs_layernorm_bwd(accumulate = 1) computes from the stored dX, without the launch. */
   float* ln_g_io; int ldgio; void* ln_gb_out; int ldgb; float* ln_part_out;
+  /* The NEXT block's LayerNorm 1 in the epilogue (forward modes; vision_transformer.py:110 `self.norm1` of block l + 1): with
+   * next_ln_gamma != NULL the finished rows of `out` are normalised where they sit in registers -- next_ln_out (bf16 [M, 384]) =
+   * LayerNorm(out; next_ln_gamma, next_ln_beta, next_ln_eps), next_ln_stats (f32 [M, 2], may be NULL) = (mean, rstd) -- what
+   * lafs_layernorm_fwd on `out` computes, bit for bit at >= 4096 rows (the summation order of its two-rows-per-wave kernel is repeated). */
+  const float* next_ln_gamma; const float* next_ln_beta; float next_ln_eps;
+  float* next_ln_stats; void* next_ln_out; int ldnln_next;
 } lafs_mlp_args;
 int lafs_mlp_fused(const lafs_mlp_args* args, hipStream_t stream);
 /* Slots a LAFS_MLP_BWD launch with the LayerNorm epilogue writes for M rows (one per 128-row workgroup). */

@@ -34,7 +34,9 @@ class MlpArgs(C.Structure):
                 ("save_act", C.c_void_p), ("ldsa", C.c_int), ("ctx", C.c_void_p),
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
                 ("ln_stats", C.c_void_p), ("ln_out", C.c_void_p), ("ldln", C.c_int),
-                ("ln_g_io", C.c_void_p), ("ldgio", C.c_int), ("ln_gb_out", C.c_void_p), ("ldgb", C.c_int), ("ln_part_out", C.c_void_p)]
+                ("ln_g_io", C.c_void_p), ("ldgio", C.c_int), ("ln_gb_out", C.c_void_p), ("ldgb", C.c_int), ("ln_part_out", C.c_void_p),
+                ("next_ln_gamma", C.c_void_p), ("next_ln_beta", C.c_void_p), ("next_ln_eps", C.c_float),
+                ("next_ln_stats", C.c_void_p), ("next_ln_out", C.c_void_p), ("ldnln_next", C.c_int)]
 
 
 class WgradItem(C.Structure):

@@ -9,7 +9,7 @@
 
 static const int kDefaults[LAFS_OPT_COUNT] = {
     /* SIDE_STREAMS */ 1, /* ROW_CHAINS */ 2, /* KRES_MASK */ 15, /* KRES_MIN_ITEMS */ 4, /* NT_WIDE */ 1, /* NT_TALL */ 1, /* COMM_CUS */ 0,
-    /* NT_BIG */ 1, /* MLP_FUSED */ 15};
+    /* NT_BIG */ 1, /* MLP_FUSED */ 79};
 
 int lafs_ctx_opt(const lafs_ctx* c, int opt) {
   if (opt < 0 || opt >= LAFS_OPT_COUNT) return 0;

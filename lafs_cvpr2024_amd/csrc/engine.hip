@@ -268,6 +268,9 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       lay_in[l] = cur; lay_out[l] = nxt; cur = nxt;
     }
   }
+  // LAFS_OPT_MLP_FUSED bit 64: the fused MLP of block l also writes LayerNorm 1 of block l + 1 (not with the merged launch of bit 32, whose
+  // row count differs from the attention branch's)
+  const bool next_ln_opt = (lafs_ctx_opt(d->ctx, LAFS_OPT_MLP_FUSED) & (64 | 32)) == 64;
   // layers [l_lo, l_hi); parts: 1 = the attention branch (LayerNorm 1 .. projection + residual), 2 = the MLP branch
   auto chain = [&](int r0, int R, int g_lo, int g_hi, int seq_lo, int nseq, hipStream_t st, bool attn_two_streams, int l_lo, int l_hi,
                    int parts) -> int {
@@ -282,7 +285,10 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       const size_t rD = (size_t)r0 * D, rI = (size_t)r0 * I, rM = (size_t)r0 * M;
       const float dp = d->dropout_p;
       const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
+      // LayerNorm 1 of this layer was produced by the previous layer's fused MLP (its epilogue holds the finished rows in registers)
+      const bool ln1_done = l > 0 && next_ln_opt && mlp_fused_on(d, save_for_backward ? 2 : 1, R);
       if (parts & 1) {
+      if (!ln1_done)
       RUN(lafs_layernorm_fwd(cur + rD, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1 + rD, D, nullptr, 0, b.st1 + 2 * (size_t)r0,
                              R, D, st));
       RUN(gemm(cx, b.h1 + rD, D, sh + o.w_qkv, D, R, 3 * I, D, LAFS_EPI_BF16, b.qkv + 3 * rI, 3 * I, o.b_qkv >= 0 ? d->master + o.b_qkv : nullptr, st));
@@ -326,6 +332,13 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
         if (ln_inside) {
           m.X = nullptr; m.ln_gamma = d->master + o.ln2_g; m.ln_beta = d->master + o.ln2_b; m.ln_eps = d->ln_eps;
           if (save_for_backward) { m.ln_stats = b.st2 + 2 * (size_t)r0; m.ln_out = b.h2 + rD; m.ldln = D; }
+        }
+        if (l + 1 < d->depth && next_ln_opt) {        // the next block's LayerNorm 1, from the rows in this launch's registers
+          const lafs_block_offsets& on = d->blocks[l + 1];
+          const LayerBuf& bn = c.layers[save_for_backward ? l + 1 : 0];
+          m.next_ln_gamma = d->master + on.ln1_g; m.next_ln_beta = d->master + on.ln1_b; m.next_ln_eps = d->ln_eps;
+          m.next_ln_out = bn.h1 + rD; m.ldnln_next = D;
+          m.next_ln_stats = save_for_backward ? bn.st1 + 2 * (size_t)r0 : nullptr;
         }
         m.ctx = cx;
         RUN(lafs_mlp_fused(&m, st));

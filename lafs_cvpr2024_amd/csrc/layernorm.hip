@@ -223,6 +223,108 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
   }
 }
 
+// The same pass with TWO rows per wave (D = 128 NI <= 512: 32 lanes x NI float4 cover a row exactly, where the kernel above leaves half
+// of its last 256-column chunk idle at D = 384 -- a quarter of its load / store instructions carry 32 lanes) -- the backward
+// counterpart of ln_fwd2_kernel.  Lane l of a half-wave holds columns 4 l + 128 i of its row; the two halves keep separate gamma /
+// beta sums for the same columns, added once at the end.  Row reductions are 32-lane butterflies.
+template <int NI, int NW>
+__global__ __launch_bounds__(NW * 64) void ln_bwd2_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     float* __restrict__ g_io, int ldg, int accumulate,
+                                                     bf16_t* __restrict__ gb, int ldgb, const float* __restrict__ seq_scale,
+                                                     const int* __restrict__ row2seq, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ part_out, int rows, DropCfg drop_in) {
+  constexpr int D = NI * 128;
+  const DropCfg drop = drop_resolve(drop_in);
+  __shared__ float red[NW][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l = lane & 31;
+  float4 gam[NI], ag[NI], ab[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    gam[i] = *reinterpret_cast<const float4*>(gamma + l * 4 + 128 * i);
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto half_sum = [](float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  struct RowIn { float4 xv[NI], old[NI]; uint2 dw[NI]; float mean, rstd, sc; };
+  auto load_row = [&](int row, RowIn& r) {
+    const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)row);
+    r.mean = st.x; r.rstd = st.y;
+    r.sc = (seq_scale != nullptr) ? seq_scale[row2seq[row]] : 1.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = l * 4 + 128 * i;
+      r.xv[i] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
+      r.dw[i] = *reinterpret_cast<const uint2*>(dy + (size_t)row * lddy + c);
+      r.old[i] = accumulate ? *reinterpret_cast<const float4*>(g_io + (size_t)row * ldg + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  const int stride = gridDim.x * NW * 2;
+  int row = (blockIdx.x * NW + wave) * 2 + (lane >> 5);
+  RowIn cur;
+  if (row < rows) load_row(row, cur);
+  for (; row < rows; row += stride) {
+    RowIn nxt;
+    const bool more = row + stride < rows;              // (uniform per half-wave)
+    if (more) load_row(row + stride, nxt);
+    const float mean = cur.mean, rstd = cur.rstd;
+    float4 xh[NI], d[NI];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float4 xv = cur.xv[i];
+      d[i] = make_float4(bf_lo(cur.dw[i].x), bf_hi(cur.dw[i].x), bf_lo(cur.dw[i].y), bf_hi(cur.dw[i].y));
+      xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+      ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+      d[i].x *= gam[i].x; d[i].y *= gam[i].y; d[i].z *= gam[i].z; d[i].w *= gam[i].w;
+      s1 += d[i].x + d[i].y + d[i].z + d[i].w;
+      s2 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
+    }
+    const float m1 = half_sum(s1) / (float)D, m2 = half_sum(s2) / (float)D;
+    const float sc = cur.sc;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = l * 4 + 128 * i;
+      float4 o = make_float4(rstd * (d[i].x - m1 - xh[i].x * m2), rstd * (d[i].y - m1 - xh[i].y * m2),
+                             rstd * (d[i].z - m1 - xh[i].z * m2), rstd * (d[i].w - m1 - xh[i].w * m2));
+      o.x += cur.old[i].x; o.y += cur.old[i].y; o.z += cur.old[i].z; o.w += cur.old[i].w;
+      *reinterpret_cast<float4*>(g_io + (size_t)row * ldg + c) = o;
+      if (gb != nullptr) {
+        float4 q = make_float4(sc * o.x, sc * o.y, sc * o.z, sc * o.w);
+        if (drop.thresh) {                              // gradient entering the dropped-out branch output
+          const unsigned idx = (unsigned)row * (unsigned)D + (unsigned)c;
+          q.x *= drop_mult(drop, idx); q.y *= drop_mult(drop, idx + 1); q.z *= drop_mult(drop, idx + 2); q.w *= drop_mult(drop, idx + 3);
+        }
+        *reinterpret_cast<uint2*>(gb + (size_t)row * ldgb + c) = make_uint2(pack_bf2(q.x, q.y), pack_bf2(q.z, q.w));
+      }
+    }
+    if (more) cur = nxt;
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {               // gamma sums, then beta sums, through the same LDS image
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float4 v = pass ? ab[i] : ag[i];                  // the wave's two rows-halves first
+      v.x += __shfl_xor(v.x, 32, 64); v.y += __shfl_xor(v.y, 32, 64); v.z += __shfl_xor(v.z, 32, 64); v.w += __shfl_xor(v.w, 32, 64);
+      if (lane < 32) *reinterpret_cast<float4*>(&red[wave][l * 4 + 128 * i]) = v;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += NW * 64) {
+      float sg = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) sg += red[w][c];
+      if (part_out != nullptr) part_out[((size_t)blockIdx.x * 2 + pass) * D + c] = sg;     // (slots: see ln_bwd_kernel)
+      else atomicAdd((pass ? dbeta : dgamma) + c, sg);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void scale_cast_kernel(const float* __restrict__ g, int ldg, bf16_t* __restrict__ gb, int ldgb,
                                                         const float* __restrict__ seq_scale, const int* __restrict__ row2seq,
                                                         int rows, int D, DropCfg drop_in) {
@@ -385,6 +487,23 @@ extern "C" int lafs_layernorm_bwd(const void* dy_bf16, int lddy, const float* dy
   LAFS_CHECK_ARG(seq_scale == nullptr || row2seq != nullptr, "seq_scale needs row2seq");
   const int ni = ceil_div(D, 256);
   const dim3 grid(lafs_layernorm_bwd_parts(rows, D));
+#ifndef LAFS_LAB_LN_BWD1
+  if (dy_f32 == nullptr && D % 128 == 0 && D <= 512 && rows >= 4096) {      // two rows per wave (see ln_bwd2_kernel); same grid, same slots
+    const DropCfg dc = make_drop(drop_p, drop_seed, drop_step, (unsigned)drop_row0 * (unsigned)D);
+#define LN_BWD2(NI_, NW_)                                                                                                                  \
+    hipLaunchKernelGGL((ln_bwd2_kernel<NI_, NW_>), grid, dim3(NW_ * 64), 0, stream, (const bf16_t*)dy_bf16, lddy, x, ldx, stats, gamma, g_io, \
+                       ldg, accumulate, (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, part_out, rows, dc)
+    switch (D / 128) {
+      case 1: LN_BWD2(1, 8); break;
+      case 2: LN_BWD2(2, 8); break;
+      case 3: LN_BWD2(3, 8); break;
+      default: LN_BWD2(4, 8); break;
+    }
+#undef LN_BWD2
+    LAFS_LAUNCH_CHECK();
+    return LAFS_OK;
+  }
+#endif
   if (dy_f32 != nullptr) {
     LN_BWD_DISPATCH(ni, true, (const bf16_t*)dy_bf16, lddy, dy_f32, lddyf, x, ldx, stats, gamma, g_io, ldg, accumulate,
                     (bf16_t*)gb_out, ldgb, seq_scale, row2seq, dgamma, dbeta, part_out, rows, D,

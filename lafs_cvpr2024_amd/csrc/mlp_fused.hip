@@ -76,6 +76,8 @@ struct MArgs {
   // gradient stream g_io (read-modify-write), its DropPath-scaled bf16 copy gb (the projection input gradient's operand), and this
   // workgroup's gamma / beta sums part[blockIdx][2][384]
   float* g_io; int ldgio; bf16_t* gb; int ldgb; float* part;
+  // forward modes: the NEXT block's LayerNorm 1 on the finished rows, in the final epilogue (they are in registers there: no loads)
+  const float* nln_g; const float* nln_b; float nln_eps; float* nln_stats; bf16_t* nln_out; int ldnln;
   const float* ln_g; const float* ln_b; float ln_eps;   // LNP: X = LayerNorm(resid) computed in the prologue
   float* ln_stats; bf16_t* ln_out; int ldln;            //      (mean, rstd) per row and the bf16 operand as by-products (optional)
   int unit_waves;                            // waves of a workgroup that own rows (8: 128-row units; 4: 64-row units, one computing wave per SIMD)
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
   __shared__ __attribute__((aligned(16))) float sba[FWD ? MAXH : 4];
   __shared__ __attribute__((aligned(16))) float sbb[(FWD || LNP) ? D : 4];        // forward: fc2 bias; backward + LNP: gamma
+  __shared__ __attribute__((aligned(16))) float snl[FWD ? 2 * D : 4];             // forward: the next block's LayerNorm 1 gamma | beta
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15, q = lane >> 4;
@@ -135,6 +138,8 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     if (p.seq_scale != nullptr) sc = p.seq_scale[p.row2seq[rowc]];
     for (int i = tid; i < p.H; i += NTH) sba[i] = p.bias_a ? p.bias_a[i] : 0.f;
     for (int i = tid; i < D; i += NTH) sbb[i] = p.bias_b ? p.bias_b[i] : 0.f;
+    if (p.nln_g != nullptr)
+      for (int i = tid; i < D; i += NTH) { snl[i] = p.nln_g[i]; snl[D + i] = p.nln_b[i]; }
     __syncthreads();                                   // (also keeps these loads out of the counted waits below)
   } else if constexpr (LNP) {
     for (int i = tid; i < D; i += NTH) sbb[i] = p.ln_g[i];
@@ -558,6 +563,38 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
         w[0] = __uint_as_float(r4[j].x) + sc * w[0]; w[1] = __uint_as_float(r4[j].y) + sc * w[1];
         w[2] = __uint_as_float(r4[j].z) + sc * w[2]; w[3] = __uint_as_float(r4[j].w) + sc * w[3];
         st16f(o + n, w[0], w[1], w[2], w[3]);
+        acc2[o0 + j] = f32x4_t{w[0], w[1], w[2], w[3]};          // (kept: the next block's LayerNorm below)
+      }
+    }
+    if (p.nln_g != nullptr) {
+      // LayerNorm 1 of the NEXT block (vision_transformer.py:110 `self.norm1` of block l + 1) on the rows just finished: lane (t, q) holds
+      // the float4 groups f = 4 ob + q of its row, the row's other three lanes (q') the rest.  The sums are formed in the ORDER of
+      // ln_fwd2_kernel (csrc/layernorm.hip: lane l of 32 holds f = l, l + 32, l + 64 and the 32 partial sums meet in an xor
+      // butterfly 16, 8, 4, 2, 1): here l = 4 (ob % 8) + q, so the butterfly's first three levels are register adds and the last
+      // two the exchanges with q' -- the operand and the statistics are bit-identical to the LayerNorm launch this replaces.  No
+      // global load at all (gamma / beta sit in LDS since the kernel's start): the launch and its read of the residual stream are gone.
+      static_assert(NOB == 24, "the reduction tree below is ln_fwd2_kernel<3>'s");
+      auto tree = [&](auto&& part) {                      // part(ob): this lane's contribution of group ob
+        float pm[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) pm[m] = part(part(part(0.f, m), m + 8), m + 16);
+        float v = ((pm[0] + pm[4]) + (pm[2] + pm[6])) + ((pm[1] + pm[5]) + (pm[3] + pm[7]));
+        v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64);
+        return v;
+      };
+      const float sm = tree([&](float s, int ob) { return ln_sum4(s, make_float4(acc2[ob][0], acc2[ob][1], acc2[ob][2], acc2[ob][3])); });
+      const float mean = sm / (float)D;
+      const float qs = tree([&](float s, int ob) { return ln_sq4(s, make_float4(acc2[ob][0], acc2[ob][1], acc2[ob][2], acc2[ob][3]), mean); });
+      const float rstd = rsqrtf(qs / (float)D + p.nln_eps);
+      if (p.nln_stats != nullptr && q == 0) *reinterpret_cast<float2*>(p.nln_stats + 2 * (size_t)row) = make_float2(mean, rstd);
+      bf16_t* ho = p.nln_out + (size_t)row * p.ldnln;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        const int n = 16 * ob + 4 * q;
+        const float4 g4 = *reinterpret_cast<const float4*>(snl + n), b4 = *reinterpret_cast<const float4*>(snl + D + n);
+        const float h0 = ln_out1(acc2[ob][0], mean, rstd, g4.x, b4.x), h1 = ln_out1(acc2[ob][1], mean, rstd, g4.y, b4.y);
+        const float h2 = ln_out1(acc2[ob][2], mean, rstd, g4.z, b4.z), h3 = ln_out1(acc2[ob][3], mean, rstd, g4.w, b4.w);
+        *reinterpret_cast<uint2*>(ho + n) = make_uint2(pack_bf2(h0, h1), pack_bf2(h2, h3));
       }
     }
   } else {
@@ -613,6 +650,9 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
   LAFS_CHECK_ARG(g != nullptr, "null arguments");
   LAFS_CHECK_ARG(g->mode == LAFS_MLP_FWD || g->mode == LAFS_MLP_FWD_SAVE || g->mode == LAFS_MLP_BWD, "bad mode");
   LAFS_CHECK_ARG(lafs_mlp_fused_supported(D, g->H, g->M), "hidden width must be a multiple of 64 in [128, 1536], M > 0 (the embedding width is 384)");
+  LAFS_CHECK_ARG(g->mode == LAFS_MLP_BWD || g->next_ln_gamma == nullptr ||
+                 (g->next_ln_beta != nullptr && g->next_ln_out != nullptr && g->ldnln_next >= D && g->ldnln_next % 4 == 0),
+                 "next block's LayerNorm: beta, output and its stride");
   const bool has_ln = g->mode != LAFS_MLP_BWD && g->ln_gamma != nullptr;
   if (g->mode == LAFS_MLP_BWD && g->ln_gamma != nullptr) {
     LAFS_CHECK_ARG(g->resid != nullptr && g->ldr >= D && g->ldr % 4 == 0 && g->ln_stats != nullptr, "LayerNorm backward: x and its statistics");
@@ -643,6 +683,8 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
   a.unit_waves = NWV; a.row0 = 0;
   a.stamps = MABL(128) ? (unsigned long long*)g->ctx : nullptr;
   const int n_cu = (g->ctx != nullptr && !MABL(128)) ? g->ctx->n_cu : 0;                      // (no context: one launch of 128-row units)
+  a.nln_g = fwd ? g->next_ln_gamma : nullptr; a.nln_b = g->next_ln_beta; a.nln_eps = g->next_ln_eps; a.nln_stats = g->next_ln_stats;
+  a.nln_out = (bf16_t*)g->next_ln_out; a.ldnln = g->ldnln_next;
   const bool lnp = fwd && g->ln_gamma != nullptr;
   a.ln_g = g->ln_gamma; a.ln_b = g->ln_beta; a.ln_eps = g->ln_eps; a.ln_stats = g->ln_stats; a.ln_out = (bf16_t*)g->ln_out; a.ldln = g->ldln;
   switch (g->mode) {

@@ -94,7 +94,7 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
 
 
 def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=None, row2seq=None, out=None, save_grad=None, save_act=None, ctx=None,
-              ln=None, ln_stats=None, ln_out=None, ln_bwd=None):
+              ln=None, ln_stats=None, ln_out=None, ln_bwd=None, next_ln=None):
     """The fused MLP of a ViT-S block (lafs_mlp_fused, csrc/mlp_fused.hip; vision_transformer.py:59-65,112).
     MLP_FWD / MLP_FWD_SAVE: out(f32) = resid + seq_scale[row2seq] * (gelu(X Wa^T + bias_a) Wb^T + bias_b), the saving form also
     writes save_grad = gelu'(u) and save_act = gelu(u); MLP_BWD: save_act = du = (X Wa^T) * save_grad, out(bf16) = du Wb^T."""
@@ -136,6 +136,12 @@ def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=N
         _chk(save_grad, bf16, "save_grad"); a.save_grad, a.ldsg = save_grad.data_ptr(), _ld(save_grad)
     if save_act is not None:
         _chk(save_act, bf16, "save_act"); a.save_act, a.ldsa = save_act.data_ptr(), _ld(save_act)
+    if next_ln is not None:                              # forward modes: (gamma, beta, eps, out bf16, stats or None) -- the next block's LayerNorm 1
+        ng, nb, ne, no_, ns = next_ln
+        _chk(ng, torch.float32, "next gamma"); _chk(nb, torch.float32, "next beta"); _chk(no_, bf16, "next_ln out")
+        a.next_ln_gamma, a.next_ln_beta, a.next_ln_eps, a.next_ln_out, a.ldnln_next = ng.data_ptr(), nb.data_ptr(), float(ne), no_.data_ptr(), _ld(no_)
+        if ns is not None:
+            _chk(ns, torch.float32, "next_ln stats"); a.next_ln_stats = ns.data_ptr()
     if ln_bwd is not None:                               # MLP_BWD: (x, stats, gamma, g_io, gb_out, part_out) -- LayerNorm backward in the epilogue
         x_, st_, gam_, gio_, gbo_, part_ = ln_bwd
         _chk(x_, torch.float32, "x"); _chk(st_, torch.float32, "stats"); _chk(gam_, torch.float32, "gamma"); _chk(gio_, torch.float32, "g_io")

@@ -796,6 +796,44 @@ def test_fused_mlp_layernorm_prologue_equals_the_layernorm_launch_bit_for_bit(M)
     assert relerr(h.float(), ref) < 8e-3
 
 
+@pytest.mark.parametrize("M", [128 * 33, 128 * 33 + 50])
+@pytest.mark.parametrize("mode", ["fwd", "save"])
+def test_fused_mlp_writes_the_next_blocks_layernorm(M, mode):
+    """LayerNorm 1 of block l + 1 (vision_transformer.py:110 `self.norm1`, eps 1e-6) in the fused MLP's final epilogue, from the rows
+    the launch holds in registers: the residual stream `out` is bit-identical to the launch without it, and the bf16 operand and the
+    (mean, rstd) statistics are bit-identical to lafs_layernorm_fwd on `out` (>= 4096 rows: the two-rows-per-wave kernel, whose
+    summation order the epilogue repeats); against torch's fp32 layer_norm; rows past M are not written."""
+    D, H = 384, 1536
+    g = torch.Generator().manual_seed(101)
+    x = (torch.randn(M, D, generator=g) * 1.7 + 0.3).to(DEV)
+    gam, bet = (1.0 + 0.2 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    ngam, nbet = (1.0 + 0.2 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    W1, W2 = rnd_bf(H, D, scale=0.05, seed=103).to(DEV), rnd_bf(D, H, scale=0.03, seed=104).to(DEV)
+    b1, b2 = (torch.randn(H, generator=g) * 0.1).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
+    nseq = 9
+    row2seq = (torch.arange(M) * nseq // M).int().to(DEV)
+    sc = torch.tensor([0.0 if i % 4 == 1 else 1.0 / 0.9 for i in range(nseq)]).to(DEV)
+    md = _lib.MLP_FWD if mode == "fwd" else _lib.MLP_FWD_SAVE
+    kw = dict(bias_a=b1, bias_b=b2, resid=x, seq_scale=sc, row2seq=row2seq, ln=(gam, bet, 1e-6))
+    ref = ops.mlp_fused(None, W1, W2, md, **kw)
+    guard = 5.0
+    hn = torch.full((M + 64, D), guard, device=DEV, dtype=bf16); sn = torch.full((M + 64, 2), guard, device=DEV)
+    got = ops.mlp_fused(None, W1, W2, md, next_ln=(ngam, nbet, 1e-6, hn[:M], sn[:M] if mode == "save" else None), **kw)
+    for a, b in zip(got, ref):
+        assert (a is None and b is None) or torch.equal(a, b)
+    assert float((hn[M:].float() - guard).abs().max()) == 0.0 and float((sn[M:] - guard).abs().max()) == 0.0, "rows past M were written"
+    y = ref[0]
+    h = torch.empty(M, D, device=DEV, dtype=bf16); st = torch.empty(M, 2, device=DEV)
+    call("lafs_layernorm_fwd", _p(y), D, _p(ngam), _p(nbet), 1e-6, _p(h), D, None, 0, _p(st), M, D)
+    if mode == "save":
+        assert torch.equal(sn[:M], st), f"statistics: max {float((sn[:M] - st).abs().max()):.3e}"
+    else:
+        assert float((sn[:M] - guard).abs().max()) == 0.0, "statistics written without a pointer"
+    assert torch.equal(hn[:M], h), f"{int((hn[:M] != h).sum())} of {M * D} operand values differ"
+    t = F.layer_norm(y.float().cpu(), (D,), ngam.cpu(), nbet.cpu(), 1e-6)
+    assert relerr(hn[:M].float(), t) < 8e-3
+
+
 @pytest.mark.parametrize("M", [128 * 35, 128 * 33 + 50])
 def test_fused_mlp_backward_with_the_layernorm_backward_in_its_epilogue(M):
     """LAFS_MLP_BWD with the LayerNorm-2 backward in the epilogue (vision_transformer.py:112 backward) against the separate path --

@@ -587,16 +587,19 @@ print("CHAINS_DONE")
 def test_row_chains_equal_the_single_chain(tmp_path):
     """The trunk passes as two chains of launches over the row ranges of the two crop-resolution groups (csrc/engine.hip:
     row_ranges; LAFS_ROW_CHAINS, read once per process) against ONE chain over all rows: four captured steps from the same
-    initialisation -- and the two-chain run a second time, which must repeat BIT FOR BIT (losses and every weight); the first loss is identical, the later ones and the weights agree up to the grouping of the LayerNorm / bias
+    initialisation -- and the two-chain run a second time, which must repeat BIT FOR BIT (losses and every weight), as must the run
+    with every LayerNorm 1 launched on its own instead of written by the previous block's fused MLP; the first loss is identical, the later ones and the weights agree up to the grouping of the LayerNorm / bias
     gradients' partial sums (per chain, then folded in a fixed order) as Adam's first steps amplify it."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for mode in ("2", "0", "2 again"):
+    for mode in ("2", "0", "2 again", "2 ln1 launched"):
         f = str(tmp_path / f"chains{mode[0]}{len(mode)}.pt")
         env = dict(os.environ, LAFS_ROW_CHAINS=mode[0], PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        if mode == "2 ln1 launched":                     # LAFS_OPT_MLP_FUSED without bit 64: every LayerNorm 1 as its own launch
+            env["LAFS_MLP_FUSED"] = "15"
         r = subprocess.run([sys.executable, "-c", _CHAINS_SNIPPET, f], env=env, capture_output=True, text=True, timeout=600, cwd=root)
         assert r.returncode == 0 and "CHAINS_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         out[mode] = torch.load(f)
@@ -605,6 +608,11 @@ def test_row_chains_equal_the_single_chain(tmp_path):
     for name in ("teacher", "student"):
         for k, v in out["2"][name].items():
             assert torch.equal(v, out["2 again"][name][k]), (name, k)
+    # LayerNorm 1 of blocks 1.. written by the previous block's fused MLP (the default) or by lafs_layernorm_fwd: the same bits
+    assert out["2"]["losses"] == out["2 ln1 launched"]["losses"], (out["2"]["losses"], out["2 ln1 launched"]["losses"])
+    for name in ("teacher", "student"):
+        for k, v in out["2"][name].items():
+            assert torch.equal(v, out["2 ln1 launched"][name][k]), (name, k)
     la, lb = out["2"]["losses"], out["0"]["losses"]
     print("[row-chains] relative loss differences, steps 0-3: " + " ".join(f"{abs(a - b) / abs(b):.2e}" for a, b in zip(la, lb)))
     assert abs(la[0] - lb[0]) < 1e-6 * abs(lb[0]), (la, lb)            # same weights: the forward is the same arithmetic

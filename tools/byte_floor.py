@@ -42,7 +42,8 @@ ROUND5 = "--round5" in sys.argv
 if not ROUND5:
     # forward: LN 1 (4 in, 2 out) | qkv | attention | projection | fused MLP: residual stream in (4: LayerNorm input AND residual) and out (4),
     #          student also h2 (2), gelu'(u) and gelu(u) (2 x 2 MLP)
-    fwd = {"LayerNorm forward (LN 1)": 4 + 2, "qkv GEMM": 2 + 6, "attention forward": 6 + 2, "projection + residual": 2 + 4 + 4,
+    #          LN 1: block 0 is a launch (4 in, 2 out); blocks 1.. are written by the previous block's fused MLP from registers (2 out)
+    fwd = {"LayerNorm forward (LN 1)": (4 + 2 + 2 * (DEPTH - 1)) / DEPTH, "qkv GEMM": 2 + 6, "attention forward": 6 + 2, "projection + residual": 2 + 4 + 4,
            "fused MLP forward (LN 2 + fc1 + GELU + fc2 + residual)": 4 + 4 + 2 + 2 * 2 * MLP}
     fwd_t = dict(fwd, **{"fused MLP forward (LN 2 + fc1 + GELU + fc2 + residual)": 4 + 4})
     # backward: fused MLP (dY 2 + gelu' 2 MLP in; du 2 MLP + dX 2 out) | the rest as before

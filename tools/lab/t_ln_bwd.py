@@ -1,30 +1,62 @@
-"""GPU box: LayerNorm backward at D = 384 / 768, with and without the dropout mask and the DropPath scale (what mynet runs)."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+"""Lab: lafs_layernorm_bwd, two rows per wave (product, ln_bwd2_kernel) against one row per wave (tools/lab/libln_bwd1.so: the same
+source with -DLAFS_LAB_LN_BWD1), ViT-S row counts, HIP events, interleaved; and the difference of their results.
+usage: python tools/lab/t_ln_bwd.py [reps]"""
+import ctypes as C
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import torch
-from lafs_cvpr2024_amd import ops
-dev = "cuda"
-T = 44160
-def timeit(fn, n=200):
-    for _ in range(n): fn()
+from lafs_cvpr2024_amd import _lib
+
+DEV, bf16 = "cuda", torch.bfloat16
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+D = 384
+new = _lib.lib()
+old = C.CDLL(os.path.join(ROOT, "tools", "lab", "libln_bwd1.so"))
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def run(lib, dy, x, st, gam, g, gb, sc, r2s, part, M):
+    rc = lib.lafs_layernorm_bwd(P(dy), D, None, 0, P(x), D, P(st), P(gam), P(g), D, 1, P(gb), D, P(sc), P(r2s), None, None, M, D,
+                                C.c_float(0.0), 0, None, 0, P(part), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+
+
+def timeit(fn, n=reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(); e0.record()
-    for _ in range(n): fn()
+    e0.record()
+    for _ in range(n):
+        fn()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3
-lens = [197] * 128 + [37] * 512
-row2seq = torch.repeat_interleave(torch.arange(640, device=dev, dtype=torch.int32), torch.tensor(lens, device=dev))
-scale = (torch.rand(640, device=dev) > 0.1).float() / 0.9
-for D in (384, 768):
-    x = torch.randn(T, D, device=dev); dy = torch.randn(T, D, device=dev).to(torch.bfloat16); dyf = torch.randn(T, D, device=dev)
-    stats = torch.stack([x.mean(1), x.var(1, unbiased=False).add(1e-6).rsqrt()], 1).contiguous()
-    gamma = torch.ones(D, device=dev); g = torch.zeros(T, D, device=dev); dg = torch.zeros(D, device=dev); db = torch.zeros(D, device=dev)
-    gb = torch.empty(T, D, device=dev, dtype=torch.bfloat16)
-    byt = T * D * (2 + 4 + 4 + 4)
-    for name, kw in (("plain", {}), ("gb_out", dict(gb_out=gb)), ("gb_out+scale", dict(gb_out=gb, seq_scale=scale, row2seq=row2seq)),
-                     ("gb_out+scale+dropout", dict(gb_out=gb, seq_scale=scale, row2seq=row2seq, drop_p=0.1, drop_seed=5)),
-                     ("dropout only", dict(drop_p=0.1, drop_seed=5))):
-        t = timeit(lambda: ops.layernorm_bwd(dy, x, stats, gamma, g, dg, db, accumulate=True, **kw))
-        print(f"D={D} {name:24s} {t:7.1f} us  {byt / t / 1e6:6.2f} TB/s (of the plain form's bytes)")
-    t = timeit(lambda: ops.layernorm_bwd(dyf, x, stats, gamma, g, dg, db, accumulate=True))
-    print(f"D={D} f32 dy                   {t:7.1f} us")
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+for M in (25216, 12608, 18944, 44160):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(M, D, generator=g) * 1.3 + 0.2).to(DEV)
+    gam = (1.0 + 0.2 * torch.randn(D, generator=g)).to(DEV); bet = torch.zeros(D, device=DEV)
+    h = torch.empty(M, D, device=DEV, dtype=bf16); st = torch.empty(M, 2, device=DEV)
+    new.lafs_layernorm_fwd(P(x), D, P(gam), P(bet), C.c_float(1e-6), P(h), D, None, 0, P(st), M, D, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    dy = torch.randn(M, D, generator=g).to(bf16).to(DEV)
+    g0 = torch.randn(M, D, generator=g).to(DEV)
+    r2s = (torch.arange(M) * 64 // M).int().to(DEV); sc = torch.full((64,), 1.0 / 0.9, device=DEV)
+    nparts = int(new.lafs_layernorm_bwd_parts(M, D))
+    outs = {}
+    for name, lib in (("one", old), ("two", new)):
+        gg = g0.clone(); gb = torch.empty(M, D, device=DEV, dtype=bf16); part = torch.zeros(nparts, 2, D, device=DEV)
+        run(lib, dy, x, st, gam, gg, gb, sc, r2s, part, M)
+        outs[name] = (gg, gb.float(), part.double().sum(0))
+    dif = [float((a - b).abs().max() / b.abs().max()) for a, b in zip(outs["two"], outs["one"])]
+    gg = g0.clone(); gb = torch.empty(M, D, device=DEV, dtype=bf16); part = torch.zeros(nparts, 2, D, device=DEV)
+    res = {}
+    for rnd in range(3):
+        for name, lib in (("one", old), ("two", new)):
+            res.setdefault(name, []).append(timeit(lambda: run(lib, dy, x, st, gam, gg, gb, sc, r2s, part, M)))
+    byt = M * D * 16.0
+    print(f"M={M:6d} parts={nparts}  one row/wave {min(res['one']):6.1f} us ({byt / min(res['one']) / 1e6:.2f} TB/s)   two rows/wave "
+          f"{min(res['two']):6.1f} us ({byt / min(res['two']) / 1e6:.2f} TB/s)   max rel diff g / gb / (dgamma, dbeta): "
+          + " ".join(f"{d:.1e}" for d in dif), flush=True)

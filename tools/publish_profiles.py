@@ -88,8 +88,8 @@ def main():
                             (M * 384 + 1536 * 384 + 2 * M * 1536) * 2.0, 2.0 * M * 1536 * 384),
         "fc2": kernel_entry("gemm_nt_kernel<RESID_F32, WM=2, BK=64>  M=44160 N=384 K=1536 (student fc2 forward, tiled kernel)", [FC2],
                             (M * 1536 + 384 * 1536) * 2.0 + 2.0 * M * 384 * 4.0, 2.0 * M * 384 * 1536),
-        "mlp_fused": kernel_entry("mlp_fused_kernel<FWD_SAVE, LN prologue>  M=25216 H=1536 (student LayerNorm 2 + MLP + residual, one launch)", [MLP],
-                                  25216 * 384 * 4.0 * 2 + 2 * 1536 * 384 * 2.0 + 2 * 25216 * 1536 * 2.0 + 25216 * 384 * 2.0 + 25216 * 8.0,
+        "mlp_fused": kernel_entry("mlp_fused_kernel<FWD_SAVE, LN prologue>  M=25216 H=1536 (student LayerNorm 2 + MLP + residual + next LayerNorm 1, one launch)", [MLP],
+                                  25216 * 384 * 4.0 * 2 + 2 * 1536 * 384 * 2.0 + 2 * 25216 * 1536 * 2.0 + 2 * (25216 * 384 * 2.0 + 25216 * 8.0),
                                   4.0 * 25216 * 384 * 1536),
     }
     for M, geo in ((44160, "Geo<11,4,1,4>"), (25216, "Geo<5,8,2,2>")):       # the extras' roofline kernel (bench.py roofline_partfvit_dgrad)
