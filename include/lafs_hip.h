@@ -72,7 +72,8 @@ enum {
   LAFS_OPT_MLP_FUSED = 8,      /* trunk passes: the block's MLP as ONE launch (lafs_mlp_fused) where it applies (dim 384, no element dropout): bit mask
                                   1 forward-only pass, 2 saving forward, 4 backward input gradients, 8 LayerNorm 2 inside the fused forward, 16 its backward inside the fused backward,
                                   32 (lab) one MLP launch over all row chains, 64 the NEXT block's LayerNorm 1 in the fused forward's epilogue (bit-identical
-                                  to its launch).  Default 79 = 1 + 2 + 4 + 8 + 64: step A/B in DESIGN.md section 6 */
+                                  to its launch), 128 / 256 the attention branch's output projection + residual in FRONT of the fused forward of the
+                                  forward-only / the saving pass.  Default 79 = 1 + 2 + 4 + 8 + 64: step A/B in DESIGN.md section 6 */
   LAFS_OPT_COUNT = 9
 };
 lafs_ctx* lafs_ctx_create(int device);
@@ -194,6 +195,14 @@ typedef struct lafs_mlp_args {
    * lafs_layernorm_fwd on `out` computes, bit for bit at >= 4096 rows (the summation order of its two-rows-per-wave kernel is repeated). */
   const float* next_ln_gamma; const float* next_ln_beta; float next_ln_eps;
   float* next_ln_stats; void* next_ln_out; int ldnln_next;
+  /* The attention branch's output projection in FRONT (forward modes with ln_gamma != NULL; vision_transformer.py:88-90 `self.proj`
+   * and the residual / DropPath of Block.forward :111): with proj_x != NULL (bf16 [M, 384], the attention output) the kernel first
+   * computes  resid = proj_resid + proj_scale[row2seq[m]] * (proj_x proj_w^T + proj_bias)  -- `resid` (fp32 [M, 384]) is then an
+   * OUTPUT, written once, normalised from registers (LayerNorm 2) and read back by the final epilogue as the residual; proj_w bf16
+   * [384, 384] row-major (out, in), proj_bias fp32 [384] or NULL, proj_resid fp32 [M, 384], proj_scale per sequence or NULL.
+   * Replaces lafs_gemm_nt(LAFS_EPI_RESID_F32) of the projection, bit for bit where that call runs on the K-resident kernel. */
+  const void* proj_x; int ldpx; const void* proj_w; int ldpw; const float* proj_bias;
+  const float* proj_resid; int ldpr; const float* proj_scale;
 } lafs_mlp_args;
 int lafs_mlp_fused(const lafs_mlp_args* args, hipStream_t stream);
 /* Slots a LAFS_MLP_BWD launch with the LayerNorm epilogue writes for M rows (one per 128-row workgroup). */

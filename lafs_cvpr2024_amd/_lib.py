@@ -36,7 +36,9 @@ class MlpArgs(C.Structure):
                 ("ln_stats", C.c_void_p), ("ln_out", C.c_void_p), ("ldln", C.c_int),
                 ("ln_g_io", C.c_void_p), ("ldgio", C.c_int), ("ln_gb_out", C.c_void_p), ("ldgb", C.c_int), ("ln_part_out", C.c_void_p),
                 ("next_ln_gamma", C.c_void_p), ("next_ln_beta", C.c_void_p), ("next_ln_eps", C.c_float),
-                ("next_ln_stats", C.c_void_p), ("next_ln_out", C.c_void_p), ("ldnln_next", C.c_int)]
+                ("next_ln_stats", C.c_void_p), ("next_ln_out", C.c_void_p), ("ldnln_next", C.c_int),
+                ("proj_x", C.c_void_p), ("ldpx", C.c_int), ("proj_w", C.c_void_p), ("ldpw", C.c_int), ("proj_bias", C.c_void_p),
+                ("proj_resid", C.c_void_p), ("ldpr", C.c_int), ("proj_scale", C.c_void_p)]
 
 
 class WgradItem(C.Structure):

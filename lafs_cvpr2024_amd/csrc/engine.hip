@@ -287,6 +287,10 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       const uint32_t ds = d->dropout_seed + 3u * (uint32_t)l;                 // sites: +0 to_out, +1 GELU, +2 fc2
       // LayerNorm 1 of this layer was produced by the previous layer's fused MLP (its epilogue holds the finished rows in registers)
       const bool ln1_done = l > 0 && next_ln_opt && mlp_fused_on(d, save_for_backward ? 2 : 1, R);
+      const bool mlp_one = mlp_fused_on(d, save_for_backward ? 2 : 1, R);
+      const bool ln_inside = mlp_one && mlp_fused_on(d, 8, R);          // LayerNorm 2 as the fused kernel's prologue (no launch, no h2 round trip)
+      // bits 128 (forward-only pass) / 256 (saving pass): the attention branch's projection + residual as the fused kernel's prologue
+      const bool prj = parts == 3 && ln_inside && I == D && mlp_fused_on(d, save_for_backward ? 256 : 128, R);
       if (parts & 1) {
       if (!ln1_done)
       RUN(lafs_layernorm_fwd(cur + rD, D, d->master + o.ln1_g, d->master + o.ln1_b, d->ln_eps, b.h1 + rD, D, nullptr, 0, b.st1 + 2 * (size_t)r0,
@@ -310,12 +314,11 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
       } else {
         RUN(lafs_attention_fwd(b.qkv, 3 * I, d->cu_seqlens, d->n_seq, d->max_len, d->heads, d->attn_scale, b.o, I, b.lse, st));
       }
+      if (!prj)
       RUN(gemm(cx, b.o + rI, I, sh + o.w_proj, I, R, D, I, LAFS_EPI_RESID_F32, b.x1 + rD, D, d->master + o.b_proj, st, nullptr, 0, cur + rD, D, sa,
                r2s, nullptr, 0, dp, ds + 0, 0, d->dropout_step, r0));
       }
       if (!(parts & 2)) continue;
-      const bool mlp_one = mlp_fused_on(d, save_for_backward ? 2 : 1, R);
-      const bool ln_inside = mlp_one && mlp_fused_on(d, 8, R);          // LayerNorm 2 as the fused kernel's prologue (no launch, no h2 round trip)
       if (!ln_inside)
       RUN(lafs_layernorm_fwd(b.x1 + rD, D, d->master + o.ln2_g, d->master + o.ln2_b, d->ln_eps, b.h2 + rD, D, nullptr, 0, b.st2 + 2 * (size_t)r0,
                              R, D, st));
@@ -332,6 +335,10 @@ extern "C" int lafs_trunk_forward(const lafs_trunk_desc* d, const float* x_in, f
         if (ln_inside) {
           m.X = nullptr; m.ln_gamma = d->master + o.ln2_g; m.ln_beta = d->master + o.ln2_b; m.ln_eps = d->ln_eps;
           if (save_for_backward) { m.ln_stats = b.st2 + 2 * (size_t)r0; m.ln_out = b.h2 + rD; m.ldln = D; }
+        }
+        if (prj) {                                             // x1 = cur + sa * (o Wproj^T + b) is computed (and stored to b.x1) by this launch
+          m.proj_x = b.o + rI; m.ldpx = I; m.proj_w = sh + o.w_proj; m.ldpw = I; m.proj_bias = d->master + o.b_proj;
+          m.proj_resid = cur + rD; m.ldpr = D; m.proj_scale = sa;
         }
         if (l + 1 < d->depth && next_ln_opt) {        // the next block's LayerNorm 1, from the rows in this launch's registers
           const lafs_block_offsets& on = d->blocks[l + 1];

@@ -78,6 +78,9 @@ struct MArgs {
   float* g_io; int ldgio; bf16_t* gb; int ldgb; float* part;
   // forward modes: the NEXT block's LayerNorm 1 on the finished rows, in the final epilogue (they are in registers there: no loads)
   const float* nln_g; const float* nln_b; float nln_eps; float* nln_stats; bf16_t* nln_out; int ldnln;
+  // PRJ (forward modes with LNP): the attention branch's output projection in front -- resid(x1) = resid0 + scale_p[row2seq] * (X Wp^T + bias_p)
+  // is COMPUTED here (X = the attention output rows), written to `resid`, normalised from registers and used as the residual at the end
+  const bf16_t* Wp; int ldwp; const float* bias_p; const float* resid0; int ldr0; const float* scale_p;
   const float* ln_g; const float* ln_b; float ln_eps;   // LNP: X = LayerNorm(resid) computed in the prologue
   float* ln_stats; bf16_t* ln_out; int ldln;            //      (mean, rstd) per row and the bf16 operand as by-products (optional)
   int unit_waves;                            // waves of a workgroup that own rows (8: 128-row units; 4: 64-row units, one computing wave per SIMD)
@@ -112,15 +115,22 @@ __device__ __forceinline__ float row16_sum(float v) {
 // LNP (forward modes): the GEMM-1 operand is LayerNorm(resid) (vision_transformer.py:112 norm2), computed by each wave for its own 16
 // rows with the row arithmetic of ln_fwd2_kernel (layernorm.hip: 32 lanes per row, float4 pieces at columns 4 l + 128 i, the same
 // summation order -> the same bits), written into the ring buffers as the stage-A image the fragments are read from.
-template <int MODE, bool LNP>
+// PRJ (forward modes, with LNP): the projection GEMM of the attention branch (vision_transformer.py:88-90 `self.proj`, :111 the residual and
+// DropPath of Block.forward) runs in front as six more stages of the GEMM-2 kind on the wave's 16 attention-output rows: x1 = x0 +
+// scale * (o Wp^T + b) leaves for HBM once (the backward and this kernel's own final epilogue read it), LayerNorm 2 is formed from the
+// registers, and the separate projection launch with its read of o / x0 and the prologue's read of x1 are gone.  Same MFMA, operand
+// roles, ascending k order and epilogue arithmetic as gemm_kres_kernel<RESID_F32> (accumulators start from the bias): the same bits.
+template <int MODE, bool LNP, bool PRJ = false>
 __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   constexpr bool FWD = (MODE != LAFS_MLP_BWD);
+  static_assert(!PRJ || (FWD && LNP), "the projection prologue belongs to the forward modes with LayerNorm 2 inside");
   constexpr int NS = (MODE == LAFS_MLP_FWD_SAVE) ? 4 : (MODE == LAFS_MLP_BWD ? 2 : 0);   // stores of an item's mid-epilogue (active waves)
   constexpr int NL = (MODE == LAFS_MLP_BWD) ? 2 : 0;                                     // its operand loads (every wave)
   __shared__ __attribute__((aligned(16))) unsigned char smem[NSTG * STAGE];
   __shared__ __attribute__((aligned(16))) float sba[FWD ? MAXH : 4];
   __shared__ __attribute__((aligned(16))) float sbb[(FWD || LNP) ? D : 4];        // forward: fc2 bias; backward + LNP: gamma
   __shared__ __attribute__((aligned(16))) float snl[FWD ? 2 * D : 4];             // forward: the next block's LayerNorm 1 gamma | beta
+  __shared__ __attribute__((aligned(16))) float spj[PRJ ? 3 * D : 4];             // PRJ: projection bias | LayerNorm 2 gamma | beta
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15, q = lane >> 4;
@@ -140,6 +150,8 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     for (int i = tid; i < D; i += NTH) sbb[i] = p.bias_b ? p.bias_b[i] : 0.f;
     if (p.nln_g != nullptr)
       for (int i = tid; i < D; i += NTH) { snl[i] = p.nln_g[i]; snl[D + i] = p.nln_b[i]; }
+    if constexpr (PRJ)
+      for (int i = tid; i < D; i += NTH) { spj[i] = p.bias_p ? p.bias_p[i] : 0.f; spj[D + i] = p.ln_g[i]; spj[2 * D + i] = p.ln_b[i]; }
     __syncthreads();                                   // (also keeps these loads out of the counted waits below)
   } else if constexpr (LNP) {
     for (int i = tid; i < D; i += NTH) sbb[i] = p.ln_g[i];
@@ -186,6 +198,16 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     for (int i = 0; i < NDMA; ++i) lds_dma16_m0_s(base + (size_t)i * 64 * p.ldwb, (unsigned)doffb, st + i * (NTH * 16));
     fence();
   };
+  int doffp = 0;                                       // PRJ: the projection weight's slices, stage-B images (output column = row, unpermuted)
+  if constexpr (PRJ) { const int rho = tid >> 3, cp = tid & 7, c = cp ^ (rho & 7); doffp = (rho * p.ldwp + c * 8) * 2; }
+  auto issue_p = [&](int slice, int buf) {             // Wp[:, 64 slice .. + 64) -> ring buffer buf
+    const bf16_t* base = p.Wp + (size_t)slice * HC;
+    const unsigned st = lds0 + buf * STAGE + wave * 1024;
+    fence();
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) lds_dma16_m0_s(base + (size_t)i * 64 * p.ldwp, (unsigned)doffp, st + i * (NTH * 16));
+    fence();
+  };
   auto issue_rows = [&](int half, int buf) {           // token rows [u0 + 64 half, + 64) as a stage-A image (unpermuted)
     const unsigned st = lds0 + buf * STAGE + wave * 1024;
     fence();
@@ -213,7 +235,103 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   }
 
   // ---- prologue: the unit's 128 token rows through ring buffers 0 and 1 while stage 0 flies into buffer 2
-  if constexpr (!(LNP && FWD)) {
+  // PRJ: x1 and the packed LayerNorm output of this lane's row, kept until the three stages of the main loop's start are in flight:
+  // their stores are issued BEHIND those stages, so no wait of the main loop has to drain them (58 MB per launch leave at once)
+  f32x4_t accp[PRJ ? NOB : 1];
+  uint2 hpk[PRJ ? NOB : 1];
+  float pmean = 0.f, prstd = 0.f;
+  if constexpr (PRJ) {
+    issue_rows(0, 0);                                  // the attention output rows (p.X) through buffers 0 and 1
+    issue_rows(1, 1);
+    issue_p(0, 2);
+    wait_vm<NDMA>();                                   // this thread's row pieces have landed (slice 0 is younger)
+    __builtin_amdgcn_s_barrier();
+    bf16x8_t oreg[NKK];
+    {
+      const unsigned char* st = smem + (wave >> 2) * STAGE + (wave & 3) * (16 * ROWB);
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) oreg[kk] = *reinterpret_cast<const bf16x8_t*>(st + foff[kk & 3] + (kk >> 2) * 256);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                      // buffers 0 and 1 are free again
+    issue_p(1, 0);
+    issue_p(2, 1);
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob) accp[ob] = *reinterpret_cast<const f32x4_t*>(spj + 16 * ob + 4 * q);
+    // six stages of 64 k each, ring discipline of the main loop: wait for the slice, barrier, refill the buffer read one step ago
+    // (slices 3, 4, 5, then stage 0 of the MLP into buffer 2, where the main loop expects it), 48 MFMAs
+#pragma unroll
+    for (int sl = 0; sl < D / HC; ++sl) {
+      if (sl == 0) wait_vm<2 * NDMA>(); else wait_vm<NDMA>();    // younger than slice sl: slices 1, 2 | the one stage issued a step ago
+      __builtin_amdgcn_s_barrier();
+      if (sl >= 1 && sl <= 3) issue_p(sl + 2, (sl + 1) % 3);
+      else if (sl == 4) issue_a(0, 2);
+      if (active) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned char* st = smem + ((2 + sl) % 3) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int ob = 0; ob < NOB; ++ob) {
+            const bf16x8_t w = *reinterpret_cast<const bf16x8_t*>(st + goff[ks] + ob * 2048);
+            accp[ob] = mfma16(w, oreg[2 * sl + ks], accp[ob]);
+          }
+        __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NOB - FD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, FD, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_s_barrier();                      // every wave is done with the last slice: buffers 0 and 1 take the row images
+    if (active) {
+      float sca = 1.0f;                                // DropPath scale of the attention branch
+      if (p.scale_p != nullptr) sca = p.scale_p[p.row2seq[rowc]];
+      const float* r0 = p.resid0 + (size_t)rowc * p.ldr0;
+#pragma unroll
+      for (int o0 = 0; o0 < NOB; o0 += 6) {
+        uint4 r4[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) r4[j] = *reinterpret_cast<const uint4*>(r0 + 16 * (o0 + j) + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const f32x4_t a4 = accp[o0 + j];
+          const float v0 = __uint_as_float(r4[j].x) + sca * a4[0], v1 = __uint_as_float(r4[j].y) + sca * a4[1];
+          const float v2 = __uint_as_float(r4[j].z) + sca * a4[2], v3 = __uint_as_float(r4[j].w) + sca * a4[3];
+          accp[o0 + j] = f32x4_t{v0, v1, v2, v3};
+        }
+      }
+      // LayerNorm 2 on the finished rows, in the order of ln_fwd2_kernel (see the next block's LayerNorm in the final epilogue)
+      auto tree = [&](auto&& part) {
+        float pm[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) pm[m] = part(part(part(0.f, m), m + 8), m + 16);
+        float v = ((pm[0] + pm[4]) + (pm[2] + pm[6])) + ((pm[1] + pm[5]) + (pm[3] + pm[7]));
+        v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64);
+        return v;
+      };
+      const float sm = tree([&](float s_, int ob) { return ln_sum4(s_, make_float4(accp[ob][0], accp[ob][1], accp[ob][2], accp[ob][3])); });
+      const float mean = sm / (float)D;
+      const float qs = tree([&](float s_, int ob) { return ln_sq4(s_, make_float4(accp[ob][0], accp[ob][1], accp[ob][2], accp[ob][3]), mean); });
+      const float rstd = rsqrtf(qs / (float)D + p.ln_eps);
+      pmean = mean; prstd = rstd;
+      unsigned char* img = smem + (wave >> 2) * STAGE + ((wave & 3) * 16 + t) * ROWB;      // this lane's row of the stage-A image
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) {
+        const int n = 16 * ob + 4 * q;
+        const float4 g4 = *reinterpret_cast<const float4*>(spj + D + n), b4 = *reinterpret_cast<const float4*>(spj + 2 * D + n);
+        const float h0 = ln_out1(accp[ob][0], mean, rstd, g4.x, b4.x), h1 = ln_out1(accp[ob][1], mean, rstd, g4.y, b4.y);
+        const float h2 = ln_out1(accp[ob][2], mean, rstd, g4.z, b4.z), h3 = ln_out1(accp[ob][3], mean, rstd, g4.w, b4.w);
+        const uint2 pk = make_uint2(pack_bf2(h0, h1), pack_bf2(h2, h3));
+        *reinterpret_cast<uint2*>(img + (((2 * ob + (q >> 1)) ^ t) << 4) + (q & 1) * 8) = pk;     // chunk n / 8 at position chunk ^ (row & 15)
+        hpk[ob] = pk;
+      }
+    }
+    // (a wave reads back only its own rows, and the LDS serves a wave's operations in order: no barrier in between)
+  } else if constexpr (!(LNP && FWD)) {
     issue_rows(0, 0);
     issue_rows(1, 1);
     issue_a(0, 2);
@@ -301,6 +419,20 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
   fetch_g(0);
   issue_b(0, 0);                                       // stage 1
   issue_a(1, 1);                                       // stage 2
+  const bool prj_h = PRJ && p.ln_out != nullptr;       // (uniform) the LayerNorm output also leaves for HBM: 24 more stores
+  if constexpr (PRJ) {
+    if (rowok) {                                       // (active waves issue every one of these stores: at least one of their rows exists)
+      float* x1 = const_cast<float*>(p.resid) + (size_t)row * p.ldr;
+#pragma unroll
+      for (int ob = 0; ob < NOB; ++ob) st16f(x1 + 16 * ob + 4 * q, accp[ob][0], accp[ob][1], accp[ob][2], accp[ob][3]);
+      if (prj_h) {
+#pragma unroll
+        for (int ob = 0; ob < NOB; ++ob) *reinterpret_cast<uint2*>(p.ln_out + (size_t)row * p.ldln + 16 * ob + 4 * q) = hpk[ob];
+      }
+      if (p.ln_stats != nullptr && q == 0) *reinterpret_cast<float2*>(p.ln_stats + 2 * (size_t)row) = make_float2(pmean, prstd);
+    }
+    fence();
+  }
   // in flight, oldest first: stage 0, [gelu' of item 0], stage 1, stage 2
 
   f32x4_t acc2[NOB];
@@ -336,7 +468,11 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
       for (int gi = 0; gi < 4; ++gi) acc1[gi] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     // younger than this stage's DMA: the previous item's mid-epilogue stores, the stage B issued behind it, this item's gelu' loads
-    if (it == 0) wait_vm<2 * NDMA>();                  // younger than stage 0 and the gelu' loads of item 0: stages 1 and 2
+    if (PRJ && it <= 1 && active) {                    // PRJ: the x1 (24) [+ LayerNorm output (24)] stores sit behind stages 1 and 2 (the statistics store is not counted: a stronger wait)
+      if (it == 0) { if (prj_h) wait_vm<2 * NDMA + 2 * NOB>(); else wait_vm<2 * NDMA + NOB>(); }
+      else { if (prj_h) wait_vm<NS + NDMA + 2 * NOB>(); else wait_vm<NS + NDMA + NOB>(); }
+    }
+    else if (it == 0) wait_vm<2 * NDMA>();             // younger than stage 0 and the gelu' loads of item 0: stages 1 and 2
     else if (active) wait_vm<NS + NDMA + NL>();
     else wait_vm<NDMA + NL>();
     if constexpr (!MABL(16)) __builtin_amdgcn_s_barrier();
@@ -408,7 +544,8 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
     lap(3);
     // ================= stage B of the item: acc2 += Wb slice rows x intermediate (48 MFMAs)
     // younger than this stage's DMA: the stage A issued above (if any) and the mid-epilogue's stores
-    if (has_next) { if (active) wait_vm<NDMA + NS>(); else wait_vm<NDMA>(); }
+    if (PRJ && it == 0 && active) { if (prj_h) wait_vm<NDMA + NS + 2 * NOB>(); else wait_vm<NDMA + NS + NOB>(); }   // (NI >= 2: has_next)
+    else if (has_next) { if (active) wait_vm<NDMA + NS>(); else wait_vm<NDMA>(); }
     else { if (active) wait_vm<NS>(); else wait_vm<0>(); }
     if constexpr (!MABL(16)) __builtin_amdgcn_s_barrier();
     lap(4);
@@ -614,7 +751,7 @@ __global__ __launch_bounds__(NTH, 1) void mlp_fused_kernel(MArgs p) {
 // One workgroup per CU and unit: a launch costs whole rounds of the chip.  Rows beyond the last full round of 128-row units go out as
 // a second launch of 64-row units (one computing wave per SIMD: about 0.6 of a full unit's time, tools/lab/NOTES.md) when they fit one
 // round that way -- 44 160 rows: 256 x 128 + 178 x 64 instead of two rounds of 128.
-template <int MODE, bool LNP>
+template <int MODE, bool LNP, bool PRJ = false>
 int launch(MArgs a, int n_cu, hipStream_t s) {
   const int units = (a.M + UROWS - 1) / UROWS;
   int full = units, half = 0;
@@ -629,11 +766,11 @@ int launch(MArgs a, int n_cu, hipStream_t s) {
   if (full > 0) {
     MArgs b = a;
     if (half > 0) b.M = full * UROWS;                                          // (whole units: nothing ragged in the first launch)
-    hipLaunchKernelGGL((mlp_fused_kernel<MODE, LNP>), dim3(full), dim3(NTH), 0, s, b);
+    hipLaunchKernelGGL((mlp_fused_kernel<MODE, LNP, PRJ>), dim3(full), dim3(NTH), 0, s, b);
   }
   if (half > 0) {
     a.unit_waves = 4; a.row0 = full * UROWS;
-    hipLaunchKernelGGL((mlp_fused_kernel<MODE, LNP>), dim3(half), dim3(NTH), 0, s, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<MODE, LNP, PRJ>), dim3(half), dim3(NTH), 0, s, a);
   }
   LAFS_LAUNCH_CHECK();
   return LAFS_OK;
@@ -675,7 +812,7 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
     LAFS_CHECK_ARG(g->save_grad != nullptr && g->ldsg >= g->H && g->ldsg % 8 == 0, "gelu'(u) buffer");
     LAFS_CHECK_ARG(g->save_act != nullptr && g->ldsa >= g->H && g->ldsa % 8 == 0, "gelu(u) / du buffer");
   }
-  MArgs a;
+  MArgs a = {};
   a.X = (const bf16_t*)g->X; a.ldx = g->ldx; a.Wa = (const bf16_t*)g->Wa; a.ldwa = g->ldwa; a.Wb = (const bf16_t*)g->Wb; a.ldwb = g->ldwb;
   a.M = g->M; a.H = g->H; a.bias_a = fwd ? g->bias_a : nullptr; a.bias_b = fwd ? g->bias_b : nullptr;
   a.resid = g->resid; a.ldr = g->ldr; a.seq_scale = g->seq_scale; a.row2seq = g->row2seq;
@@ -687,9 +824,17 @@ extern "C" int lafs_mlp_fused(const lafs_mlp_args* g, hipStream_t stream) {
   a.nln_out = (bf16_t*)g->next_ln_out; a.ldnln = g->ldnln_next;
   const bool lnp = fwd && g->ln_gamma != nullptr;
   a.ln_g = g->ln_gamma; a.ln_b = g->ln_beta; a.ln_eps = g->ln_eps; a.ln_stats = g->ln_stats; a.ln_out = (bf16_t*)g->ln_out; a.ldln = g->ldln;
+  const bool prj = lnp && g->proj_x != nullptr;
+  if (prj) {
+    LAFS_CHECK_ARG(g->proj_w != nullptr && g->proj_resid != nullptr && g->ldpx >= D && g->ldpx % 8 == 0 && g->ldpw >= D && g->ldpw % 8 == 0 &&
+                   g->ldpr >= D && g->ldpr % 4 == 0, "projection prologue: weight, residual and strides");
+    LAFS_CHECK_ARG(g->proj_scale == nullptr || g->row2seq != nullptr, "proj_scale needs row2seq");
+    a.X = (const bf16_t*)g->proj_x; a.ldx = g->ldpx; a.Wp = (const bf16_t*)g->proj_w; a.ldwp = g->ldpw; a.bias_p = g->proj_bias;
+    a.resid0 = g->proj_resid; a.ldr0 = g->ldpr; a.scale_p = g->proj_scale;
+  }
   switch (g->mode) {
-    case LAFS_MLP_FWD: return lnp ? launch<LAFS_MLP_FWD, true>(a, n_cu, stream) : launch<LAFS_MLP_FWD, false>(a, n_cu, stream);
-    case LAFS_MLP_FWD_SAVE: return lnp ? launch<LAFS_MLP_FWD_SAVE, true>(a, n_cu, stream) : launch<LAFS_MLP_FWD_SAVE, false>(a, n_cu, stream);
+    case LAFS_MLP_FWD: return prj ? launch<LAFS_MLP_FWD, true, true>(a, n_cu, stream) : lnp ? launch<LAFS_MLP_FWD, true>(a, n_cu, stream) : launch<LAFS_MLP_FWD, false>(a, n_cu, stream);
+    case LAFS_MLP_FWD_SAVE: return prj ? launch<LAFS_MLP_FWD_SAVE, true, true>(a, n_cu, stream) : lnp ? launch<LAFS_MLP_FWD_SAVE, true>(a, n_cu, stream) : launch<LAFS_MLP_FWD_SAVE, false>(a, n_cu, stream);
     default:
       if (g->ln_gamma != nullptr) {                      // LayerNorm backward in the epilogue: the slots are numbered by workgroup of ONE launch
         a.g_io = g->ln_g_io; a.ldgio = g->ldgio; a.gb = (bf16_t*)g->ln_gb_out; a.ldgb = g->ldgb; a.part = g->ln_part_out;

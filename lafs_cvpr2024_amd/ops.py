@@ -94,7 +94,7 @@ def gemm_nt(A, B, epilogue=_lib.EPI_BF16, bias=None, out=None, out2=None, resid=
 
 
 def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=None, row2seq=None, out=None, save_grad=None, save_act=None, ctx=None,
-              ln=None, ln_stats=None, ln_out=None, ln_bwd=None, next_ln=None):
+              ln=None, ln_stats=None, ln_out=None, ln_bwd=None, next_ln=None, proj=None):
     """The fused MLP of a ViT-S block (lafs_mlp_fused, csrc/mlp_fused.hip; vision_transformer.py:59-65,112).
     MLP_FWD / MLP_FWD_SAVE: out(f32) = resid + seq_scale[row2seq] * (gelu(X Wa^T + bias_a) Wb^T + bias_b), the saving form also
     writes save_grad = gelu'(u) and save_act = gelu(u); MLP_BWD: save_act = du = (X Wa^T) * save_grad, out(bf16) = du Wb^T."""
@@ -142,6 +142,14 @@ def mlp_fused(X, Wa, Wb, mode, bias_a=None, bias_b=None, resid=None, seq_scale=N
         a.next_ln_gamma, a.next_ln_beta, a.next_ln_eps, a.next_ln_out, a.ldnln_next = ng.data_ptr(), nb.data_ptr(), float(ne), no_.data_ptr(), _ld(no_)
         if ns is not None:
             _chk(ns, torch.float32, "next_ln stats"); a.next_ln_stats = ns.data_ptr()
+    if proj is not None:                                 # forward modes with ln: (o bf16, Wp bf16 [384, 384], bias or None, resid0 f32, scale or None) -- resid is WRITTEN
+        po, pw, pb, pr, ps = proj
+        _chk(po, bf16, "proj o"); _chk(pw, bf16, "proj W"); _chk(pr, torch.float32, "proj resid")
+        a.proj_x, a.ldpx, a.proj_w, a.ldpw, a.proj_resid, a.ldpr = po.data_ptr(), _ld(po), pw.data_ptr(), _ld(pw), pr.data_ptr(), _ld(pr)
+        if pb is not None:
+            _chk(pb, torch.float32, "proj bias"); a.proj_bias = pb.data_ptr()
+        if ps is not None:
+            _chk(ps, torch.float32, "proj scale"); a.proj_scale = ps.data_ptr()
     if ln_bwd is not None:                               # MLP_BWD: (x, stats, gamma, g_io, gb_out, part_out) -- LayerNorm backward in the epilogue
         x_, st_, gam_, gio_, gbo_, part_ = ln_bwd
         _chk(x_, torch.float32, "x"); _chk(st_, torch.float32, "stats"); _chk(gam_, torch.float32, "gamma"); _chk(gio_, torch.float32, "g_io")

@@ -834,6 +834,50 @@ def test_fused_mlp_writes_the_next_blocks_layernorm(M, mode):
     assert relerr(hn[:M].float(), t) < 8e-3
 
 
+@pytest.mark.parametrize("M", [128 * 33, 128 * 33 + 50, 128 * 300 + 64 * 3 + 7])
+@pytest.mark.parametrize("mode", ["fwd", "save"])
+def test_fused_mlp_with_the_attention_projection_in_front(M, mode):
+    """The attention branch's output projection + residual x DropPath (vision_transformer.py:88-90 `self.proj`, :111) as the fused
+    MLP's prologue: x1, LayerNorm 2 (operand and statistics), the saved activations and the block's output are BIT-IDENTICAL to
+    lafs_gemm_nt(RESID_F32) on the K-resident kernel followed by the fused MLP with the LayerNorm prologue -- whole units, a ragged
+    last unit, and more units than CUs (a second launch of 64-row units); rows past M of every output stay untouched."""
+    D, H = 384, 1536
+    g = torch.Generator().manual_seed(111)
+    x0 = (torch.randn(M, D, generator=g) * 1.7 + 0.3).to(DEV)
+    o = rnd_bf(M, D, seed=112).to(DEV)
+    Wp = rnd_bf(D, D, scale=0.06, seed=113).to(DEV); bp = (torch.randn(D, generator=g) * 0.1).to(DEV)
+    gam, bet = (1.0 + 0.2 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+    W1, W2 = rnd_bf(H, D, scale=0.05, seed=114).to(DEV), rnd_bf(D, H, scale=0.03, seed=115).to(DEV)
+    b1, b2 = (torch.randn(H, generator=g) * 0.1).to(DEV), (torch.randn(D, generator=g) * 0.1).to(DEV)
+    nseq = 11
+    row2seq = (torch.arange(M) * nseq // M).int().to(DEV)
+    sa = torch.tensor([0.0 if i % 4 == 2 else 1.0 / 0.9 for i in range(nseq)]).to(DEV)
+    sm = torch.tensor([0.0 if i % 3 == 1 else 1.0 / 0.9 for i in range(nseq)]).to(DEV)
+    md = _lib.MLP_FWD if mode == "fwd" else _lib.MLP_FWD_SAVE
+    guard = 7.0
+    def bufs():
+        return (torch.full((M + 64, D), guard, device=DEV), torch.full((M + 64, D), guard, device=DEV, dtype=bf16),
+                torch.full((M + 64, 2), guard, device=DEV), torch.full((M + 64, D), guard, device=DEV))
+    # ---- separate projection launch
+    x1r, h2r, str_, outr = bufs()
+    ops.gemm_nt(o, Wp, _lib.EPI_RESID_F32, bias=bp, out=x1r[:M], resid=x0, seq_scale=sa, row2seq=row2seq)
+    kw = dict(bias_a=b1, bias_b=b2, seq_scale=sm, row2seq=row2seq, ln=(gam, bet, 1e-6))
+    sv = dict(ln_stats=str_[:M], ln_out=h2r[:M]) if mode == "save" else {}
+    ref = ops.mlp_fused(None, W1, W2, md, resid=x1r[:M], out=outr[:M], **sv, **kw)
+    # ---- in front of the fused MLP
+    x1, h2, st, out = bufs()
+    sv = dict(ln_stats=st[:M], ln_out=h2[:M]) if mode == "save" else {}
+    got = ops.mlp_fused(None, W1, W2, md, resid=x1[:M], out=out[:M], proj=(o, Wp, bp, x0, sa), **sv, **kw)
+    assert torch.equal(x1[:M], x1r[:M]), f"x1: {int((x1[:M] != x1r[:M]).sum())} differing values, max {float((x1[:M] - x1r[:M]).abs().max()):.3e}"
+    for name, a, b in (("out", out, outr), ("h2", h2, h2r), ("stats", st, str_)):
+        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} differing values"          # (rows past M included: the guards)
+    assert float((x1[M:] - guard).abs().max()) == 0.0
+    for a, b in zip(got[1:], ref[1:]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    want = x0.cpu() + sa.cpu()[row2seq.cpu().long()][:, None] * (o.float().cpu() @ Wp.float().cpu().t() + bp.cpu())
+    assert relerr(x1[:M], want) < 2e-3
+
+
 @pytest.mark.parametrize("M", [128 * 35, 128 * 33 + 50])
 def test_fused_mlp_backward_with_the_layernorm_backward_in_its_epilogue(M):
     """LAFS_MLP_BWD with the LayerNorm-2 backward in the epilogue (vision_transformer.py:112 backward) against the separate path --

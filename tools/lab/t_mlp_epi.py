@@ -40,7 +40,11 @@ for M in (25216, 18944, 12608):
     ln = lambda: call("lafs_layernorm_fwd", _p(resid), D, _p(gam), _p(bet), 1e-6, _p(X), D, None, 0, _p(st), M, D)
     ln()
     sv = dict(save_grad=gs, save_act=a)
+    o = torch.randn(M, D, generator=g).to(bf16).to(DEV); Wp = (torch.randn(D, D, generator=g) * 0.05).to(bf16).to(DEV)
+    x0 = torch.randn(M, D, generator=g).to(DEV)
+    kwp = dict(kw); kwp["resid"] = resid                 # (resid is written by the projection prologue)
     fns = {
+        "proj launch": lambda: ops.gemm_nt(o, Wp, _lib.EPI_RESID_F32, bias=b2, out=resid, resid=x0, seq_scale=sc, row2seq=row2seq),
         "LN launch": ln,
         "fwd plain": lambda: ops.mlp_fused(X, W1, W2, _lib.MLP_FWD, **kw),
         "fwd +LN2": lambda: ops.mlp_fused(None, W1, W2, _lib.MLP_FWD, ln=(gam, bet, 1e-6), **kw),
@@ -49,6 +53,10 @@ for M in (25216, 18944, 12608):
         "save +LN2": lambda: ops.mlp_fused(None, W1, W2, _lib.MLP_FWD_SAVE, ln=(gam, bet, 1e-6), ln_stats=st, ln_out=h2, **sv, **kw),
         "save +LN2 +nextLN1": lambda: ops.mlp_fused(None, W1, W2, _lib.MLP_FWD_SAVE, ln=(gam, bet, 1e-6), ln_stats=st, ln_out=h2,
                                                     next_ln=(gam, bet, 1e-6, hn, sn), **sv, **kw),
+        "fwd proj+LN2+nextLN1": lambda: ops.mlp_fused(None, W1, W2, _lib.MLP_FWD, ln=(gam, bet, 1e-6), next_ln=(gam, bet, 1e-6, hn, None),
+                                                      proj=(o, Wp, b2, x0, sc), **kw),
+        "save proj+LN2+nextLN1": lambda: ops.mlp_fused(None, W1, W2, _lib.MLP_FWD_SAVE, ln=(gam, bet, 1e-6), ln_stats=st, ln_out=h2,
+                                                       next_ln=(gam, bet, 1e-6, hn, sn), proj=(o, Wp, b2, x0, sc), **sv, **kw),
     }
     res = {}
     for rnd in range(3):
