@@ -118,8 +118,10 @@ class HipLandmarkCNN:
             g = _group(c) if c % 8 == 0 else None
             return c if (side >= PACK_MIN_SIDE and g is not None and rows % g == 0) else _pad32(c)
 
-        def conv1x1(W, b, wi, wo):                                 # [cout, cin] fp64 -> device images for input / output widths wi / wo
+        def conv1x1(W, b, wi, wo, rows):                           # [cout, cin] fp64 -> device images for input / output widths wi / wo
             g = _group(wi)
+            while 2 * g * max(wi, wo) <= 128 and rows % (2 * g) == 0:      # tiny convolutions (16 -> 16): fill the GEMM's 128-wide tile
+                g *= 2
             cout, cin = W.shape
             Wd = torch.zeros(g * wo, g * wi, dtype=torch.float64)
             bd = torch.zeros(g * wo, dtype=torch.float64)
@@ -141,10 +143,10 @@ class HipLandmarkCNN:
             wo = width(L["cout"], Ho, N * Ho * Ho)
             d = dict(H=H, Ho=Ho, we=we, wo=wo, e=torch.empty(N * H * H, we, device=dev, dtype=bf16),
                      d=torch.empty(N * Ho * Ho, we, device=dev, dtype=bf16), y=torch.empty(N * Ho * Ho, wo, device=dev, dtype=bf16))
-            d["g_exp"], d["w_exp"], d["b_exp"] = conv1x1(L["w_exp"], L["b_exp"], wi, we)
+            d["g_exp"], d["w_exp"], d["b_exp"] = conv1x1(L["w_exp"], L["b_exp"], wi, we, N * H * H)
             d["w_dw"] = pad(L["w_dw"], L["k"] * L["k"], we).to(dev, f32).contiguous()
             d["b_dw"] = torch.nn.functional.pad(L["b_dw"], (0, we - L["cexp"])).to(dev, f32).contiguous()
-            d["g_proj"], d["w_proj"], d["b_proj"] = conv1x1(L["w_proj"], L["b_proj"], we, wo)
+            d["g_proj"], d["w_proj"], d["b_proj"] = conv1x1(L["w_proj"], L["b_proj"], we, wo, N * Ho * Ho)
             if "se" in L:
                 pe, ph = _pad32(L["cexp"]), _pad32(L["se"]["h"])
                 d["pe"] = pe
