@@ -32,6 +32,21 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
+// 16 bytes of an operand the BACKWARD kernels read exactly once (q, k, v, dO, O of a pair): non-temporal, so that these streams do not
+// displace what the kernels running beside the attention backward re-read from the L2.  LAFS_ATTN_NT=0: plain loads (lab).
+#ifndef LAFS_ATTN_NT
+#define LAFS_ATTN_NT 1
+#endif
+__device__ __forceinline__ uint4 ld_once16(const bf16_t* p) {
+#if LAFS_ATTN_NT
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
 __device__ __forceinline__ bf16x8_t to_frag(s16x4_t lo, s16x4_t hi) {
   s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8_t, v);
@@ -450,11 +465,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_fused_kernel(AttnArgs a) {
         vq[i] = make_uint4(0, 0, 0, 0); vd[i] = vq[i]; vk[i] = vq[i]; vv[i] = vq[i]; vo[i] = vq[i];
         if (idx < ROWS * 8 && row < len) {
           const bf16_t* qr = qb + (size_t)row * a.ldqkv + ch * 8;
-          vq[i] = *reinterpret_cast<const uint4*>(qr);
-          vk[i] = *reinterpret_cast<const uint4*>(qr + inner);
-          vv[i] = *reinterpret_cast<const uint4*>(qr + 2 * inner);
-          vd[i] = *reinterpret_cast<const uint4*>(db + (size_t)row * a.lddo + ch * 8);
-          vo[i] = *reinterpret_cast<const uint4*>(ob + (size_t)row * a.ldo + ch * 8);
+          vq[i] = ld_once16(qr);
+          vk[i] = ld_once16(qr + inner);
+          vv[i] = ld_once16(qr + 2 * inner);
+          vd[i] = ld_once16(db + (size_t)row * a.lddo + ch * 8);
+          vo[i] = ld_once16(ob + (size_t)row * a.ldo + ch * 8);
         }
       }
 #pragma unroll
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(AttnArgs a) {
     for (int i = 0; i < IT; ++i) {
       const int idx = t_ + i * 512, row = idx >> 3, ch = idx & 7;
       r[i] = make_uint4(0, 0, 0, 0);
-      if (idx < ROWS * 8 && row < s_len) r[i] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + ch * 8);
+      if (idx < ROWS * 8 && row < s_len) r[i] = ld_once16(src + (size_t)row * ld + ch * 8);
     }
   };
   auto request_lse = [&]() __attribute__((always_inline)) {

@@ -5,9 +5,35 @@
 #include <algorithm>
 #include <stdlib.h>
 #include "common.hpp"
+#ifndef LAFS_LN_NT
+#define LAFS_LN_NT 1
+#endif
 #include "lafs_hip.h"
 
 namespace {
+
+// Loads of the LayerNorm backward's operands -- x, dy and the old value of the gradient stream are each read ONCE by this pass: with
+// the non-temporal hint (global_load ... nt) they do not displace what the kernels running beside this one re-read from the L2 (the
+// fused MLP's weight slices).  Same-box A/B of the step, 9 interleaved pairs: 14.45 against 14.55 ms with plain loads; alone, on
+// operands a timing loop keeps cache-warm, the kernel is 10 % slower with it (tools/lab/NOTES.md).  LAFS_LN_NT=0: plain loads (lab).
+__device__ __forceinline__ float4 ld_stream4(const float* p) {
+#if LAFS_LN_NT
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ uint2 ld_stream2(const bf16_t* p) {
+#if LAFS_LN_NT
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+  const u2v v = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(p));
+  return make_uint2(v[0], v[1]);
+#else
+  return *reinterpret_cast<const uint2*>(p);
+#endif
+}
 
 constexpr int MAXI = 8;   // D <= 2048: lane owns float4 at columns lane*4 + 256*i
 
@@ -147,10 +173,10 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd_kernel(const bf16_t* __restric
     for (int i = 0; i < NI; ++i) {
       const int c = lane * 4 + 256 * i;
       if (c < D) {
-        r.xv[i] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
-        if constexpr (DYF) r.df[i] = *reinterpret_cast<const float4*>(dyf + (size_t)row * lddyf + c);
-        else r.dw[i] = *reinterpret_cast<const uint2*>(dy + (size_t)row * lddy + c);
-        r.old[i] = accumulate ? *reinterpret_cast<const float4*>(g_io + (size_t)row * ldg + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r.xv[i] = ld_stream4(x + (size_t)row * ldx + c);      // (single-use streams: see ld_stream4)
+        if constexpr (DYF) r.df[i] = ld_stream4(dyf + (size_t)row * lddyf + c);
+        else r.dw[i] = ld_stream2(dy + (size_t)row * lddy + c);
+        r.old[i] = accumulate ? ld_stream4(g_io + (size_t)row * ldg + c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
@@ -258,9 +284,9 @@ __global__ __launch_bounds__(NW * 64) void ln_bwd2_kernel(const bf16_t* __restri
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int c = l * 4 + 128 * i;
-      r.xv[i] = *reinterpret_cast<const float4*>(x + (size_t)row * ldx + c);
-      r.dw[i] = *reinterpret_cast<const uint2*>(dy + (size_t)row * lddy + c);
-      r.old[i] = accumulate ? *reinterpret_cast<const float4*>(g_io + (size_t)row * ldg + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+r.xv[i] = ld_stream4(x + (size_t)row * ldx + c);        // (single-use streams: see ld_stream4)
+      r.dw[i] = ld_stream2(dy + (size_t)row * lddy + c);
+      r.old[i] = accumulate ? ld_stream4(g_io + (size_t)row * ldg + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   const int stride = gridDim.x * NW * 2;

@@ -73,6 +73,32 @@ __global__ __launch_bounds__(256) void seg_step_kernel(const int* __restrict__ s
   if ((f & LAFS_SEG_TRAINABLE) && !frozen) seg_step[s] += 1;
 }
 
+// The optimizer's state streams -- gradient, both moments, the teacher's fp32 copy and the master weights are each touched once per
+// step, by this kernel, which runs on its own stream BESIDE the backward pass: non-temporal loads / stores (the moments and the
+// teacher copy; the master weights are re-read by the transposed-shadow refresh, the bf16 shadows by the next forward: plain
+// stores) keep 2 GB per step from displacing what the backward's kernels re-read from the L2.  LAFS_OPT_NT=0: plain accesses (lab).
+#ifndef LAFS_OPT_NT
+#define LAFS_OPT_NT 1
+#endif
+__device__ __forceinline__ float4 ldst4(const float* p) {
+#if LAFS_OPT_NT
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void stst4(float* p, float4 x) {
+#if LAFS_OPT_NT
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v v = {x.x, x.y, x.z, x.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<f4v*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = x;
+#endif
+}
+
 __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                             float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                                                             float* __restrict__ teacher, bf16_t* __restrict__ param_bf,
@@ -85,7 +111,7 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(float* __restrict__
   const int flags = seg_flags[seg];
   const bool frozen = (flags & LAFS_SEG_LAST_LAYER) && hyper[LAFS_HP_FREEZE_LAST] != 0.f;
   const bool update = (flags & LAFS_SEG_TRAINABLE) && !frozen;
-  float4 p = *reinterpret_cast<const float4*>(param + i);
+  float4 p = ldst4(param + i);
   if (update) {
     const float lr = hyper[LAFS_HP_LR];
     const float wd = (flags & LAFS_SEG_LOW_DECAY) ? hyper[LAFS_HP_WD_LOW] : ((flags & LAFS_SEG_DECAY) ? hyper[LAFS_HP_WD] : 0.f);
@@ -98,9 +124,9 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(float* __restrict__
     const float t = (float)seg_step[seg];
     const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
-    float4 g = *reinterpret_cast<const float4*>(grad + i);
-    float4 m = *reinterpret_cast<const float4*>(exp_avg + i);
-    float4 v = *reinterpret_cast<const float4*>(exp_avg_sq + i);
+    float4 g = ldst4(grad + i);
+    float4 m = ldst4(exp_avg + i);
+    float4 v = ldst4(exp_avg_sq + i);
     const float decay = 1.f - lr * wd;
 #define LAFS_ADAM(c)                                              \
     {                                                             \
@@ -113,16 +139,16 @@ __global__ __launch_bounds__(256) void clip_adamw_ema_kernel(float* __restrict__
     LAFS_ADAM(x) LAFS_ADAM(y) LAFS_ADAM(z) LAFS_ADAM(w)
 #undef LAFS_ADAM
     *reinterpret_cast<float4*>(param + i) = p;
-    *reinterpret_cast<float4*>(exp_avg + i) = m;
-    *reinterpret_cast<float4*>(exp_avg_sq + i) = v;
+    stst4(exp_avg + i, m);
+    stst4(exp_avg_sq + i, v);
     if (param_bf != nullptr) *reinterpret_cast<uint2*>(param_bf + i) = make_uint2(pack_bf2(p.x, p.y), pack_bf2(p.z, p.w));
   }
   if (teacher != nullptr) {                                 // EMA covers every parameter, trainable or not
     const float em = hyper[LAFS_HP_EMA_M];
-    float4 tp = *reinterpret_cast<const float4*>(teacher + i);
+    float4 tp = ldst4(teacher + i);
     tp.x = tp.x * em + (1.f - em) * p.x; tp.y = tp.y * em + (1.f - em) * p.y;
     tp.z = tp.z * em + (1.f - em) * p.z; tp.w = tp.w * em + (1.f - em) * p.w;
-    *reinterpret_cast<float4*>(teacher + i) = tp;
+    stst4(teacher + i, tp);
     if (teacher_bf != nullptr) *reinterpret_cast<uint2*>(teacher_bf + i) = make_uint2(pack_bf2(tp.x, tp.y), pack_bf2(tp.z, tp.w));
   }
 }
